@@ -1,0 +1,257 @@
+/* mi355opt.h -- C ABI of libmi355opt.so: the MI355X (gfx950) device layer underneath the
+ * Optimization::Riemannian::TNT / Optimization::LinearAlgebra::STPCG / LOBPCG function templates.
+ *
+ * The reference (david-m-rosen/Optimization) is a header-only C++ template library with no FFI:
+ * its "interface" for this path is the implicit Vector concept (operators used at
+ * LinearAlgebra/IterativeSolvers.h:211-420, Riemannian/TNT.h:375-557) plus user-supplied
+ * std::function callables (Riemannian/Concepts.h:44-112).  This header is what a C++ maintainer
+ * binds underneath those templates: every entry point below names the
+ * reference expression(s) it realises on the device.  File:line citations are relative to
+ * /root/reference/include/Optimization.
+ *
+ * Conventions
+ *   - plain C, opaque handles, no C++/torch types; every function returns an mi_status (0 = ok);
+ *     mi_last_error() gives the message of the calling thread's last failure.
+ *   - all work is enqueued on the context's HIP stream and is asynchronous unless documented as
+ *     synchronous ("sync").  One context = one GPU = one stream; not thread-safe per context (the
+ *     reference is single-threaded).
+ *   - vectors are flat fp64 arrays in HBM.  A Stiefel / Euclidean n x p matrix is row-major
+ *     (p contiguous), SO(3)^N variables are N row-major 3x3 blocks, so(3)^N tangents are 3N doubles.
+ *   - there is NO CPU fallback: without a GPU every compute entry point fails with
+ *     MI_ERR_NO_DEVICE.
+ */
+#ifndef MI355OPT_H
+#define MI355OPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_API __attribute__((visibility("default")))
+
+typedef enum mi_status {
+  MI_OK = 0,
+  MI_ERR_INVALID_ARGUMENT = 1, /* the checks the reference answers with std::invalid_argument */
+  MI_ERR_HIP = 2,
+  MI_ERR_OOM = 3,
+  MI_ERR_NO_DEVICE = 4,
+  MI_ERR_COMM = 5,
+  MI_ERR_INTERNAL = 6
+} mi_status;
+
+typedef struct mi_ctx mi_ctx;       /* device context: stream, memory pool, scalar file, communicator */
+typedef struct mi_vec mi_vec;       /* fp64 device vector */
+typedef struct mi_csr mi_csr;       /* sparse matrix (CSR on input, sliced-ELL-64 in HBM) */
+typedef struct mi_bsr3 mi_bsr3;     /* 3x3-block sparse matrix (pose-graph Hessians) */
+typedef struct mi_op mi_op;         /* symmetric linear operator on tangent vectors (the HVP) */
+typedef struct mi_precon mi_precon; /* preconditioner v = M^-1 r */
+typedef struct mi_stiefel_rq mi_stiefel_rq; /* Rayleigh-quotient problem on St(n,p) */
+typedef struct mi_so3n mi_so3n;             /* chordal rotation-averaging problem on SO(3)^N */
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) context / stream / pool
+ * ------------------------------------------------------------------------------------------- */
+MI_API const char *mi_version(void);
+MI_API const char *mi_last_error(void);
+MI_API const char *mi_status_string(int status);
+MI_API int mi_device_count(int *count);
+MI_API int mi_ctx_create(int device, mi_ctx **out);
+MI_API int mi_ctx_destroy(mi_ctx *ctx);
+MI_API int mi_ctx_sync(mi_ctx *ctx);                   /* sync: hipStreamSynchronize */
+MI_API int mi_ctx_stream(mi_ctx *ctx, void **stream);  /* the hipStream_t all work is enqueued on */
+MI_API int mi_ctx_device_name(mi_ctx *ctx, char *buf, size_t buflen);
+MI_API int mi_ctx_pool_bytes(mi_ctx *ctx, size_t *bytes_reserved);
+
+/* HIP-event timing of whole regions and of individual kernels (bench.py's roofline leg).
+ * Kernel ids are the MI_K_* values; when timing is enabled for an id every launch of that kernel is
+ * bracketed by an event pair on the context stream. */
+enum {
+  MI_K_NONE = 0,
+  MI_K_CG_INIT, MI_K_CG_DOT3, MI_K_CG_SCALAR_A, MI_K_CG_UPDATE, MI_K_CG_SCALAR_B, MI_K_CG_PUPDATE,
+  MI_K_SPMM, MI_K_STIEFEL_SPMM_GRAM, MI_K_STIEFEL_GRAM_REDUCE, MI_K_STIEFEL_FINISH_DOTS,
+  MI_K_STIEFEL_RETRACT, MI_K_BSR3_SPMV_DOTS, MI_K_BLAS1, MI_K_LOBPCG_GRAM, MI_K_LOBPCG_UPDATE,
+  MI_K_LOBPCG_RESIDUAL, MI_K_COUNT
+};
+MI_API int mi_ktime_enable(mi_ctx *ctx, int kernel_id, int on);
+MI_API int mi_ktime_reset(mi_ctx *ctx);
+/* sync: resolves recorded event pairs; returns launches and total milliseconds for kernel_id */
+MI_API int mi_ktime_read(mi_ctx *ctx, int kernel_id, size_t *launches, double *total_ms);
+MI_API const char *mi_kernel_name(int kernel_id);
+MI_API int mi_timer_start(mi_ctx *ctx);             /* records an event on the stream */
+MI_API int mi_timer_stop(mi_ctx *ctx, double *ms);  /* sync: records, waits, returns elapsed ms */
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) vectors -- the implicit Vector concept
+ * ------------------------------------------------------------------------------------------- */
+MI_API int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out); /* `Vector v;` + sizing; pooled */
+MI_API int mi_vec_destroy(mi_vec *v);                           /* returns storage to the pool */
+MI_API int mi_vec_len(const mi_vec *v, size_t *n);
+MI_API int mi_vec_data(const mi_vec *v, void **device_ptr);
+MI_API int mi_vec_upload(mi_vec *v, const double *host, size_t n);         /* sync */
+MI_API int mi_vec_download(const mi_vec *v, double *host, size_t n);       /* sync */
+MI_API int mi_vec_copy(mi_vec *dst, const mi_vec *src);   /* `r_k = g;` IterativeSolvers.h:214,231,383 */
+MI_API int mi_vec_fill(mi_vec *v, double a);
+MI_API int mi_vec_scale(mi_vec *v, double a);             /* `p_k *= -1;` :324 ; `u /= beta` :653 */
+MI_API int mi_vec_axpy(mi_vec *y, double a, const mi_vec *x); /* `s_k += sigma_k * p_k;` :336,360,377 */
+/* z = a*x + b*y (z may alias x or y): `s_k = s_k + alpha_k*p_k` :374, `p_k = -v_k + beta_k*p_k` :420,
+ * `0 * g` :211, unary minus :256, `X + V` Riemannian/Concepts.h:189 */
+MI_API int mi_vec_axpby(mi_vec *z, double a, const mi_vec *x, double b, const mi_vec *y);
+/* sync: `V1.dot(V2)` Riemannian/Concepts.h:178 -- deterministic two-stage reduction */
+MI_API int mi_vec_dot(const mi_vec *x, const mi_vec *y, double *out);
+/* k <= 4 inner products in one pass, results to host (sync) */
+MI_API int mi_vec_dot_batch(mi_ctx *ctx, int k, const mi_vec *const *x, const mi_vec *const *y,
+                            double *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) sparse operators (user HVP building blocks; the reference has none -- its HVP is a user
+ *     callable invoked at IterativeSolvers.h:294 and TNT.h:512)
+ * ------------------------------------------------------------------------------------------- */
+MI_API int mi_csr_create(mi_ctx *ctx, size_t n, size_t nnz, const int32_t *rowptr,
+                         const int32_t *col, const double *val, mi_csr **out); /* sync (upload) */
+MI_API int mi_csr_destroy(mi_csr *A);
+/* W (n x p row-major) = A V ; p in {1,2,3,4} */
+MI_API int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) linear operators and preconditioners handed to STPCG
+ *     mi_op     <-> SymmetricLinearOperator<Vector> H   (LinearAlgebra/Concepts.h:20-21; called at
+ *                   IterativeSolvers.h:294)
+ *     mi_precon <-> STPCGPreconditioner<Vector,Multiplier> P with Multiplier = nullptr_t
+ *                   (IterativeSolvers.h:83-85; called at :234,386; TNT.h:413-419)
+ * ------------------------------------------------------------------------------------------- */
+/* callback: must ENQUEUE out = Op(in) on the context stream and return MI_OK without synchronising */
+typedef int (*mi_apply_fn)(void *user, const mi_vec *in, mi_vec *out);
+MI_API int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_op **out);
+MI_API int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out);           /* Hp = d .* p */
+MI_API int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out);     /* Hp = A p    */
+MI_API int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out);
+MI_API int mi_op_destroy(mi_op *op);
+
+MI_API int mi_precon_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user,
+                                     mi_precon **out);
+MI_API int mi_precon_create_diag(mi_ctx *ctx, const mi_vec *dinv, mi_precon **out); /* v = dinv .* r */
+/* 3x3 block-Jacobi: blocks holds N row-major 3x3 INVERSE diagonal blocks (9N doubles) */
+MI_API int mi_precon_create_block3(mi_ctx *ctx, const mi_vec *inv_blocks, mi_precon **out);
+MI_API int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v);
+MI_API int mi_precon_destroy(mi_precon *P);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) fused Steihaug-Toint truncated preconditioned CG -- LinearAlgebra::STPCG
+ *     (IterativeSolvers.h:166-426, unconstrained form: At == nullopt), metric = Euclidean/Frobenius
+ *     dot of the coordinate arrays.  Device-resident scalar recurrences (:259-279,330-345,412-417);
+ *     the host only polls a pinned status word and keeps `run_ahead` iterations enqueued.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mi_stpcg_params {
+  double Delta;          /* :171 */
+  size_t max_iterations; /* :172 (1000) */
+  double kappa_fgr;      /* :172 (.1) */
+  double theta;          /* :172 (.5) */
+  double epsilon;        /* :179 (1e-8) */
+  int run_ahead;         /* iterations the host may enqueue beyond the last one known complete (0 -> default 3) */
+} mi_stpcg_params;
+
+enum {
+  MI_STPCG_EXIT_RESIDUAL = 0, /* :290 */
+  MI_STPCG_EXIT_MAXIT = 1,    /* :285 loop exhausted */
+  MI_STPCG_EXIT_KERNEL = 2,   /* :305-337 */
+  MI_STPCG_EXIT_BOUNDARY = 3  /* :347-361 */
+};
+
+typedef struct mi_stpcg_result {
+  double update_step_M_norm; /* :334,359,424 */
+  size_t num_iterations;     /* :285 (not incremented on boundary exits) */
+  int exit_reason;
+  size_t hvp_calls;          /* operator applications enqueued (incl. speculative ones past the exit) */
+  double rv_final;           /* last <r,v> */
+} mi_stpcg_result;
+
+typedef struct mi_stpcg_trace { /* optional per-iteration scalars, host arrays of capacity cap */
+  size_t cap, len;
+  double *alpha, *beta, *kappa, *rv;
+} mi_stpcg_trace;
+
+MI_API void mi_stpcg_default_params(mi_stpcg_params *p);
+/* sync at exit.  s_out must have g's length.  Returns MI_ERR_INVALID_ARGUMENT for the argument
+ * ranges the reference rejects (:183-205). */
+MI_API int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P /*nullable*/,
+                    const mi_stpcg_params *params, mi_vec *s_out, mi_stpcg_result *result,
+                    mi_stpcg_trace *trace /*nullable*/);
+
+/* ---------------------------------------------------------------------------------------------
+ * (6) Stiefel manifold St(n,p), p in {1,2,3,4}, embedded metric -- the callables a client of
+ *     TNT supplies (Objective, QuadraticModel, RiemannianMetric, Retraction; sphere analogue in
+ *     the reference: tests/TNT_unit_test.cpp:73-117)
+ * ------------------------------------------------------------------------------------------- */
+MI_API int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z,
+                           double *G_host /* p*p row-major, sync */);
+MI_API int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z,
+                              mi_vec *out); /* Z - X sym(X'Z) */
+MI_API int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *V,
+                              mi_vec *Y);   /* polar: (X+V) ((X+V)'(X+V))^-1/2 */
+/* f(X) = .5 tr(X' A X) */
+MI_API int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stiefel_rq **out);
+MI_API int mi_stiefel_rq_destroy(mi_stiefel_rq *prob);
+MI_API int mi_stiefel_rq_objective(mi_stiefel_rq *prob, const mi_vec *X, double *f); /* sync */
+/* QuadraticModel: grad = AX - X sym(X'AX); caches S = sym(X'AX) on the device and binds the
+ * Hessian operator  Hess[V] = P_X(A V - V S)  to X (X must outlive the operator's use). */
+MI_API int mi_stiefel_rq_model(mi_stiefel_rq *prob, const mi_vec *X, mi_vec *grad, mi_op **hess);
+/* row-scaling (Jacobi) preconditioner projected to the tangent space: v = P_X(dinv_rows .* r) */
+MI_API int mi_stiefel_rq_precon(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *dinv_rows,
+                                mi_precon **out);
+
+/* ---------------------------------------------------------------------------------------------
+ * (7) SO(3)^N chordal rotation averaging  f(R) = .5 sum_e w_e |R_j - R_i Rt_e|_F^2
+ * ------------------------------------------------------------------------------------------- */
+MI_API int mi_so3n_create(mi_ctx *ctx, size_t N, size_t n_edges, const int32_t *ei,
+                          const int32_t *ej, const double *Rt /*9 per edge*/, const double *w,
+                          mi_so3n **out); /* sync (upload) */
+MI_API int mi_so3n_destroy(mi_so3n *prob);
+MI_API int mi_so3n_objective(mi_so3n *prob, const mi_vec *R, double *f); /* sync */
+/* QuadraticModel: gradient in so(3)^N coordinates, Hessian operator as a symmetric 3x3-block
+ * sparse matrix rebuilt at R, optional 3x3 block-Jacobi preconditioner from its diagonal blocks */
+MI_API int mi_so3n_model(mi_so3n *prob, const mi_vec *R, mi_vec *grad, mi_op **hess,
+                         mi_precon **block_jacobi /*nullable*/);
+MI_API int mi_so3n_retract(mi_so3n *prob, const mi_vec *R, const mi_vec *xi, mi_vec *Y);
+
+/* ---------------------------------------------------------------------------------------------
+ * (8) LOBPCG building blocks (LinearAlgebra/LOBPCG.h:131-337).  Panels are column-major m x k
+ *     (ld = m), matching the reference's Eigen dense layout.
+ * ------------------------------------------------------------------------------------------- */
+/* G (ka x kb, column-major, host, sync) = S' * AS  -- LOBPCG.h:223,271-272 ; fp64 MFMA */
+MI_API int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *AS,
+                          double *G_host);
+/* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
+MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
+                            const double *C_host, int ldc, mi_vec *Y);
+/* R = AX - BX diag(theta); rnorm[j] = |R_j|, xnorm[j] = |X_j| (host, sync) -- LOBPCG.h:230,285,293,302 */
+MI_API int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi_vec *BX,
+                              const mi_vec *X, const double *theta_host, mi_vec *R, double *rnorm,
+                              double *xnorm);
+/* Rayleigh-Ritz on the host (ns <= 96): LOBPCG.h:53-62.  Theta ascending, C'AC = Theta, C'BC = I */
+MI_API int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C);
+
+/* ---------------------------------------------------------------------------------------------
+ * (9) multi-GPU: one process per GPU, tangent vectors row-sharded, inner products completed by an
+ *     in-stream RCCL all-reduce of the scalar slots.  uid = ncclUniqueId bytes
+ *     obtained on rank 0 with mi_comm_unique_id and broadcast by the launcher.
+ * ------------------------------------------------------------------------------------------- */
+#define MI_COMM_UID_BYTES 128
+MI_API int mi_comm_unique_id(unsigned char uid[MI_COMM_UID_BYTES]);
+MI_API int mi_comm_init(mi_ctx *ctx, int world_size, int rank,
+                        const unsigned char uid[MI_COMM_UID_BYTES]); /* sync */
+MI_API int mi_comm_finalize(mi_ctx *ctx);
+MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
+/* halo description for a row-sharded sparse operator: rows [row_begin,row_end) of a global n x n
+ * matrix are local; columns outside are fetched from the owning neighbour before each SpMM */
+MI_API int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t row_end,
+                                 size_t nnz_local, const int32_t *rowptr, const int64_t *col_global,
+                                 const double *val, const size_t *row_starts /*world_size+1*/,
+                                 mi_csr **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355OPT_H */

@@ -1,0 +1,70 @@
+"""Build libmi355opt.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+Usage:  python -m optimization_amd.build [--force] [-j N]
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libmi355opt.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+CFLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+    "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", "/opt/rocm/include",
+]
+LDFLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(f) > t for f in [src] + deps)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if not force and not _newer(src, obj, deps):
+        return obj, False, ""
+    cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-6000:]}")
+    return obj, True, r.stderr
+
+
+def build(force=False, jobs=None, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if not srcs:
+        raise RuntimeError("no HIP sources found")
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    objs, rebuilt = [], False
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for obj, did, err in ex.map(lambda s: _compile(s, force), srcs):
+            objs.append(obj)
+            rebuilt |= did
+            if verbose and err.strip():
+                print(err, file=sys.stderr)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, f"--offload-arch={ARCH}"] + objs + LDFLAGS + ["-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-6000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    print(build(force=force, verbose=True))

@@ -1,0 +1,481 @@
+"""ctypes binding of the C ABI in include/mi355opt.h (libmi355opt.so).
+
+This is harness plumbing for tests/ and bench.py: the product is the shared library (HIP kernels
+behind a C ABI) and the C++ template layer in optimization_amd/include/.  There is no CPU fallback:
+if the library is missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355opt.so")
+
+MI_OK = 0
+STATUS = {0: "MI_OK", 1: "MI_ERR_INVALID_ARGUMENT", 2: "MI_ERR_HIP", 3: "MI_ERR_OOM",
+          4: "MI_ERR_NO_DEVICE", 5: "MI_ERR_COMM", 6: "MI_ERR_INTERNAL"}
+KERNELS = ["none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
+           "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
+           "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
+           "lobpcg_residual"]
+KID = {k: i for i, k in enumerate(KERNELS)}
+STPCG_EXIT = ["RESIDUAL", "MAXIT", "KERNEL", "BOUNDARY"]
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_size_p = C.POINTER(C.c_size_t)
+vp = C.c_void_p
+
+APPLY_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp)
+
+
+class MiError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class StpcgParams(C.Structure):
+    _fields_ = [("Delta", C.c_double), ("max_iterations", C.c_size_t), ("kappa_fgr", C.c_double),
+                ("theta", C.c_double), ("epsilon", C.c_double), ("run_ahead", C.c_int)]
+
+
+class StpcgResult(C.Structure):
+    _fields_ = [("update_step_M_norm", C.c_double), ("num_iterations", C.c_size_t),
+                ("exit_reason", C.c_int), ("hvp_calls", C.c_size_t), ("rv_final", C.c_double)]
+
+
+class StpcgTrace(C.Structure):
+    _fields_ = [("cap", C.c_size_t), ("len", C.c_size_t), ("alpha", c_double_p), ("beta", c_double_p),
+                ("kappa", c_double_p), ("rv", c_double_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load libmi355opt.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not found: run `python -m optimization_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.mi_version.restype = C.c_char_p
+    L.mi_last_error.restype = C.c_char_p
+    L.mi_status_string.restype = C.c_char_p
+    L.mi_status_string.argtypes = [C.c_int]
+    L.mi_kernel_name.restype = C.c_char_p
+    L.mi_kernel_name.argtypes = [C.c_int]
+    sigs = {
+        "mi_device_count": [C.POINTER(C.c_int)],
+        "mi_ctx_create": [C.c_int, C.POINTER(vp)],
+        "mi_ctx_destroy": [vp],
+        "mi_ctx_sync": [vp],
+        "mi_ctx_stream": [vp, C.POINTER(vp)],
+        "mi_ctx_device_name": [vp, C.c_char_p, C.c_size_t],
+        "mi_ctx_pool_bytes": [vp, c_size_p],
+        "mi_ktime_enable": [vp, C.c_int, C.c_int],
+        "mi_ktime_reset": [vp],
+        "mi_ktime_read": [vp, C.c_int, c_size_p, c_double_p],
+        "mi_timer_start": [vp],
+        "mi_timer_stop": [vp, c_double_p],
+        "mi_vec_create": [vp, C.c_size_t, C.POINTER(vp)],
+        "mi_vec_destroy": [vp],
+        "mi_vec_len": [vp, c_size_p],
+        "mi_vec_data": [vp, C.POINTER(vp)],
+        "mi_vec_upload": [vp, c_double_p, C.c_size_t],
+        "mi_vec_download": [vp, c_double_p, C.c_size_t],
+        "mi_vec_copy": [vp, vp],
+        "mi_vec_fill": [vp, C.c_double],
+        "mi_vec_scale": [vp, C.c_double],
+        "mi_vec_axpy": [vp, C.c_double, vp],
+        "mi_vec_axpby": [vp, C.c_double, vp, C.c_double, vp],
+        "mi_vec_dot": [vp, vp, c_double_p],
+        "mi_vec_dot_batch": [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), c_double_p],
+        "mi_csr_create": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, C.POINTER(vp)],
+        "mi_csr_destroy": [vp],
+        "mi_csr_spmm": [vp, C.c_int, vp, vp],
+        "mi_op_create_callback": [vp, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
+        "mi_op_create_diag": [vp, vp, C.POINTER(vp)],
+        "mi_op_create_csr": [vp, vp, C.c_int, C.POINTER(vp)],
+        "mi_op_apply": [vp, vp, vp],
+        "mi_op_destroy": [vp],
+        "mi_precon_create_callback": [vp, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
+        "mi_precon_create_diag": [vp, vp, C.POINTER(vp)],
+        "mi_precon_create_block3": [vp, vp, C.POINTER(vp)],
+        "mi_precon_apply": [vp, vp, vp],
+        "mi_precon_destroy": [vp],
+        "mi_stpcg": [vp, vp, vp, vp, C.POINTER(StpcgParams), vp, C.POINTER(StpcgResult),
+                     C.POINTER(StpcgTrace)],
+        "mi_stiefel_gram": [vp, C.c_size_t, C.c_int, vp, vp, c_double_p],
+        "mi_stiefel_project": [vp, C.c_size_t, C.c_int, vp, vp, vp],
+        "mi_stiefel_retract": [vp, C.c_size_t, C.c_int, vp, vp, vp],
+        "mi_stiefel_rq_create": [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)],
+        "mi_stiefel_rq_destroy": [vp],
+        "mi_stiefel_rq_objective": [vp, vp, c_double_p],
+        "mi_stiefel_rq_model": [vp, vp, vp, C.POINTER(vp)],
+        "mi_stiefel_rq_precon": [vp, vp, vp, C.POINTER(vp)],
+        "mi_so3n_create": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, c_double_p,
+                           C.POINTER(vp)],
+        "mi_so3n_destroy": [vp],
+        "mi_so3n_objective": [vp, vp, c_double_p],
+        "mi_so3n_model": [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)],
+        "mi_so3n_retract": [vp, vp, vp, vp],
+        "mi_lobpcg_gram": [vp, C.c_size_t, C.c_int, C.c_int, vp, vp, c_double_p],
+        "mi_lobpcg_update": [vp, C.c_size_t, C.c_int, C.c_int, vp, c_double_p, C.c_int, vp],
+        "mi_lobpcg_residual": [vp, C.c_size_t, C.c_int, vp, vp, vp, c_double_p, vp, c_double_p,
+                               c_double_p],
+        "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
+        "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
+        "mi_comm_init": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
+        "mi_comm_finalize": [vp],
+        "mi_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mi_csr_create_sharded": [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
+                                  c_int64_p, c_double_p, c_size_p, C.POINTER(vp)],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    L.mi_stpcg_default_params.restype = None
+    L.mi_stpcg_default_params.argtypes = [C.POINTER(StpcgParams)]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != MI_OK:
+        raise MiError(status, load().mi_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().mi_device_count(C.byref(n)))
+    return n.value
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = vp()
+        check(self.L.mi_ctx_create(device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.mi_ctx_destroy(self.h)
+            self.h = vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        check(self.L.mi_ctx_sync(self.h))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        check(self.L.mi_ctx_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    # vectors ------------------------------------------------------------------------------
+    def vec(self, n):
+        return Vec(self, n)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        v = Vec(self, arr.size)
+        check(self.L.mi_vec_upload(v.h, _dp(arr), arr.size))
+        return v
+
+    def dot_batch(self, xs, ys):
+        k = len(xs)
+        X = (vp * k)(*[x.h for x in xs])
+        Y = (vp * k)(*[y.h for y in ys])
+        out = np.zeros(k)
+        check(self.L.mi_vec_dot_batch(self.h, k, X, Y, _dp(out)))
+        return out
+
+    # timing ---------------------------------------------------------------------------------
+    def timer_start(self):
+        check(self.L.mi_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        check(self.L.mi_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def ktime_enable(self, name, on=True):
+        check(self.L.mi_ktime_enable(self.h, KID[name], int(on)))
+
+    def ktime_reset(self):
+        check(self.L.mi_ktime_reset(self.h))
+
+    def ktime_read(self, name):
+        n = C.c_size_t(0)
+        ms = C.c_double(0)
+        check(self.L.mi_ktime_read(self.h, KID[name], C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # operators ------------------------------------------------------------------------------
+    def csr(self, n, rowptr, col, val):
+        return Csr(self, n, rowptr, col, val)
+
+    def op_diag(self, d):
+        h = vp()
+        check(self.L.mi_op_create_diag(self.h, d.h, C.byref(h)))
+        return Op(self, h, keep=[d])
+
+    def op_csr(self, A, p):
+        h = vp()
+        check(self.L.mi_op_create_csr(self.h, A.h, p, C.byref(h)))
+        return Op(self, h, keep=[A])
+
+    def op_callback(self, n, fn):
+        """fn(in_vec: Vec, out_vec: Vec) enqueues out = Op(in)."""
+        def cb(_u, pin, pout):
+            try:
+                fn(Vec(self, 0, handle=vp(pin)), Vec(self, 0, handle=vp(pout)))
+                return 0
+            except Exception:  # noqa
+                import traceback
+                traceback.print_exc()
+                return 6
+        cfn = APPLY_FN(cb)
+        h = vp()
+        check(self.L.mi_op_create_callback(self.h, n, cfn, None, C.byref(h)))
+        return Op(self, h, keep=[cfn])
+
+    def precon_diag(self, dinv):
+        h = vp()
+        check(self.L.mi_precon_create_diag(self.h, dinv.h, C.byref(h)))
+        return Precon(self, h, keep=[dinv])
+
+    def precon_block3(self, inv_blocks):
+        h = vp()
+        check(self.L.mi_precon_create_block3(self.h, inv_blocks.h, C.byref(h)))
+        return Precon(self, h, keep=[inv_blocks])
+
+    def precon_callback(self, n, fn):
+        def cb(_u, pin, pout):
+            try:
+                fn(Vec(self, 0, handle=vp(pin)), Vec(self, 0, handle=vp(pout)))
+                return 0
+            except Exception:  # noqa
+                import traceback
+                traceback.print_exc()
+                return 6
+        cfn = APPLY_FN(cb)
+        h = vp()
+        check(self.L.mi_precon_create_callback(self.h, n, cfn, None, C.byref(h)))
+        return Precon(self, h, keep=[cfn])
+
+    # fused STPCG ------------------------------------------------------------------------------
+    def stpcg(self, g, H, P=None, Delta=1.0, max_iterations=1000, kappa_fgr=.1, theta=.5,
+              epsilon=1e-8, run_ahead=0, trace_cap=0, s_out=None):
+        prm = StpcgParams(Delta, max_iterations, kappa_fgr, theta, epsilon, run_ahead)
+        res = StpcgResult()
+        s = s_out if s_out is not None else Vec(self, g.n)
+        tr = None
+        arrs = {}
+        if trace_cap:
+            arrs = {k: np.zeros(trace_cap) for k in ("alpha", "beta", "kappa", "rv")}
+            tr = StpcgTrace(trace_cap, 0, _dp(arrs["alpha"]), _dp(arrs["beta"]), _dp(arrs["kappa"]),
+                            _dp(arrs["rv"]))
+        check(self.L.mi_stpcg(self.h, g.h, H.h, P.h if P is not None else None, C.byref(prm), s.h,
+                              C.byref(res), C.byref(tr) if tr else None))
+        out = dict(s=s, M_norm=res.update_step_M_norm, iterations=res.num_iterations,
+                   exit_reason=res.exit_reason, hvp_calls=res.hvp_calls, rv_final=res.rv_final)
+        if tr:
+            out["trace"] = {k: v[:tr.len].copy() for k, v in arrs.items()}
+        return out
+
+    # Stiefel ----------------------------------------------------------------------------------
+    def stiefel_gram(self, n, p, X, Z):
+        G = np.zeros(p * p)
+        check(self.L.mi_stiefel_gram(self.h, n, p, X.h, Z.h, _dp(G)))
+        return G.reshape(p, p)
+
+    def stiefel_project(self, n, p, X, Z):
+        out = Vec(self, n * p)
+        check(self.L.mi_stiefel_project(self.h, n, p, X.h, Z.h, out.h))
+        return out
+
+    def stiefel_retract(self, n, p, X, V):
+        Y = Vec(self, n * p)
+        check(self.L.mi_stiefel_retract(self.h, n, p, X.h, V.h, Y.h))
+        return Y
+
+    def stiefel_rq(self, A, n, p):
+        return StiefelRQ(self, A, n, p)
+
+    # comm -------------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * 128)()
+        check(self.L.mi_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, world_size, rank, uid):
+        buf = (C.c_ubyte * 128)(*uid)
+        check(self.L.mi_comm_init(self.h, world_size, rank, buf))
+
+    def comm_finalize(self):
+        check(self.L.mi_comm_finalize(self.h))
+
+
+class Vec:
+    def __init__(self, ctx, n, handle=None):
+        self.ctx = ctx
+        self.L = ctx.L
+        self.owned = handle is None
+        if handle is None:
+            self.h = vp()
+            check(self.L.mi_vec_create(ctx.h, n, C.byref(self.h)))
+            self.n = n
+        else:
+            self.h = handle
+            m = C.c_size_t(0)
+            check(self.L.mi_vec_len(self.h, C.byref(m)))
+            self.n = m.value
+
+    def __del__(self):
+        try:
+            if self.owned and self.h and self.ctx.h:
+                self.L.mi_vec_destroy(self.h)
+        except Exception:  # noqa
+            pass
+
+    def numpy(self):
+        out = np.zeros(self.n)
+        check(self.L.mi_vec_download(self.h, _dp(out), self.n))
+        return out
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        check(self.L.mi_vec_upload(self.h, _dp(arr), arr.size))
+        return self
+
+    def copy(self):
+        v = Vec(self.ctx, self.n)
+        check(self.L.mi_vec_copy(v.h, self.h))
+        return v
+
+    def fill(self, a):
+        check(self.L.mi_vec_fill(self.h, a))
+        return self
+
+    def scale(self, a):
+        check(self.L.mi_vec_scale(self.h, a))
+        return self
+
+    def axpy(self, a, x):
+        check(self.L.mi_vec_axpy(self.h, a, x.h))
+        return self
+
+    def axpby(self, a, x, b, y):
+        check(self.L.mi_vec_axpby(self.h, a, x.h, b, y.h))
+        return self
+
+    def dot(self, other):
+        out = C.c_double(0)
+        check(self.L.mi_vec_dot(self.h, other.h, C.byref(out)))
+        return out.value
+
+
+class Csr:
+    def __init__(self, ctx, n, rowptr, col, val):
+        self.ctx, self.L = ctx, ctx.L
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        self.n, self.nnz = n, int(rowptr[-1])
+        self.h = vp()
+        check(self.L.mi_csr_create(ctx.h, n, self.nnz, rowptr.ctypes.data_as(c_int32_p),
+                                   col.ctypes.data_as(c_int32_p), _dp(val), C.byref(self.h)))
+
+    def spmm(self, p, V, W=None):
+        W = W if W is not None else Vec(self.ctx, self.n * p)
+        check(self.L.mi_csr_spmm(self.h, p, V.h, W.h))
+        return W
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.mi_csr_destroy(self.h)
+        except Exception:  # noqa
+            pass
+
+
+class Op:
+    def __init__(self, ctx, h, keep=(), borrowed=False):
+        self.ctx, self.L, self.h, self.keep, self.borrowed = ctx, ctx.L, h, list(keep), borrowed
+
+    def apply(self, x, out=None):
+        out = out if out is not None else Vec(self.ctx, x.n)
+        check(self.L.mi_op_apply(self.h, x.h, out.h))
+        return out
+
+    def __del__(self):
+        try:
+            if not self.borrowed and self.h and self.ctx.h:
+                self.L.mi_op_destroy(self.h)
+        except Exception:  # noqa
+            pass
+
+
+class Precon:
+    def __init__(self, ctx, h, keep=()):
+        self.ctx, self.L, self.h, self.keep = ctx, ctx.L, h, list(keep)
+
+    def apply(self, r, out=None):
+        out = out if out is not None else Vec(self.ctx, r.n)
+        check(self.L.mi_precon_apply(self.h, r.h, out.h))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.mi_precon_destroy(self.h)
+        except Exception:  # noqa
+            pass
+
+
+class StiefelRQ:
+    def __init__(self, ctx, A, n, p):
+        self.ctx, self.L, self.A, self.n, self.p = ctx, ctx.L, A, n, p
+        self.h = vp()
+        check(self.L.mi_stiefel_rq_create(ctx.h, A.h, n, p, C.byref(self.h)))
+
+    def objective(self, X):
+        f = C.c_double(0)
+        check(self.L.mi_stiefel_rq_objective(self.h, X.h, C.byref(f)))
+        return f.value
+
+    def model(self, X):
+        """returns (grad Vec, Hessian Op bound to X)"""
+        g = Vec(self.ctx, self.n * self.p)
+        hop = vp()
+        check(self.L.mi_stiefel_rq_model(self.h, X.h, g.h, C.byref(hop)))
+        return g, Op(self.ctx, hop, keep=[self, X], borrowed=True)
+
+    def precon(self, X, dinv_rows):
+        h = vp()
+        check(self.L.mi_stiefel_rq_precon(self.h, X.h, dinv_rows.h, C.byref(h)))
+        return Precon(self.ctx, h, keep=[self, X, dinv_rows])
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.mi_stiefel_rq_destroy(self.h)
+        except Exception:  # noqa
+            pass

@@ -1,0 +1,231 @@
+// blas1.hip -- device vectors and the Vector-concept operators as
+// HBM-streaming gfx950 kernels: 16 B/lane loads, grid-stride over <= 2048 workgroups, deterministic
+// two-stage reductions (per-workgroup partial -> one-workgroup fixed-order sum; no fp64 atomics).
+#include "mi_internal.h"
+
+using namespace mi;
+
+namespace {
+
+// z = a*x + b*y  (MODE 0); y += a*x handled as z=y alias; scale: z = a*x (b unused, MODE 1); fill MODE 2
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_axpby(size_t n, double a, const double *__restrict__ x,
+                                                  double b, const double *__restrict__ y,
+                                                  double *__restrict__ z) {
+  const size_t n2 = n >> 1;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    double2 r;
+    if (MODE == 2) {
+      r.x = a; r.y = a;
+    } else {
+      const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+      if (MODE == 1) {
+        r.x = a * xv.x; r.y = a * xv.y;
+      } else {
+        const double2 yv = reinterpret_cast<const double2 *>(y)[i];
+        r.x = a * xv.x + b * yv.x;
+        r.y = a * xv.y + b * yv.y;
+      }
+    }
+    reinterpret_cast<double2 *>(z)[i] = r;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const size_t i = n - 1;
+    z[i] = (MODE == 2) ? a : (MODE == 1) ? a * x[i] : a * x[i] + b * y[i];
+  }
+}
+
+struct DotArgs {
+  const double *x[4];
+  const double *y[4];
+};
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_dot(size_t n, DotArgs args, double *__restrict__ partials) {
+  __shared__ double lds[8];
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0;
+  const size_t n2 = n >> 1;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const double2 xv = reinterpret_cast<const double2 *>(args.x[k])[i];
+      const double2 yv = reinterpret_cast<const double2 *>(args.y[k])[i];
+      acc[k] += xv.x * yv.x;
+      acc[k] += xv.y * yv.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] += args.x[k][n - 1] * args.y[k][n - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double r = block_reduce_sum(acc[k], lds);
+    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialStride + k] = r;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_to_slots(const double *__restrict__ partials, int count,
+                                                            int k, double *__restrict__ slots) {
+  __shared__ double lds[8];
+  for (int c = 0; c < k; ++c) {
+    const double t = reduce_partials(partials, count, c, lds);
+    if (threadIdx.x == 0) slots[c] = t;
+  }
+}
+
+int check_same(const mi_vec *a, const mi_vec *b) {
+  MI_REQUIRE(a && b, "null vector");
+  MI_REQUIRE(a->ctx == b->ctx, "vectors belong to different contexts");
+  MI_REQUIRE(a->n == b->n, "vector length mismatch (%zu vs %zu)", a->n, b->n);
+  return MI_OK;
+}
+
+}  // namespace
+
+namespace mi {
+// enqueue k dot products -> ctx->scalars[slot0 .. slot0+k) (device), all-reduced across ranks
+int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double *const *y, size_t n,
+                       int slot0) {
+  DotArgs a;
+  for (int i = 0; i < 4; ++i) {
+    a.x[i] = x[i < k ? i : 0];
+    a.y[i] = y[i < k ? i : 0];
+  }
+  const int grid = grid_for(n, 8);
+  {
+    KScope ks(ctx, MI_K_BLAS1);
+    switch (k) {
+      case 1: hipLaunchKernelGGL(k_dot<1>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
+      case 2: hipLaunchKernelGGL(k_dot<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
+      case 3: hipLaunchKernelGGL(k_dot<3>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
+      default: hipLaunchKernelGGL(k_dot<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
+    }
+  }
+  hipLaunchKernelGGL(k_reduce_to_slots, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials_user, grid, k,
+                     ctx->scalars + slot0);
+  MI_HIP(hipGetLastError());
+  return comm_allreduce(ctx, ctx->scalars + slot0, k);
+}
+
+int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out) {
+  MI_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + slot0, sizeof(double) * k,
+                        hipMemcpyDeviceToHost, ctx->stream));
+  MI_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < k; ++i) out[i] = ctx->host_scalars[i];
+  return MI_OK;
+}
+}  // namespace mi
+
+extern "C" {
+
+int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out) {
+  MI_REQUIRE(ctx && out, "null argument");
+  void *p = nullptr;
+  MI_TRY(pool_alloc(ctx, n * sizeof(double), &p));
+  mi_vec *v = new mi_vec{ctx, n, (double *)p, true};
+  *out = v;
+  return MI_OK;
+}
+
+int mi_vec_destroy(mi_vec *v) {
+  if (!v) return MI_OK;
+  if (v->owned) pool_free(v->ctx, v->d);
+  delete v;
+  return MI_OK;
+}
+
+int mi_vec_len(const mi_vec *v, size_t *n) {
+  MI_REQUIRE(v && n, "null argument");
+  *n = v->n;
+  return MI_OK;
+}
+
+int mi_vec_data(const mi_vec *v, void **p) {
+  MI_REQUIRE(v && p, "null argument");
+  *p = v->d;
+  return MI_OK;
+}
+
+int mi_vec_upload(mi_vec *v, const double *host, size_t n) {
+  MI_REQUIRE(v && (host || n == 0), "null argument");
+  MI_REQUIRE(n == v->n, "upload length %zu != vector length %zu", n, v->n);
+  MI_HIP(hipMemcpyAsync(v->d, host, n * sizeof(double), hipMemcpyHostToDevice, v->ctx->stream));
+  MI_HIP(hipStreamSynchronize(v->ctx->stream));
+  return MI_OK;
+}
+
+int mi_vec_download(const mi_vec *v, double *host, size_t n) {
+  MI_REQUIRE(v && (host || n == 0), "null argument");
+  MI_REQUIRE(n == v->n, "download length %zu != vector length %zu", n, v->n);
+  MI_HIP(hipMemcpyAsync(host, v->d, n * sizeof(double), hipMemcpyDeviceToHost, v->ctx->stream));
+  MI_HIP(hipStreamSynchronize(v->ctx->stream));
+  return MI_OK;
+}
+
+int mi_vec_copy(mi_vec *dst, const mi_vec *src) {
+  MI_TRY(check_same(dst, src));
+  if (dst->d == src->d) return MI_OK;
+  MI_HIP(hipMemcpyAsync(dst->d, src->d, src->n * sizeof(double), hipMemcpyDeviceToDevice,
+                        dst->ctx->stream));
+  return MI_OK;
+}
+
+int mi_vec_fill(mi_vec *v, double a) {
+  MI_REQUIRE(v, "null vector");
+  if (v->n == 0) return MI_OK;
+  KScope ks(v->ctx, MI_K_BLAS1);
+  hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->n, 8)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+                     (const double *)nullptr, 0.0, (const double *)nullptr, v->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_vec_scale(mi_vec *v, double a) {
+  MI_REQUIRE(v, "null vector");
+  if (v->n == 0) return MI_OK;
+  KScope ks(v->ctx, MI_K_BLAS1);
+  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->n, 8)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+                     (const double *)v->d, 0.0, (const double *)nullptr, v->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_vec_axpby(mi_vec *z, double a, const mi_vec *x, double b, const mi_vec *y) {
+  MI_TRY(check_same(z, x));
+  MI_TRY(check_same(z, y));
+  if (z->n == 0) return MI_OK;
+  KScope ks(z->ctx, MI_K_BLAS1);
+  hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->n, 8)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
+                     (const double *)x->d, b, (const double *)y->d, z->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_vec_axpy(mi_vec *y, double a, const mi_vec *x) { return mi_vec_axpby(y, a, x, 1.0, y); }
+
+int mi_vec_dot_batch(mi_ctx *ctx, int k, const mi_vec *const *x, const mi_vec *const *y, double *out) {
+  MI_REQUIRE(ctx && x && y && out, "null argument");
+  MI_REQUIRE(k >= 1 && k <= 4, "k must be in [1,4], got %d", k);
+  const double *xs[4], *ys[4];
+  for (int i = 0; i < k; ++i) {
+    MI_TRY(check_same(x[i], y[i]));
+    MI_REQUIRE(x[i]->n == x[0]->n && x[i]->ctx == ctx, "batched vectors must share length and context");
+    xs[i] = x[i]->d;
+    ys[i] = y[i]->d;
+  }
+  MI_TRY(dot_batch_to_slots(ctx, k, xs, ys, x[0]->n, 0));
+  return read_slots_sync(ctx, 0, k, out);
+}
+
+int mi_vec_dot(const mi_vec *x, const mi_vec *y, double *out) {
+  MI_TRY(check_same(x, y));
+  const mi_vec *xs[1] = {x}, *ys[1] = {y};
+  return mi_vec_dot_batch(x->ctx, 1, xs, ys, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// context.hip -- context, stream, pooled allocator, event timing, error reporting.
+#include "mi_internal.h"
+
+namespace mi {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  (void)hipGetLastError();
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return MI_ERR_NO_DEVICE;
+  if (e == hipErrorOutOfMemory) return MI_ERR_OOM;
+  return MI_ERR_HIP;
+}
+
+int ensure_device() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (hipGetDeviceCount: %s, count=%d); libmi355opt has no CPU "
+              "fallback",
+              hipGetErrorString(e), count);
+    return MI_ERR_NO_DEVICE;
+  }
+  return MI_OK;
+}
+
+int pool_alloc(mi_ctx *ctx, size_t bytes, void **out) {
+  if (bytes == 0) bytes = 8;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = ctx->pool_free.find(bytes);
+  if (it != ctx->pool_free.end()) {
+    *out = it->second;
+    ctx->pool_free.erase(it);
+    return MI_OK;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // release cached blocks and retry once
+    for (auto &kv : ctx->pool_free) {
+      (void)hipFree(kv.second);
+      ctx->pool_all.erase(kv.second);
+      ctx->pool_bytes -= kv.first;
+    }
+    ctx->pool_free.clear();
+    (void)hipGetLastError();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  }
+  ctx->pool_all[p] = bytes;
+  ctx->pool_bytes += bytes;
+  *out = p;
+  return MI_OK;
+}
+
+void pool_free(mi_ctx *ctx, void *p) {
+  if (!p) return;
+  auto it = ctx->pool_all.find(p);
+  if (it == ctx->pool_all.end()) return;
+  ctx->pool_free.insert({it->second, p});
+}
+
+hipEvent_t event_get(mi_ctx *ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+KScope::KScope(mi_ctx *c, int kid) : ctx(c), id(kid) {
+  if (ctx->ktime[id].enabled) {
+    e0 = event_get(ctx);
+    e1 = event_get(ctx);
+    if (e0) (void)hipEventRecord(e0, ctx->stream);
+  }
+}
+KScope::~KScope() {
+  if (e0 && e1) {
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->ktime[id].pending.push_back({e0, e1});
+  }
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+const char *mi_version(void) { return "mi355opt 0.1.0 (gfx950)"; }
+const char *mi_last_error(void) { return g_err; }
+const char *mi_status_string(int s) {
+  switch (s) {
+    case MI_OK: return "ok";
+    case MI_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MI_ERR_HIP: return "HIP runtime error";
+    case MI_ERR_OOM: return "out of device memory";
+    case MI_ERR_NO_DEVICE: return "no MI355X/HIP device (no CPU fallback)";
+    case MI_ERR_COMM: return "RCCL communicator error";
+    case MI_ERR_INTERNAL: return "internal error";
+  }
+  return "unknown status";
+}
+
+static const char *kKernelNames[MI_K_COUNT] = {
+    "none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
+    "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
+    "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
+    "lobpcg_residual"};
+const char *mi_kernel_name(int id) {
+  if (id < 0 || id >= MI_K_COUNT) return "?";
+  return kKernelNames[id];
+}
+
+int mi_device_count(int *count) {
+  MI_REQUIRE(count, "count is null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    c = 0;
+  }
+  *count = c;
+  return MI_OK;
+}
+
+int mi_ctx_create(int device, mi_ctx **out) {
+  MI_REQUIRE(out, "out is null");
+  MI_TRY(ensure_device());
+  MI_HIP(hipSetDevice(device));
+  mi_ctx *ctx = new mi_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  MI_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(ctx->device_name, sizeof(ctx->device_name), "%s (%s)", prop.name, prop.gcnArchName);
+  ctx->num_cu = prop.multiProcessorCount;
+  MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MI_HIP(hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxGrid * kPartialStride));
+  MI_HIP(hipMalloc((void **)&ctx->partials2, sizeof(double) * kMaxGrid * kPartialStride));
+  MI_HIP(hipMalloc((void **)&ctx->partials_user, sizeof(double) * kMaxGrid * kPartialStride));
+  MI_HIP(hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots));
+  MI_HIP(hipMemset(ctx->scalars, 0, sizeof(double) * kScalarSlots));
+  MI_HIP(hipMalloc((void **)&ctx->cg, sizeof(CgState)));
+  MI_HIP(hipMemset(ctx->cg, 0, sizeof(CgState)));
+  MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState), hipHostMallocDefault));
+  MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
+                       hipHostMallocMapped | hipHostMallocCoherent));
+  memset((void *)ctx->status, 0, sizeof(HostStatus));
+  MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
+  MI_HIP(hipEventCreate(&ctx->t_start));
+  MI_HIP(hipEventCreate(&ctx->t_stop));
+  *out = ctx;
+  return MI_OK;
+}
+
+int mi_comm_finalize(mi_ctx *ctx);
+
+int mi_ctx_destroy(mi_ctx *ctx) {
+  if (!ctx) return MI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mi_comm_finalize(ctx);
+  for (auto &kv : ctx->pool_all) (void)hipFree(kv.first);
+  for (int i = 0; i < MI_K_COUNT; ++i)
+    for (auto &pr : ctx->ktime[i].pending) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->partials2);
+  (void)hipFree(ctx->partials_user);
+  (void)hipFree(ctx->scalars);
+  (void)hipFree(ctx->cg);
+  (void)hipFree(ctx->trace_dev);
+  (void)hipHostFree(ctx->host_scalars);
+  (void)hipHostFree(ctx->cg_host);
+  (void)hipHostFree((void *)ctx->status);
+  (void)hipEventDestroy(ctx->t_start);
+  (void)hipEventDestroy(ctx->t_stop);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MI_OK;
+}
+
+int mi_ctx_sync(mi_ctx *ctx) {
+  MI_REQUIRE(ctx, "ctx is null");
+  MI_HIP(hipStreamSynchronize(ctx->stream));
+  return MI_OK;
+}
+
+int mi_ctx_stream(mi_ctx *ctx, void **stream) {
+  MI_REQUIRE(ctx && stream, "null argument");
+  *stream = (void *)ctx->stream;
+  return MI_OK;
+}
+
+int mi_ctx_device_name(mi_ctx *ctx, char *buf, size_t buflen) {
+  MI_REQUIRE(ctx && buf && buflen, "null argument");
+  snprintf(buf, buflen, "%s", ctx->device_name);
+  return MI_OK;
+}
+
+int mi_ctx_pool_bytes(mi_ctx *ctx, size_t *bytes) {
+  MI_REQUIRE(ctx && bytes, "null argument");
+  *bytes = ctx->pool_bytes;
+  return MI_OK;
+}
+
+int mi_ktime_enable(mi_ctx *ctx, int id, int on) {
+  MI_REQUIRE(ctx && id > 0 && id < MI_K_COUNT, "bad kernel id %d", id);
+  ctx->ktime[id].enabled = on != 0;
+  return MI_OK;
+}
+
+static int ktime_resolve(mi_ctx *ctx, int id) {
+  KTimer &t = ctx->ktime[id];
+  if (t.pending.empty()) return MI_OK;
+  MI_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto &pr : t.pending) {
+    float ms = 0;
+    MI_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    t.total_ms += ms;
+    t.launches++;
+    ctx->event_pool.push_back(pr.first);
+    ctx->event_pool.push_back(pr.second);
+  }
+  t.pending.clear();
+  return MI_OK;
+}
+
+int mi_ktime_reset(mi_ctx *ctx) {
+  MI_REQUIRE(ctx, "ctx is null");
+  for (int i = 1; i < MI_K_COUNT; ++i) {
+    MI_TRY(ktime_resolve(ctx, i));
+    ctx->ktime[i].launches = 0;
+    ctx->ktime[i].total_ms = 0;
+  }
+  return MI_OK;
+}
+
+int mi_ktime_read(mi_ctx *ctx, int id, size_t *launches, double *total_ms) {
+  MI_REQUIRE(ctx && id > 0 && id < MI_K_COUNT, "bad kernel id %d", id);
+  MI_TRY(ktime_resolve(ctx, id));
+  if (launches) *launches = ctx->ktime[id].launches;
+  if (total_ms) *total_ms = ctx->ktime[id].total_ms;
+  return MI_OK;
+}
+
+int mi_timer_start(mi_ctx *ctx) {
+  MI_REQUIRE(ctx, "ctx is null");
+  MI_HIP(hipEventRecord(ctx->t_start, ctx->stream));
+  return MI_OK;
+}
+
+int mi_timer_stop(mi_ctx *ctx, double *ms) {
+  MI_REQUIRE(ctx && ms, "null argument");
+  MI_HIP(hipEventRecord(ctx->t_stop, ctx->stream));
+  MI_HIP(hipEventSynchronize(ctx->t_stop));
+  float f = 0;
+  MI_HIP(hipEventElapsedTime(&f, ctx->t_start, ctx->t_stop));
+  *ms = f;
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+// mi_internal.h -- shared internals of libmi355opt.so (not installed; the public surface is
+// include/mi355opt.h).  gfx950 only: wave = 64 lanes, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "mi355opt.h"
+
+namespace mi {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;         // threads per workgroup for streaming kernels (4 waves)
+constexpr int kMaxGrid = 2048;      // 256 CUs x 8 workgroups: cap for grid-stride streaming kernels
+constexpr int kNumXCD = 8;
+constexpr int kPartialStride = 16;  // doubles reserved per workgroup in the partial-sum buffer
+constexpr int kScalarSlots = 64;    // device scalar file (doubles)
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define MI_HIP(expr)                                                   \
+  do {                                                                 \
+    hipError_t _e = (expr);                                            \
+    if (_e != hipSuccess) return ::mi::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define MI_TRY(expr)          \
+  do {                        \
+    int _s = (expr);          \
+    if (_s != MI_OK) return _s; \
+  } while (0)
+
+#define MI_REQUIRE(cond, ...)              \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::mi::set_error(__VA_ARGS__);        \
+      return MI_ERR_INVALID_ARGUMENT;      \
+    }                                      \
+  } while (0)
+
+// Host-visible progress word written by the device scalar kernels (fine-grained pinned memory).
+struct HostStatus {
+  volatile uint64_t iters_done;  // completed STPCG iterations of the current solve
+  volatile uint32_t done;        // nonzero once the solve has reached a terminal state
+  volatile uint32_t epoch;       // solve counter (guards against stale reads across solves)
+};
+
+// Device-resident state of one STPCG solve (IterativeSolvers.h:259-283).
+struct CgState {
+  double sk_M_pk, sk_M_2, pk_M_2;  // :259,263,266
+  double Delta_2, target_rk_norm;  // :271,278
+  double rv;                       // current <r,v>
+  double alpha, beta, kappa, sigma;
+  double M_norm;                   // update_step_M_norm
+  double kappa_fgr, theta, epsilon;
+  unsigned long long k;            // num_iterations
+  unsigned long long max_iterations;
+  int mode;                        // CgMode
+  int exit_reason;
+  unsigned int epoch;
+  int pad;
+};
+enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_APPLY_SIGMA_LATE = 3, CG_DONE = 4 };
+
+struct KTimer {
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  size_t launches = 0;
+  double total_ms = 0;
+};
+
+}  // namespace mi
+
+struct mi_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  char device_name[128] = {0};
+  int num_cu = 256;
+  // memory pool: free lists keyed by byte size
+  std::multimap<size_t, void *> pool_free;
+  std::map<void *, size_t> pool_all;
+  size_t pool_bytes = 0;
+  // reductions
+  double *partials = nullptr;   // kMaxGrid x kPartialStride doubles
+  double *partials2 = nullptr;  // second buffer (operator-internal reductions, e.g. Stiefel Gram)
+  double *partials_user = nullptr;  // third buffer (mi_vec_dot*: safe to call from callbacks)
+  double *scalars = nullptr;    // kScalarSlots doubles
+  double *host_scalars = nullptr;  // pinned staging for scalar read-backs
+  mi::CgState *cg = nullptr;       // device
+  mi::CgState *cg_host = nullptr;  // pinned copy for read-back
+  mi::HostStatus *status = nullptr;      // pinned, device-visible
+  mi::HostStatus *status_dev = nullptr;  // device pointer of the same memory
+  double *trace_dev = nullptr;           // 4 x trace_cap doubles
+  size_t trace_cap = 0;
+  unsigned int epoch = 0;
+  // timing
+  mi::KTimer ktime[MI_K_COUNT];
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  // comm (RCCL); opaque here, defined in comm.hip
+  void *comm = nullptr;
+  int world_size = 1, rank = 0;
+};
+
+struct mi_vec {
+  mi_ctx *ctx;
+  size_t n;
+  double *d;
+  bool owned;  // storage belongs to the pool
+};
+
+namespace mi {
+
+int pool_alloc(mi_ctx *ctx, size_t bytes, void **out);
+void pool_free(mi_ctx *ctx, void *p);
+int ensure_device();
+
+inline int grid_for(size_t n, int per_thread) {
+  size_t blocks = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
+  if (blocks < 1) blocks = 1;
+  if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
+  return (int)blocks;
+}
+
+// Kernel-timing scope: brackets a launch with an event pair when enabled for `id`.
+struct KScope {
+  mi_ctx *ctx;
+  int id;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  KScope(mi_ctx *c, int kid);
+  ~KScope();
+};
+hipEvent_t event_get(mi_ctx *ctx);
+
+// all-reduce (sum) of `count` doubles at device pointer `buf`, in-stream; no-op when world_size==1
+int comm_allreduce(mi_ctx *ctx, double *buf, int count);
+
+// k <= 4 dot products -> ctx->scalars[slot0..slot0+k) on the device (all-reduced across ranks)
+int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double *const *y, size_t n,
+                       int slot0);
+int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out);
+// per-workgroup partials of <x,y>,<y,y>,<x,x> into ctx->partials components 0,1,2
+int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts);
+
+// scalar-file slot map
+enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GRAM_M = 32, SLOT_MISC = 48 };
+
+// ---- device helpers ---------------------------------------------------------------------
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum across a 256-thread workgroup; result valid in thread 0.  Fixed shape => deterministic.
+__device__ __forceinline__ double block_reduce_sum(double v, double *lds /* >= 4 doubles */) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) r = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  __syncthreads();
+  return r;
+}
+
+// Deterministic sum of `count` per-workgroup partials (stride kPartialStride, component c) by one
+// 256-thread workgroup; every thread returns the total.
+__device__ __forceinline__ double reduce_partials(const double *partials, int count, int c,
+                                                  double *lds /* >= 5 doubles */) {
+  double v = 0;
+  for (int i = threadIdx.x; i < count; i += kBlock) v += partials[(size_t)i * kPartialStride + c];
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) lds[4] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  __syncthreads();
+  return lds[4];
+}
+
+// XCD-aware workgroup remap (guide T1): consecutive logical tiles land on the same XCD so that a
+// contiguous row range shares one L2.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb) {
+  const unsigned q = nb / kNumXCD, r = nb % kNumXCD, xcd = b % kNumXCD, idx = b / kNumXCD;
+  const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace mi
+
+// Sparse matrix in sliced-ELL-64 (one slice = one wavefront of rows): element (slice s, k, lane)
+// lives at (slice_ptr[s] + k) * 64 + lane, so that a wave's loads of values and column indices are
+// perfectly coalesced.  Padding entries have val = 0 and col = own row.
+struct mi_csr {
+  mi_ctx *ctx = nullptr;
+  size_t n = 0;        // local rows
+  size_t ncols = 0;    // local columns incl. halo (== n when not sharded)
+  size_t nnz = 0;      // true non-zeros (algorithmic byte accounting uses this)
+  size_t padded = 0;   // stored entries
+  size_t nslices = 0;
+  long long *slice_ptr = nullptr;  // device, nslices + 1
+  int *col = nullptr;              // device, padded
+  double *val = nullptr;           // device, padded
+  // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
+  // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
+  // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.
+  size_t halo_lo = 0, halo_hi = 0;  // rows received from rank-1 / rank+1
+  size_t send_lo = 0, send_hi = 0;  // rows sent to rank-1 (our first rows) / rank+1 (our last rows)
+  double *halo = nullptr;           // device, (halo_lo + halo_hi) * 4 doubles (p <= 4)
+};
+
+namespace mi {
+// In-stream halo exchange of the n x p field V into A->halo (no-op when not sharded).
+int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V);
+int comm_exchange_halo_counts(mi_ctx *ctx, size_t need_lo, size_t need_hi, size_t *send_lo,
+                              size_t *send_hi);
+// W = A V without the halo exchange (callers that fuse do it themselves)
+int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W);
+}  // namespace mi
+
+// operator / preconditioner objects --------------------------------------------------------
+struct mi_op {
+  mi_ctx *ctx = nullptr;
+  size_t n = 0;
+  // out = Op(in)
+  int (*apply)(mi_op *self, const mi_vec *in, mi_vec *out) = nullptr;
+  // out = Op(in) and per-workgroup partials of <in,out>, <out,out>, <in,in> in ctx->partials
+  // components 0,1,2; *nparts = number of workgroups that wrote partials.  nullptr => generic dot3.
+  int (*apply_dots)(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) = nullptr;
+  void (*destroy)(mi_op *self) = nullptr;
+  void *impl = nullptr;
+  bool borrowed = false;  // owned by a problem object; mi_op_destroy is a no-op
+};
+
+struct mi_precon {
+  mi_ctx *ctx = nullptr;
+  size_t n = 0;
+  int kind = 0;  // 0 callback/generic, 1 diag (fusable), 2 block3 (fusable)
+  const double *data = nullptr;  // dinv (n) or inverse blocks (9 * n/3)
+  int (*apply)(mi_precon *self, const mi_vec *r, mi_vec *v) = nullptr;
+  void (*destroy)(mi_precon *self) = nullptr;
+  void *impl = nullptr;
+  bool borrowed = false;
+};

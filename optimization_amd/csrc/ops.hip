@@ -1,0 +1,230 @@
+// ops.hip -- generic linear operators and preconditioners handed to mi_stpcg:
+//   mi_op     <-> SymmetricLinearOperator<Vector> (LinearAlgebra/Concepts.h:20-21)
+//   mi_precon <-> STPCGPreconditioner<Vector, nullptr_t> (IterativeSolvers.h:83-85)
+#include "mi_internal.h"
+
+using namespace mi;
+
+namespace {
+
+struct CallbackImpl {
+  mi_apply_fn fn;
+  void *user;
+};
+
+int op_callback_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  CallbackImpl *c = (CallbackImpl *)self->impl;
+  int s = c->fn(c->user, in, out);
+  if (s != MI_OK) set_error("operator callback returned status %d", s);
+  return s;
+}
+void op_callback_destroy(mi_op *self) { delete (CallbackImpl *)self->impl; }
+
+// Hp = d .* p fused with the three curvature dots (diagonal test operator of
+// tests/IterativeSolvers_unit_test.cpp:99,107,112)
+__global__ __launch_bounds__(kBlock) void k_diag_apply_dots(size_t n, const double *__restrict__ d,
+                                                            const double *__restrict__ p,
+                                                            double *__restrict__ Hp,
+                                                            double *__restrict__ partials) {
+  __shared__ double lds[8];
+  double a0 = 0, a1 = 0, a2 = 0;
+  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    const double2 dv = reinterpret_cast<const double2 *>(d)[i];
+    const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+    const double2 hv = make_double2(dv.x * pv.x, dv.y * pv.y);
+    reinterpret_cast<double2 *>(Hp)[i] = hv;
+    a0 += pv.x * hv.x; a0 += pv.y * hv.y;
+    a1 += hv.x * hv.x; a1 += hv.y * hv.y;
+    a2 += pv.x * pv.x; a2 += pv.y * pv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const double pv = p[n - 1], hv = d[n - 1] * pv;
+    Hp[n - 1] = hv;
+    a0 += pv * hv; a1 += hv * hv; a2 += pv * pv;
+  }
+  if (!partials) return;
+  const double t0 = block_reduce_sum(a0, lds);
+  const double t1 = block_reduce_sum(a1, lds);
+  const double t2 = block_reduce_sum(a2, lds);
+  if (threadIdx.x == 0) {
+    double *o = partials + (size_t)blockIdx.x * kPartialStride;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+
+struct DiagImpl {
+  const double *d;
+};
+int op_diag_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
+  mi_ctx *ctx = self->ctx;
+  const int grid = grid_for(self->n, 8);
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid), dim3(kBlock), 0, ctx->stream, self->n,
+                     ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d, ctx->partials);
+  *nparts = grid;
+  return MI_OK;
+}
+int op_diag_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  mi_ctx *ctx = self->ctx;
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 8)), dim3(kBlock), 0, ctx->stream,
+                     self->n, ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d,
+                     (double *)nullptr);
+  return MI_OK;
+}
+void op_diag_destroy(mi_op *self) { delete (DiagImpl *)self->impl; }
+
+struct CsrOpImpl {
+  const mi_csr *A;
+  int p;
+};
+int op_csr_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  CsrOpImpl *c = (CsrOpImpl *)self->impl;
+  return mi_csr_spmm(c->A, c->p, in, out);
+}
+void op_csr_destroy(mi_op *self) { delete (CsrOpImpl *)self->impl; }
+
+int precon_callback_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
+  CallbackImpl *c = (CallbackImpl *)self->impl;
+  int s = c->fn(c->user, r, v);
+  if (s != MI_OK) set_error("preconditioner callback returned status %d", s);
+  return s;
+}
+void precon_callback_destroy(mi_precon *self) { delete (CallbackImpl *)self->impl; }
+
+__global__ __launch_bounds__(kBlock) void k_block3_apply(size_t nb, const double *__restrict__ M,
+                                                         const double *__restrict__ r,
+                                                         double *__restrict__ v) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < nb; b += stride) {
+    const double r0 = r[3 * b], r1 = r[3 * b + 1], r2 = r[3 * b + 2];
+    const double *m = M + 9 * b;
+    v[3 * b] = m[0] * r0 + m[1] * r1 + m[2] * r2;
+    v[3 * b + 1] = m[3] * r0 + m[4] * r1 + m[5] * r2;
+    v[3 * b + 2] = m[6] * r0 + m[7] * r1 + m[8] * r2;
+  }
+}
+
+int precon_diag_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 8)), dim3(kBlock), 0, self->ctx->stream,
+                     self->n, self->data, (const double *)r->d, v->d, (double *)nullptr);
+  return MI_OK;
+}
+int precon_block3_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
+  const size_t nb = self->n / 3;
+  hipLaunchKernelGGL(k_block3_apply, dim3(grid_for(nb, 2)), dim3(kBlock), 0, self->ctx->stream, nb,
+                     self->data, (const double *)r->d, v->d);
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_op **out) {
+  MI_REQUIRE(ctx && fn && out, "null argument");
+  mi_op *op = new mi_op();
+  op->ctx = ctx;
+  op->n = n;
+  op->apply = op_callback_apply;
+  op->destroy = op_callback_destroy;
+  op->impl = new CallbackImpl{fn, user};
+  *out = op;
+  return MI_OK;
+}
+
+int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out) {
+  MI_REQUIRE(ctx && d && out, "null argument");
+  MI_REQUIRE(d->ctx == ctx, "vector belongs to another context");
+  mi_op *op = new mi_op();
+  op->ctx = ctx;
+  op->n = d->n;
+  op->apply = op_diag_apply;
+  op->apply_dots = op_diag_apply_dots;
+  op->destroy = op_diag_destroy;
+  op->impl = new DiagImpl{d->d};
+  *out = op;
+  return MI_OK;
+}
+
+int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out) {
+  MI_REQUIRE(ctx && A && out, "null argument");
+  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4]");
+  const size_t n = A->n;
+  mi_op *op = new mi_op();
+  op->ctx = ctx;
+  op->n = n * (size_t)p;
+  op->apply = op_csr_apply;
+  op->destroy = op_csr_destroy;
+  op->impl = new CsrOpImpl{A, p};
+  *out = op;
+  return MI_OK;
+}
+
+int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out) {
+  MI_REQUIRE(op && in && out, "null argument");
+  MI_REQUIRE(in->n == op->n && out->n == op->n, "operator dimension mismatch");
+  MI_REQUIRE(in->d != out->d, "operator input and output must not alias");
+  return op->apply(op, in, out);
+}
+
+int mi_op_destroy(mi_op *op) {
+  if (!op || op->borrowed) return MI_OK;
+  if (op->destroy) op->destroy(op);
+  delete op;
+  return MI_OK;
+}
+
+int mi_precon_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_precon **out) {
+  MI_REQUIRE(ctx && fn && out, "null argument");
+  mi_precon *P = new mi_precon();
+  P->ctx = ctx;
+  P->n = n;
+  P->kind = 0;
+  P->apply = precon_callback_apply;
+  P->destroy = precon_callback_destroy;
+  P->impl = new CallbackImpl{fn, user};
+  *out = P;
+  return MI_OK;
+}
+
+int mi_precon_create_diag(mi_ctx *ctx, const mi_vec *dinv, mi_precon **out) {
+  MI_REQUIRE(ctx && dinv && out, "null argument");
+  MI_REQUIRE(dinv->ctx == ctx, "vector belongs to another context");
+  mi_precon *P = new mi_precon();
+  P->ctx = ctx;
+  P->n = dinv->n;
+  P->kind = 1;
+  P->data = dinv->d;
+  P->apply = precon_diag_apply;
+  *out = P;
+  return MI_OK;
+}
+
+int mi_precon_create_block3(mi_ctx *ctx, const mi_vec *inv_blocks, mi_precon **out) {
+  MI_REQUIRE(ctx && inv_blocks && out, "null argument");
+  MI_REQUIRE(inv_blocks->ctx == ctx, "vector belongs to another context");
+  MI_REQUIRE(inv_blocks->n % 9 == 0, "inverse blocks vector must hold 9 doubles per block");
+  mi_precon *P = new mi_precon();
+  P->ctx = ctx;
+  P->n = inv_blocks->n / 3;
+  P->kind = 2;
+  P->data = inv_blocks->d;
+  P->apply = precon_block3_apply;
+  *out = P;
+  return MI_OK;
+}
+
+int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v) {
+  MI_REQUIRE(P && r && v, "null argument");
+  MI_REQUIRE(r->n == P->n && v->n == P->n, "preconditioner dimension mismatch");
+  return P->apply(P, r, v);
+}
+
+int mi_precon_destroy(mi_precon *P) {
+  if (!P || P->borrowed) return MI_OK;
+  if (P->destroy) P->destroy(P);
+  delete P;
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// sparse.hip -- sparse SPD operator storage (CSR in, sliced-ELL-64 in HBM) and W = A V for
+// tall-skinny V (n x p row-major, p <= 4).  This is the user-side HVP building block: the reference
+// has no sparse code (its HVP is a user callable invoked at IterativeSolvers.h:294, TNT.h:512).
+//
+// Algorithmic bytes: 12*nnz + 4*(n+1) + 16*n*p.
+#include "spmm_core.h"
+
+#include <algorithm>
+
+using namespace mi;
+
+namespace {
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_spmm(SellView A, const double *__restrict__ V,
+                                                 double *__restrict__ W) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ngroups = (A.nslices + 3) / 4;
+  size_t g0, g1;
+  group_range(ngroups, g0, g1);
+  for (size_t g = g0; g < g1; ++g) {
+    const size_t slice = g * 4 + w;
+    if (slice >= A.nslices) continue;
+    const size_t row = slice * 64 + lane;
+    double acc[P];
+    sell_row_times<P>(A, slice, lane, V, acc);
+    if (row < A.n) {
+#pragma unroll
+      for (int c = 0; c < P; ++c) W[row * P + c] = acc[c];
+    }
+  }
+}
+
+int upload(void **dst, const void *src, size_t bytes) {
+  MI_HIP(hipMalloc(dst, bytes ? bytes : 8));
+  if (bytes) MI_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MI_OK;
+}
+
+// Build the sliced-ELL image on the host from CSR with LOCAL column indices.
+int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *rowptr,
+               const int32_t *col, const double *val, mi_csr **out) {
+  const size_t nslices = (n + 63) / 64;
+  std::vector<long long> sp(nslices + 1, 0);
+  for (size_t s = 0; s < nslices; ++s) {
+    int w = 0;
+    for (size_t r = s * 64; r < std::min(n, (s + 1) * 64); ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
+    sp[s + 1] = sp[s] + w;
+  }
+  const size_t padded = (size_t)sp[nslices] * 64;
+  std::vector<int> pcol(padded);
+  std::vector<double> pval(padded, 0.0);
+  for (size_t s = 0; s < nslices; ++s) {
+    const long long w = sp[s + 1] - sp[s];
+    for (int lane = 0; lane < 64; ++lane) {
+      const size_t r = s * 64 + lane;
+      const int len = (r < n) ? rowptr[r + 1] - rowptr[r] : 0;
+      const int self = (int)std::min(r, n ? n - 1 : 0);
+      for (long long k = 0; k < w; ++k) {
+        const size_t e = (size_t)(sp[s] + k) * 64 + lane;
+        if (k < len) {
+          pcol[e] = col[rowptr[r] + k];
+          pval[e] = val[rowptr[r] + k];
+        } else {
+          pcol[e] = self;
+        }
+      }
+    }
+  }
+  mi_csr *A = new mi_csr();
+  A->ctx = ctx;
+  A->n = n;
+  A->ncols = ncols;
+  A->nnz = nnz;
+  A->padded = padded;
+  A->nslices = nslices;
+  MI_TRY(upload((void **)&A->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
+  MI_TRY(upload((void **)&A->col, pcol.data(), padded * sizeof(int)));
+  MI_TRY(upload((void **)&A->val, pval.data(), padded * sizeof(double)));
+  *out = A;
+  return MI_OK;
+}
+
+}  // namespace
+
+namespace mi {
+
+int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
+  mi_ctx *ctx = A->ctx;
+  if (A->n == 0) return MI_OK;
+  const size_t ngroups = (A->nslices + 3) / 4;
+  const int grid = (int)std::min<size_t>(ngroups, kMaxGrid);
+  SellView view = sell_view(A);
+  KScope ks(ctx, MI_K_SPMM);
+  switch (p) {
+    case 1: hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 2: hipLaunchKernelGGL(k_spmm<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 3: hipLaunchKernelGGL(k_spmm<3>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 4: hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT;
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+}  // namespace mi
+
+extern "C" {
+
+int mi_csr_create(mi_ctx *ctx, size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col,
+                  const double *val, mi_csr **out) {
+  MI_REQUIRE(ctx && rowptr && out && (nnz == 0 || (col && val)), "null argument");
+  MI_REQUIRE(n < (size_t)INT32_MAX, "n too large for int32 column indices");
+  MI_REQUIRE(rowptr[0] == 0 && (size_t)rowptr[n] == nnz, "rowptr inconsistent with nnz");
+  for (size_t i = 0; i < n; ++i) MI_REQUIRE(rowptr[i + 1] >= rowptr[i], "rowptr not monotone at row %zu", i);
+  for (size_t k = 0; k < nnz; ++k)
+    MI_REQUIRE(col[k] >= 0 && (size_t)col[k] < n, "column index out of range at entry %zu", k);
+  return build_sell(ctx, n, n, nnz, rowptr, col, val, out);
+}
+
+int mi_csr_destroy(mi_csr *A) {
+  if (!A) return MI_OK;
+  (void)hipFree(A->slice_ptr);
+  (void)hipFree(A->col);
+  (void)hipFree(A->val);
+  (void)hipFree(A->halo);
+  delete A;
+  return MI_OK;
+}
+
+int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W) {
+  MI_REQUIRE(A && V && W, "null argument");
+  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  MI_REQUIRE(V->n == A->n * (size_t)p && W->n == A->n * (size_t)p,
+             "SpMM dimension mismatch: A has %zu rows, p=%d, V %zu, W %zu", A->n, p, V->n, W->n);
+  MI_REQUIRE(V->d != W->d, "SpMM input and output must not alias");
+  MI_TRY(comm_halo_exchange(A->ctx, A, p, V->d));
+  return csr_spmm_launch(A, p, V->d, W->d);
+}
+
+int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t row_end,
+                          size_t nnz_local, const int32_t *rowptr, const int64_t *col_global,
+                          const double *val, const size_t *row_starts, mi_csr **out) {
+  MI_REQUIRE(ctx && rowptr && col_global && val && row_starts && out, "null argument");
+  MI_REQUIRE(row_begin <= row_end && row_end <= n_global, "bad local row range");
+  const size_t n = row_end - row_begin;
+  MI_REQUIRE((size_t)rowptr[n] == nnz_local, "rowptr inconsistent with nnz_local");
+  const int ws = ctx->world_size, rk = ctx->rank;
+  MI_REQUIRE(row_starts[rk] == row_begin && row_starts[rk + 1] == row_end,
+             "row_starts does not match this rank's range");
+  // halo extents: the columns outside [row_begin,row_end) must belong to the adjacent ranks
+  size_t need_lo = 0, need_hi = 0;
+  for (size_t k = 0; k < nnz_local; ++k) {
+    const int64_t c = col_global[k];
+    MI_REQUIRE(c >= 0 && (size_t)c < n_global, "global column out of range at entry %zu", k);
+    if ((size_t)c < row_begin) need_lo = std::max(need_lo, row_begin - (size_t)c);
+    if ((size_t)c >= row_end) need_hi = std::max(need_hi, (size_t)c - row_end + 1);
+  }
+  if (need_lo) MI_REQUIRE(rk > 0 && need_lo <= row_begin - row_starts[rk - 1],
+                          "rank %d needs %zu rows below its range: not nearest-neighbour banded", rk, need_lo);
+  if (need_hi) MI_REQUIRE(rk + 1 < ws && need_hi <= row_starts[rk + 2] - row_end,
+                          "rank %d needs %zu rows above its range: not nearest-neighbour banded", rk, need_hi);
+  MI_REQUIRE(n + need_lo + need_hi < (size_t)INT32_MAX, "local problem too large for int32 indices");
+  std::vector<int32_t> lcol(nnz_local);
+  for (size_t k = 0; k < nnz_local; ++k) {
+    const size_t c = (size_t)col_global[k];
+    if (c < row_begin) lcol[k] = (int32_t)(n + (need_lo - (row_begin - c)));  // [n, n+need_lo)
+    else if (c >= row_end) lcol[k] = (int32_t)(n + need_lo + (c - row_end));
+    else lcol[k] = (int32_t)(c - row_begin);
+  }
+  mi_csr *A = nullptr;
+  MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A));
+  A->halo_lo = need_lo;
+  A->halo_hi = need_hi;
+  MI_HIP(hipMalloc((void **)&A->halo, std::max<size_t>(1, (need_lo + need_hi) * 4) * sizeof(double)));
+  MI_HIP(hipMemset(A->halo, 0, std::max<size_t>(1, (need_lo + need_hi) * 4) * sizeof(double)));
+  // what we must SEND equals what the neighbours need; exchanged once through the communicator
+  MI_TRY(comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi));
+  MI_REQUIRE(A->send_lo <= n && A->send_hi <= n, "neighbour halo request exceeds local rows");
+  *out = A;
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,488 @@
+// stiefel.hip -- Stiefel manifold St(n,p) (p <= 4, embedded metric) kernels and the Rayleigh-quotient
+// problem  f(X) = .5 tr(X' A X):  the Objective / QuadraticModel / RiemannianMetric / Retraction
+// callables a TNT client supplies (Riemannian/Concepts.h:44-112).  The reference ships only the
+// S^2 = St(3,1) lambdas of tests/TNT_unit_test.cpp:73-117; these are their n x p generalisation:
+//     project  P_X(Z) = Z - X sym(X'Z)                      (sphere: V - X.dot(V) X,  :73-75)
+//     gradient P_X(A X)                                     (:79-85)
+//     Hessian  P_X(A V - V sym(X'AX))                       (:94-97)
+//     retract  polar factor of X + V                        ((X+V).normalized(),      :106-108)
+//
+// Per Hessian application (N = n p doubles, A in sliced-ELL):
+//   k_st_spmm_gram   reads A, V (gathered through L2), X; writes Z; partial X'Z   [12 nnz + 4n + 8(3N)]
+//   k_st_gram_reduce one workgroup: X'Z -> sym -> device constants
+//   k_st_finish      reads X, Z, V; writes Hp; partials <V,Hp>,<Hp,Hp>,<V,V>     [8(4N)]
+// i.e. the three curvature inner products of STPCG (IterativeSolvers.h:300,305-306) cost no extra pass.
+#include "spmm_core.h"
+
+#include <algorithm>
+
+using namespace mi;
+
+namespace {
+
+enum { POST_NONE = 0, POST_SYM = 1, POST_INVSQRT = 2 };
+
+// ---- small dense helpers (device) --------------------------------------------------------
+template <int P>
+__device__ void dev_sym_invsqrt(const double *G, double *out) {
+  // cyclic Jacobi on the P x P symmetric matrix G; out = Q diag(w^-1/2) Q'
+  double M[P * P], Q[P * P];
+  for (int i = 0; i < P * P; ++i) { M[i] = G[i]; Q[i] = 0; }
+  for (int i = 0; i < P; ++i) Q[i * P + i] = 1;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < P; ++i)
+      for (int j = i + 1; j < P; ++j) off += M[i * P + j] * M[i * P + j];
+    if (off == 0) break;
+    for (int i = 0; i + 1 < P; ++i)
+      for (int j = i + 1; j < P; ++j) {
+        const double apq = M[i * P + j];
+        if (apq == 0) continue;
+        const double tau = (M[j * P + j] - M[i * P + i]) / (2 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+        const double c = 1 / sqrt(1 + t * t), s = t * c;
+        for (int k = 0; k < P; ++k) {
+          const double a = M[k * P + i], b = M[k * P + j];
+          M[k * P + i] = c * a - s * b;
+          M[k * P + j] = s * a + c * b;
+        }
+        for (int k = 0; k < P; ++k) {
+          const double a = M[i * P + k], b = M[j * P + k];
+          M[i * P + k] = c * a - s * b;
+          M[j * P + k] = s * a + c * b;
+        }
+        for (int k = 0; k < P; ++k) {
+          const double a = Q[k * P + i], b = Q[k * P + j];
+          Q[k * P + i] = c * a - s * b;
+          Q[k * P + j] = s * a + c * b;
+        }
+      }
+  }
+  for (int i = 0; i < P; ++i)
+    for (int j = 0; j < P; ++j) {
+      double acc = 0;
+      for (int k = 0; k < P; ++k) acc += Q[i * P + k] * (1.0 / sqrt(M[k * P + k])) * Q[j * P + k];
+      out[i * P + j] = acc;
+    }
+}
+
+template <int P>
+__device__ void dev_post(int post, const double *G, double *dst) {
+  if (post == POST_SYM || post == POST_INVSQRT) {
+    double S[P * P];
+    for (int a = 0; a < P; ++a)
+      for (int b = 0; b < P; ++b) S[a * P + b] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
+    if (post == POST_SYM) {
+      for (int i = 0; i < P * P; ++i) dst[i] = S[i];
+    } else {
+      dev_sym_invsqrt<P>(S, dst);
+    }
+  }
+}
+
+// ---- kernels -----------------------------------------------------------------------------
+
+// Z = A V - V S (S may be null => Z = A V); partial Gram X'Z
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const double *__restrict__ V,
+                                                         const double *__restrict__ X,
+                                                         const double *__restrict__ S,
+                                                         double *__restrict__ Z,
+                                                         double *__restrict__ partials) {
+  __shared__ double lds[4 * P * P];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double Sm[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) Sm[i] = S ? S[i] : 0.0;
+  double G[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) G[i] = 0;
+  const size_t ngroups = (A.nslices + 3) / 4;
+  size_t g0, g1;
+  group_range(ngroups, g0, g1);
+  for (size_t g = g0; g < g1; ++g) {
+    const size_t slice = g * 4 + w;
+    if (slice >= A.nslices) continue;
+    const size_t row = slice * 64 + lane;
+    double acc[P];
+    sell_row_times<P>(A, slice, lane, V, acc);
+    if (row < A.n) {
+      double x[P], v[P];
+#pragma unroll
+      for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; v[c] = V[row * P + c]; }
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) t += v[a] * Sm[a * P + b];
+        acc[b] -= t;
+        Z[row * P + b] = acc[b];
+      }
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * acc[b];
+    }
+  }
+  const double t = block_reduce_multi<P * P>(G, lds);
+  if (threadIdx.x < P * P) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = t;
+}
+
+// partial Gram X'Z of two dense n x P fields; ADD: Y = X + Vadd first and Gram of Y'Y;
+// SCALE: Z = dinv_rows .* R first
+template <int P, int VARIANT>  // 0 plain gram(X,Z); 1 Y = X + V, gram(Y,Y); 2 Z = dinv .* R, gram(X,Z)
+__global__ __launch_bounds__(kBlock) void k_st_gram(size_t n, const double *__restrict__ X,
+                                                    const double *__restrict__ Zin,
+                                                    const double *__restrict__ dinv,
+                                                    double *__restrict__ out,
+                                                    double *__restrict__ partials) {
+  __shared__ double lds[4 * P * P];
+  double G[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) G[i] = 0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
+    double x[P], z[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; z[c] = Zin[row * P + c]; }
+    if (VARIANT == 1) {
+#pragma unroll
+      for (int c = 0; c < P; ++c) { x[c] = x[c] + z[c]; z[c] = x[c]; out[row * P + c] = x[c]; }
+    } else if (VARIANT == 2) {
+      const double d = dinv[row];
+#pragma unroll
+      for (int c = 0; c < P; ++c) { z[c] = d * z[c]; out[row * P + c] = z[c]; }
+    }
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+      for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * z[b];
+  }
+  const double t = block_reduce_multi<P * P>(G, lds);
+  if (threadIdx.x < P * P) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = t;
+}
+
+// sum the per-workgroup Gram partials in fixed order -> raw (P*P doubles); optional post-processing
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_st_gram_reduce(const double *__restrict__ partials, int count,
+                                                           double *__restrict__ raw, int post,
+                                                           double *__restrict__ dst) {
+  __shared__ double lds[8];
+  __shared__ double G[P * P];
+  for (int c = 0; c < P * P; ++c) {
+    const double t = reduce_partials(partials, count, c, lds);
+    if (threadIdx.x == 0) { G[c] = t; raw[c] = t; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && post != POST_NONE) dev_post<P>(post, G, dst);
+}
+
+template <int P>
+__global__ void k_st_post(const double *__restrict__ raw, int post, double *__restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dev_post<P>(post, raw, dst);
+}
+
+// out = Z - X M;  DOTS: partials of <Vin,out>, <out,out>, <Vin,Vin>
+template <int P, bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const double *__restrict__ X,
+                                                      const double *__restrict__ Z,
+                                                      const double *__restrict__ Vin,
+                                                      const double *__restrict__ M,
+                                                      double *__restrict__ out,
+                                                      double *__restrict__ partials) {
+  __shared__ double lds[8];
+  double Mm[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) Mm[i] = M[i];
+  double a0 = 0, a1 = 0, a2 = 0;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
+    double x[P], z[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; z[c] = Z[row * P + c]; }
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < P; ++a) t += x[a] * Mm[a * P + b];
+      const double o = z[b] - t;
+      out[row * P + b] = o;
+      if (DOTS) {
+        const double v = Vin[row * P + b];
+        a0 += v * o; a1 += o * o; a2 += v * v;
+      }
+    }
+  }
+  if (!DOTS) return;
+  const double t0 = block_reduce_sum(a0, lds);
+  const double t1 = block_reduce_sum(a1, lds);
+  const double t2 = block_reduce_sum(a2, lds);
+  if (threadIdx.x == 0) {
+    double *o = partials + (size_t)blockIdx.x * kPartialStride;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+
+// Y <- Y M (in place, M is P x P)
+template <int P>
+__global__ __launch_bounds__(kBlock) void k_st_rightmul(size_t n, double *__restrict__ Y,
+                                                        const double *__restrict__ M) {
+  double Mm[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) Mm[i] = M[i];
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
+    double y[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) y[c] = Y[row * P + c];
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < P; ++a) t += y[a] * Mm[a * P + b];
+      Y[row * P + b] = t;
+    }
+  }
+}
+
+// ---- launch helpers (dispatch on p) --------------------------------------------------------
+#define DISPATCH_P(p, ...)                                          \
+  switch (p) {                                                      \
+    case 1: { constexpr int P = 1; __VA_ARGS__; } break;            \
+    case 2: { constexpr int P = 2; __VA_ARGS__; } break;            \
+    case 3: { constexpr int P = 3; __VA_ARGS__; } break;            \
+    case 4: { constexpr int P = 4; __VA_ARGS__; } break;            \
+    default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT; \
+  }
+
+inline int row_grid(size_t n) { return grid_for(n, 2); }
+
+// reduce partials2[0..count) -> ctx->scalars[SLOT_GRAM..], all-reduce when sharded, post -> dst
+int gram_finish(mi_ctx *ctx, int p, int count, int post, double *dst) {
+  double *raw = ctx->scalars + SLOT_GRAM;
+  KScope ks(ctx, MI_K_STIEFEL_GRAM_REDUCE);
+  if (ctx->world_size > 1) {
+    DISPATCH_P(p, hipLaunchKernelGGL(k_st_gram_reduce<P>, dim3(1), dim3(kBlock), 0, ctx->stream,
+                                     (const double *)ctx->partials2, count, raw, (int)POST_NONE, dst));
+    MI_TRY(comm_allreduce(ctx, raw, p * p));
+    if (post != POST_NONE)
+      DISPATCH_P(p, hipLaunchKernelGGL(k_st_post<P>, dim3(1), dim3(64), 0, ctx->stream, (const double *)raw,
+                                       post, dst));
+  } else {
+    DISPATCH_P(p, hipLaunchKernelGGL(k_st_gram_reduce<P>, dim3(1), dim3(kBlock), 0, ctx->stream,
+                                     (const double *)ctx->partials2, count, raw, post, dst));
+  }
+  return MI_OK;
+}
+
+int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const double *V, const double *X,
+                     const double *S, double *Z, int *count) {
+  const size_t ngroups = (A->nslices + 3) / 4;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>(ngroups, kMaxGrid));
+  SellView view = sell_view(A);
+  MI_TRY(comm_halo_exchange(ctx, A, p, V));
+  KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
+  DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, X,
+                                   S, Z, ctx->partials2));
+  *count = grid;
+  return MI_OK;
+}
+
+int launch_finish(mi_ctx *ctx, size_t n, int p, const double *X, const double *Z, const double *Vin,
+                  const double *M, double *out, bool dots, int *nparts) {
+  const int grid = row_grid(n);
+  KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
+  if (dots) {
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n, X,
+                                      Z, Vin, M, out, ctx->partials));
+  } else {
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                      X, Z, Vin, M, out, (double *)nullptr));
+  }
+  if (nparts) *nparts = grid;
+  return MI_OK;
+}
+
+int check_np(mi_ctx *ctx, size_t n, int p, const mi_vec *a, const mi_vec *b, const mi_vec *c) {
+  MI_REQUIRE(ctx, "ctx is null");
+  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  const mi_vec *vs[3] = {a, b, c};
+  for (const mi_vec *v : vs) {
+    if (!v) continue;
+    MI_REQUIRE(v->ctx == ctx, "vector belongs to another context");
+    MI_REQUIRE(v->n == n * (size_t)p, "expected an n x p = %zu x %d field, got %zu doubles", n, p, v->n);
+  }
+  return MI_OK;
+}
+
+}  // namespace
+
+struct mi_stiefel_rq {
+  mi_ctx *ctx;
+  const mi_csr *A;
+  size_t n;
+  int p;
+  double *S_dev;  // P*P: sym(X'AX) of the last model() call
+  double *M_dev;  // P*P scratch: sym(X'Z) of the current operator application
+  mi_vec *Z;      // n x p scratch
+  mi_op hess;     // borrowed operator object bound to X
+  const mi_vec *X;
+};
+
+namespace {
+
+int rq_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int *nparts) {
+  mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
+  mi_ctx *ctx = q->ctx;
+  int count = 0;
+  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, in->d, q->X->d, q->S_dev, q->Z->d, &count));
+  MI_TRY(gram_finish(ctx, q->p, count, POST_SYM, q->M_dev));
+  return launch_finish(ctx, q->n, q->p, q->X->d, q->Z->d, in->d, q->M_dev, out->d, dots, nparts);
+}
+int rq_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  return rq_apply_common(self, in, out, false, nullptr);
+}
+int rq_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
+  return rq_apply_common(self, in, out, true, nparts);
+}
+
+struct RqPreconImpl {
+  mi_stiefel_rq *q;
+  const mi_vec *X;
+  const mi_vec *dinv;
+};
+int rq_precon_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
+  RqPreconImpl *im = (RqPreconImpl *)self->impl;
+  mi_stiefel_rq *q = im->q;
+  mi_ctx *ctx = q->ctx;
+  const int grid = row_grid(q->n);
+  {
+    const int p = q->p;
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, q->n,
+                                      (const double *)im->X->d, (const double *)r->d,
+                                      (const double *)im->dinv->d, q->Z->d, ctx->partials2));
+  }
+  MI_TRY(gram_finish(ctx, q->p, grid, POST_SYM, q->M_dev));
+  return launch_finish(ctx, q->n, q->p, im->X->d, q->Z->d, nullptr, q->M_dev, v->d, false, nullptr);
+}
+void rq_precon_destroy(mi_precon *self) { delete (RqPreconImpl *)self->impl; }
+
+}  // namespace
+
+extern "C" {
+
+int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, double *G_host) {
+  MI_TRY(check_np(ctx, n, p, X, Z, nullptr));
+  MI_REQUIRE(X && Z && G_host, "null argument");
+  const int grid = row_grid(n);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
+                                    (double *)nullptr, ctx->partials2));
+  MI_TRY(gram_finish(ctx, p, grid, POST_NONE, nullptr));
+  return read_slots_sync(ctx, SLOT_GRAM, p * p, G_host);
+}
+
+int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, mi_vec *out) {
+  MI_TRY(check_np(ctx, n, p, X, Z, out));
+  MI_REQUIRE(X && Z && out, "null argument");
+  const int grid = row_grid(n);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
+                                    (double *)nullptr, ctx->partials2));
+  double *M = ctx->scalars + SLOT_GRAM_M;
+  MI_TRY(gram_finish(ctx, p, grid, POST_SYM, M));
+  return launch_finish(ctx, n, p, X->d, Z->d, nullptr, M, out->d, false, nullptr);
+}
+
+int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *V, mi_vec *Y) {
+  MI_TRY(check_np(ctx, n, p, X, V, Y));
+  MI_REQUIRE(X && V && Y, "null argument");
+  const int grid = row_grid(n);
+  KScope ks(ctx, MI_K_STIEFEL_RETRACT);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                    (const double *)X->d, (const double *)V->d, (const double *)nullptr,
+                                    Y->d, ctx->partials2));
+  double *M = ctx->scalars + SLOT_GRAM_M;
+  MI_TRY(gram_finish(ctx, p, grid, POST_INVSQRT, M));
+  DISPATCH_P(p, hipLaunchKernelGGL(k_st_rightmul<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, Y->d,
+                                   (const double *)M));
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stiefel_rq **out) {
+  MI_REQUIRE(ctx && A && out, "null argument");
+  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  MI_REQUIRE(A->n == n && A->ctx == ctx, "matrix has %zu rows, expected %zu", A->n, n);
+  mi_stiefel_rq *q = new mi_stiefel_rq();
+  q->ctx = ctx;
+  q->A = A;
+  q->n = n;
+  q->p = p;
+  q->X = nullptr;
+  MI_HIP(hipMalloc((void **)&q->S_dev, 32 * sizeof(double)));
+  MI_HIP(hipMemset(q->S_dev, 0, 32 * sizeof(double)));
+  q->M_dev = q->S_dev + 16;
+  MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Z));
+  q->hess.ctx = ctx;
+  q->hess.n = n * (size_t)p;
+  q->hess.apply = rq_apply;
+  q->hess.apply_dots = rq_apply_dots;
+  q->hess.impl = q;
+  q->hess.borrowed = true;
+  *out = q;
+  return MI_OK;
+}
+
+int mi_stiefel_rq_destroy(mi_stiefel_rq *q) {
+  if (!q) return MI_OK;
+  (void)hipStreamSynchronize(q->ctx->stream);
+  (void)hipFree(q->S_dev);
+  mi_vec_destroy(q->Z);
+  delete q;
+  return MI_OK;
+}
+
+int mi_stiefel_rq_objective(mi_stiefel_rq *q, const mi_vec *X, double *f) {
+  MI_REQUIRE(q && X && f, "null argument");
+  MI_TRY(check_np(q->ctx, q->n, q->p, X, nullptr, nullptr));
+  int count = 0;
+  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, X->d, X->d, nullptr, q->Z->d, &count));
+  MI_TRY(gram_finish(q->ctx, q->p, count, POST_NONE, nullptr));
+  double G[16];
+  MI_TRY(read_slots_sync(q->ctx, SLOT_GRAM, q->p * q->p, G));
+  double tr = 0;
+  for (int a = 0; a < q->p; ++a) tr += G[a * q->p + a];
+  *f = .5 * tr;
+  return MI_OK;
+}
+
+int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op **hess) {
+  MI_REQUIRE(q && X && grad, "null argument");
+  MI_TRY(check_np(q->ctx, q->n, q->p, X, grad, nullptr));
+  int count = 0;
+  // Z = A X ; S = sym(X'AX) ; grad = Z - X S
+  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, X->d, X->d, nullptr, q->Z->d, &count));
+  MI_TRY(gram_finish(q->ctx, q->p, count, POST_SYM, q->S_dev));
+  MI_TRY(launch_finish(q->ctx, q->n, q->p, X->d, q->Z->d, nullptr, q->S_dev, grad->d, false, nullptr));
+  q->X = X;
+  if (hess) *hess = &q->hess;
+  return MI_OK;
+}
+
+int mi_stiefel_rq_precon(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *dinv_rows, mi_precon **out) {
+  MI_REQUIRE(q && X && dinv_rows && out, "null argument");
+  MI_TRY(check_np(q->ctx, q->n, q->p, X, nullptr, nullptr));
+  MI_REQUIRE(dinv_rows->n == q->n, "dinv_rows must have one entry per row");
+  mi_precon *P = new mi_precon();
+  P->ctx = q->ctx;
+  P->n = q->n * (size_t)q->p;
+  P->kind = 0;
+  P->apply = rq_precon_apply;
+  P->destroy = rq_precon_destroy;
+  P->impl = new RqPreconImpl{q, X, dinv_rows};
+  *out = P;
+  return MI_OK;
+}
+
+}  // extern "C"

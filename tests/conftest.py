@@ -1,0 +1,55 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    return oracle_py.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The real reference templates (oracle/_ref/libref.so), when prebuilt."""
+    import oracle_py
+    if not oracle_py.have_reference():
+        pytest.skip("oracle/_ref/libref.so not built (needs /root/reference)")
+    return oracle_py.Reference()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        with open(os.path.join(GOLDEN, name)) as f:
+            return json.load(f)
+    return load
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """GPU context through the C ABI.  No fallback: fails when the library or the GPU is missing."""
+    from optimization_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(np.linalg.norm(b), 1e-300)
+    return np.linalg.norm(a - b) / den
