@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- TNT Steihaug-CG HVP + inner-product throughput on MI355X (BASELINE.json metric).
+
+One "step" = one COMPLETED inner iteration of the fused device STPCG (reference:
+LinearAlgebra/IterativeSolvers.h:285-422): one Riemannian Hessian-vector product, the curvature and
+residual inner products, the s/r/p updates and the device-side scalar recurrences + branch tests,
+on BASELINE cfg2: Stiefel(1e6 x world_size, 3), f(X) = .5 tr(X'AX), A = 7-point Laplacian + 0.1 I
+(100^3 per GPU, z-slab sharded), fp64, at a point near the minimiser (where TNT spends its inner
+iterations).  Steps are executed as STPCG solves of max_TPCG_iterations = 50 (cfg2), i.e. the timed
+region also contains each solve's initialisation and final read-back.
+
+value = steps * algorithmic_bytes_per_step / time, algorithmic bytes per SURVEY.md 8(d):
+88*N (CG) + 12*nnz + 4*(n+1) + 16*n*p + 56*N (Stiefel HVP), inputs resident in HBM.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL for the data path,
+        torch.distributed/gloo only for rendezvous, barriers and the max-over-ranks time.)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from optimization_amd import capi, workloads as wl  # noqa: E402  (loads ROCm before torch)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+TPCG = 50              # cfg2: max_TPCG_iterations
+
+
+def kernel_bytes(n, nnz, p):
+    """Per-launch compulsory HBM bytes of each hot kernel (every operand streamed once)."""
+    N = n * p
+    return {
+        "stiefel_spmm_gram": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,   # A; V gathered, X read; Z written
+        "stiefel_finish_dots": 8 * 4 * N,                           # X, Z, V read; Hp written
+        "cg_update": 8 * 6 * N,                                     # s,p,r,Hp read; s,r written
+        "cg_pupdate": 8 * 3 * N,                                    # v(=r), p read; p written
+    }
+
+
+def run_steps(ctx, g, H, s_out, steps):
+    """Execute exactly `steps` completed STPCG inner iterations; returns number of solves."""
+    done, solves = 0, 0
+    while done < steps:
+        r = ctx.stpcg(g, H, Delta=1e3, max_iterations=min(TPCG, steps - done), kappa_fgr=1e-12,
+                      theta=1.0, s_out=s_out)
+        solves += 1
+        if r["iterations"] == 0:
+            raise RuntimeError("STPCG made no progress (exit %d)" % r["exit_reason"])
+        done += r["iterations"]
+    return solves
+
+
+def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step):
+    """The reference's own CPU path (oracle/_ref/libref.so = the reference templates compiled from
+    /root/reference, single-threaded like the reference) on a bounded sample of the same workload;
+    falls back to the plain-C oracle ("port") if the reference build is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    O = oracle_py.Oracle()
+    lib, kind = (oracle_py.Reference(), "reference") if oracle_py.have_reference() else (O, "port")
+    n = nx * ny * nz
+    prob = O.stiefel_rq(n, p, rowptr, col, val)
+    g = O.eval_grad(prob, Xb.ravel())
+    solves, iters = 3, 0
+    O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=2, kappa_fgr=1e-12, theta=1.0, lib=lib)
+    t0 = time.perf_counter()
+    for _ in range(solves):
+        r = O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=TPCG, kappa_fgr=1e-12, theta=1.0,
+                            lib=lib)
+        iters += r["iterations"]
+    dt = time.perf_counter() - t0
+    O.free(prob)
+    cpu = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": iters * bytes_per_step / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": f"{solves} STPCG solves x {TPCG} inner iterations of the same St(1e6,3) workload "
+                      f"({iters} steps, {dt:.1f} s)",
+            "ms_per_step": 1e3 * dt / max(iters, 1), "cpu": cpu, "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # gloo: control plane only
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    ctx = capi.Context(local_rank)
+    if world > 1:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+
+    # ---- workload ------------------------------------------------------------------------------
+    p = 3
+    nx, ny, nz = wl.cfg2_grid(world)
+    z0, z1 = wl.shard_rows(nz, world)[rank]
+    n_glob = nx * ny * nz
+    n = nx * ny * (z1 - z0)
+    Xb_glob, modes = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)
+    Xb = np.ascontiguousarray(Xb_glob[nx * ny * z0: nx * ny * z1])
+    if world == 1:
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+        A = ctx.csr(n, rowptr, col, val)
+    else:
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
+        starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
+        A = ctx.csr_sharded(n_glob, nx * ny * z0, nx * ny * z1, rowptr, col, val, starts)
+    nnz = int(rowptr[-1])
+    prob = ctx.stiefel_rq(A, n, p)
+    X = ctx.upload(Xb)
+    g, H = prob.model(X)
+    s_out = ctx.vec(n * p)
+    N = n * p
+    bytes_per_step = wl.cg_bytes_per_iter(N) + wl.stiefel_hvp_bytes(n, nnz, p)  # per GPU
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warmup + timed region -----------------------------------------------------------------
+    if args.warmup > 0:
+        run_steps(ctx, g, H, s_out, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    solves = run_steps(ctx, g, H, s_out, args.steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    value = world * args.steps * bytes_per_step / dt / 1e9
+
+    # ---- roofline leg: same steps again with HIP-event pairs around every hot kernel ------------
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        kb = kernel_bytes(n, nnz, p)
+        names = list(kb) + ["stiefel_gram_reduce", "cg_scalar_a", "cg_scalar_b"]
+        for k in names:
+            ctx.ktime_enable(k, True)
+        ctx.ktime_reset()
+        run_steps(ctx, g, H, s_out, min(args.steps, 200))
+        per = {}
+        for k in names:
+            cnt, ms = ctx.ktime_read(k)
+            per[k] = {"launches": cnt, "avg_us": 1e3 * ms / max(cnt, 1)}
+            ctx.ktime_enable(k, False)
+        dom = max(kb, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
+        achieved = kb[dom] / (per[dom]["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": kb[dom],
+                    "avg_launch_us": per[dom]["avg_us"],
+                    "kernels": {k: dict(per[k], **({"GBps": kb[k] / (per[k]["avg_us"] * 1e-6) / 1e9,
+                                                     "bytes": kb[k]} if k in kb else {}))
+                                for k in names}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step)
+
+    if rank == 0:
+        out = {
+            "metric": "TNT Steihaug-CG HVP+inner-product throughput", "value": value, "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2 Stiefel({n_glob},{p}) Rayleigh quotient, 7-pt Laplacian "
+                                   f"{nx}x{ny}x{nz}+0.1I, fused device STPCG in solves of {TPCG} inner "
+                                   f"iterations at a near-optimal iterate (modes {modes})",
+                       "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
+                       "algorithmic_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
+                       "parallelism": f"row-sharded z-slabs x{world}" if world > 1 else "single GPU",
+                       "device": ctx.device_name()},
+            "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        ctx.comm_finalize()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -231,6 +231,21 @@ class Context:
     def csr(self, n, rowptr, col, val):
         return Csr(self, n, rowptr, col, val)
 
+    def csr_sharded(self, n_global, row_begin, row_end, rowptr, col_global, val, row_starts):
+        A = Csr.__new__(Csr)
+        A.ctx, A.L = self, self.L
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col_global = np.ascontiguousarray(col_global, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        starts = (C.c_size_t * len(row_starts))(*[int(x) for x in row_starts])
+        A.n, A.nnz = row_end - row_begin, int(rowptr[-1])
+        A.h = vp()
+        check(self.L.mi_csr_create_sharded(self.h, n_global, row_begin, row_end, A.nnz,
+                                           rowptr.ctypes.data_as(c_int32_p),
+                                           col_global.ctypes.data_as(c_int64_p), _dp(val), starts,
+                                           C.byref(A.h)))
+        return A
+
     def op_diag(self, d):
         h = vp()
         check(self.L.mi_op_create_diag(self.h, d.h, C.byref(h)))

@@ -1,13 +1,13 @@
 // blas1.hip -- device vectors and the Vector-concept operators as
-// HBM-streaming gfx950 kernels: 16 B/lane loads, grid-stride over <= 2048 workgroups, deterministic
-// two-stage reductions (per-workgroup partial -> one-workgroup fixed-order sum; no fp64 atomics).
+// HBM-streaming gfx950 kernels: 16 B/lane loads, grid-stride over <= 512 fat workgroups,
+// deterministic two-stage reductions (per-workgroup partial row -> fixed-order sum; no fp64 atomics).
 #include "mi_internal.h"
 
 using namespace mi;
 
 namespace {
 
-// z = a*x + b*y  (MODE 0); y += a*x handled as z=y alias; scale: z = a*x (b unused, MODE 1); fill MODE 2
+// MODE 0: z = a*x + b*y ; MODE 1: z = a*x ; MODE 2: z = a
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_axpby(size_t n, double a, const double *__restrict__ x,
                                                   double b, const double *__restrict__ y,
@@ -43,7 +43,7 @@ struct DotArgs {
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_dot(size_t n, DotArgs args, double *__restrict__ partials) {
-  __shared__ double lds[8];
+  __shared__ double lds[K * kWaves];
   double acc[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) acc[k] = 0;
@@ -62,19 +62,18 @@ __global__ __launch_bounds__(kBlock) void k_dot(size_t n, DotArgs args, double *
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] += args.x[k][n - 1] * args.y[k][n - 1];
   }
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const double r = block_reduce_sum(acc[k], lds);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialStride + k] = r;
-  }
+  block_partials_store<K>(acc, lds, partials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_reduce_to_slots(const double *__restrict__ partials, int count,
-                                                            int k, double *__restrict__ slots) {
-  __shared__ double lds[8];
-  for (int c = 0; c < k; ++c) {
-    const double t = reduce_partials(partials, count, c, lds);
-    if (threadIdx.x == 0) slots[c] = t;
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_reduce_rows_to_slots(const double *__restrict__ partials,
+                                                                 int count, double *__restrict__ slots) {
+  __shared__ double lds[K * (kWaves + 1)];
+  double out[K];
+  reduce_rows<K>(partials, count, out, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) slots[k] = out[k];
   }
 }
 
@@ -88,6 +87,26 @@ int check_same(const mi_vec *a, const mi_vec *b) {
 }  // namespace
 
 namespace mi {
+
+int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots) {
+#define RR(K) \
+  hipLaunchKernelGGL(k_reduce_rows_to_slots<K>, dim3(1), dim3(kBlock), 0, ctx->stream, partials, count, slots)
+  switch (k) {
+    case 1: RR(1); break;
+    case 2: RR(2); break;
+    case 3: RR(3); break;
+    case 4: RR(4); break;
+    case 6: RR(6); break;
+    case 9: RR(9); break;
+    case 10: RR(10); break;
+    case 16: RR(16); break;
+    default: set_error("unsupported reduction width %d", k); return MI_ERR_INTERNAL;
+  }
+#undef RR
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 // enqueue k dot products -> ctx->scalars[slot0 .. slot0+k) (device), all-reduced across ranks
 int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double *const *y, size_t n,
                        int slot0) {
@@ -96,7 +115,7 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
     a.x[i] = x[i < k ? i : 0];
     a.y[i] = y[i < k ? i : 0];
   }
-  const int grid = grid_for(n, 8);
+  const int grid = grid_for(n, 4);
   {
     KScope ks(ctx, MI_K_BLAS1);
     switch (k) {
@@ -106,9 +125,7 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
       default: hipLaunchKernelGGL(k_dot<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
     }
   }
-  hipLaunchKernelGGL(k_reduce_to_slots, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials_user, grid, k,
-                     ctx->scalars + slot0);
-  MI_HIP(hipGetLastError());
+  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials_user, grid, k, ctx->scalars + slot0));
   return comm_allreduce(ctx, ctx->scalars + slot0, k);
 }
 
@@ -179,7 +196,7 @@ int mi_vec_fill(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->n, 8)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+  hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)nullptr, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -189,7 +206,7 @@ int mi_vec_scale(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->n, 8)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)v->d, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -200,7 +217,7 @@ int mi_vec_axpby(mi_vec *z, double a, const mi_vec *x, double b, const mi_vec *y
   MI_TRY(check_same(z, y));
   if (z->n == 0) return MI_OK;
   KScope ks(z->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->n, 8)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
+  hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
                      (const double *)x->d, b, (const double *)y->d, z->d);
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -145,22 +145,30 @@ int mi_ctx_create(int device, mi_ctx **out) {
   ctx->device = device;
   hipDeviceProp_t prop;
   MI_HIP(hipGetDeviceProperties(&prop, device));
-  snprintf(ctx->device_name, sizeof(ctx->device_name), "%s (%s)", prop.name, prop.gcnArchName);
+  snprintf(ctx->device_name, sizeof(ctx->device_name), "%s (%s, %d CUs)",
+           prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
   ctx->num_cu = prop.multiProcessorCount;
   MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  MI_HIP(hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxGrid * kPartialStride));
-  MI_HIP(hipMalloc((void **)&ctx->partials2, sizeof(double) * kMaxGrid * kPartialStride));
-  MI_HIP(hipMalloc((void **)&ctx->partials_user, sizeof(double) * kMaxGrid * kPartialStride));
+  const size_t pbytes = sizeof(double) * kMaxComps * kMaxRows;
+  MI_HIP(hipMalloc((void **)&ctx->partials, pbytes));
+  MI_HIP(hipMalloc((void **)&ctx->partials_b, pbytes));
+  MI_HIP(hipMalloc((void **)&ctx->partials2, pbytes));
+  MI_HIP(hipMalloc((void **)&ctx->partials_user, pbytes));
+  MI_HIP(hipMemset(ctx->partials, 0, pbytes));
+  MI_HIP(hipMemset(ctx->partials_b, 0, pbytes));
+  MI_HIP(hipMemset(ctx->partials2, 0, pbytes));
+  MI_HIP(hipMemset(ctx->partials_user, 0, pbytes));
   MI_HIP(hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots));
   MI_HIP(hipMemset(ctx->scalars, 0, sizeof(double) * kScalarSlots));
-  MI_HIP(hipMalloc((void **)&ctx->cg, sizeof(CgState)));
-  MI_HIP(hipMemset(ctx->cg, 0, sizeof(CgState)));
+  MI_HIP(hipMalloc((void **)&ctx->cg, 2 * sizeof(CgState)));
+  MI_HIP(hipMemset(ctx->cg, 0, 2 * sizeof(CgState)));
   MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots, hipHostMallocDefault));
   MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState), hipHostMallocDefault));
   MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
                        hipHostMallocMapped | hipHostMallocCoherent));
   memset((void *)ctx->status, 0, sizeof(HostStatus));
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
+  { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
   *out = ctx;
@@ -182,6 +190,7 @@ int mi_ctx_destroy(mi_ctx *ctx) {
     }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->partials_b);
   (void)hipFree(ctx->partials2);
   (void)hipFree(ctx->partials_user);
   (void)hipFree(ctx->scalars);

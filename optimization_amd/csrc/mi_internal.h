@@ -16,12 +16,20 @@
 
 namespace mi {
 
+// Launch geometry of the streaming kernels.  Workgroups are FAT (1024 threads = 16 waves) and FEW
+// (<= 512 = 2 per CU, i.e. all 32 wave slots of every CU) on purpose: every global reduction is a
+// per-workgroup partial row that the NEXT kernel's workgroups all re-reduce in their prologue
+// (deterministic, no atomics, no separate one-workgroup kernel -- a dependent one-workgroup kernel
+// costs ~10 us on MI355X: boundary + cross-XCD read of the partials).  Few rows keep that prologue
+// at a few KB per workgroup.
 constexpr int kWave = 64;
-constexpr int kBlock = 256;         // threads per workgroup for streaming kernels (4 waves)
-constexpr int kMaxGrid = 2048;      // 256 CUs x 8 workgroups: cap for grid-stride streaming kernels
+constexpr int kBlock = 1024;
+constexpr int kWaves = kBlock / kWave;  // 16
+constexpr int kMaxGrid = 512;
+constexpr int kMaxRows = kMaxGrid;      // partial rows per component
+constexpr int kMaxComps = 16;           // components per partial buffer (component-major layout)
 constexpr int kNumXCD = 8;
-constexpr int kPartialStride = 16;  // doubles reserved per workgroup in the partial-sum buffer
-constexpr int kScalarSlots = 64;    // device scalar file (doubles)
+constexpr int kScalarSlots = 64;        // device scalar file (doubles)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -46,29 +54,29 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     }                                      \
   } while (0)
 
-// Host-visible progress word written by the device scalar kernels (fine-grained pinned memory).
+// Host-visible progress word written by the device (fine-grained pinned memory).
 struct HostStatus {
   volatile uint64_t iters_done;  // completed STPCG iterations of the current solve
   volatile uint32_t done;        // nonzero once the solve has reached a terminal state
-  volatile uint32_t epoch;       // solve counter (guards against stale reads across solves)
+  volatile uint32_t epoch;
 };
 
-// Device-resident state of one STPCG solve (IterativeSolvers.h:259-283).
+// Device-resident state of one STPCG solve (IterativeSolvers.h:259-283).  Two copies ping-pong:
+// a kernel reads st[i] and its workgroup 0 writes st[i^1] (no intra-kernel read/write race).
 struct CgState {
   double sk_M_pk, sk_M_2, pk_M_2;  // :259,263,266
-  double Delta_2, target_rk_norm;  // :271,278
+  double Delta, Delta_2, target_rk_norm;  // :171,271,278
   double rv;                       // current <r,v>
   double alpha, beta, kappa, sigma;
+  double skplus1_M_2;              // :344, carried from the A-step to the B-step
   double M_norm;                   // update_step_M_norm
-  double kappa_fgr, theta, epsilon;
+  double epsilon;
   unsigned long long k;            // num_iterations
   unsigned long long max_iterations;
   int mode;                        // CgMode
   int exit_reason;
-  unsigned int epoch;
-  int pad;
 };
-enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_APPLY_SIGMA_LATE = 3, CG_DONE = 4 };
+enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_DONE = 3 };
 
 struct KTimer {
   bool enabled = false;
@@ -88,14 +96,16 @@ struct mi_ctx {
   std::multimap<size_t, void *> pool_free;
   std::map<void *, size_t> pool_all;
   size_t pool_bytes = 0;
-  // reductions
-  double *partials = nullptr;   // kMaxGrid x kPartialStride doubles
-  double *partials2 = nullptr;  // second buffer (operator-internal reductions, e.g. Stiefel Gram)
-  double *partials_user = nullptr;  // third buffer (mi_vec_dot*: safe to call from callbacks)
-  double *scalars = nullptr;    // kScalarSlots doubles
-  double *host_scalars = nullptr;  // pinned staging for scalar read-backs
-  mi::CgState *cg = nullptr;       // device
-  mi::CgState *cg_host = nullptr;  // pinned copy for read-back
+  // reductions: component-major partial buffers, kMaxComps x kMaxRows doubles each
+  double *partials = nullptr;       // operator -> CG (curvature dots)
+  double *partials_b = nullptr;     // CG update -> CG direction (<r,v>)
+  double *partials2 = nullptr;      // operator-internal (e.g. Stiefel Gram)
+  double *partials_user = nullptr;  // mi_vec_dot* (safe to call from callbacks)
+  double *scalars = nullptr;        // kScalarSlots doubles
+  double *host_scalars = nullptr;   // pinned staging for scalar read-backs
+  mi::CgState *cg = nullptr;        // device, 2 copies
+  mi::CgState *cg_host = nullptr;   // pinned copy for read-back
+  const mi::CgState *cg_live = nullptr;  // state copy operators may consult to skip work after exit
   mi::HostStatus *status = nullptr;      // pinned, device-visible
   mi::HostStatus *status_dev = nullptr;  // device pointer of the same memory
   double *trace_dev = nullptr;           // 4 x trace_cap doubles
@@ -108,6 +118,7 @@ struct mi_ctx {
   // comm (RCCL); opaque here, defined in comm.hip
   void *comm = nullptr;
   int world_size = 1, rank = 0;
+  bool force_slot_path = false;  // env MI355OPT_FORCE_SLOT_PATH=1: use the multi-GPU (reduce-kernel + slots) path on one GPU
 };
 
 struct mi_vec {
@@ -123,6 +134,8 @@ int pool_alloc(mi_ctx *ctx, size_t bytes, void **out);
 void pool_free(mi_ctx *ctx, void *p);
 int ensure_device();
 
+// workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements
+// per grid-stride step
 inline int grid_for(size_t n, int per_thread) {
   size_t blocks = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
   if (blocks < 1) blocks = 1;
@@ -149,6 +162,8 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
 int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out);
 // per-workgroup partials of <x,y>,<y,y>,<x,x> into ctx->partials components 0,1,2
 int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts);
+// one-workgroup kernel: sum `count` partial rows of components [0,k) -> slots[0..k)
+int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
 
 // scalar-file slot map
 enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GRAM_M = 32, SLOT_MISC = 48 };
@@ -160,32 +175,51 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
   return v;
 }
 
-// Sum across a 256-thread workgroup; result valid in thread 0.  Fixed shape => deterministic.
-__device__ __forceinline__ double block_reduce_sum(double v, double *lds /* >= 4 doubles */) {
-  v = wave_reduce_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) lds[w] = v;
-  __syncthreads();
-  double r = 0;
-  if (threadIdx.x == 0) r = (lds[0] + lds[1]) + (lds[2] + lds[3]);
-  __syncthreads();
-  return r;
+// fixed-order sum of the 16 per-wave values lds[0..15]
+__device__ __forceinline__ double sum16(const double *l) {
+  return (((l[0] + l[1]) + (l[2] + l[3])) + ((l[4] + l[5]) + (l[6] + l[7]))) +
+         (((l[8] + l[9]) + (l[10] + l[11])) + ((l[12] + l[13]) + (l[14] + l[15])));
 }
 
-// Deterministic sum of `count` per-workgroup partials (stride kPartialStride, component c) by one
-// 256-thread workgroup; every thread returns the total.
-__device__ __forceinline__ double reduce_partials(const double *partials, int count, int c,
-                                                  double *lds /* >= 5 doubles */) {
-  double v = 0;
-  for (int i = threadIdx.x; i < count; i += kBlock) v += partials[(size_t)i * kPartialStride + c];
-  v = wave_reduce_sum(v);
+// Workgroup-wide sums of K per-thread accumulators, written as this workgroup's partial row
+// (component-major: partials[c * kMaxRows + blockIdx.x]).  Fixed shape => deterministic.
+// lds: >= K * 16 doubles.  Contains barriers: call from uniform control flow.
+template <int K>
+__device__ __forceinline__ void block_partials_store(const double (&acc)[K], double *lds,
+                                                     double *__restrict__ partials) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = wave_reduce_sum(acc[k]);
+    if (lane == 0) lds[k * kWaves + w] = v;
+  }
   __syncthreads();
-  if (lane == 0) lds[w] = v;
+  if (threadIdx.x < K) partials[(size_t)threadIdx.x * kMaxRows + blockIdx.x] = sum16(lds + threadIdx.x * kWaves);
   __syncthreads();
-  if (threadIdx.x == 0) lds[4] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// Every thread of the workgroup obtains the fixed-order sums over `count` (<= kMaxRows) partial rows
+// of components [0,K).  All workgroups of a kernel run identical code on identical data, so they
+// all obtain bit-identical totals.  lds: >= K * 17 doubles.  Contains barriers.
+template <int K>
+__device__ __forceinline__ void reduce_rows(const double *__restrict__ partials, int count,
+                                            double (&out)[K], double *lds) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    v[k] = ((int)threadIdx.x < count) ? partials[(size_t)k * kMaxRows + threadIdx.x] : 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double t = wave_reduce_sum(v[k]);
+    if (lane == 0) lds[k * kWaves + w] = t;
+  }
   __syncthreads();
-  return lds[4];
+  if (threadIdx.x < K) lds[K * kWaves + threadIdx.x] = sum16(lds + threadIdx.x * kWaves);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = lds[K * kWaves + k];
+  __syncthreads();
 }
 
 // XCD-aware workgroup remap (guide T1): consecutive logical tiles land on the same XCD so that a
@@ -235,7 +269,9 @@ struct mi_op {
   // out = Op(in)
   int (*apply)(mi_op *self, const mi_vec *in, mi_vec *out) = nullptr;
   // out = Op(in) and per-workgroup partials of <in,out>, <out,out>, <in,in> in ctx->partials
-  // components 0,1,2; *nparts = number of workgroups that wrote partials.  nullptr => generic dot3.
+  // components 0,1,2; *nparts = number of partial rows written.  nullptr => generic dot3 kernel.
+  // Implementations may consult ctx->cg_live (device CgState, may be null) to skip work once the
+  // solve has left CG_RUN.
   int (*apply_dots)(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) = nullptr;
   void (*destroy)(mi_op *self) = nullptr;
   void *impl = nullptr;

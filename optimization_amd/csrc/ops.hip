@@ -26,31 +26,25 @@ __global__ __launch_bounds__(kBlock) void k_diag_apply_dots(size_t n, const doub
                                                             const double *__restrict__ p,
                                                             double *__restrict__ Hp,
                                                             double *__restrict__ partials) {
-  __shared__ double lds[8];
-  double a0 = 0, a1 = 0, a2 = 0;
+  __shared__ double lds[3 * kWaves];
+  double a[3] = {0, 0, 0};
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
     const double2 dv = reinterpret_cast<const double2 *>(d)[i];
     const double2 pv = reinterpret_cast<const double2 *>(p)[i];
     const double2 hv = make_double2(dv.x * pv.x, dv.y * pv.y);
     reinterpret_cast<double2 *>(Hp)[i] = hv;
-    a0 += pv.x * hv.x; a0 += pv.y * hv.y;
-    a1 += hv.x * hv.x; a1 += hv.y * hv.y;
-    a2 += pv.x * pv.x; a2 += pv.y * pv.y;
+    a[0] += pv.x * hv.x; a[0] += pv.y * hv.y;
+    a[1] += hv.x * hv.x; a[1] += hv.y * hv.y;
+    a[2] += pv.x * pv.x; a[2] += pv.y * pv.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double pv = p[n - 1], hv = d[n - 1] * pv;
     Hp[n - 1] = hv;
-    a0 += pv * hv; a1 += hv * hv; a2 += pv * pv;
+    a[0] += pv * hv; a[1] += hv * hv; a[2] += pv * pv;
   }
   if (!partials) return;
-  const double t0 = block_reduce_sum(a0, lds);
-  const double t1 = block_reduce_sum(a1, lds);
-  const double t2 = block_reduce_sum(a2, lds);
-  if (threadIdx.x == 0) {
-    double *o = partials + (size_t)blockIdx.x * kPartialStride;
-    o[0] = t0; o[1] = t1; o[2] = t2;
-  }
+  block_partials_store<3>(a, lds, partials);
 }
 
 struct DiagImpl {
@@ -58,7 +52,7 @@ struct DiagImpl {
 };
 int op_diag_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
   mi_ctx *ctx = self->ctx;
-  const int grid = grid_for(self->n, 8);
+  const int grid = grid_for(self->n, 4);
   hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid), dim3(kBlock), 0, ctx->stream, self->n,
                      ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d, ctx->partials);
   *nparts = grid;
@@ -66,7 +60,7 @@ int op_diag_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) 
 }
 int op_diag_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
   mi_ctx *ctx = self->ctx;
-  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 8)), dim3(kBlock), 0, ctx->stream,
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 4)), dim3(kBlock), 0, ctx->stream,
                      self->n, ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d,
                      (double *)nullptr);
   return MI_OK;
@@ -105,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_block3_apply(size_t nb, const double
 }
 
 int precon_diag_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
-  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 8)), dim3(kBlock), 0, self->ctx->stream,
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 4)), dim3(kBlock), 0, self->ctx->stream,
                      self->n, self->data, (const double *)r->d, v->d, (double *)nullptr);
   return MI_OK;
 }

@@ -15,11 +15,11 @@ template <int P>
 __global__ __launch_bounds__(kBlock) void k_spmm(SellView A, const double *__restrict__ V,
                                                  double *__restrict__ W) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const size_t ngroups = (A.nslices + 3) / 4;
+  const size_t ngroups = (A.nslices + kSlicesPerGroup - 1) / kSlicesPerGroup;
   size_t g0, g1;
   group_range(ngroups, g0, g1);
   for (size_t g = g0; g < g1; ++g) {
-    const size_t slice = g * 4 + w;
+    const size_t slice = g * kSlicesPerGroup + w;
     if (slice >= A.nslices) continue;
     const size_t row = slice * 64 + lane;
     double acc[P];
@@ -88,7 +88,7 @@ namespace mi {
 int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
   mi_ctx *ctx = A->ctx;
   if (A->n == 0) return MI_OK;
-  const size_t ngroups = (A->nslices + 3) / 4;
+  const size_t ngroups = sell_groups(A);
   const int grid = (int)std::min<size_t>(ngroups, kMaxGrid);
   SellView view = sell_view(A);
   KScope ks(ctx, MI_K_SPMM);

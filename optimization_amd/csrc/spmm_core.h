@@ -17,6 +17,8 @@ inline SellView sell_view(const mi_csr *A) {
   return SellView{A->n, A->nslices, A->slice_ptr, A->col, A->val, A->halo};
 }
 
+constexpr int kSlicesPerGroup = kWaves;  // one workgroup pass covers 16 slices = 1024 rows
+
 // acc[0..P) = row `row` of A times V.  One lane per row; a wave owns one slice, so the loads of
 // val/col at (base + k) * 64 + lane are contiguous across the wave (512 B + 256 B per k).
 template <int P>
@@ -36,32 +38,15 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
   }
 }
 
-// Workgroup -> contiguous range of slice groups (4 slices = 256 rows per group), XCD-aware: the
-// workgroups of one XCD cover one contiguous row range, so the gathers of V (rows i +- 1, +- nx,
-// +- nx*ny of a stencil) stay inside that XCD's L2.
+// Workgroup -> contiguous range of slice groups, XCD-aware: the workgroups of one XCD cover one
+// contiguous row range, so the gathers of V (rows i +- 1, +- nx, +- nx*ny of a stencil) stay inside
+// that XCD's L2.
 __device__ __forceinline__ void group_range(size_t ngroups, size_t &g0, size_t &g1) {
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
   g0 = (ngroups * lb) / nb;
   g1 = (ngroups * (lb + 1)) / nb;
 }
 
-// Sum K per-thread accumulators across a 256-thread workgroup; thread t < K ends with total[t].
-template <int K>
-__device__ __forceinline__ double block_reduce_multi(double (&acc)[K], double *lds /* >= 4*K */) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const double v = wave_reduce_sum(acc[k]);
-    if (lane == 0) lds[w * K + k] = v;
-  }
-  __syncthreads();
-  double r = 0;
-  if (threadIdx.x < K) {
-    const int k = threadIdx.x;
-    r = (lds[k] + lds[K + k]) + (lds[2 * K + k] + lds[3 * K + k]);
-  }
-  __syncthreads();
-  return r;
-}
+inline size_t sell_groups(const mi_csr *A) { return (A->nslices + kSlicesPerGroup - 1) / kSlicesPerGroup; }
 
 }  // namespace mi

@@ -7,11 +7,13 @@
 //     Hessian  P_X(A V - V sym(X'AX))                       (:94-97)
 //     retract  polar factor of X + V                        ((X+V).normalized(),      :106-108)
 //
-// Per Hessian application (N = n p doubles, A in sliced-ELL):
-//   k_st_spmm_gram   reads A, V (gathered through L2), X; writes Z; partial X'Z   [12 nnz + 4n + 8(3N)]
-//   k_st_gram_reduce one workgroup: X'Z -> sym -> device constants
-//   k_st_finish      reads X, Z, V; writes Hp; partials <V,Hp>,<Hp,Hp>,<V,V>     [8(4N)]
-// i.e. the three curvature inner products of STPCG (IterativeSolvers.h:300,305-306) cost no extra pass.
+// Per Hessian application (N = n p doubles, A in sliced-ELL) exactly two kernels run:
+//   k_st_spmm_gram  reads A, V (gathered through L2), X; writes Z = A V - V S; one partial row of
+//                   sym(X'Z) per workgroup                                  [12 nnz + 4 n + 8 (3N)]
+//   k_st_finish     prologue: every workgroup re-reduces those <= 512 rows (deterministic);
+//                   body: Hp = Z - X sym(X'Z); partial rows of <V,Hp>, <Hp,Hp>, <V,V>      [8 (4N)]
+// so the three curvature inner products of STPCG (IterativeSolvers.h:300,305-306) cost no extra pass
+// and no scalar kernel sits between the passes.
 #include "spmm_core.h"
 
 #include <algorithm>
@@ -20,7 +22,15 @@ using namespace mi;
 
 namespace {
 
-enum { POST_NONE = 0, POST_SYM = 1, POST_INVSQRT = 2 };
+enum { POST_SYM = 1, POST_INVSQRT = 2 };
+
+template <int P>
+struct SymIdx {
+  static constexpr int NS = P * (P + 1) / 2;
+  __host__ __device__ static constexpr int at(int a, int b) {  // a <= b
+    return a * P - a * (a - 1) / 2 + (b - a);
+  }
+};
 
 // ---- small dense helpers (device) --------------------------------------------------------
 template <int P>
@@ -66,30 +76,54 @@ __device__ void dev_sym_invsqrt(const double *G, double *out) {
     }
 }
 
+// per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
 template <int P>
-__device__ void dev_post(int post, const double *G, double *dst) {
-  if (post == POST_SYM || post == POST_INVSQRT) {
-    double S[P * P];
-    for (int a = 0; a < P; ++a)
-      for (int b = 0; b < P; ++b) S[a * P + b] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
-    if (post == POST_SYM) {
-      for (int i = 0; i < P * P; ++i) dst[i] = S[i];
-    } else {
-      dev_sym_invsqrt<P>(S, dst);
-    }
+__device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], double *lds,
+                                                   double *__restrict__ partials) {
+  constexpr int NS = SymIdx<P>::NS;
+  double Gs[NS];
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = a; b < P; ++b)
+      Gs[SymIdx<P>::at(a, b)] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
+  block_partials_store<NS>(Gs, lds, partials);
+}
+
+// every thread: full symmetric P x P matrix M from the reduced rows (or all-reduced slots)
+template <int P, bool FROM_SLOTS>
+__device__ __forceinline__ void load_sym(const double *__restrict__ partials, int count,
+                                         const double *__restrict__ slots, double (&M)[P * P],
+                                         double *lds) {
+  constexpr int NS = SymIdx<P>::NS;
+  double s[NS];
+  if (FROM_SLOTS) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = slots[i];
+  } else {
+    reduce_rows<NS>(partials, count, s, lds);
   }
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = a; b < P; ++b) {
+      M[a * P + b] = s[SymIdx<P>::at(a, b)];
+      M[b * P + a] = s[SymIdx<P>::at(a, b)];
+    }
 }
 
 // ---- kernels -----------------------------------------------------------------------------
 
-// Z = A V - V S (S may be null => Z = A V); partial Gram X'Z
+// Z = A V - V S (S may be null => Z = A V); partial row of sym(X'Z)
 template <int P>
-__global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const double *__restrict__ V,
+__global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgState *__restrict__ st,
+                                                         const double *__restrict__ V,
                                                          const double *__restrict__ X,
                                                          const double *__restrict__ S,
                                                          double *__restrict__ Z,
                                                          double *__restrict__ partials) {
-  __shared__ double lds[4 * P * P];
+  __shared__ double lds[SymIdx<P>::NS * kWaves];
+  if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double Sm[P * P];
 #pragma unroll
@@ -97,11 +131,11 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const doubl
   double G[P * P];
 #pragma unroll
   for (int i = 0; i < P * P; ++i) G[i] = 0;
-  const size_t ngroups = (A.nslices + 3) / 4;
+  const size_t ngroups = (A.nslices + kSlicesPerGroup - 1) / kSlicesPerGroup;
   size_t g0, g1;
   group_range(ngroups, g0, g1);
   for (size_t g = g0; g < g1; ++g) {
-    const size_t slice = g * 4 + w;
+    const size_t slice = g * kSlicesPerGroup + w;
     if (slice >= A.nslices) continue;
     const size_t row = slice * 64 + lane;
     double acc[P];
@@ -124,19 +158,20 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const doubl
         for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * acc[b];
     }
   }
-  const double t = block_reduce_multi<P * P>(G, lds);
-  if (threadIdx.x < P * P) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = t;
+  store_sym_partials<P>(G, lds, partials);
 }
 
-// partial Gram X'Z of two dense n x P fields; ADD: Y = X + Vadd first and Gram of Y'Y;
-// SCALE: Z = dinv_rows .* R first
-template <int P, int VARIANT>  // 0 plain gram(X,Z); 1 Y = X + V, gram(Y,Y); 2 Z = dinv .* R, gram(X,Z)
+// Gram partial rows of two dense n x P fields.
+//   VARIANT 0: gram(X,Z)              1: Y = X + Z written to out, gram(Y,Y)
+//           2: Z' = dinv_rows .* Z written to out, gram(X,Z')
+//   SYM: symmetrised partials (P(P+1)/2 components) else raw (P*P components)
+template <int P, int VARIANT, bool SYM>
 __global__ __launch_bounds__(kBlock) void k_st_gram(size_t n, const double *__restrict__ X,
                                                     const double *__restrict__ Zin,
                                                     const double *__restrict__ dinv,
                                                     double *__restrict__ out,
                                                     double *__restrict__ partials) {
-  __shared__ double lds[4 * P * P];
+  __shared__ double lds[P * P * kWaves];
   double G[P * P];
 #pragma unroll
   for (int i = 0; i < P * P; ++i) G[i] = 0;
@@ -158,43 +193,31 @@ __global__ __launch_bounds__(kBlock) void k_st_gram(size_t n, const double *__re
 #pragma unroll
       for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * z[b];
   }
-  const double t = block_reduce_multi<P * P>(G, lds);
-  if (threadIdx.x < P * P) partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = t;
+  if (SYM) store_sym_partials<P>(G, lds, partials);
+  else block_partials_store<P * P>(G, lds, partials);
 }
 
-// sum the per-workgroup Gram partials in fixed order -> raw (P*P doubles); optional post-processing
-template <int P>
-__global__ __launch_bounds__(kBlock) void k_st_gram_reduce(const double *__restrict__ partials, int count,
-                                                           double *__restrict__ raw, int post,
-                                                           double *__restrict__ dst) {
-  __shared__ double lds[8];
-  __shared__ double G[P * P];
-  for (int c = 0; c < P * P; ++c) {
-    const double t = reduce_partials(partials, count, c, lds);
-    if (threadIdx.x == 0) { G[c] = t; raw[c] = t; }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && post != POST_NONE) dev_post<P>(post, G, dst);
-}
-
-template <int P>
-__global__ void k_st_post(const double *__restrict__ raw, int post, double *__restrict__ dst) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) dev_post<P>(post, raw, dst);
-}
-
-// out = Z - X M;  DOTS: partials of <Vin,out>, <out,out>, <Vin,Vin>
-template <int P, bool DOTS>
-__global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const double *__restrict__ X,
+// prologue: M = sym Gram (re-reduced by every workgroup, or read from all-reduced slots);
+// body: out = Z - X M;  DOTS: partial rows of <Vin,out>, <out,out>, <Vin,Vin>;  M_out (nullable): M
+template <int P, bool DOTS, bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *__restrict__ st,
+                                                      const double *__restrict__ X,
                                                       const double *__restrict__ Z,
                                                       const double *__restrict__ Vin,
-                                                      const double *__restrict__ M,
+                                                      const double *__restrict__ gram_partials, int count,
+                                                      const double *__restrict__ slots,
+                                                      double *__restrict__ M_out,
                                                       double *__restrict__ out,
                                                       double *__restrict__ partials) {
-  __shared__ double lds[8];
+  __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
+  if (st && st->mode != CG_RUN) return;
   double Mm[P * P];
+  load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
+  if (M_out && blockIdx.x == 0 && threadIdx.x == 0) {
 #pragma unroll
-  for (int i = 0; i < P * P; ++i) Mm[i] = M[i];
-  double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = 0; i < P * P; ++i) M_out[i] = Mm[i];
+  }
+  double a[3] = {0, 0, 0};
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
     double x[P], z[P];
@@ -204,32 +227,32 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const double *__
     for (int b = 0; b < P; ++b) {
       double t = 0;
 #pragma unroll
-      for (int a = 0; a < P; ++a) t += x[a] * Mm[a * P + b];
+      for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
       const double o = z[b] - t;
       out[row * P + b] = o;
       if (DOTS) {
         const double v = Vin[row * P + b];
-        a0 += v * o; a1 += o * o; a2 += v * v;
+        a[0] += v * o; a[1] += o * o; a[2] += v * v;
       }
     }
   }
-  if (!DOTS) return;
-  const double t0 = block_reduce_sum(a0, lds);
-  const double t1 = block_reduce_sum(a1, lds);
-  const double t2 = block_reduce_sum(a2, lds);
-  if (threadIdx.x == 0) {
-    double *o = partials + (size_t)blockIdx.x * kPartialStride;
-    o[0] = t0; o[1] = t1; o[2] = t2;
-  }
+  if (DOTS) block_partials_store<3>(a, lds, partials);
 }
 
-// Y <- Y M (in place, M is P x P)
-template <int P>
-__global__ __launch_bounds__(kBlock) void k_st_rightmul(size_t n, double *__restrict__ Y,
-                                                        const double *__restrict__ M) {
+// retraction finish: Y <- Y (Y'Y)^-1/2, the P x P inverse square root computed once per workgroup
+template <int P, bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_st_polar(size_t n, double *__restrict__ Y,
+                                                     const double *__restrict__ gram_partials, int count,
+                                                     const double *__restrict__ slots) {
+  __shared__ double lds[SymIdx<P>::NS * (kWaves + 1)];
+  __shared__ double Minv[P * P];
+  double G[P * P];
+  load_sym<P, FROM_SLOTS>(gram_partials, count, slots, G, lds);
+  if (threadIdx.x == 0) dev_sym_invsqrt<P>(G, Minv);
+  __syncthreads();
   double Mm[P * P];
 #pragma unroll
-  for (int i = 0; i < P * P; ++i) Mm[i] = M[i];
+  for (int i = 0; i < P * P; ++i) Mm[i] = Minv[i];
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
     double y[P];
@@ -256,50 +279,47 @@ __global__ __launch_bounds__(kBlock) void k_st_rightmul(size_t n, double *__rest
   }
 
 inline int row_grid(size_t n) { return grid_for(n, 2); }
+inline int nsym(int p) { return p * (p + 1) / 2; }
 
-// reduce partials2[0..count) -> ctx->scalars[SLOT_GRAM..], all-reduce when sharded, post -> dst
-int gram_finish(mi_ctx *ctx, int p, int count, int post, double *dst) {
-  double *raw = ctx->scalars + SLOT_GRAM;
-  KScope ks(ctx, MI_K_STIEFEL_GRAM_REDUCE);
-  if (ctx->world_size > 1) {
-    DISPATCH_P(p, hipLaunchKernelGGL(k_st_gram_reduce<P>, dim3(1), dim3(kBlock), 0, ctx->stream,
-                                     (const double *)ctx->partials2, count, raw, (int)POST_NONE, dst));
-    MI_TRY(comm_allreduce(ctx, raw, p * p));
-    if (post != POST_NONE)
-      DISPATCH_P(p, hipLaunchKernelGGL(k_st_post<P>, dim3(1), dim3(64), 0, ctx->stream, (const double *)raw,
-                                       post, dst));
-  } else {
-    DISPATCH_P(p, hipLaunchKernelGGL(k_st_gram_reduce<P>, dim3(1), dim3(kBlock), 0, ctx->stream,
-                                     (const double *)ctx->partials2, count, raw, post, dst));
-  }
-  return MI_OK;
+// sharded only: partial rows -> slots -> all-reduce
+int sharded_reduce(mi_ctx *ctx, int count, int k, double *slots) {
+  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, count, k, slots));
+  return comm_allreduce(ctx, slots, k);
 }
 
-int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const double *V, const double *X,
-                     const double *S, double *Z, int *count) {
-  const size_t ngroups = (A->nslices + 3) / 4;
+int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, const double *V,
+                     const double *X, const double *S, double *Z, int *count) {
+  const size_t ngroups = sell_groups(A);
   const int grid = (int)std::max<size_t>(1, std::min<size_t>(ngroups, kMaxGrid));
   SellView view = sell_view(A);
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
-  DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, X,
-                                   S, Z, ctx->partials2));
+  DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
+                                   X, S, Z, ctx->partials2));
   *count = grid;
   return MI_OK;
 }
 
-int launch_finish(mi_ctx *ctx, size_t n, int p, const double *X, const double *Z, const double *Vin,
-                  const double *M, double *out, bool dots, int *nparts) {
+// out = Z - X sym(Gram) where the symmetrised Gram partial rows are in ctx->partials2
+int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double *X, const double *Z,
+                  const double *Vin, int count, double *M_out, double *out, bool dots, int *nparts) {
   const int grid = row_grid(n);
+  double *slots = ctx->scalars + SLOT_GRAM;
+  const bool sharded = ctx->world_size > 1 || ctx->force_slot_path;
+  if (sharded) MI_TRY(sharded_reduce(ctx, count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
+#define FIN(D, F)                                                                                       \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, D, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, n, st, \
+                                   X, Z, Vin, (const double *)ctx->partials2, count,                    \
+                                   (const double *)slots, M_out, out, ctx->partials))
   if (dots) {
-    DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n, X,
-                                      Z, Vin, M, out, ctx->partials));
+    if (sharded) { FIN(true, true); } else { FIN(true, false); }
   } else {
-    DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
-                                      X, Z, Vin, M, out, (double *)nullptr));
+    if (sharded) { FIN(false, true); } else { FIN(false, false); }
   }
+#undef FIN
   if (nparts) *nparts = grid;
+  MI_HIP(hipGetLastError());
   return MI_OK;
 }
 
@@ -323,7 +343,6 @@ struct mi_stiefel_rq {
   size_t n;
   int p;
   double *S_dev;  // P*P: sym(X'AX) of the last model() call
-  double *M_dev;  // P*P scratch: sym(X'Z) of the current operator application
   mi_vec *Z;      // n x p scratch
   mi_op hess;     // borrowed operator object bound to X
   const mi_vec *X;
@@ -335,9 +354,9 @@ int rq_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int *
   mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
   mi_ctx *ctx = q->ctx;
   int count = 0;
-  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, in->d, q->X->d, q->S_dev, q->Z->d, &count));
-  MI_TRY(gram_finish(ctx, q->p, count, POST_SYM, q->M_dev));
-  return launch_finish(ctx, q->n, q->p, q->X->d, q->Z->d, in->d, q->M_dev, out->d, dots, nparts);
+  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, ctx->cg_live, in->d, q->X->d, q->S_dev, q->Z->d, &count));
+  return launch_finish(ctx, q->n, q->p, ctx->cg_live, q->X->d, q->Z->d, in->d, count, nullptr, out->d, dots,
+                       nparts);
 }
 int rq_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
   return rq_apply_common(self, in, out, false, nullptr);
@@ -356,14 +375,12 @@ int rq_precon_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
   mi_stiefel_rq *q = im->q;
   mi_ctx *ctx = q->ctx;
   const int grid = row_grid(q->n);
-  {
-    const int p = q->p;
-    DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, q->n,
-                                      (const double *)im->X->d, (const double *)r->d,
-                                      (const double *)im->dinv->d, q->Z->d, ctx->partials2));
-  }
-  MI_TRY(gram_finish(ctx, q->p, grid, POST_SYM, q->M_dev));
-  return launch_finish(ctx, q->n, q->p, im->X->d, q->Z->d, nullptr, q->M_dev, v->d, false, nullptr);
+  const int p = q->p;
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q->n,
+                                   (const double *)im->X->d, (const double *)r->d,
+                                   (const double *)im->dinv->d, q->Z->d, ctx->partials2));
+  return launch_finish(ctx, q->n, q->p, nullptr, im->X->d, q->Z->d, nullptr, grid, nullptr, v->d, false,
+                       nullptr);
 }
 void rq_precon_destroy(mi_precon *self) { delete (RqPreconImpl *)self->impl; }
 
@@ -375,10 +392,12 @@ int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec 
   MI_TRY(check_np(ctx, n, p, X, Z, nullptr));
   MI_REQUIRE(X && Z && G_host, "null argument");
   const int grid = row_grid(n);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
-                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
-                                    (double *)nullptr, ctx->partials2));
-  MI_TRY(gram_finish(ctx, p, grid, POST_NONE, nullptr));
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                   (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
+                                   (double *)nullptr, ctx->partials2));
+  double *slots = ctx->scalars + SLOT_GRAM;
+  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, p * p, slots));
+  MI_TRY(comm_allreduce(ctx, slots, p * p));
   return read_slots_sync(ctx, SLOT_GRAM, p * p, G_host);
 }
 
@@ -386,12 +405,10 @@ int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
   MI_TRY(check_np(ctx, n, p, X, Z, out));
   MI_REQUIRE(X && Z && out, "null argument");
   const int grid = row_grid(n);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
-                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
-                                    (double *)nullptr, ctx->partials2));
-  double *M = ctx->scalars + SLOT_GRAM_M;
-  MI_TRY(gram_finish(ctx, p, grid, POST_SYM, M));
-  return launch_finish(ctx, n, p, X->d, Z->d, nullptr, M, out->d, false, nullptr);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                   (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
+                                   (double *)nullptr, ctx->partials2));
+  return launch_finish(ctx, n, p, nullptr, X->d, Z->d, nullptr, grid, nullptr, out->d, false, nullptr);
 }
 
 int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *V, mi_vec *Y) {
@@ -399,13 +416,18 @@ int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
   MI_REQUIRE(X && V && Y, "null argument");
   const int grid = row_grid(n);
   KScope ks(ctx, MI_K_STIEFEL_RETRACT);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
-                                    (const double *)X->d, (const double *)V->d, (const double *)nullptr,
-                                    Y->d, ctx->partials2));
-  double *M = ctx->scalars + SLOT_GRAM_M;
-  MI_TRY(gram_finish(ctx, p, grid, POST_INVSQRT, M));
-  DISPATCH_P(p, hipLaunchKernelGGL(k_st_rightmul<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, Y->d,
-                                   (const double *)M));
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                   (const double *)X->d, (const double *)V->d, (const double *)nullptr,
+                                   Y->d, ctx->partials2));
+  double *slots = ctx->scalars + SLOT_GRAM;
+  if (ctx->world_size > 1 || ctx->force_slot_path) {
+    MI_TRY(sharded_reduce(ctx, grid, nsym(p), slots));
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                     Y->d, (const double *)ctx->partials2, grid, (const double *)slots));
+  } else {
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+                                     Y->d, (const double *)ctx->partials2, grid, (const double *)slots));
+  }
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -420,9 +442,8 @@ int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stief
   q->n = n;
   q->p = p;
   q->X = nullptr;
-  MI_HIP(hipMalloc((void **)&q->S_dev, 32 * sizeof(double)));
-  MI_HIP(hipMemset(q->S_dev, 0, 32 * sizeof(double)));
-  q->M_dev = q->S_dev + 16;
+  MI_HIP(hipMalloc((void **)&q->S_dev, 16 * sizeof(double)));
+  MI_HIP(hipMemset(q->S_dev, 0, 16 * sizeof(double)));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Z));
   q->hess.ctx = ctx;
   q->hess.n = n * (size_t)p;
@@ -446,13 +467,20 @@ int mi_stiefel_rq_destroy(mi_stiefel_rq *q) {
 int mi_stiefel_rq_objective(mi_stiefel_rq *q, const mi_vec *X, double *f) {
   MI_REQUIRE(q && X && f, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, nullptr, nullptr));
+  mi_ctx *ctx = q->ctx;
   int count = 0;
-  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, X->d, X->d, nullptr, q->Z->d, &count));
-  MI_TRY(gram_finish(q->ctx, q->p, count, POST_NONE, nullptr));
+  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Z->d, &count));
+  double *slots = ctx->scalars + SLOT_GRAM;
+  const int ns = nsym(q->p);
+  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, count, ns, slots));
+  MI_TRY(comm_allreduce(ctx, slots, ns));
   double G[16];
-  MI_TRY(read_slots_sync(q->ctx, SLOT_GRAM, q->p * q->p, G));
+  MI_TRY(read_slots_sync(ctx, SLOT_GRAM, ns, G));
   double tr = 0;
-  for (int a = 0; a < q->p; ++a) tr += G[a * q->p + a];
+  for (int a = 0, idx = 0; a < q->p; ++a) {  // diagonal entries of the packed symmetric Gram
+    tr += G[idx];
+    idx += q->p - a;
+  }
   *f = .5 * tr;
   return MI_OK;
 }
@@ -461,10 +489,10 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   MI_REQUIRE(q && X && grad, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, grad, nullptr));
   int count = 0;
-  // Z = A X ; S = sym(X'AX) ; grad = Z - X S
-  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, X->d, X->d, nullptr, q->Z->d, &count));
-  MI_TRY(gram_finish(q->ctx, q->p, count, POST_SYM, q->S_dev));
-  MI_TRY(launch_finish(q->ctx, q->n, q->p, X->d, q->Z->d, nullptr, q->S_dev, grad->d, false, nullptr));
+  // Z = A X ; S = sym(X'AX) (kept on the device for the Hessian) ; grad = Z - X S
+  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Z->d, &count));
+  MI_TRY(launch_finish(q->ctx, q->n, q->p, nullptr, X->d, q->Z->d, nullptr, count, q->S_dev, grad->d, false,
+                       nullptr));
   q->X = X;
   if (hess) *hess = &q->hess;
   return MI_OK;

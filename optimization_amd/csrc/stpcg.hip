@@ -3,19 +3,26 @@
 //
 // Design (MI355X-first):
 //   * every vector phase between two global reductions is ONE streaming kernel (16 B/lane loads,
-//     <= 2048 workgroups, grid-stride), producing per-workgroup partial sums;
-//   * the scalar recurrences (:259-283,330-345,412-417) live in a device-resident CgState and are
-//     advanced by one-workgroup "scalar" kernels that also sum the partials in a fixed order
-//     (deterministic; no fp64 atomics) and take every branch decision of the reference loop;
+//     <= 512 fat workgroups, grid-stride) that ends by writing one partial-sum row per workgroup;
+//   * there are NO scalar kernels in the loop: the next streaming kernel's workgroups each re-reduce
+//     those <= 512 rows in their prologue (identical code on identical data => bit-identical totals
+//     in every workgroup, deterministic, no fp64 atomics) and each advance the reference's scalar
+//     recurrences (:259-283,330-345,412-417) and take its branch decisions themselves; workgroup 0
+//     persists the new state.  The state is double-buffered (read st_in, write st_out) so no
+//     workgroup can observe a half-updated state;
 //   * the host never reads a scalar back inside the loop: it enqueues iterations speculatively,
-//     bounded by `run_ahead`, and watches a pinned progress word written by the scalar kernels;
-//     kernels enqueued past the exit see mode != CG_RUN and return immediately;
-//   * row-sharded multi-GPU: partials -> scalar slots -> in-stream RCCL all-reduce -> scalar kernel
-//     (the recurrences are replicated; all ranks take identical decisions).
+//     bounded by `run_ahead`, and watches a pinned progress word; kernels enqueued past the exit see
+//     mode == CG_DONE and return immediately;
+//   * row-sharded multi-GPU: partial rows -> one-workgroup reduce -> in-stream RCCL all-reduce ->
+//     the consumers read the all-reduced slots instead (the recurrences are replicated; every rank
+//     takes identical decisions because ncclAllReduce returns identical bits everywhere).
 //
-// Algorithmic HBM traffic per completed iteration (N fp64 per vector), excluding the operator:
-//   dots 2N (or fused into the operator's last kernel), update 6N, direction 3N  => 88*N bytes;
-//   +2N with a diagonal preconditioner (104*N), +4N with 3x3 block-Jacobi (120*N).
+// Per completed iteration the CG part launches 2 kernels:
+//   k_cg_update   A-step prologue (kappa, kernel test, alpha, boundary test :300-362) +
+//                 s += alpha p, r += alpha Hp, v = M^-1 r, partial <r,v> (:374-408)      [6N (+2N/+4N)]
+//   k_cg_pupdate  B-step prologue (beta, M-norm recurrences, loop control :408-417,285,290) +
+//                 p = -v + beta p (:420)                                                [3N]
+// and the operator supplies <p,Hp>, <Hp,Hp>, <p,p> partials from its last pass (else k_cg_dot3, 2N).
 #include "mi_internal.h"
 
 #include <cmath>
@@ -26,8 +33,102 @@ namespace {
 
 enum { PRE_NONE = 0, PRE_DIAG = 1, PRE_BLOCK3 = 2, PRE_EXTERNAL = 3 };
 
+__device__ __forceinline__ void publish(HostStatus *hs, unsigned long long k, int done) {
+  // relaxed system-scope stores: the host only looks at these two words (results are read after a
+  // stream synchronisation), so no release/write-back of the L2 is needed here
+  __hip_atomic_store(&hs->iters_done, (uint64_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (done) __hip_atomic_store(&hs->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Field-by-field state copies.  An aggregate copy (`*dst = cs`) makes the compiler keep the
+// per-thread struct in memory (promoted to 56 B/thread of LDS + scratch: +7-10 us per kernel,
+// tools/microbench/prologue.hip); explicit fields let SROA keep everything in registers.
+#define CG_FIELDS(X)                                                                               \
+  X(sk_M_pk) X(sk_M_2) X(pk_M_2) X(Delta) X(Delta_2) X(target_rk_norm) X(rv) X(alpha) X(beta)      \
+  X(kappa) X(sigma) X(skplus1_M_2) X(M_norm) X(epsilon) X(k) X(max_iterations) X(mode) X(exit_reason)
+__device__ __forceinline__ CgState load_state(const CgState *__restrict__ src) {
+  CgState s;
+#define X(f) s.f = src->f;
+  CG_FIELDS(X)
+#undef X
+  return s;
+}
+__device__ __forceinline__ void store_state(CgState *__restrict__ dst, const CgState &s) {
+#define X(f) dst->f = s.f;
+  CG_FIELDS(X)
+#undef X
+}
+
 // ---------------------------------------------------------------------------------------------
-// vector kernels
+// scalar steps.  fp contraction is off so the recurrences round exactly like the reference's
+// scalar C++ on the host.
+// ---------------------------------------------------------------------------------------------
+
+// after the operator: kappa, kernel test, alpha, boundary test (:300-362)
+__device__ __forceinline__ void step_a(CgState &s, double pHp, double HpHp, double pp) {
+#pragma clang fp contract(off)
+  const double kappa = pHp;  // :300
+  s.kappa = kappa;
+  if (sqrt(HpHp) / sqrt(pp) < s.epsilon) {  // :305-307
+    s.mode = CG_KERNEL_PENDING;              // needs <p,r> (:320): supplied by k_cg_update's body
+    return;
+  }
+  const double alpha = s.rv / kappa;                                               // :341
+  const double skplus1 = s.sk_M_2 + 2 * alpha * s.sk_M_pk + alpha * alpha * s.pk_M_2;  // :344-345
+  if ((kappa <= 0) || (skplus1 > s.Delta_2)) {                                     // :347
+    s.sigma = (-s.sk_M_pk + sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) /
+              s.pk_M_2;  // :355-357
+    s.mode = CG_APPLY_SIGMA;
+    s.exit_reason = MI_STPCG_EXIT_BOUNDARY;
+    return;
+  }
+  s.alpha = alpha;
+  s.skplus1_M_2 = skplus1;
+}
+
+// after the update: resolves every mode; returns true if a direction update p = -v + beta p follows
+__device__ __forceinline__ void step_b(CgState &s, double red) {
+#pragma clang fp contract(off)
+  if (s.mode == CG_APPLY_SIGMA) {  // boundary step applied by k_cg_update (:359-361)
+    s.M_norm = s.Delta;
+    s.mode = CG_DONE;
+    return;
+  }
+  if (s.mode == CG_KERNEL_PENDING) {  // :320-337, red = <p,r>
+    double sk_M_pk = s.sk_M_pk;
+    const bool flip = red < 0;
+    if (flip) sk_M_pk *= -1;  // :325
+    const double sigma =
+        (-sk_M_pk + sqrt(sk_M_pk * sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;  // :330
+    s.sk_M_pk = sk_M_pk;
+    s.sigma = flip ? -sigma : sigma;  // s += sigma * (-p)  ==  s += (-sigma) * p   (:324,336)
+    s.M_norm = s.Delta;               // :334
+    s.exit_reason = MI_STPCG_EXIT_KERNEL;
+    s.mode = CG_DONE;                 // k_cg_pupdate's body applies the step
+    return;
+  }
+  // CG_RUN, red = <r,v> after the update
+  const double rk_vk = red;                                  // :408
+  const double beta = rk_vk / (s.alpha * s.kappa);           // :412
+  s.sk_M_2 = s.skplus1_M_2;                                  // :415
+  s.sk_M_pk = beta * (s.sk_M_pk + s.alpha * s.pk_M_2);       // :416
+  s.pk_M_2 = rk_vk + beta * beta * s.pk_M_2;                 // :417
+  s.rv = rk_vk;
+  s.beta = beta;
+  s.k = s.k + 1;
+  if (s.k >= s.max_iterations) {  // :285
+    s.exit_reason = MI_STPCG_EXIT_MAXIT;
+    s.M_norm = sqrt(s.sk_M_2);  // :424
+    s.mode = CG_DONE;
+  } else if (sqrt(rk_vk) <= s.target_rk_norm) {  // :290 (top of the next pass)
+    s.exit_reason = MI_STPCG_EXIT_RESIDUAL;
+    s.M_norm = sqrt(s.sk_M_2);
+    s.mode = CG_DONE;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
 // ---------------------------------------------------------------------------------------------
 
 // r = g; s = 0*g (:211,214); v = P r (:231/234); p = -v (:256); partial <r,v> (:266)
@@ -37,8 +138,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(size_t n, const double *__re
                                                     double *__restrict__ r, double *__restrict__ v,
                                                     double *__restrict__ p, double *__restrict__ s,
                                                     double *__restrict__ partials) {
-  __shared__ double lds[8];
-  double acc = 0;
+  __shared__ double lds[kWaves];
+  double acc[1] = {0};
   const size_t stride = (size_t)gridDim.x * kBlock;
   if (PRE == PRE_BLOCK3) {
     const size_t nb = n / 3;
@@ -52,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(size_t n, const double *__re
       s[3 * b] = 0 * g0; s[3 * b + 1] = 0 * g1; s[3 * b + 2] = 0 * g2;
       v[3 * b] = v0; v[3 * b + 1] = v1; v[3 * b + 2] = v2;
       p[3 * b] = -v0; p[3 * b + 1] = -v1; p[3 * b + 2] = -v2;
-      acc += g0 * v0; acc += g1 * v1; acc += g2 * v2;
+      acc[0] += g0 * v0; acc[0] += g1 * v1; acc[0] += g2 * v2;
     }
   } else {
     const size_t n2 = n >> 1;
@@ -68,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(size_t n, const double *__re
         reinterpret_cast<double2 *>(v)[i] = vv;
       }
       reinterpret_cast<double2 *>(p)[i] = make_double2(-vv.x, -vv.y);
-      acc += gv.x * vv.x; acc += gv.y * vv.y;
+      acc[0] += gv.x * vv.x; acc[0] += gv.y * vv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
       const size_t i = n - 1;
@@ -78,86 +179,144 @@ __global__ __launch_bounds__(kBlock) void k_cg_init(size_t n, const double *__re
         double vv = gv;
         if (PRE == PRE_DIAG) { vv = pre[i] * gv; v[i] = vv; }
         p[i] = -vv;
-        acc += gv * vv;
+        acc[0] += gv * vv;
       }
     }
   }
   if (PRE == PRE_EXTERNAL) return;
-  const double t = block_reduce_sum(acc, lds);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialStride] = t;
+  block_partials_store<1>(acc, lds, partials);
 }
 
-// external preconditioner path: partial <r,v>; optionally p = -v (initialisation, :256)
+// external preconditioner path: partial <r,v>; NEG_P: also p = -v (initialisation, :256)
 template <bool NEG_P>
 __global__ __launch_bounds__(kBlock) void k_cg_dot_rv(size_t n, const CgState *__restrict__ st,
                                                       const double *__restrict__ r,
                                                       const double *__restrict__ v,
                                                       double *__restrict__ p,
                                                       double *__restrict__ partials) {
-  __shared__ double lds[8];
-  if (!NEG_P && st->mode != CG_RUN) return;
-  double acc = 0;
+  __shared__ double lds[kWaves];
+  if (!NEG_P && st->mode != CG_RUN) return;  // the update kernel already left the partial it needs
+  double acc[1] = {0};
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
     const double2 rv = reinterpret_cast<const double2 *>(r)[i];
     const double2 vv = reinterpret_cast<const double2 *>(v)[i];
     if (NEG_P) reinterpret_cast<double2 *>(p)[i] = make_double2(-vv.x, -vv.y);
-    acc += rv.x * vv.x; acc += rv.y * vv.y;
+    acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     if (NEG_P) p[n - 1] = -v[n - 1];
-    acc += r[n - 1] * v[n - 1];
+    acc[0] += r[n - 1] * v[n - 1];
   }
-  const double t = block_reduce_sum(acc, lds);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialStride] = t;
+  block_partials_store<1>(acc, lds, partials);
 }
 
 // partials of <x,y>, <y,y>, <x,x>  (kappa :300, kernel test :305-306) for operators without fused dots
-__global__ __launch_bounds__(kBlock) void k_cg_dot3(size_t n, const double *__restrict__ x,
+__global__ __launch_bounds__(kBlock) void k_cg_dot3(size_t n, const CgState *__restrict__ st,
+                                                    const double *__restrict__ x,
                                                     const double *__restrict__ y,
                                                     double *__restrict__ partials) {
-  __shared__ double lds[8];
-  double a0 = 0, a1 = 0, a2 = 0;
+  __shared__ double lds[3 * kWaves];
+  if (st && st->mode != CG_RUN) return;
+  double a[3] = {0, 0, 0};
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
     const double2 xv = reinterpret_cast<const double2 *>(x)[i];
     const double2 yv = reinterpret_cast<const double2 *>(y)[i];
-    a0 += xv.x * yv.x; a0 += xv.y * yv.y;
-    a1 += yv.x * yv.x; a1 += yv.y * yv.y;
-    a2 += xv.x * xv.x; a2 += xv.y * xv.y;
+    a[0] += xv.x * yv.x; a[0] += xv.y * yv.y;
+    a[1] += yv.x * yv.x; a[1] += yv.y * yv.y;
+    a[2] += xv.x * xv.x; a[2] += xv.y * xv.y;
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const double xv = x[n - 1], yv = y[n - 1];
-    a0 += xv * yv; a1 += yv * yv; a2 += xv * xv;
+    a[0] += xv * yv; a[1] += yv * yv; a[2] += xv * xv;
   }
-  const double t0 = block_reduce_sum(a0, lds);
-  const double t1 = block_reduce_sum(a1, lds);
-  const double t2 = block_reduce_sum(a2, lds);
-  if (threadIdx.x == 0) {
-    double *o = partials + (size_t)blockIdx.x * kPartialStride;
-    o[0] = t0; o[1] = t1; o[2] = t2;
-  }
+  block_partials_store<3>(a, lds, partials);
 }
 
-// CG_RUN:            s = s + alpha p (:374); r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)
-// CG_APPLY_SIGMA:    s += sigma p (:360)
-// CG_KERNEL_PENDING: partial <p,r> (:320)
-template <int PRE>
-__global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *__restrict__ st,
+struct CgSetup {
+  double Delta, kappa_fgr, theta, epsilon;
+  unsigned long long max_iterations;
+};
+
+// one workgroup, once per solve: :259-279 and the first pass of :285-290
+template <bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup cfg,
+                                                           const double *partials, int nparts,
+                                                           const double *slots, HostStatus *hs) {
+#pragma clang fp contract(off)
+  __shared__ double lds[kWaves + 1];
+  double red[1];
+  if (FROM_SLOTS) red[0] = slots[0];
+  else reduce_rows<1>(partials, nparts, red, lds);
+  if (threadIdx.x != 0) return;
+  CgState s;
+  const double rv0 = red[0];
+  s.sk_M_pk = 0;                        // :259
+  s.sk_M_2 = 0;                         // :263
+  s.pk_M_2 = rv0;                       // :266
+  s.Delta = cfg.Delta;
+  s.Delta_2 = cfg.Delta * cfg.Delta;    // :271
+  const double r0_norm = sqrt(rv0);     // :275
+  const double pw = pow(r0_norm, cfg.theta);
+  s.target_rk_norm = r0_norm * ((pw < cfg.kappa_fgr) ? pw : cfg.kappa_fgr);  // :278-279 (std::min)
+  s.rv = rv0;
+  s.alpha = s.beta = s.kappa = s.sigma = s.skplus1_M_2 = 0;
+  s.M_norm = 0;
+  s.epsilon = cfg.epsilon;
+  s.k = 0;
+  s.max_iterations = cfg.max_iterations;
+  s.exit_reason = MI_STPCG_EXIT_MAXIT;
+  s.mode = CG_RUN;
+  if (cfg.max_iterations == 0) {  // :285 body never runs
+    s.mode = CG_DONE;
+    s.M_norm = sqrt(0.0);  // :424
+  } else if (sqrt(rv0) <= s.target_rk_norm) {  // :290
+    s.mode = CG_DONE;
+    s.exit_reason = MI_STPCG_EXIT_RESIDUAL;
+    s.M_norm = sqrt(0.0);
+  }
+  store_state(st, s);
+  store_state(st + 1, s);
+  publish(hs, 0, s.mode == CG_DONE);
+}
+
+// A-step prologue + body:
+//   CG_RUN:            s = s + alpha p (:374); r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)
+//   CG_APPLY_SIGMA:    s += sigma p (:360)
+//   CG_KERNEL_PENDING: partial <p,r> (:320)
+template <int PRE, bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *__restrict__ st_in,
+                                                      CgState *__restrict__ st_out,
+                                                      const double *__restrict__ partials_a, int nparts_a,
+                                                      const double *__restrict__ slots,
                                                       const double *__restrict__ p,
                                                       const double *__restrict__ Hp,
                                                       const double *__restrict__ pre,
                                                       double *__restrict__ s, double *__restrict__ r,
                                                       double *__restrict__ v,
-                                                      double *__restrict__ partials) {
-  __shared__ double lds[8];
-  const int mode = st->mode;
-  if (mode == CG_DONE || mode == CG_APPLY_SIGMA_LATE) return;
+                                                      double *__restrict__ partials_b) {
+  __shared__ double lds[3 * (kWaves + 1)];
+  CgState cs = load_state(st_in);
+  if (cs.mode == CG_DONE) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
+    return;
+  }
+  double d[3];
+  if (FROM_SLOTS) {
+    d[0] = slots[0]; d[1] = slots[1]; d[2] = slots[2];
+  } else {
+    reduce_rows<3>(partials_a, nparts_a, d, lds);
+  }
+  step_a(cs, d[0], d[1], d[2]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
+
+  const int mode = cs.mode;
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  double acc = 0;
+  double acc[1] = {0};
   if (mode == CG_APPLY_SIGMA) {
-    const double sigma = st->sigma;
+    const double sigma = cs.sigma;
     for (size_t i = i0; i < n2; i += stride) {
       const double2 pv = reinterpret_cast<const double2 *>(p)[i];
       double2 sv = reinterpret_cast<double2 *>(s)[i];
@@ -171,11 +330,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
     for (size_t i = i0; i < n2; i += stride) {
       const double2 pv = reinterpret_cast<const double2 *>(p)[i];
       const double2 rv = reinterpret_cast<const double2 *>(r)[i];
-      acc += pv.x * rv.x; acc += pv.y * rv.y;
+      acc[0] += pv.x * rv.x; acc[0] += pv.y * rv.y;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += p[n - 1] * r[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc[0] += p[n - 1] * r[n - 1];
   } else {  // CG_RUN
-    const double alpha = st->alpha;
+    const double alpha = cs.alpha;
     if (PRE == PRE_BLOCK3) {
       const size_t nb = n / 3;
       for (size_t b = i0; b < nb; b += stride) {
@@ -192,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
         for (int c = 0; c < 3; ++c) {
           const double vv = M[3 * c] * rr[0] + M[3 * c + 1] * rr[1] + M[3 * c + 2] * rr[2];
           v[3 * b + c] = vv;
-          acc += rr[c] * vv;
+          acc[0] += rr[c] * vv;
         }
       }
     } else {
@@ -208,11 +367,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
         if (PRE == PRE_EXTERNAL) continue;
         double2 vv = rv;
         if (PRE == PRE_DIAG) {
-          const double2 d = reinterpret_cast<const double2 *>(pre)[i];
-          vv.x = d.x * rv.x; vv.y = d.y * rv.y;
+          const double2 dd = reinterpret_cast<const double2 *>(pre)[i];
+          vv.x = dd.x * rv.x; vv.y = dd.y * rv.y;
           reinterpret_cast<double2 *>(v)[i] = vv;
         }
-        acc += rv.x * vv.x; acc += rv.y * vv.y;
+        acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
       }
       if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
@@ -222,215 +381,70 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
         if (PRE != PRE_EXTERNAL) {
           double vv = rv;
           if (PRE == PRE_DIAG) { vv = pre[i] * rv; v[i] = vv; }
-          acc += rv * vv;
+          acc[0] += rv * vv;
         }
       }
     }
-    if (PRE == PRE_EXTERNAL) return;
+    if (PRE == PRE_EXTERNAL) return;  // v = P(r) and <r,v> follow (k_cg_dot_rv)
   }
-  const double t = block_reduce_sum(acc, lds);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kPartialStride] = t;
+  block_partials_store<1>(acc, lds, partials_b);
 }
 
-// CG_RUN: p = -v + beta p (:420);  CG_APPLY_SIGMA_LATE: s += sigma p (:336)
-__global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *__restrict__ st,
+// B-step prologue + body:  CG_RUN: p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
+template <bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *__restrict__ st_in,
+                                                       CgState *__restrict__ st_out,
+                                                       const double *__restrict__ partials_b, int nparts_b,
+                                                       const double *__restrict__ slots,
                                                        const double *__restrict__ v,
-                                                       double *__restrict__ p, double *__restrict__ s) {
-  const int mode = st->mode;
+                                                       double *__restrict__ p, double *__restrict__ s,
+                                                       HostStatus *hs, double *__restrict__ trace,
+                                                       size_t trace_cap) {
+  __shared__ double lds[kWaves + 1];
+  CgState cs = load_state(st_in);
+  const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+  if (cs.mode == CG_DONE) {
+    if (leader) store_state(st_out, cs);
+    return;
+  }
+  const int mode_in = cs.mode;
+  double red[1] = {0};
+  if (mode_in != CG_APPLY_SIGMA) {
+    if (FROM_SLOTS) red[0] = slots[0];
+    else reduce_rows<1>(partials_b, nparts_b, red, lds);
+  }
+  step_b(cs, red[0]);
+  if (leader) {
+    store_state(st_out, cs);
+    if (mode_in == CG_RUN && trace && cs.k - 1 < trace_cap) {
+      const size_t k = (size_t)(cs.k - 1);
+      trace[k] = cs.alpha;
+      trace[trace_cap + k] = cs.beta;
+      trace[2 * trace_cap + k] = cs.kappa;
+      trace[3 * trace_cap + k] = cs.rv;
+    }
+    publish(hs, cs.k, cs.mode == CG_DONE);
+  }
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (mode == CG_RUN) {
-    const double beta = st->beta;
-    for (size_t i = i0; i < n2; i += stride) {
-      const double2 vv = reinterpret_cast<const double2 *>(v)[i];
-      double2 pv = reinterpret_cast<double2 *>(p)[i];
-      pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
-      reinterpret_cast<double2 *>(p)[i] = pv;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = -v[n - 1] + beta * p[n - 1];
-  } else if (mode == CG_APPLY_SIGMA_LATE) {
-    const double sigma = st->sigma;
+  if (mode_in == CG_KERNEL_PENDING) {
+    const double sigma = cs.sigma;
     for (size_t i = i0; i < n2; i += stride) {
       const double2 pv = reinterpret_cast<const double2 *>(p)[i];
       double2 sv = reinterpret_cast<double2 *>(s)[i];
       sv.x += sigma * pv.x; sv.y += sigma * pv.y;
       reinterpret_cast<double2 *>(s)[i] = sv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] += sigma * p[n - 1];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// scalar kernels (one workgroup).  fp contraction is off so the recurrences round exactly like
-// the reference's scalar C++ on the host.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void publish(HostStatus *hs, unsigned long long k, int done) {
-  __hip_atomic_store(&hs->iters_done, (uint64_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (done) __hip_atomic_store(&hs->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-struct CgSetup {
-  double Delta, kappa_fgr, theta, epsilon;
-  unsigned long long max_iterations;
-  unsigned int epoch;
-};
-
-// input values come either from per-workgroup partials (single GPU) or from all-reduced slots
-template <bool FROM_SLOTS>
-__device__ __forceinline__ double fetch(const double *partials, int nparts, const double *slots, int c,
-                                        double *lds) {
-  if (FROM_SLOTS) return slots[c];
-  return reduce_partials(partials, nparts, c, lds);
-}
-
-template <bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup cfg,
-                                                           const double *partials, int nparts,
-                                                           const double *slots, HostStatus *hs) {
-#pragma clang fp contract(off)
-  __shared__ double lds[8];
-  const double rv0 = fetch<FROM_SLOTS>(partials, nparts, slots, 0, lds);
-  if (threadIdx.x != 0) return;
-  st->sk_M_pk = 0;                 // :259
-  st->sk_M_2 = 0;                  // :263
-  st->pk_M_2 = rv0;                // :266
-  st->Delta_2 = cfg.Delta * cfg.Delta;  // :271
-  const double r0_norm = sqrt(rv0);     // :275
-  const double pw = pow(r0_norm, cfg.theta);
-  st->target_rk_norm = r0_norm * ((pw < cfg.kappa_fgr) ? pw : cfg.kappa_fgr);  // :278-279
-  st->rv = rv0;
-  st->alpha = st->beta = st->kappa = st->sigma = 0;
-  st->M_norm = 0;
-  st->kappa_fgr = cfg.kappa_fgr; st->theta = cfg.theta; st->epsilon = cfg.epsilon;
-  st->k = 0;
-  st->max_iterations = cfg.max_iterations;
-  st->epoch = cfg.epoch;
-  st->exit_reason = MI_STPCG_EXIT_MAXIT;
-  int mode = CG_RUN;
-  if (cfg.max_iterations == 0) {  // :285 loop body never runs
-    mode = CG_DONE;
-    st->M_norm = sqrt(0.0);  // :424
-  } else if (sqrt(rv0) <= st->target_rk_norm) {  // :290
-    mode = CG_DONE;
-    st->exit_reason = MI_STPCG_EXIT_RESIDUAL;
-    st->M_norm = sqrt(0.0);
-  }
-  st->mode = mode;
-  publish(hs, 0, mode == CG_DONE);
-}
-
-// after the operator: kappa, kernel test, alpha, boundary test (:300-362)
-template <bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_cg_scalar_a(CgState *st, const double *partials, int nparts,
-                                                        const double *slots, HostStatus *hs) {
-#pragma clang fp contract(off)
-  __shared__ double lds[8];
-  const int mode = st->mode;
-  if (mode == CG_DONE) return;
-  if (mode == CG_APPLY_SIGMA_LATE) {  // the late boundary step has been applied by k_cg_pupdate
-    if (threadIdx.x == 0) {
-      st->mode = CG_DONE;
-      publish(hs, st->k, 1);
+    if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
+  } else if (mode_in == CG_RUN && cs.mode == CG_RUN) {
+    const double beta = cs.beta;
+    for (size_t i = i0; i < n2; i += stride) {
+      const double2 vv = reinterpret_cast<const double2 *>(v)[i];
+      double2 pv = reinterpret_cast<double2 *>(p)[i];
+      pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
+      reinterpret_cast<double2 *>(p)[i] = pv;
     }
-    return;
-  }
-  const double pHp = fetch<FROM_SLOTS>(partials, nparts, slots, 0, lds);
-  const double HpHp = fetch<FROM_SLOTS>(partials, nparts, slots, 1, lds);
-  const double pp = fetch<FROM_SLOTS>(partials, nparts, slots, 2, lds);
-  if (threadIdx.x != 0) return;
-  const double kappa = pHp;  // :300
-  st->kappa = kappa;
-  if (sqrt(HpHp) / sqrt(pp) < st->epsilon) {  // :305-307
-    st->mode = CG_KERNEL_PENDING;            // needs <p,r> (:320) -> k_cg_update
-    return;
-  }
-  const double alpha = st->rv / kappa;  // :341
-  const double skplus1_M_2 =
-      st->sk_M_2 + 2 * alpha * st->sk_M_pk + alpha * alpha * st->pk_M_2;  // :344-345
-  if ((kappa <= 0) || (skplus1_M_2 > st->Delta_2)) {                     // :347
-    const double sk_M_pk = st->sk_M_pk;
-    st->sigma = (-sk_M_pk + sqrt(sk_M_pk * sk_M_pk + st->pk_M_2 * (st->Delta_2 - st->sk_M_2))) /
-                st->pk_M_2;        // :355-357
-    st->mode = CG_APPLY_SIGMA;
-    st->exit_reason = MI_STPCG_EXIT_BOUNDARY;
-    return;
-  }
-  st->alpha = alpha;
-  st->beta = skplus1_M_2;  // parked until k_cg_scalar_b consumes it
-}
-
-// after the update: beta and the M-norm recurrences (:408-417), loop control (:285,290)
-template <bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_cg_scalar_b(CgState *st, double Delta, const double *partials,
-                                                        int nparts, const double *slots, HostStatus *hs,
-                                                        double *trace, size_t trace_cap) {
-#pragma clang fp contract(off)
-  __shared__ double lds[8];
-  const int mode = st->mode;
-  if (mode == CG_DONE || mode == CG_APPLY_SIGMA_LATE) return;
-  if (mode == CG_APPLY_SIGMA) {  // boundary step applied by k_cg_update (:359-361)
-    if (threadIdx.x == 0) {
-      st->M_norm = Delta;
-      st->mode = CG_DONE;
-      publish(hs, st->k, 1);
-    }
-    return;
-  }
-  const double red = fetch<FROM_SLOTS>(partials, nparts, slots, 0, lds);
-  if (threadIdx.x != 0) return;
-  if (mode == CG_KERNEL_PENDING) {  // :320-337
-    double sk_M_pk = st->sk_M_pk;
-    const bool flip = red < 0;  // <p,r> < 0
-    if (flip) sk_M_pk *= -1;    // :325
-    const double sigma =
-        (-sk_M_pk + sqrt(sk_M_pk * sk_M_pk + st->pk_M_2 * (st->Delta_2 - st->sk_M_2))) / st->pk_M_2;
-    st->sk_M_pk = sk_M_pk;
-    st->sigma = flip ? -sigma : sigma;  // s += sigma * (-p)  ==  s += (-sigma) * p
-    st->M_norm = Delta;                 // :334
-    st->exit_reason = MI_STPCG_EXIT_KERNEL;
-    st->mode = CG_APPLY_SIGMA_LATE;
-    return;
-  }
-  // CG_RUN
-  const double rk_vk = red;                         // :408
-  const double alpha = st->alpha, kappa = st->kappa;
-  const double beta = rk_vk / (alpha * kappa);      // :412
-  const double skplus1_M_2 = st->beta;              // parked by k_cg_scalar_a
-  st->sk_M_2 = skplus1_M_2;                         // :415
-  st->sk_M_pk = beta * (st->sk_M_pk + alpha * st->pk_M_2);  // :416
-  st->pk_M_2 = rk_vk + beta * beta * st->pk_M_2;            // :417
-  st->rv = rk_vk;
-  st->beta = beta;
-  const unsigned long long k = st->k;
-  if (trace && k < trace_cap) {
-    trace[k] = alpha;
-    trace[trace_cap + k] = beta;
-    trace[2 * trace_cap + k] = kappa;
-    trace[3 * trace_cap + k] = rk_vk;
-  }
-  st->k = k + 1;
-  int done = 0;
-  if (k + 1 >= st->max_iterations) {  // :285
-    done = 1;
-    st->exit_reason = MI_STPCG_EXIT_MAXIT;
-  } else if (sqrt(rk_vk) <= st->target_rk_norm) {  // :290 (evaluated at the top of the next pass)
-    done = 1;
-    st->exit_reason = MI_STPCG_EXIT_RESIDUAL;
-  }
-  if (done) {
-    st->M_norm = sqrt(st->sk_M_2);  // :424
-    st->mode = CG_DONE;
-  }
-  publish(hs, k + 1, done);
-}
-
-__global__ __launch_bounds__(kBlock) void k_reduce_partials_to_slots(const double *__restrict__ partials,
-                                                                     int count, int k,
-                                                                     double *__restrict__ slots) {
-  __shared__ double lds[8];
-  for (int c = 0; c < k; ++c) {
-    const double t = reduce_partials(partials, count, c, lds);
-    if (threadIdx.x == 0) slots[c] = t;
+    if ((n & 1) && leader) p[n - 1] = -v[n - 1] + beta * p[n - 1];
   }
 }
 
@@ -440,9 +454,10 @@ inline void cpu_relax() { __builtin_ia32_pause(); }
 
 namespace mi {
 int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts) {
-  const int grid = grid_for(n, 8);
+  const int grid = grid_for(n, 4);
   KScope ks(ctx, MI_K_CG_DOT3);
-  hipLaunchKernelGGL(k_cg_dot3, dim3(grid), dim3(kBlock), 0, ctx->stream, n, x, y, ctx->partials);
+  hipLaunchKernelGGL(k_cg_dot3, dim3(grid), dim3(kBlock), 0, ctx->stream, n, ctx->cg_live, x, y,
+                     ctx->partials);
   *nparts = grid;
   return MI_OK;
 }
@@ -466,6 +481,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   MI_REQUIRE(g->ctx == ctx && s_out->ctx == ctx && H->ctx == ctx, "objects belong to another context");
   MI_REQUIRE(g->n == s_out->n && g->n == H->n, "dimension mismatch: g %zu, s %zu, H %zu", g->n,
              s_out->n, H->n);
+  MI_REQUIRE(g->d != s_out->d, "g and s_out must not alias");
   MI_REQUIRE(!P || (P->ctx == ctx && P->n == g->n), "preconditioner dimension/context mismatch");
   // reference argument checks, IterativeSolvers.h:183-205
   MI_REQUIRE(prm->Delta > 0, "Trust-region radius (Delta) must be a positive real value");
@@ -481,7 +497,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const size_t n = g->n;
   const int pre = !P ? PRE_NONE : (P->kind == 1 ? PRE_DIAG : (P->kind == 2 ? PRE_BLOCK3 : PRE_EXTERNAL));
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");
-  const bool sharded = ctx->world_size > 1;
+  const bool sharded = ctx->world_size > 1 || ctx->force_slot_path;
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
 
   mi_vec *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr;
@@ -492,14 +508,12 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   double *vd = (pre == PRE_NONE) ? r->d : v->d;  // v aliases r when P is absent (:231,383)
   const double *pred = P ? P->data : nullptr;
 
-  // trace storage
   size_t tcap = 0;
   if (trace && trace->cap) {
-    tcap = trace->cap;
-    if (ctx->trace_cap < tcap) {
+    if (ctx->trace_cap < trace->cap) {
       if (ctx->trace_dev) MI_HIP(hipFree(ctx->trace_dev));
-      MI_HIP(hipMalloc((void **)&ctx->trace_dev, 4 * tcap * sizeof(double)));
-      ctx->trace_cap = tcap;
+      MI_HIP(hipMalloc((void **)&ctx->trace_dev, 4 * trace->cap * sizeof(double)));
+      ctx->trace_cap = trace->cap;
     }
     tcap = ctx->trace_cap;  // layout stride
   }
@@ -510,59 +524,61 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   ctx->status->epoch = ctx->epoch;
 
   CgSetup cfg{prm->Delta, prm->kappa_fgr, prm->theta, prm->epsilon,
-              (unsigned long long)prm->max_iterations, ctx->epoch};
+              (unsigned long long)prm->max_iterations};
   hipStream_t st = ctx->stream;
-  const int grid = grid_for(n, 8);
-  double *slots = ctx->scalars + SLOT_CG;
+  const int grid = (pre == PRE_BLOCK3) ? grid_for(n / 3, 2) : grid_for(n, 4);
+  double *slots_a = ctx->scalars + SLOT_CG, *slots_b = ctx->scalars + SLOT_CG + 4;
+  CgState *st0 = ctx->cg, *st1 = ctx->cg + 1;
+  double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
+  ctx->cg_live = st0;
 
-#define CG_CHECK(expr)              \
-  do {                              \
-    int _s = (expr);                \
-    if (_s != MI_OK) {              \
-      ret = _s;                     \
-      goto cleanup;                 \
-    }                               \
+#define CG_CHECK(expr)   \
+  do {                   \
+    int _s = (expr);     \
+    if (_s != MI_OK) {   \
+      ret = _s;          \
+      goto cleanup;      \
+    }                    \
   } while (0)
+#define LAUNCH_PRE(KERNEL, ...)                                                                   \
+  switch (pre) {                                                                                  \
+    case PRE_NONE: hipLaunchKernelGGL((KERNEL<PRE_NONE>), dim3(grid), dim3(kBlock), 0, st, __VA_ARGS__); break;     \
+    case PRE_DIAG: hipLaunchKernelGGL((KERNEL<PRE_DIAG>), dim3(grid), dim3(kBlock), 0, st, __VA_ARGS__); break;     \
+    case PRE_BLOCK3: hipLaunchKernelGGL((KERNEL<PRE_BLOCK3>), dim3(grid), dim3(kBlock), 0, st, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<PRE_EXTERNAL>), dim3(grid), dim3(kBlock), 0, st, __VA_ARGS__); break;       \
+  }
+#define LAUNCH_UPDATE(FS)                                                                              \
+  switch (pre) {                                                                                       \
+    case PRE_NONE: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;     \
+    case PRE_DIAG: hipLaunchKernelGGL((k_cg_update<PRE_DIAG, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;     \
+    case PRE_BLOCK3: hipLaunchKernelGGL((k_cg_update<PRE_BLOCK3, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break; \
+    default: hipLaunchKernelGGL((k_cg_update<PRE_EXTERNAL, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;       \
+  }
 
   // --- initialisation -----------------------------------------------------------------------
   {
     KScope ks(ctx, MI_K_CG_INIT);
-    switch (pre) {
-      case PRE_NONE:
-        hipLaunchKernelGGL(k_cg_init<PRE_NONE>, dim3(grid), dim3(kBlock), 0, st, n, g->d, pred, r->d,
-                           vd, p->d, s_out->d, ctx->partials);
-        break;
-      case PRE_DIAG:
-        hipLaunchKernelGGL(k_cg_init<PRE_DIAG>, dim3(grid), dim3(kBlock), 0, st, n, g->d, pred, r->d,
-                           vd, p->d, s_out->d, ctx->partials);
-        break;
-      case PRE_BLOCK3:
-        hipLaunchKernelGGL(k_cg_init<PRE_BLOCK3>, dim3(grid), dim3(kBlock), 0, st, n, g->d, pred, r->d,
-                           vd, p->d, s_out->d, ctx->partials);
-        break;
-      default:
-        hipLaunchKernelGGL(k_cg_init<PRE_EXTERNAL>, dim3(grid), dim3(kBlock), 0, st, n, g->d, pred,
-                           r->d, vd, p->d, s_out->d, ctx->partials);
-        break;
-    }
+    LAUNCH_PRE(k_cg_init, n, (const double *)g->d, pred, r->d, vd, p->d, s_out->d, ctx->partials_b);
   }
   if (pre == PRE_EXTERNAL) {
     CG_CHECK(P->apply(P, r, v));
-    hipLaunchKernelGGL(k_cg_dot_rv<true>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg, r->d, v->d,
-                       p->d, ctx->partials);
+    hipLaunchKernelGGL(k_cg_dot_rv<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st0,
+                       (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
   }
   if (sharded) {
-    hipLaunchKernelGGL(k_reduce_partials_to_slots, dim3(1), dim3(kBlock), 0, st, ctx->partials, grid, 1,
-                       slots);
-    CG_CHECK(comm_allreduce(ctx, slots, 1));
-    hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, ctx->cg, cfg,
-                       ctx->partials, grid, slots, ctx->status_dev);
+    CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials_b, grid, 1, slots_b));
+    CG_CHECK(comm_allreduce(ctx, slots_b, 1));
+    hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
+                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
   } else {
-    hipLaunchKernelGGL(k_cg_scalar_init<false>, dim3(1), dim3(kBlock), 0, st, ctx->cg, cfg,
-                       ctx->partials, grid, slots, ctx->status_dev);
+    hipLaunchKernelGGL(k_cg_scalar_init<false>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
+                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
   }
-  if (hipGetLastError() != hipSuccess) CG_CHECK(hip_fail(hipErrorLaunchFailure, "stpcg init", __FILE__, __LINE__));
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg init launch", __FILE__, __LINE__));
+  }
 
   // --- main loop: speculative enqueue with bounded run-ahead -----------------------------------
   {
@@ -572,7 +588,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       while (!ctx->status->done && k > ctx->status->iters_done + (uint64_t)run_ahead) cpu_relax();
       if (ctx->status->done) break;
 
-      // Hp = H(p) (:294) + partials of <p,Hp>, <Hp,Hp>, <p,p>
+      // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials
       int nparts = 0;
       if (H->apply_dots) {
         CG_CHECK(H->apply_dots(H, p, Hp, &nparts));
@@ -581,66 +597,36 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         CG_CHECK(launch_dot3_partials(ctx, n, p->d, Hp->d, &nparts));
       }
       ++hvp;
-      {
-        KScope ks(ctx, MI_K_CG_SCALAR_A);
-        if (sharded) {
-          hipLaunchKernelGGL(k_reduce_partials_to_slots, dim3(1), dim3(kBlock), 0, st, ctx->partials,
-                             nparts, 3, slots);
-          CG_CHECK(comm_allreduce(ctx, slots, 3));
-          hipLaunchKernelGGL(k_cg_scalar_a<true>, dim3(1), dim3(kBlock), 0, st, ctx->cg, ctx->partials,
-                             nparts, slots, ctx->status_dev);
-        } else {
-          hipLaunchKernelGGL(k_cg_scalar_a<false>, dim3(1), dim3(kBlock), 0, st, ctx->cg, ctx->partials,
-                             nparts, slots, ctx->status_dev);
-        }
-      }
-      {
+#define UPD_ARGS                                                                                      \
+  n, (const CgState *)st0, st1, (const double *)ctx->partials, nparts, (const double *)slots_a,      \
+      (const double *)p->d, (const double *)Hp->d, pred, s_out->d, r->d, vd, ctx->partials_b
+      if (sharded) {
+        CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials, nparts, 3, slots_a));
+        CG_CHECK(comm_allreduce(ctx, slots_a, 3));
         KScope ks(ctx, MI_K_CG_UPDATE);
-        switch (pre) {
-          case PRE_NONE:
-            hipLaunchKernelGGL(k_cg_update<PRE_NONE>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg, p->d,
-                               Hp->d, pred, s_out->d, r->d, vd, ctx->partials);
-            break;
-          case PRE_DIAG:
-            hipLaunchKernelGGL(k_cg_update<PRE_DIAG>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg, p->d,
-                               Hp->d, pred, s_out->d, r->d, vd, ctx->partials);
-            break;
-          case PRE_BLOCK3:
-            hipLaunchKernelGGL(k_cg_update<PRE_BLOCK3>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg,
-                               p->d, Hp->d, pred, s_out->d, r->d, vd, ctx->partials);
-            break;
-          default:
-            hipLaunchKernelGGL(k_cg_update<PRE_EXTERNAL>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg,
-                               p->d, Hp->d, pred, s_out->d, r->d, vd, ctx->partials);
-            break;
-        }
+        LAUNCH_UPDATE(true);
+      } else {
+        KScope ks(ctx, MI_K_CG_UPDATE);
+        LAUNCH_UPDATE(false);
       }
+#undef UPD_ARGS
       if (pre == PRE_EXTERNAL) {
-        // v = P(r) (:386) then <r,v>; in the (rare) non-RUN modes the update kernel has already
-        // written the partial it needs and k_cg_dot_rv<false> leaves it untouched.
-        CG_CHECK(P->apply(P, r, v));
-        hipLaunchKernelGGL(k_cg_dot_rv<false>, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg, r->d, v->d,
-                           p->d, ctx->partials);
+        CG_CHECK(P->apply(P, r, v));  // v = P(r) (:386)
+        hipLaunchKernelGGL(k_cg_dot_rv<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1,
+                           (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
       }
-      {
-        KScope ks(ctx, MI_K_CG_SCALAR_B);
-        if (sharded) {
-          hipLaunchKernelGGL(k_reduce_partials_to_slots, dim3(1), dim3(kBlock), 0, st, ctx->partials,
-                             grid, 1, slots);
-          CG_CHECK(comm_allreduce(ctx, slots, 1));
-          hipLaunchKernelGGL(k_cg_scalar_b<true>, dim3(1), dim3(kBlock), 0, st, ctx->cg, prm->Delta,
-                             ctx->partials, grid, slots, ctx->status_dev, tcap ? ctx->trace_dev : nullptr,
-                             tcap);
-        } else {
-          hipLaunchKernelGGL(k_cg_scalar_b<false>, dim3(1), dim3(kBlock), 0, st, ctx->cg, prm->Delta,
-                             ctx->partials, grid, slots, ctx->status_dev, tcap ? ctx->trace_dev : nullptr,
-                             tcap);
-        }
-      }
-      {
+      if (sharded) {
+        CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials_b, grid, 1, slots_b));
+        CG_CHECK(comm_allreduce(ctx, slots_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL(k_cg_pupdate, dim3(grid), dim3(kBlock), 0, st, n, ctx->cg, vd, p->d,
-                           s_out->d);
+        hipLaunchKernelGGL(k_cg_pupdate<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
+                           (const double *)ctx->partials_b, grid, (const double *)slots_b,
+                           (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
+      } else {
+        KScope ks(ctx, MI_K_CG_PUPDATE);
+        hipLaunchKernelGGL(k_cg_pupdate<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
+                           (const double *)ctx->partials_b, grid, (const double *)slots_b,
+                           (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
       }
     }
     result->hvp_calls = hvp;
@@ -648,7 +634,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
   // --- read back the final state ----------------------------------------------------------------
   {
-    hipError_t e = hipMemcpyAsync(ctx->cg_host, ctx->cg, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
     const CgState &f = *ctx->cg_host;
@@ -671,6 +657,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
 cleanup:
 #undef CG_CHECK
+#undef LAUNCH_PRE
+#undef LAUNCH_UPDATE
+  ctx->cg_live = nullptr;
   if (ret != MI_OK) (void)hipStreamSynchronize(st);
   mi_vec_destroy(r);
   mi_vec_destroy(p);
