@@ -201,24 +201,32 @@ __device__ __forceinline__ void block_partials_store(const double (&acc)[K], dou
 // Every thread of the workgroup obtains the fixed-order sums over `count` (<= kMaxRows) partial rows
 // of components [0,K).  All workgroups of a kernel run identical code on identical data, so they
 // all obtain bit-identical totals.  lds: >= K * 17 doubles.  Contains barriers.
+// One wave per component (K <= 16 waves): each lane sums its <= 8 rows in row order from 8
+// independent coalesced loads, then a single wave reduction; one barrier publishes the K totals.
+// (The earlier all-waves form cost K x 16 fp64 wave reductions = hundreds of ds_bpermute per
+// workgroup, ~2-4 us at the head of every consumer kernel.)
 template <int K>
 __device__ __forceinline__ void reduce_rows(const double *__restrict__ partials, int count,
                                             double (&out)[K], double *lds) {
+  static_assert(K <= kWaves, "one wave per component");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  double v[K];
+  if (w < K) {
+    const double *src = partials + (size_t)w * kMaxRows;
+    double t[kMaxRows / 64];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
-    v[k] = ((int)threadIdx.x < count) ? partials[(size_t)k * kMaxRows + threadIdx.x] : 0.0;
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (r < count) ? src[r] : 0.0;
+    }
+    double v = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const double t = wave_reduce_sum(v[k]);
-    if (lane == 0) lds[k * kWaves + w] = t;
+    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+    if (lane == 0) lds[w] = v;
   }
   __syncthreads();
-  if (threadIdx.x < K) lds[K * kWaves + threadIdx.x] = sum16(lds + threadIdx.x * kWaves);
-  __syncthreads();
 #pragma unroll
-  for (int k = 0; k < K; ++k) out[k] = lds[K * kWaves + k];
+  for (int k = 0; k < K; ++k) out[k] = lds[k];
   __syncthreads();
 }
 

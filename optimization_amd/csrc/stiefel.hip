@@ -211,6 +211,20 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
                                                       double *__restrict__ partials) {
   __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
   if (st && st->mode != CG_RUN) return;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const size_t row0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  // prefetch the first grid-stride step before the prologue's reduction (hides its latency)
+  double x[P], z[P], vi[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) { x[c] = 0; z[c] = 0; vi[c] = 0; }
+  if (row0 < n) {
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      x[c] = X[row0 * P + c];
+      z[c] = Z[row0 * P + c];
+      if (DOTS) vi[c] = Vin[row0 * P + c];
+    }
+  }
   double Mm[P * P];
   load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
   if (M_out && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -218,11 +232,19 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
     for (int i = 0; i < P * P; ++i) M_out[i] = Mm[i];
   }
   double a[3] = {0, 0, 0};
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
-    double x[P], z[P];
+  for (size_t row = row0; row < n;) {
+    const size_t rnext = row + stride;
+    double xn[P], zn[P], vn[P];
 #pragma unroll
-    for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; z[c] = Z[row * P + c]; }
+    for (int c = 0; c < P; ++c) { xn[c] = x[c]; zn[c] = z[c]; vn[c] = vi[c]; }
+    if (rnext < n) {
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        xn[c] = X[rnext * P + c];
+        zn[c] = Z[rnext * P + c];
+        if (DOTS) vn[c] = Vin[rnext * P + c];
+      }
+    }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       double t = 0;
@@ -230,11 +252,11 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
       for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
       const double o = z[b] - t;
       out[row * P + b] = o;
-      if (DOTS) {
-        const double v = Vin[row * P + b];
-        a[0] += v * o; a[1] += o * o; a[2] += v * v;
-      }
+      if (DOTS) { a[0] += vi[b] * o; a[1] += o * o; a[2] += vi[b] * vi[b]; }
     }
+    row = rnext;
+#pragma unroll
+    for (int c = 0; c < P; ++c) { x[c] = xn[c]; z[c] = zn[c]; vi[c] = vn[c]; }
   }
   if (DOTS) block_partials_store<3>(a, lds, partials);
 }

@@ -302,6 +302,17 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
     if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
     return;
   }
+  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  // software prefetch of the first grid-stride step: its HBM latency overlaps the prologue's
+  // reduction (tools/microbench/prologue.hip: hides the ~2.2 us prologue completely)
+  double2 pv0 = make_double2(0, 0), hv0 = pv0, sv0 = pv0, rv0 = pv0;
+  if (PRE != PRE_BLOCK3 && i0 < n2) {
+    pv0 = reinterpret_cast<const double2 *>(p)[i0];
+    hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
+    sv0 = reinterpret_cast<double2 *>(s)[i0];
+    rv0 = reinterpret_cast<double2 *>(r)[i0];
+  }
   double d[3];
   if (FROM_SLOTS) {
     d[0] = slots[0]; d[1] = slots[1]; d[2] = slots[2];
@@ -312,8 +323,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
   if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
 
   const int mode = cs.mode;
-  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
-  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   double acc[1] = {0};
   if (mode == CG_APPLY_SIGMA) {
     const double sigma = cs.sigma;
@@ -355,23 +364,30 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
         }
       }
     } else {
-      for (size_t i = i0; i < n2; i += stride) {
-        const double2 pv = reinterpret_cast<const double2 *>(p)[i];
-        const double2 hv = reinterpret_cast<const double2 *>(Hp)[i];
-        double2 sv = reinterpret_cast<double2 *>(s)[i];
-        double2 rv = reinterpret_cast<double2 *>(r)[i];
+      double2 pv = pv0, hv = hv0, sv = sv0, rv = rv0;
+      for (size_t i = i0; i < n2;) {
+        const size_t inext = i + stride;
+        double2 pn = pv, hn = hv, sn = sv, rn = rv;
+        if (inext < n2) {  // next step's operands are in flight while this one is computed
+          pn = reinterpret_cast<const double2 *>(p)[inext];
+          hn = reinterpret_cast<const double2 *>(Hp)[inext];
+          sn = reinterpret_cast<double2 *>(s)[inext];
+          rn = reinterpret_cast<double2 *>(r)[inext];
+        }
         sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
         rv.x += alpha * hv.x; rv.y += alpha * hv.y;
         reinterpret_cast<double2 *>(s)[i] = sv;
         reinterpret_cast<double2 *>(r)[i] = rv;
-        if (PRE == PRE_EXTERNAL) continue;
-        double2 vv = rv;
-        if (PRE == PRE_DIAG) {
-          const double2 dd = reinterpret_cast<const double2 *>(pre)[i];
-          vv.x = dd.x * rv.x; vv.y = dd.y * rv.y;
-          reinterpret_cast<double2 *>(v)[i] = vv;
+        if (PRE != PRE_EXTERNAL) {
+          double2 vv = rv;
+          if (PRE == PRE_DIAG) {
+            const double2 dd = reinterpret_cast<const double2 *>(pre)[i];
+            vv.x = dd.x * rv.x; vv.y = dd.y * rv.y;
+            reinterpret_cast<double2 *>(v)[i] = vv;
+          }
+          acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
         }
-        acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
+        i = inext; pv = pn; hv = hn; sv = sn; rv = rn;
       }
       if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
@@ -408,6 +424,13 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
     return;
   }
   const int mode_in = cs.mode;
+  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
+  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  double2 vv0 = make_double2(0, 0), pv0 = vv0;  // prefetch: overlaps the prologue's reduction
+  if (i0 < n2) {
+    vv0 = reinterpret_cast<const double2 *>(v)[i0];
+    pv0 = reinterpret_cast<double2 *>(p)[i0];
+  }
   double red[1] = {0};
   if (mode_in != CG_APPLY_SIGMA) {
     if (FROM_SLOTS) red[0] = slots[0];
@@ -425,8 +448,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
     }
     publish(hs, cs.k, cs.mode == CG_DONE);
   }
-  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
-  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (mode_in == CG_KERNEL_PENDING) {
     const double sigma = cs.sigma;
     for (size_t i = i0; i < n2; i += stride) {
@@ -438,11 +459,17 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
     if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
   } else if (mode_in == CG_RUN && cs.mode == CG_RUN) {
     const double beta = cs.beta;
-    for (size_t i = i0; i < n2; i += stride) {
-      const double2 vv = reinterpret_cast<const double2 *>(v)[i];
-      double2 pv = reinterpret_cast<double2 *>(p)[i];
+    double2 vv = vv0, pv = pv0;
+    for (size_t i = i0; i < n2;) {
+      const size_t inext = i + stride;
+      double2 vn = vv, pn = pv;
+      if (inext < n2) {
+        vn = reinterpret_cast<const double2 *>(v)[inext];
+        pn = reinterpret_cast<double2 *>(p)[inext];
+      }
       pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
       reinterpret_cast<double2 *>(p)[i] = pv;
+      i = inext; vv = vn; pv = pn;
     }
     if ((n & 1) && leader) p[n - 1] = -v[n - 1] + beta * p[n - 1];
   }
