@@ -65,6 +65,46 @@ def build(force=False, jobs=None, verbose=False):
     return LIB
 
 
+def build_harness(force=False):
+    """C++ test harnesses on top of the drop-in template layer (g++; plus a clang syntax check so
+    the headers stay compilable by hipcc's front end):
+      tests/cpp/libharness_host.so    templates on a host vector, same driver code as the real
+                                      reference build (oracle/template_driver.inc)
+      tests/cpp/libharness_device.so  templates on MI355::DeviceVector, linked to libmi355opt.so"""
+    tdir = os.path.join(ROOT, "tests", "cpp")
+    inc = ["-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "oracle")]
+    common = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-type-limits"]
+    hdrs = glob.glob(os.path.join(HERE, "include", "Optimization", "*", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "oracle", "*.inc")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    out = []
+    host_src = os.path.join(tdir, "harness_host.cpp")
+    host_so = os.path.join(tdir, "libharness_host.so")
+    if force or _newer(host_src, host_so, hdrs):
+        r = subprocess.run(common + ["-march=x86-64-v3"] + inc + [host_src, "-o", host_so],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host harness build failed:\n" + r.stderr[-6000:])
+    out.append(host_so)
+    dev_src = os.path.join(tdir, "harness_device.cpp")
+    dev_so = os.path.join(tdir, "libharness_device.so")
+    if force or _newer(dev_src, dev_so, hdrs + [LIB]):
+        cmd = common + inc + ["-I", os.path.join(ROOT, "include"), dev_src, "-o", dev_so, "-L", HERE,
+                              "-lmi355opt", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("device harness build failed:\n" + r.stderr[-6000:])
+        # the same translation unit must also pass clang's front end (hipcc users)
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+        if os.path.exists(clang):
+            r = subprocess.run([clang, "-std=c++17", "-fsyntax-only"] + inc +
+                               ["-I", os.path.join(ROOT, "include"), dev_src], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("clang front-end check of the template layer failed:\n" + r.stderr[-6000:])
+    out.append(dev_so)
+    return out
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build(force=force, verbose=True))
+    print(build_harness(force=force))

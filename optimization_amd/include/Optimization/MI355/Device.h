@@ -1,0 +1,280 @@
+// Optimization/MI355/Device.h -- the device-side "Vector" of the MI355X build and the tagged
+// callables through which the generic templates (TNT, STPCG, ...) recognise that they can run
+// their fused HIP path.  Thin C++17 over the C ABI of include/mi355opt.h; g++- and clang-compilable;
+// no HIP headers needed by client code.
+//
+//   DeviceVector     satisfies the implicit Vector concept of the reference's templates (SURVEY.md
+//                    Appendix A: `0 * g`, copy, unary minus, `*=`, `+=`, `-=`, `a * v`, `+`, `-`,
+//                    `/ a`, `.dot`) with every operator ENQUEUED on the context stream; only
+//                    `.dot()` / `.norm()` / host copies synchronise.
+//   FrobeniusMetric / FrobeniusInnerProduct / DeviceHessian / DeviceOperator / DevicePreconditioner
+//                    function objects to put inside the reference-style std::function arguments.
+//                    The templates detect them with std::function::target<>() and then hand the
+//                    whole inner loop to mi_stpcg (device-resident scalars, no host read-backs);
+//                    any other callable still works through the generic (operator-by-operator)
+//                    path, on the GPU, just with one synchronisation per inner product.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mi355opt.h"
+
+namespace Optimization {
+namespace MI355 {
+
+// status -> exception: invalid arguments keep the reference's exception type
+inline void check(int status) {
+  if (status == MI_OK) return;
+  const std::string msg = std::string(mi_status_string(status)) + ": " + mi_last_error();
+  if (status == MI_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+// One GPU, one stream, one memory pool.  Shared by every DeviceVector created from it.
+class Context {
+ public:
+  explicit Context(int device = 0) {
+    mi_ctx *c = nullptr;
+    check(mi_ctx_create(device, &c));
+    h_ = std::shared_ptr<mi_ctx>(c, [](mi_ctx *p) { mi_ctx_destroy(p); });
+  }
+  mi_ctx *get() const { return h_.get(); }
+  void synchronize() const { check(mi_ctx_sync(h_.get())); }
+
+ private:
+  std::shared_ptr<mi_ctx> h_;
+};
+
+class DeviceVector {
+ public:
+  DeviceVector() = default;  // `Vector v;` -- empty until assigned (IterativeSolvers.h:217-226)
+  DeviceVector(const Context &ctx, size_t n) : ctx_(ctx.get()) { check(mi_vec_create(ctx_, n, &v_)); }
+  DeviceVector(const Context &ctx, const std::vector<double> &host) : DeviceVector(ctx, host.size()) {
+    check(mi_vec_upload(v_, host.data(), host.size()));
+  }
+  DeviceVector(const Context &ctx, const double *host, size_t n) : DeviceVector(ctx, n) {
+    check(mi_vec_upload(v_, host, n));
+  }
+  DeviceVector(const DeviceVector &o) : ctx_(o.ctx_) {
+    if (o.v_) {
+      check(mi_vec_create(ctx_, o.size(), &v_));
+      check(mi_vec_copy(v_, o.v_));
+    }
+  }
+  DeviceVector(DeviceVector &&o) noexcept : ctx_(o.ctx_), v_(o.v_), borrowed_(o.borrowed_) {
+    o.v_ = nullptr;
+    o.borrowed_ = false;
+  }
+  ~DeviceVector() { release(); }
+
+  DeviceVector &operator=(const DeviceVector &o) {
+    if (this == &o) return *this;
+    if (!o.v_) {
+      release();
+      ctx_ = o.ctx_;
+      return *this;
+    }
+    if (!v_ || size() != o.size() || borrowed_) {
+      release();
+      ctx_ = o.ctx_;
+      check(mi_vec_create(ctx_, o.size(), &v_));
+    }
+    check(mi_vec_copy(v_, o.v_));
+    return *this;
+  }
+  DeviceVector &operator=(DeviceVector &&o) noexcept {
+    if (this != &o) {
+      release();
+      ctx_ = o.ctx_;
+      v_ = o.v_;
+      borrowed_ = o.borrowed_;
+      o.v_ = nullptr;
+      o.borrowed_ = false;
+    }
+    return *this;
+  }
+
+  // non-owning view of a handle owned by the C layer (operator callbacks)
+  static DeviceVector view(mi_ctx *ctx, mi_vec *v) {
+    DeviceVector d;
+    d.ctx_ = ctx;
+    d.v_ = v;
+    d.borrowed_ = true;
+    return d;
+  }
+
+  bool empty() const { return v_ == nullptr; }
+  size_t size() const {
+    size_t n = 0;
+    if (v_) check(mi_vec_len(v_, &n));
+    return n;
+  }
+  mi_vec *handle() const { return v_; }
+  mi_ctx *context() const { return ctx_; }
+
+  std::vector<double> to_host() const {
+    std::vector<double> h(size());
+    if (v_) check(mi_vec_download(v_, h.data(), h.size()));
+    return h;
+  }
+
+  // --- the Vector concept -----------------------------------------------------------------
+  double dot(const DeviceVector &o) const {  // Riemannian/Concepts.h:178
+    double out = 0;
+    check(mi_vec_dot(v_, o.v_, &out));
+    return out;
+  }
+  double squaredNorm() const { return dot(*this); }
+  double norm() const;
+  DeviceVector &operator+=(const DeviceVector &o) {
+    check(mi_vec_axpy(v_, 1.0, o.v_));
+    return *this;
+  }
+  DeviceVector &operator-=(const DeviceVector &o) {
+    check(mi_vec_axpy(v_, -1.0, o.v_));
+    return *this;
+  }
+  DeviceVector &operator*=(double a) {
+    check(mi_vec_scale(v_, a));
+    return *this;
+  }
+  DeviceVector &operator/=(double a) {  // `u /= beta` IterativeSolvers.h:653: true division
+    check(mi_vec_axpby(v_, 1.0 / a, v_, 0.0, v_));
+    return *this;
+  }
+  // z = a x + b y without temporaries
+  static DeviceVector axpby(double a, const DeviceVector &x, double b, const DeviceVector &y) {
+    DeviceVector z = like(x);
+    check(mi_vec_axpby(z.v_, a, x.v_, b, y.v_));
+    return z;
+  }
+  static DeviceVector like(const DeviceVector &x) {
+    DeviceVector z;
+    z.ctx_ = x.ctx_;
+    check(mi_vec_create(x.ctx_, x.size(), &z.v_));
+    return z;
+  }
+
+ private:
+  void release() {
+    if (v_ && !borrowed_) mi_vec_destroy(v_);
+    v_ = nullptr;
+    borrowed_ = false;
+  }
+  mi_ctx *ctx_ = nullptr;
+  mi_vec *v_ = nullptr;
+  bool borrowed_ = false;
+};
+
+inline DeviceVector operator*(double a, const DeviceVector &v) {  // `0 * g`, `alpha * p`
+  return DeviceVector::axpby(a, v, 0.0, v);
+}
+inline DeviceVector operator*(const DeviceVector &v, double a) { return a * v; }
+inline DeviceVector operator/(const DeviceVector &v, double a) {
+  DeviceVector z(v);
+  z /= a;
+  return z;
+}
+inline DeviceVector operator+(const DeviceVector &a, const DeviceVector &b) {
+  return DeviceVector::axpby(1.0, a, 1.0, b);
+}
+inline DeviceVector operator-(const DeviceVector &a, const DeviceVector &b) {
+  return DeviceVector::axpby(1.0, a, -1.0, b);
+}
+inline DeviceVector operator-(const DeviceVector &a) { return DeviceVector::axpby(-1.0, a, 0.0, a); }
+// rvalue overloads reuse the temporary's storage: `s + alpha * p`, `-v + beta * p`
+inline DeviceVector operator+(const DeviceVector &a, DeviceVector &&b) {
+  check(mi_vec_axpy(b.handle(), 1.0, a.handle()));
+  return std::move(b);
+}
+inline DeviceVector operator+(DeviceVector &&a, const DeviceVector &b) {
+  check(mi_vec_axpy(a.handle(), 1.0, b.handle()));
+  return std::move(a);
+}
+inline DeviceVector operator+(DeviceVector &&a, DeviceVector &&b) {
+  check(mi_vec_axpy(a.handle(), 1.0, b.handle()));
+  return std::move(a);
+}
+inline DeviceVector operator-(DeviceVector &&a) {
+  check(mi_vec_scale(a.handle(), -1.0));
+  return std::move(a);
+}
+inline double DeviceVector::norm() const { return std::sqrt(squaredNorm()); }
+
+template <typename T>
+struct is_device_vector : std::false_type {};
+template <>
+struct is_device_vector<DeviceVector> : std::true_type {};
+
+// ---------------------------------------------------------------------------------------------
+// tagged callables
+// ---------------------------------------------------------------------------------------------
+
+// metric(X, V1, V2) = <V1, V2>_F -- the embedded metric of Stiefel / product manifolds and the
+// coordinate metric of so(3)^N.  Put it into RiemannianMetric<DeviceVector, DeviceVector, double, ...>.
+struct FrobeniusMetric {
+  template <typename... A>
+  double operator()(const DeviceVector &, const DeviceVector &V1, const DeviceVector &V2, A &...) const {
+    return V1.dot(V2);
+  }
+};
+// inner_product(a, b) = <a, b>_F for LinearAlgebra::InnerProduct<DeviceVector, double, ...>
+struct FrobeniusInnerProduct {
+  template <typename... A>
+  double operator()(const DeviceVector &a, const DeviceVector &b, A &...) const {
+    return a.dot(b);
+  }
+};
+
+// LinearAlgebra::SymmetricLinearOperator<DeviceVector, ...> backed by an mi_op
+struct DeviceOperator {
+  mi_op *op = nullptr;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &v, A &...) const {
+    DeviceVector out = DeviceVector::like(v);
+    check(mi_op_apply(op, v.handle(), out.handle()));
+    return out;
+  }
+};
+// Riemannian::LinearOperator<DeviceVector, DeviceVector, ...> (the Hessian set by a QuadraticModel)
+// backed by an mi_op that is already bound to the base point X
+struct DeviceHessian {
+  mi_op *op = nullptr;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &, const DeviceVector &v, A &...) const {
+    DeviceVector out = DeviceVector::like(v);
+    check(mi_op_apply(op, v.handle(), out.handle()));
+    return out;
+  }
+};
+// Riemannian::LinearOperator used as TNT's `precon`, backed by an mi_precon bound to X
+struct DevicePreconditioner {
+  mi_precon *P = nullptr;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &, const DeviceVector &r, A &...) const {
+    DeviceVector out = DeviceVector::like(r);
+    check(mi_precon_apply(P, r.handle(), out.handle()));
+    return out;
+  }
+};
+// STPCGPreconditioner<DeviceVector, Multiplier, ...>: P(r) = (M^-1 r, Multiplier())
+template <typename Multiplier>
+struct DeviceSTPCGPreconditioner {
+  mi_precon *P = nullptr;
+  template <typename... A>
+  std::pair<DeviceVector, Multiplier> operator()(const DeviceVector &r, A &...) const {
+    DeviceVector out = DeviceVector::like(r);
+    check(mi_precon_apply(P, r.handle(), out.handle()));
+    return std::make_pair(std::move(out), Multiplier());
+  }
+};
+
+}  // namespace MI355
+}  // namespace Optimization

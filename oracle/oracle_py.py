@@ -109,6 +109,23 @@ class _Lib:
         self.tnt_fn.restype = C.c_int
         self.tnt_fn.argtypes = [C.POINTER(Problem), c_double_p, C.POINTER(TntParams),
                                 C.POINTER(TntResult)]
+        if hasattr(L, prefix + "_gd"):  # template drivers (oracle/template_driver.inc)
+            self.gd_fn = getattr(L, prefix + "_gd")
+            self.gd_fn.restype = C.c_int
+            self.gd_fn.argtypes = [C.POINTER(Problem), c_double_p, C.c_size_t, C.c_double, C.c_double,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_size_t, c_double_p,
+                                   c_double_p, c_double_p, c_int_p, c_size_p, C.c_size_t, c_double_p,
+                                   c_size_p]
+            self.lsqr_fn = getattr(L, prefix + "_lsqr_dense")
+            self.lsqr_fn.restype = C.c_int
+            self.lsqr_fn.argtypes = [C.c_size_t, C.c_size_t, c_double_p, c_double_p, C.c_size_t, C.c_double,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p,
+                                     c_size_p]
+            self.tnls_fn = getattr(L, prefix + "_tnls_sinfit")
+            self.tnls_fn.restype = C.c_int
+            self.tnls_fn.argtypes = [C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_size_t, c_double_p, c_double_p, c_double_p,
+                                     c_int_p, c_size_p, c_size_p]
         if with_problems:
             L.orc_tnt_default_params.argtypes = [C.POINTER(TntParams)]
             L.orc_problem_free.argtypes = [C.POINTER(Problem)]
@@ -216,6 +233,51 @@ class _Lib:
             gain_ratios=bufs["gain_ratios"][:no].copy(),
             calls=dict(f=p.n_f, grad=p.n_grad, hess=p.n_hess, metric=p.n_metric,
                        retract=p.n_retract, precon=p.n_precon))
+
+
+    # ---- template drivers: GradientDescent / LSQR / TNLS -------------------------------------
+    def gd(self, prob, x0, max_iterations=1000, gradient_tolerance=1e-6, relative_decrease_tolerance=1e-6,
+           stepsize_tolerance=1e-6, alpha=1.0, beta=.5, sigma=.5, max_ls_iterations=100, cap=4096):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        p = prob.contents
+        x = np.zeros(p.nvar)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, it = C.c_int(-1), C.c_size_t(0)
+        fv = np.zeros(cap)
+        ls = np.zeros(cap, dtype=np.uint64)
+        rc = self.gd_fn(prob, _dp(x0), max_iterations, gradient_tolerance, relative_decrease_tolerance,
+                        stepsize_tolerance, alpha, beta, sigma, max_ls_iterations, _dp(x), C.byref(f),
+                        C.byref(gn), C.byref(st), C.byref(it), cap, _dp(fv), ls.ctypes.data_as(c_size_p))
+        n = min(it.value, cap)
+        return dict(rc=rc, x=x, f=f.value, gradfx_norm=gn.value, status=st.value, iterations=it.value,
+                    objective_values=fv[:n].copy(), linesearch_iterations=ls[:n].astype(np.int64))
+
+    def lsqr_dense(self, A, b, max_iterations=1000, lam=0.0, btol=1e-6, Atol=1e-6, Acond_limit=1e8,
+                   Delta=None):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m, n = A.shape
+        if Delta is None:
+            Delta = float(np.sqrt(np.finfo(np.float64).max))
+        x = np.zeros(n)
+        xn, it = C.c_double(0), C.c_size_t(0)
+        rc = self.lsqr_fn(m, n, _dp(A), _dp(b), max_iterations, lam, btol, Atol, Acond_limit, Delta, _dp(x),
+                          C.byref(xn), C.byref(it))
+        return dict(rc=rc, x=x, xnorm=xn.value, iterations=it.value)
+
+    def tnls_sinfit(self, t, y, beta0, with_precon=False, root_tolerance=1e-6, gradient_tolerance=0.0,
+                    Delta_tolerance=0.0, max_iterations=100):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        b0 = np.ascontiguousarray(beta0, dtype=np.float64)
+        beta = np.zeros(2)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, outer, inner = C.c_int(-1), C.c_size_t(0), C.c_size_t(0)
+        rc = self.tnls_fn(t.size, _dp(t), _dp(y), _dp(b0), int(with_precon), root_tolerance,
+                          gradient_tolerance, Delta_tolerance, max_iterations, _dp(beta), C.byref(f),
+                          C.byref(gn), C.byref(st), C.byref(outer), C.byref(inner))
+        return dict(rc=rc, beta=beta, f=f.value, gradfx_norm=gn.value, status=st.value, outer=outer.value,
+                    inner_total=inner.value)
 
 
 def _seq_dot(a, b):
@@ -402,3 +464,15 @@ class Reference(_Lib):
 
 def have_reference():
     return os.path.exists(_REF)
+
+
+class TemplateHarness(_Lib):
+    """The MI355X build's own template layer instantiated on a host vector through the same driver
+    code as Reference (tests/cpp/libharness_host.so, entry points hz_*)."""
+
+    PATH = os.path.join(os.path.dirname(_HERE), "tests", "cpp", "libharness_host.so")
+
+    def __init__(self):
+        if not os.path.exists(self.PATH):
+            raise FileNotFoundError(self.PATH + " (run __graft_entry__.build())")
+        super().__init__(self.PATH, "hz", False)

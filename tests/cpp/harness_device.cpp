@@ -1,0 +1,258 @@
+// harness_device.cpp -- the drop-in template API exercised with Vector = MI355::DeviceVector, i.e.
+// the way a client of the reference would use the MI355X build: same function templates, same
+// std::function callables, vectors living in HBM.  Mirrors the reference's own unit tests
+// (tests/IterativeSolvers_unit_test.cpp STPCG cases, tests/TNT_unit_test.cpp sphere cases,
+// tests/GradientDescent_unit_test.cpp sphere case) plus the BASELINE cfg2 Stiefel problem.
+// Entry points hd_* are called from pytest (-m gpu) and compared with the oracle / golden fixtures.
+#include <cstring>
+#include <optional>
+#include <vector>
+
+#include "Optimization/LinearAlgebra/IterativeSolvers.h"
+#include "Optimization/MI355/Device.h"
+#include "Optimization/MI355/Stiefel.h"
+#include "Optimization/Riemannian/GradientDescent.h"
+#include "Optimization/Riemannian/TNT.h"
+#include "oracle.h"  // result / parameter structs only (plain data)
+
+using namespace Optimization;
+using MI355::Context;
+using MI355::DeviceVector;
+namespace LA = Optimization::LinearAlgebra;
+namespace RM = Optimization::Riemannian;
+
+static thread_local std::string g_msg;
+extern "C" const char *hd_last_error() { return g_msg.c_str(); }
+
+#define HD_GUARD_BEGIN try {
+#define HD_GUARD_END                         \
+  }                                          \
+  catch (const std::invalid_argument &e) {   \
+    g_msg = e.what();                        \
+    return -1;                               \
+  }                                          \
+  catch (const std::exception &e) {          \
+    g_msg = e.what();                        \
+    return -2;                               \
+  }                                          \
+  return 0;
+
+static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
+  tp.max_iterations = p->max_iterations;
+  tp.max_computation_time = p->max_computation_time;
+  tp.gradient_tolerance = p->gradient_tolerance;
+  tp.relative_decrease_tolerance = p->relative_decrease_tolerance;
+  tp.stepsize_tolerance = p->stepsize_tolerance;
+  tp.Delta0 = p->Delta0;
+  tp.eta1 = p->eta1;
+  tp.eta2 = p->eta2;
+  tp.alpha1 = p->alpha1;
+  tp.alpha2 = p->alpha2;
+  tp.max_TPCG_iterations = p->max_TPCG_iterations;
+  tp.kappa_fgr = p->kappa_fgr;
+  tp.theta = p->theta;
+  tp.preconditioned_gradient_tolerance = p->preconditioned_gradient_tolerance;
+  tp.Delta_tolerance = p->Delta_tolerance;
+}
+
+static void export_result(const RM::TNTResult<DeviceVector, double> &r, size_t accepted, orc_tnt_result *res) {
+  const std::vector<double> x = r.x.to_host();
+  std::memcpy(res->x, x.data(), x.size() * sizeof(double));
+  res->f = r.f;
+  res->gradfx_norm = r.gradfx_norm;
+  res->preconditioned_gradfx_norm = r.preconditioned_grad_f_x_norm;
+  res->status = static_cast<int>(r.status);
+  res->outer_iterations = r.inner_iterations.size();
+  res->n_trace = r.objective_values.size();
+  for (size_t i = 0; i < res->n_trace; ++i) {
+    res->objective_values[i] = r.objective_values[i];
+    res->gradient_norms[i] = r.gradient_norms[i];
+    res->preconditioned_gradient_norms[i] = r.preconditioned_gradient_norms[i];
+    res->trust_region_radius[i] = r.trust_region_radius[i];
+  }
+  for (size_t i = 0; i < res->outer_iterations; ++i) {
+    res->inner_iterations[i] = r.inner_iterations[i];
+    res->update_step_norms[i] = r.update_step_norms[i];
+    res->update_step_M_norms[i] = r.update_step_M_norms[i];
+    res->gain_ratios[i] = r.gain_ratios[i];
+  }
+  res->accepted = accepted;
+}
+
+// ------------------------------------------------------------------------------------------------
+// STPCG on a diagonal Hessian (tests/IterativeSolvers_unit_test.cpp:86-130,138-310).
+//   mode 0: tagged device callables -> fused HIP loop;  mode 1: plain lambdas -> generic loop whose
+//   every Vector operator runs on the GPU.  Multiplier = Vector as in the reference's tests.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_stpcg_diag(size_t n, const double *g, const double *D, const double *Minv, double Delta,
+                             size_t max_iterations, double kappa, double theta, int mode, double *s_out,
+                             double *M_norm, size_t *iterations) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  DeviceVector gd(ctx, g, n), Dd(ctx, D, n);
+  mi_op *op = nullptr;
+  MI355::check(mi_op_create_diag(ctx.get(), Dd.handle(), &op));
+  mi_precon *pc = nullptr;
+  std::optional<DeviceVector> Mi;
+  if (Minv) {
+    Mi = DeviceVector(ctx, Minv, n);
+    MI355::check(mi_precon_create_diag(ctx.get(), Mi->handle(), &pc));
+  }
+  LA::SymmetricLinearOperator<DeviceVector> H;
+  LA::InnerProduct<DeviceVector> ip;
+  std::optional<LA::STPCGPreconditioner<DeviceVector, DeviceVector>> P;
+  if (mode == 0) {
+    H = MI355::DeviceOperator{op};
+    ip = MI355::FrobeniusInnerProduct{};
+    if (pc) P = MI355::DeviceSTPCGPreconditioner<DeviceVector>{pc};
+  } else {
+    H = [op](const DeviceVector &v) { return MI355::DeviceOperator{op}(v); };
+    ip = [](const DeviceVector &a, const DeviceVector &b) { return a.dot(b); };
+    if (pc)
+      P = [pc](const DeviceVector &v) -> std::pair<DeviceVector, DeviceVector> {
+        return MI355::DeviceSTPCGPreconditioner<DeviceVector>{pc}(v);
+      };
+  }
+  double mn = 0;
+  size_t it = 0;
+  DeviceVector s = LA::STPCG<DeviceVector, DeviceVector>(gd, H, ip, mn, it, Delta, max_iterations, kappa, theta, P);
+  const std::vector<double> sh = s.to_host();
+  std::memcpy(s_out, sh.data(), n * sizeof(double));
+  *M_norm = mn;
+  *iterations = it;
+  mi_op_destroy(op);
+  if (pc) mi_precon_destroy(pc);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// TNT on St(n,p): f(X) = 1/2 tr(X'AX) (BASELINE cfg2).  mode 0: tagged callables (fused inner loop);
+// mode 1: the same callables hidden inside plain lambdas (generic path, all on the GPU).
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int32_t *col, const double *val,
+                              const double *X0, const orc_tnt_params *params, int mode, orc_tnt_result *res) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  MI355::StiefelRayleighQuotient prob(ctx, n, p, rowptr, col, val);
+  DeviceVector x0(ctx, X0, n * (size_t)p);
+  RM::TNTParams<double> tp;
+  fill_params(tp, params);
+  size_t accepted = 0;
+  std::optional<RM::TNTUserFunction<DeviceVector, DeviceVector>> uf =
+      [&](size_t, double, const DeviceVector &, double, const DeviceVector &,
+          const RM::LinearOperator<DeviceVector, DeviceVector> &, double, size_t, const DeviceVector &, double,
+          double, bool acc) {
+        accepted += acc;
+        return false;
+      };
+  Objective<DeviceVector> f = prob.objective();
+  RM::QuadraticModel<DeviceVector, DeviceVector> QM = prob.quadratic_model();
+  RM::RiemannianMetric<DeviceVector, DeviceVector> metric = prob.metric();
+  RM::Retraction<DeviceVector, DeviceVector> retract = prob.retraction();
+  if (mode == 1) {  // hide the tags
+    auto QMt = prob.quadratic_model();
+    QM = [QMt](const DeviceVector &X, DeviceVector &g, RM::LinearOperator<DeviceVector, DeviceVector> &Hs) {
+      RM::LinearOperator<DeviceVector, DeviceVector> tagged;
+      QMt(X, g, tagged);
+      Hs = [tagged](const DeviceVector &Y, const DeviceVector &V) { return tagged(Y, V); };
+    };
+    metric = [](const DeviceVector &, const DeviceVector &a, const DeviceVector &b) { return a.dot(b); };
+  }
+  RM::TNTResult<DeviceVector, double> r =
+      RM::TNT<DeviceVector, DeviceVector>(f, QM, metric, retract, x0,
+                                          std::optional<RM::LinearOperator<DeviceVector, DeviceVector>>(), tp, uf);
+  export_result(r, accepted, res);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's sphere problem (tests/TNT_unit_test.cpp:63-122) with DeviceVector and the
+// extra-argument pack Args = {DeviceVector} (the fixed point P), written with Vector operators only.
+// ------------------------------------------------------------------------------------------------
+namespace {
+DeviceVector sphere_project(const DeviceVector &X, const DeviceVector &V) { return V - X.dot(V) * X; }
+struct SphereProblem {
+  Objective<DeviceVector, double, DeviceVector> F;
+  RM::VectorField<DeviceVector, DeviceVector, DeviceVector> gradF;
+  RM::LinearOperatorConstructor<DeviceVector, DeviceVector, DeviceVector> HessCon;
+  RM::RiemannianMetric<DeviceVector, DeviceVector, double, DeviceVector> metric;
+  RM::Retraction<DeviceVector, DeviceVector, DeviceVector> retract;
+  RM::LinearOperator<DeviceVector, DeviceVector, DeviceVector> precon;
+  SphereProblem(const Context &ctx) {
+    F = [](const DeviceVector &X, DeviceVector &P) { return (X - P).squaredNorm(); };
+    gradF = [](const DeviceVector &X, DeviceVector &P) { return sphere_project(X, 2 * (X - P)); };
+    auto gradFc = gradF;
+    HessCon = [gradFc](const DeviceVector &, DeviceVector &) {
+      RM::LinearOperator<DeviceVector, DeviceVector, DeviceVector> Hs =
+          [gradFc](const DeviceVector &X, const DeviceVector &Xdot, DeviceVector &P) -> DeviceVector {
+        return sphere_project(X, 2 * Xdot) - X.dot(gradFc(X, P)) * Xdot;
+      };
+      return Hs;
+    };
+    metric = [](const DeviceVector &, const DeviceVector &a, const DeviceVector &b, DeviceVector &) {
+      return a.dot(b);
+    };
+    retract = [](const DeviceVector &X, const DeviceVector &V, DeviceVector &) {
+      DeviceVector Y = X + V;
+      return Y / Y.norm();
+    };
+    // preconditioner diag(1,2,3) (tests/TNT_unit_test.cpp:111-117) as a device operator
+    auto keep = std::make_shared<DeviceVector>(ctx, std::vector<double>{1.0, 2.0, 3.0});
+    mi_op *raw = nullptr;
+    MI355::check(mi_op_create_diag(ctx.get(), keep->handle(), &raw));
+    std::shared_ptr<mi_op> op2(raw, [](mi_op *o) { mi_op_destroy(o); });
+    precon = [keep, op2](const DeviceVector &, const DeviceVector &V, DeviceVector &) {
+      return MI355::DeviceOperator{op2.get()}(V);
+    };
+  }
+};
+}  // namespace
+
+extern "C" int hd_tnt_sphere(int with_precon, const double *x0, const orc_tnt_params *params,
+                             orc_tnt_result *res) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  SphereProblem sp(ctx);
+  DeviceVector P(ctx, std::vector<double>{0.0, 0.0, 1.0});
+  DeviceVector X0(ctx, x0, 3);
+  RM::TNTParams<double> tp;
+  fill_params(tp, params);
+  size_t accepted = 0;
+  std::optional<RM::TNTUserFunction<DeviceVector, DeviceVector, double, DeviceVector>> uf =
+      [&](size_t, double, const DeviceVector &, double, const DeviceVector &,
+          const RM::LinearOperator<DeviceVector, DeviceVector, DeviceVector> &, double, size_t,
+          const DeviceVector &, double, double, bool acc, DeviceVector &) {
+        accepted += acc;
+        return false;
+      };
+  std::optional<RM::LinearOperator<DeviceVector, DeviceVector, DeviceVector>> pc;
+  if (with_precon) pc = sp.precon;
+  RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector, double, DeviceVector>(
+      sp.F, sp.gradF, sp.HessCon, sp.metric, sp.retract, X0, P, pc, tp, uf);
+  export_result(r, accepted, res);
+  HD_GUARD_END
+}
+
+// RiemannianGradientDescentSphere (tests/GradientDescent_unit_test.cpp:76-130) on the device
+extern "C" int hd_gd_sphere(const double *x0, double *x_out, double *f_out, double *gradnorm_out,
+                            int *status_out, size_t *iterations_out) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  SphereProblem sp(ctx);
+  DeviceVector P(ctx, std::vector<double>{0.0, 0.0, 1.0});
+  DeviceVector X0(ctx, x0, 3);
+  RM::GradientDescentParams<double> gp;
+  gp.gradient_tolerance = 1e-6;
+  gp.relative_decrease_tolerance = 0;
+  gp.stepsize_tolerance = 0;
+  gp.max_iterations = 1000000;
+  RM::GradientDescentResult<DeviceVector, double> r = RM::GradientDescent<DeviceVector, DeviceVector, double, DeviceVector>(
+      sp.F, sp.gradF, sp.metric, sp.retract, X0, P, gp);
+  const std::vector<double> x = r.x.to_host();
+  std::memcpy(x_out, x.data(), 3 * sizeof(double));
+  *f_out = r.f;
+  *gradnorm_out = r.gradfx_norm;
+  *status_out = static_cast<int>(r.status);
+  *iterations_out = r.linesearch_iterations.size();
+  HD_GUARD_END
+}

@@ -1,0 +1,104 @@
+"""ctypes access to tests/cpp/libharness_device.so: the drop-in C++ template API exercised with
+MI355::DeviceVector (built by optimization_amd.build.build_harness())."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_py as op
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "cpp", "libharness_device.so")
+
+dp = C.POINTER(C.c_double)
+sp = C.POINTER(C.c_size_t)
+ip32 = C.POINTER(C.c_int32)
+
+
+def _dp(a):
+    return a.ctypes.data_as(dp)
+
+
+class DeviceHarness:
+    def __init__(self):
+        if not os.path.exists(PATH):
+            raise FileNotFoundError(PATH + " (run __graft_entry__.build())")
+        L = self.L = C.CDLL(PATH)
+        L.hd_last_error.restype = C.c_char_p
+        L.hd_stpcg_diag.restype = C.c_int
+        L.hd_stpcg_diag.argtypes = [C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t, C.c_double, C.c_double,
+                                    C.c_int, dp, dp, sp]
+        L.hd_tnt_stiefel.restype = C.c_int
+        L.hd_tnt_stiefel.argtypes = [C.c_size_t, C.c_int, ip32, ip32, dp, dp, C.POINTER(op.TntParams), C.c_int,
+                                     C.POINTER(op.TntResult)]
+        L.hd_tnt_sphere.restype = C.c_int
+        L.hd_tnt_sphere.argtypes = [C.c_int, dp, C.POINTER(op.TntParams), C.POINTER(op.TntResult)]
+        L.hd_gd_sphere.restype = C.c_int
+        L.hd_gd_sphere.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_int), sp]
+
+    def err(self):
+        return self.L.hd_last_error().decode()
+
+    def stpcg_diag(self, g, D, Minv, Delta, max_iterations, kappa, theta, mode):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        Mi = np.ascontiguousarray(Minv, dtype=np.float64) if Minv is not None else None
+        s = np.zeros(g.size)
+        mn, it = C.c_double(0), C.c_size_t(0)
+        rc = self.L.hd_stpcg_diag(g.size, _dp(g), _dp(D), _dp(Mi) if Mi is not None else None, Delta,
+                                  max_iterations, kappa, theta, mode, _dp(s), C.byref(mn), C.byref(it))
+        return dict(rc=rc, s=s, M_norm=mn.value, iterations=it.value, err=self.err() if rc else "")
+
+    @staticmethod
+    def _result_buffers(nvar, params):
+        cap = params.max_iterations + 2
+        bufs = dict(x=np.zeros(nvar), objective_values=np.zeros(cap), gradient_norms=np.zeros(cap),
+                    preconditioned_gradient_norms=np.zeros(cap), trust_region_radius=np.zeros(cap),
+                    inner_iterations=np.zeros(cap, dtype=np.uint64), update_step_norms=np.zeros(cap),
+                    update_step_M_norms=np.zeros(cap), gain_ratios=np.zeros(cap))
+        res = op.TntResult()
+        res.x = _dp(bufs["x"])
+        for k in ("objective_values", "gradient_norms", "preconditioned_gradient_norms", "trust_region_radius",
+                  "update_step_norms", "update_step_M_norms", "gain_ratios"):
+            setattr(res, k, _dp(bufs[k]))
+        res.inner_iterations = bufs["inner_iterations"].ctypes.data_as(sp)
+        return bufs, res
+
+    @staticmethod
+    def _unpack(rc, bufs, res, err):
+        if rc:
+            return dict(rc=rc, err=err)
+        nt, no = res.n_trace, res.outer_iterations
+        return dict(rc=0, x=bufs["x"], f=res.f, gradfx_norm=res.gradfx_norm, status=res.status,
+                    outer_iterations=no, accepted=res.accepted,
+                    objective_values=bufs["objective_values"][:nt].copy(),
+                    gradient_norms=bufs["gradient_norms"][:nt].copy(),
+                    trust_region_radius=bufs["trust_region_radius"][:nt].copy(),
+                    inner_iterations=bufs["inner_iterations"][:no].astype(np.int64),
+                    update_step_norms=bufs["update_step_norms"][:no].copy(),
+                    update_step_M_norms=bufs["update_step_M_norms"][:no].copy(),
+                    gain_ratios=bufs["gain_ratios"][:no].copy())
+
+    def tnt_stiefel(self, n, p, rowptr, col, val, X0, params, mode=0):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        X0 = np.ascontiguousarray(X0, dtype=np.float64).ravel()
+        bufs, res = self._result_buffers(n * p, params)
+        rc = self.L.hd_tnt_stiefel(n, p, rowptr.ctypes.data_as(ip32), col.ctypes.data_as(ip32), _dp(val), _dp(X0),
+                                   C.byref(params), mode, C.byref(res))
+        return self._unpack(rc, bufs, res, self.err() if rc else "")
+
+    def tnt_sphere(self, with_precon, x0, params):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        bufs, res = self._result_buffers(3, params)
+        rc = self.L.hd_tnt_sphere(int(with_precon), _dp(x0), C.byref(params), C.byref(res))
+        return self._unpack(rc, bufs, res, self.err() if rc else "")
+
+    def gd_sphere(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x = np.zeros(3)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, it = C.c_int(-1), C.c_size_t(0)
+        rc = self.L.hd_gd_sphere(_dp(x0), _dp(x), C.byref(f), C.byref(gn), C.byref(st), C.byref(it))
+        return dict(rc=rc, x=x, f=f.value, gradfx_norm=gn.value, status=st.value, iterations=it.value)
