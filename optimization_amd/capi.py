@@ -334,6 +334,9 @@ class Context:
     def stiefel_rq(self, A, n, p):
         return StiefelRQ(self, A, n, p)
 
+    def so3n(self, N, ei, ej, Rt, w):
+        return So3N(self, N, ei, ej, Rt, w)
+
     # comm -------------------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = (C.c_ubyte * 128)()
@@ -461,6 +464,57 @@ class Precon:
         try:
             if self.h and self.ctx.h:
                 self.L.mi_precon_destroy(self.h)
+        except Exception:  # noqa
+            pass
+
+
+class _BorrowedPrecon(Precon):
+    """A preconditioner owned by a problem object (never destroyed from Python)."""
+
+    def __del__(self):
+        pass
+
+
+class So3N:
+    """Chordal rotation averaging on SO(3)^N (mi_so3n_*)."""
+
+    def __init__(self, ctx, N, ei, ej, Rt, w):
+        self.ctx, self.L, self.N = ctx, ctx.L, N
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        ej = np.ascontiguousarray(ej, dtype=np.int32)
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self.E = ei.size
+        self.h = vp()
+        check(self.L.mi_so3n_create(ctx.h, N, ei.size, ei.ctypes.data_as(c_int32_p),
+                                    ej.ctypes.data_as(c_int32_p), _dp(Rt), _dp(w), C.byref(self.h)))
+
+    def objective(self, R):
+        f = C.c_double(0)
+        check(self.L.mi_so3n_objective(self.h, R.h, C.byref(f)))
+        return f.value
+
+    def model(self, R, with_precon=True):
+        """returns (grad Vec, Hessian Op, block-Jacobi Precon or None), all bound to R"""
+        g = Vec(self.ctx, 3 * self.N)
+        hop, pc = vp(), vp()
+        check(self.L.mi_so3n_model(self.h, R.h, g.h, C.byref(hop), C.byref(pc) if with_precon else None))
+        P = None
+        if with_precon:
+            P = Precon.__new__(Precon)
+            P.ctx, P.L, P.h, P.keep = self.ctx, self.L, pc, [self, R]
+            P.__class__ = _BorrowedPrecon
+        return g, Op(self.ctx, hop, keep=[self, R], borrowed=True), P
+
+    def retract(self, R, xi):
+        Y = Vec(self.ctx, 9 * self.N)
+        check(self.L.mi_so3n_retract(self.h, R.h, xi.h, Y.h))
+        return Y
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.L.mi_so3n_destroy(self.h)
         except Exception:  # noqa
             pass
 

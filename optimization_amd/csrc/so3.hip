@@ -1,0 +1,427 @@
+// so3.hip -- chordal rotation averaging on SO(3)^N (BASELINE cfg3):
+//     f(R) = 1/2 sum_e w_e | R_j - R_i Rt_e |_F^2 ,  e = (i -> j)
+// as device callables for TNT (Objective, QuadraticModel, Retraction; metric = coordinate dot).
+// The reference has no manifold code beyond S^2 (tests/TNT_unit_test.cpp:73-117); problem definition
+// and formulas are shared with the CPU oracle (oracle/problems.c, "SO(3)^N"):
+//     tangent at R_i: R_i hat(xi_i), xi in R^3;  grad_i = vee(Q_i - Q_i'),  Q_i = R_i' (L R)_i
+//     Hess[xi]_i = vee(T_i - T_i'),  T_i = R_i' (L V)_i - hat(xi_i) sym(Q_i),  V_i = R_i hat(xi_i)
+// with L the connection Laplacian.  Hess is LINEAR in xi with 3x3 blocks, so the quadratic model is
+// assembled ONCE per outer iteration as a symmetric 3x3-block sparse matrix
+//     h_i = D_i xi_i - sum_{inc (i,j)} w B_ij xi_j ,   D_i = 2 degw_i I - (tr(C_i) I - C_i),  C_i = sym(Q_i)
+// and every STPCG pass is ONE kernel: block-ELL SpMV fused with the three curvature inner products
+// <xi,h>, <h,h>, <xi,xi> (IterativeSolvers.h:300,305-306).  D_i^-1 is the 3x3 block-Jacobi
+// preconditioner (fused into k_cg_update, PRE_BLOCK3).
+//
+// Layout: incidences in sliced-ELL-64 over nodes; block component c of entry (slice s, k, lane) at
+// ((slice_ptr[s] + k) * 9 + c) * 64 + lane  => each of the 9 component streams is coalesced.
+// Algorithmic bytes per HVP: 72 (nnzb + N) + 4 nnzb + 8 (3N read + 3N written)  [nnzb = incidences].
+#include <algorithm>
+
+#include "mi_internal.h"
+
+using namespace mi;
+
+namespace {
+
+struct IncView {
+  size_t N, nslices;
+  const long long *__restrict__ slice_ptr;
+  const int *__restrict__ nbr;    // neighbour node j (padding: own node)
+  const int *__restrict__ edge;   // edge id (padding: -1)
+  const signed char *__restrict__ dir;  // +1: this node is the head j of e=(i->j), uses Rt; -1: tail, uses Rt'
+};
+
+__device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void mat3_mul_at(const double *A, const double *B, double *C) {  // A' B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+__device__ __forceinline__ void vee_skew2(const double *T, double *o) {
+  o[0] = T[7] - T[5];
+  o[1] = T[2] - T[6];
+  o[2] = T[3] - T[1];
+}
+// M = Q hat(e_m) : column operations on Q (hat(e_m) has two non-zeros)
+__device__ __forceinline__ void q_hat_basis(const double *Q, int m, double *M) {
+  // hat(e0) = [0 0 0; 0 0 -1; 0 1 0], hat(e1) = [0 0 1; 0 0 0; -1 0 0], hat(e2) = [0 -1 0; 1 0 0; 0 0 0]
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double q0 = Q[r * 3], q1 = Q[r * 3 + 1], q2 = Q[r * 3 + 2];
+    if (m == 0) { M[r * 3] = 0; M[r * 3 + 1] = q2; M[r * 3 + 2] = -q1; }
+    else if (m == 1) { M[r * 3] = -q2; M[r * 3 + 1] = 0; M[r * 3 + 2] = q0; }
+    else { M[r * 3] = q1; M[r * 3 + 1] = -q0; M[r * 3 + 2] = 0; }
+  }
+}
+
+// One thread per node: gradient, C_i, D_i, D_i^-1, and the off-diagonal blocks w B_ij of the Hessian.
+__global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
+                                                   const double *__restrict__ Rt, const double *__restrict__ w,
+                                                   double *__restrict__ grad, double *__restrict__ Dblk,
+                                                   double *__restrict__ Dinv, double *__restrict__ Bblk) {
+  const int lane = threadIdx.x & 63;
+  const size_t slice = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slice >= inc.nslices) return;
+  const size_t i = slice * 64 + lane;
+  const bool live = i < inc.N;
+  double Ri[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Ri[c] = live ? R[9 * i + c] : (c % 4 == 0 ? 1.0 : 0.0);
+  double EG[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double degw = 0;
+  const long long b0 = inc.slice_ptr[slice], b1 = inc.slice_ptr[slice + 1];
+  for (long long k = b0; k < b1; ++k) {
+    const size_t e0 = (size_t)k * 64 + lane;
+    const int eid = inc.edge[e0];
+    double Bk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live && eid >= 0) {
+      const size_t j = (size_t)inc.nbr[e0];
+      const double we = w[eid];
+      double S[9], Rj[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
+      if (inc.dir[e0] > 0) {  // this node is the head: term R_i - R_j Rt  (j = tail)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] = Rt[9 * (size_t)eid + c];
+      } else {                // this node is the tail: term R_i - R_j Rt'
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) S[r * 3 + c] = Rt[9 * (size_t)eid + c * 3 + r];
+      }
+      double RjS[9];
+      mat3_mul(Rj, S, RjS);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) EG[c] += we * (Ri[c] - RjS[c]);
+      degw += we;
+      double Q[9];
+      mat3_mul_at(Ri, Rj, Q);  // R_i' R_j
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double M[9], MS[9], col[3];
+        q_hat_basis(Q, m, M);
+        mat3_mul(M, S, MS);
+        vee_skew2(MS, col);
+        Bk[0 * 3 + m] = we * col[0];
+        Bk[1 * 3 + m] = we * col[1];
+        Bk[2 * 3 + m] = we * col[2];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Bblk[((size_t)k * 9 + c) * 64 + lane] = Bk[c];
+  }
+  if (!live) return;
+  double Q[9], C[9];
+  mat3_mul_at(Ri, EG, Q);
+  vee_skew2(Q, grad + 3 * i);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) C[a * 3 + b] = .5 * (Q[a * 3 + b] + Q[b * 3 + a]);
+  const double tr = C[0] + C[4] + C[8], d = 2 * degw - tr;
+  const double a = d + C[0], b = C[1], c = C[2], e = d + C[4], f = C[5], g = d + C[8];
+  double *D = Dblk + 9 * i;
+  D[0] = a; D[1] = b; D[2] = c; D[3] = b; D[4] = e; D[5] = f; D[6] = c; D[7] = f; D[8] = g;
+  const double c00 = e * g - f * f, c01 = c * f - b * g, c02 = b * f - c * e;
+  const double c11 = a * g - c * c, c12 = b * c - a * f, c22 = a * e - b * b;
+  const double det = a * c00 + b * c01 + c * c02;
+  double *Di = Dinv + 9 * i;
+  Di[0] = c00 / det; Di[1] = c01 / det; Di[2] = c02 / det;
+  Di[3] = c01 / det; Di[4] = c11 / det; Di[5] = c12 / det;
+  Di[6] = c02 / det; Di[7] = c12 / det; Di[8] = c22 / det;
+}
+
+// h = D xi - sum B_ij xi_j, fused with the three curvature dots (one 256-thread workgroup = 4 slices)
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_bsr3_spmv(IncView inc, const CgState *__restrict__ st,
+                                                      const double *__restrict__ Dblk,
+                                                      const double *__restrict__ Bblk,
+                                                      const double *__restrict__ xi, double *__restrict__ h,
+                                                      double *__restrict__ partials) {
+  __shared__ double lds[3 * kWaves];
+  if (st && st->mode != CG_RUN) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double a[3] = {0, 0, 0};
+  const size_t ngroups = (inc.nslices + kWaves - 1) / kWaves;
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t g0 = (ngroups * lb) / nb, g1 = (ngroups * (lb + 1)) / nb;
+  for (size_t g = g0; g < g1; ++g) {
+    const size_t slice = g * kWaves + w;
+    if (slice >= inc.nslices) continue;
+    const size_t i = slice * 64 + lane;
+    if (i >= inc.N) continue;
+    const double x0 = xi[3 * i], x1 = xi[3 * i + 1], x2 = xi[3 * i + 2];
+    const double *D = Dblk + 9 * i;
+    double h0 = D[0] * x0 + D[1] * x1 + D[2] * x2;
+    double h1 = D[3] * x0 + D[4] * x1 + D[5] * x2;
+    double h2 = D[6] * x0 + D[7] * x1 + D[8] * x2;
+    const long long b0 = inc.slice_ptr[slice], b1 = inc.slice_ptr[slice + 1];
+    for (long long k = b0; k < b1; ++k) {
+      const size_t e0 = (size_t)k * 64 + lane;
+      const size_t j = (size_t)inc.nbr[e0];
+      const double y0 = xi[3 * j], y1 = xi[3 * j + 1], y2 = xi[3 * j + 2];
+      const double *B = Bblk + (size_t)k * 9 * 64 + lane;
+      h0 -= B[0] * y0 + B[64] * y1 + B[128] * y2;
+      h1 -= B[192] * y0 + B[256] * y1 + B[320] * y2;
+      h2 -= B[384] * y0 + B[448] * y1 + B[512] * y2;
+    }
+    h[3 * i] = h0; h[3 * i + 1] = h1; h[3 * i + 2] = h2;
+    if (DOTS) {
+      a[0] += x0 * h0; a[0] += x1 * h1; a[0] += x2 * h2;
+      a[1] += h0 * h0; a[1] += h1 * h1; a[1] += h2 * h2;
+      a[2] += x0 * x0; a[2] += x1 * x1; a[2] += x2 * x2;
+    }
+  }
+  if (DOTS) block_partials_store<3>(a, lds, partials);
+}
+
+// partial rows of sum_e w |R_j - R_i Rt|^2 (one thread per edge)
+__global__ __launch_bounds__(kBlock) void k_so3_objective(size_t E, const int *__restrict__ ei,
+                                                          const int *__restrict__ ej,
+                                                          const double *__restrict__ Rt,
+                                                          const double *__restrict__ w,
+                                                          const double *__restrict__ R,
+                                                          double *__restrict__ partials) {
+  __shared__ double lds[kWaves];
+  double acc[1] = {0};
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
+    const size_t i = (size_t)ei[e], j = (size_t)ej[e];
+    double Ri[9], S[9], T[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { Ri[c] = R[9 * i + c]; S[c] = Rt[9 * e + c]; }
+    mat3_mul(Ri, S, T);
+    double q = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double d = R[9 * j + c] - T[c];
+      q += d * d;
+    }
+    acc[0] += w[e] * q;
+  }
+  block_partials_store<1>(acc, lds, partials);
+}
+
+// Y_i = R_i exp(hat(xi_i))  (Rodrigues; same series switch as oracle/problems.c: orc_so3_exp)
+__global__ __launch_bounds__(kBlock) void k_so3_retract(size_t N, const double *__restrict__ R,
+                                                        const double *__restrict__ xi, double *__restrict__ Y) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+    const double x0 = xi[3 * i], x1 = xi[3 * i + 1], x2 = xi[3 * i + 2];
+    const double th2 = x0 * x0 + x1 * x1 + x2 * x2, th = sqrt(th2);
+    double a, b;
+    if (th < 1e-4) {
+      a = 1 - th2 / 6 + th2 * th2 / 120;
+      b = .5 - th2 / 24 + th2 * th2 / 720;
+    } else {
+      a = sin(th) / th;
+      b = (1 - cos(th)) / th2;
+    }
+    const double K[9] = {0, -x2, x1, x2, 0, -x0, -x1, x0, 0};
+    double K2[9], Ex[9], Ri[9], Yi[9];
+    mat3_mul(K, K, K2);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ex[c] = a * K[c] + b * K2[c];
+    Ex[0] += 1; Ex[4] += 1; Ex[8] += 1;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ri[c] = R[9 * i + c];
+    mat3_mul(Ri, Ex, Yi);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Y[9 * i + c] = Yi[c];
+  }
+}
+
+int upload(void **dst, const void *src, size_t bytes) {
+  MI_HIP(hipMalloc(dst, bytes ? bytes : 8));
+  if (bytes) MI_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return MI_OK;
+}
+
+}  // namespace
+
+struct mi_so3n {
+  mi_ctx *ctx = nullptr;
+  size_t N = 0, E = 0, nslices = 0, nnzb = 0, padded = 0;
+  int *ei = nullptr, *ej = nullptr;
+  double *Rt = nullptr, *w = nullptr;
+  long long *slice_ptr = nullptr;
+  int *nbr = nullptr, *edge = nullptr;
+  signed char *dir = nullptr;
+  mi_vec *Dblk = nullptr, *Dinv = nullptr;  // 9N each
+  double *Bblk = nullptr;                   // padded * 9
+  mi_op hess;
+  mi_precon bj;
+};
+
+namespace {
+
+IncView view(const mi_so3n *q) { return IncView{q->N, q->nslices, q->slice_ptr, q->nbr, q->edge, q->dir}; }
+
+int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int *nparts) {
+  mi_so3n *q = (mi_so3n *)self->impl;
+  mi_ctx *ctx = q->ctx;
+  const size_t ngroups = (q->nslices + kWaves - 1) / kWaves;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>(ngroups, kMaxGrid));
+  KScope ks(ctx, MI_K_BSR3_SPMV_DOTS);
+  if (dots)
+    hipLaunchKernelGGL(k_bsr3_spmv<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), ctx->cg_live,
+                       (const double *)q->Dblk->d, (const double *)q->Bblk, (const double *)in->d, out->d,
+                       ctx->partials);
+  else
+    hipLaunchKernelGGL(k_bsr3_spmv<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q),
+                       (const CgState *)nullptr, (const double *)q->Dblk->d, (const double *)q->Bblk,
+                       (const double *)in->d, out->d, (double *)nullptr);
+  if (nparts) *nparts = grid;
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+int so3_apply(mi_op *self, const mi_vec *in, mi_vec *out) { return so3_apply_common(self, in, out, false, nullptr); }
+int so3_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *np) {
+  return so3_apply_common(self, in, out, true, np);
+}
+int so3_bj_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
+  mi_precon *tmp = nullptr;
+  MI_TRY(mi_precon_create_block3(self->ctx, ((mi_so3n *)self->impl)->Dinv, &tmp));
+  const int s = mi_precon_apply(tmp, r, v);
+  mi_precon_destroy(tmp);
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int32_t *ej, const double *Rt,
+                   const double *w, mi_so3n **out) {
+  MI_REQUIRE(ctx && out && (E == 0 || (ei && ej && Rt && w)), "null argument");
+  MI_REQUIRE(N > 0 && N < (size_t)INT32_MAX, "bad number of rotations");
+  for (size_t e = 0; e < E; ++e)
+    MI_REQUIRE(ei[e] >= 0 && (size_t)ei[e] < N && ej[e] >= 0 && (size_t)ej[e] < N && ei[e] != ej[e],
+               "edge %zu has invalid endpoints", e);
+  // incidence lists: node -> (neighbour, edge, direction), in edge order
+  std::vector<std::vector<int>> lists(N);
+  for (size_t e = 0; e < E; ++e) {
+    lists[(size_t)ej[e]].push_back((int)e + 1);      // head: +(e+1)
+    lists[(size_t)ei[e]].push_back(-((int)e + 1));   // tail: -(e+1)
+  }
+  const size_t nslices = (N + 63) / 64;
+  std::vector<long long> sp(nslices + 1, 0);
+  for (size_t s = 0; s < nslices; ++s) {
+    size_t wmax = 0;
+    for (size_t i = s * 64; i < std::min(N, (s + 1) * 64); ++i) wmax = std::max(wmax, lists[i].size());
+    sp[s + 1] = sp[s] + (long long)wmax;
+  }
+  const size_t padded = (size_t)sp[nslices] * 64;
+  std::vector<int> nbr(padded), edge(padded, -1);
+  std::vector<signed char> dir(padded, 0);
+  size_t nnzb = 0;
+  for (size_t s = 0; s < nslices; ++s)
+    for (int lane = 0; lane < 64; ++lane) {
+      const size_t i = s * 64 + lane;
+      for (long long k = 0; k < sp[s + 1] - sp[s]; ++k) {
+        const size_t e0 = (size_t)(sp[s] + k) * 64 + lane;
+        nbr[e0] = (int)std::min(i, N - 1);
+        if (i < N && (size_t)k < lists[i].size()) {
+          const int code = lists[i][(size_t)k];
+          const int e = std::abs(code) - 1;
+          edge[e0] = e;
+          dir[e0] = code > 0 ? 1 : -1;
+          nbr[e0] = code > 0 ? ei[e] : ej[e];
+          ++nnzb;
+        }
+      }
+    }
+  mi_so3n *q = new mi_so3n();
+  q->ctx = ctx;
+  q->N = N;
+  q->E = E;
+  q->nslices = nslices;
+  q->nnzb = nnzb;
+  q->padded = padded;
+  MI_TRY(upload((void **)&q->ei, ei, E * sizeof(int)));
+  MI_TRY(upload((void **)&q->ej, ej, E * sizeof(int)));
+  MI_TRY(upload((void **)&q->Rt, Rt, 9 * E * sizeof(double)));
+  MI_TRY(upload((void **)&q->w, w, E * sizeof(double)));
+  MI_TRY(upload((void **)&q->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
+  MI_TRY(upload((void **)&q->nbr, nbr.data(), padded * sizeof(int)));
+  MI_TRY(upload((void **)&q->edge, edge.data(), padded * sizeof(int)));
+  MI_TRY(upload((void **)&q->dir, dir.data(), padded * sizeof(signed char)));
+  MI_HIP(hipMalloc((void **)&q->Bblk, std::max<size_t>(1, padded * 9) * sizeof(double)));
+  MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dblk));
+  MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dinv));
+  q->hess.ctx = ctx;
+  q->hess.n = 3 * N;
+  q->hess.apply = so3_apply;
+  q->hess.apply_dots = so3_apply_dots;
+  q->hess.impl = q;
+  q->hess.borrowed = true;
+  q->bj.ctx = ctx;
+  q->bj.n = 3 * N;
+  q->bj.kind = 2;  // fusable 3x3 block-Jacobi: data = inverse blocks
+  q->bj.data = q->Dinv->d;
+  q->bj.apply = so3_bj_apply;
+  q->bj.impl = q;
+  q->bj.borrowed = true;
+  *out = q;
+  return MI_OK;
+}
+
+int mi_so3n_destroy(mi_so3n *q) {
+  if (!q) return MI_OK;
+  (void)hipStreamSynchronize(q->ctx->stream);
+  (void)hipFree(q->ei); (void)hipFree(q->ej); (void)hipFree(q->Rt); (void)hipFree(q->w);
+  (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr); (void)hipFree(q->edge); (void)hipFree(q->dir);
+  (void)hipFree(q->Bblk);
+  mi_vec_destroy(q->Dblk);
+  mi_vec_destroy(q->Dinv);
+  delete q;
+  return MI_OK;
+}
+
+int mi_so3n_objective(mi_so3n *q, const mi_vec *R, double *f) {
+  MI_REQUIRE(q && R && f, "null argument");
+  MI_REQUIRE(R->ctx == q->ctx && R->n == 9 * q->N, "R must hold N row-major 3x3 blocks");
+  mi_ctx *ctx = q->ctx;
+  const int grid = grid_for(q->E, 1);
+  hipLaunchKernelGGL(k_so3_objective, dim3(grid), dim3(kBlock), 0, ctx->stream, q->E, (const int *)q->ei,
+                     (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R->d,
+                     ctx->partials2);
+  double *slots = ctx->scalars + SLOT_MISC;
+  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, 1, slots));
+  MI_TRY(comm_allreduce(ctx, slots, 1));
+  double s = 0;
+  MI_TRY(read_slots_sync(ctx, SLOT_MISC, 1, &s));
+  *f = .5 * s;
+  return MI_OK;
+}
+
+int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_precon **block_jacobi) {
+  MI_REQUIRE(q && R && grad, "null argument");
+  MI_REQUIRE(R->ctx == q->ctx && R->n == 9 * q->N, "R must hold N row-major 3x3 blocks");
+  MI_REQUIRE(grad->n == 3 * q->N, "gradient must hold 3N doubles");
+  mi_ctx *ctx = q->ctx;
+  const int grid = (int)((q->nslices + 3) / 4);
+  hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
+                     (const double *)q->Rt, (const double *)q->w, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk);
+  MI_HIP(hipGetLastError());
+  if (hess) *hess = &q->hess;
+  if (block_jacobi) *block_jacobi = &q->bj;
+  return MI_OK;
+}
+
+int mi_so3n_retract(mi_so3n *q, const mi_vec *R, const mi_vec *xi, mi_vec *Y) {
+  MI_REQUIRE(q && R && xi && Y, "null argument");
+  MI_REQUIRE(R->n == 9 * q->N && Y->n == 9 * q->N && xi->n == 3 * q->N, "dimension mismatch");
+  hipLaunchKernelGGL(k_so3_retract, dim3(grid_for(q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
+                     (const double *)R->d, (const double *)xi->d, Y->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+}  // extern "C"

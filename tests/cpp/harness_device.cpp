@@ -10,6 +10,7 @@
 
 #include "Optimization/LinearAlgebra/IterativeSolvers.h"
 #include "Optimization/MI355/Device.h"
+#include "Optimization/MI355/SO3.h"
 #include "Optimization/MI355/Stiefel.h"
 #include "Optimization/Riemannian/GradientDescent.h"
 #include "Optimization/Riemannian/TNT.h"
@@ -161,6 +162,34 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
   RM::TNTResult<DeviceVector, double> r =
       RM::TNT<DeviceVector, DeviceVector>(f, QM, metric, retract, x0,
                                           std::optional<RM::LinearOperator<DeviceVector, DeviceVector>>(), tp, uf);
+  export_result(r, accepted, res);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// TNT on SO(3)^N chordal rotation averaging (BASELINE cfg3), optional 3x3 block-Jacobi preconditioner.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_tnt_so3n(size_t N, size_t E, const int32_t *ei, const int32_t *ej, const double *Rt,
+                           const double *w, const double *R0, const orc_tnt_params *params, int with_precon,
+                           orc_tnt_result *res) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  MI355::RotationAveraging prob(ctx, N, E, ei, ej, Rt, w);
+  DeviceVector x0(ctx, R0, 9 * N);
+  RM::TNTParams<double> tp;
+  fill_params(tp, params);
+  size_t accepted = 0;
+  std::optional<RM::TNTUserFunction<DeviceVector, DeviceVector>> uf =
+      [&](size_t, double, const DeviceVector &, double, const DeviceVector &,
+          const RM::LinearOperator<DeviceVector, DeviceVector> &, double, size_t, const DeviceVector &, double,
+          double, bool acc) {
+        accepted += acc;
+        return false;
+      };
+  std::optional<RM::LinearOperator<DeviceVector, DeviceVector>> pc;
+  if (with_precon) pc = prob.preconditioner();
+  RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector>(
+      prob.objective(), prob.quadratic_model(), prob.metric(), prob.retraction(), x0, pc, tp, uf);
   export_result(r, accepted, res);
   HD_GUARD_END
 }

@@ -89,6 +89,20 @@ class DeviceHarness:
                                    C.byref(params), mode, C.byref(res))
         return self._unpack(rc, bufs, res, self.err() if rc else "")
 
+    def tnt_so3n(self, N, ei, ej, Rt, w, R0, params, with_precon):
+        ei = np.ascontiguousarray(ei, dtype=np.int32)
+        ej = np.ascontiguousarray(ej, dtype=np.int32)
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64)
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        R0 = np.ascontiguousarray(R0, dtype=np.float64).ravel()
+        self.L.hd_tnt_so3n.restype = C.c_int
+        self.L.hd_tnt_so3n.argtypes = [C.c_size_t, C.c_size_t, ip32, ip32, dp, dp, dp, C.POINTER(op.TntParams),
+                                       C.c_int, C.POINTER(op.TntResult)]
+        bufs, res = self._result_buffers(9 * N, params)
+        rc = self.L.hd_tnt_so3n(N, ei.size, ei.ctypes.data_as(ip32), ej.ctypes.data_as(ip32), _dp(Rt), _dp(w),
+                                _dp(R0), C.byref(params), int(with_precon), C.byref(res))
+        return self._unpack(rc, bufs, res, self.err() if rc else "")
+
     def tnt_sphere(self, with_precon, x0, params):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         bufs, res = self._result_buffers(3, params)

@@ -121,6 +121,29 @@ def test_tnt_stiefel_device_vs_reference_fixture(harness, oracle, golden, mode):
     assert np.linalg.norm(X @ X.T - Xr @ Xr.T) / np.linalg.norm(Xr @ Xr.T) < 1e-8
 
 
+@pytest.mark.parametrize("key,pre", [("plain", False), ("block_jacobi", True)])
+def test_tnt_so3n_device_vs_reference_fixture(harness, oracle, golden, key, pre):
+    """TNT<DeviceVector, DeviceVector> on rotation averaging (cfg3 recipe, N = 40) against the trace
+    the REAL reference produced on the same inputs (tests/golden/tnt_so3n_40.json)."""
+    g = golden("tnt_so3n_40.json")[key]
+    N = g["N"]
+    ei, ej, Rt, w, _, Rinit = wl.pose_graph(N, seed=g["seed"])
+    prm = oracle.default_params(gradient_tolerance=1e-8, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=100)
+    r = harness.tnt_so3n(N, ei, ej, Rt, w, Rinit, prm, pre)
+    assert r["rc"] == 0, r.get("err")
+    assert r["status"] == g["status"]
+    assert r["outer_iterations"] == g["outer_iterations"]
+    assert r["accepted"] == g["accepted"]
+    assert list(r["inner_iterations"]) == g["inner_iterations"]
+    assert np.allclose(r["objective_values"], g["objective_values"], rtol=1e-10)
+    assert np.allclose(r["trust_region_radius"], g["trust_region_radius"], rtol=1e-8)
+    assert np.allclose(r["gradient_norms"][:-2], g["gradient_norms"][:-2], rtol=1e-6)
+    assert rel_err(r["x"], g["x"]) < 1e-9
+    Rb = r["x"].reshape(N, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", Rb, Rb) - np.eye(3)).max() < 1e-12
+
+
 def test_tnt_stiefel_device_medium_vs_oracle(harness, oracle):
     """A larger instance (40x36x32 = 46080 rows) against the CPU oracle run on the same arrays."""
     nx, ny, nz, p = 40, 36, 32, 3
