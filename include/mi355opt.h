@@ -88,6 +88,10 @@ MI_API int mi_timer_stop(mi_ctx *ctx, double *ms);  /* sync: records, waits, ret
  * ------------------------------------------------------------------------------------------- */
 MI_API int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out); /* `Vector v;` + sizing; pooled */
 MI_API int mi_vec_destroy(mi_vec *v);                           /* returns storage to the pool */
+/* non-owning window [offset, offset+n) of `base` (e.g. a column block of a column-major panel:
+ * `S.leftCols(ns)`, `S.middleCols(..)` LOBPCG.h:254-268); destroy with mi_vec_destroy; `base` must
+ * outlive it */
+MI_API int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out);
 MI_API int mi_vec_len(const mi_vec *v, size_t *n);
 MI_API int mi_vec_data(const mi_vec *v, void **device_ptr);
 MI_API int mi_vec_upload(mi_vec *v, const double *host, size_t n);         /* sync */
@@ -232,6 +236,11 @@ MI_API int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, c
                               double *xnorm);
 /* Rayleigh-Ritz on the host (ns <= 96): LOBPCG.h:53-62.  Theta ascending, C'AC = Theta, C'BC = I */
 MI_API int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C);
+/* Y (n x k column-major) = A X : the sparse operator of LOBPCG clients (called at LOBPCG.h:213,218,267,281) */
+MI_API int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y);
+/* Y[r,c] = d[r] X[r,c] : diagonal operator / Jacobi preconditioner on a column-major panel
+ * (the operators of tests/LOBPCG_unit_test.cpp:56-74) */
+MI_API int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_vec *X, mi_vec *Y);
 
 /* ---------------------------------------------------------------------------------------------
  * (9) multi-GPU: one process per GPU, tangent vectors row-sharded, inner products completed by an

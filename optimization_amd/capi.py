@@ -131,6 +131,9 @@ def load():
         "mi_lobpcg_residual": [vp, C.c_size_t, C.c_int, vp, vp, vp, c_double_p, vp, c_double_p,
                                c_double_p],
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
+        "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
+        "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
+        "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
         "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
         "mi_comm_init": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
         "mi_comm_finalize": [vp],
@@ -337,6 +340,40 @@ class Context:
     def so3n(self, N, ei, ej, Rt, w):
         return So3N(self, N, ei, ej, Rt, w)
 
+    # LOBPCG panels (column-major m x k) ---------------------------------------------------------
+    def lobpcg_gram(self, m, S, ka, T, kb):
+        G = np.zeros((ka, kb), order="F")
+        check(self.L.mi_lobpcg_gram(self.h, m, ka, kb, S.h, T.h, _dp(G)))
+        return G
+
+    def lobpcg_update(self, m, S, ks, Cmat):
+        Cmat = np.asfortranarray(Cmat, dtype=np.float64)
+        kc = Cmat.shape[1]
+        Y = Vec(self, m * kc)
+        check(self.L.mi_lobpcg_update(self.h, m, ks, kc, S.h, _dp(Cmat), Cmat.shape[0], Y.h))
+        return Y
+
+    def lobpcg_residual(self, m, nx, AX, BX, X, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        R = Vec(self, m * nx)
+        rn, xn = np.zeros(nx), np.zeros(nx)
+        check(self.L.mi_lobpcg_residual(self.h, m, nx, AX.h, BX.h, X.h, _dp(theta), R.h, _dp(rn), _dp(xn)))
+        return R, rn, xn
+
+    def rayleigh_ritz(self, A, B):
+        A = np.asfortranarray(A, dtype=np.float64)
+        B = np.asfortranarray(B, dtype=np.float64)
+        n = A.shape[0]
+        th = np.zeros(n)
+        Cm = np.zeros((n, n), order="F")
+        check(self.L.mi_rayleigh_ritz(n, _dp(A), _dp(B), _dp(th), _dp(Cm)))
+        return th, Cm
+
+    def panel_rowscale(self, m, k, d, X):
+        Y = Vec(self, m * k)
+        check(self.L.mi_panel_rowscale(self.h, m, k, d.h, X.h, Y.h))
+        return Y
+
     # comm -------------------------------------------------------------------------------------
     def comm_unique_id(self):
         buf = (C.c_ubyte * 128)()
@@ -425,6 +462,11 @@ class Csr:
         W = W if W is not None else Vec(self.ctx, self.n * p)
         check(self.L.mi_csr_spmm(self.h, p, V.h, W.h))
         return W
+
+    def spmm_colmajor(self, k, X, Y=None):
+        Y = Y if Y is not None else Vec(self.ctx, self.n * k)
+        check(self.L.mi_csr_spmm_colmajor(self.h, k, X.h, Y.h))
+        return Y
 
     def __del__(self):
         try:

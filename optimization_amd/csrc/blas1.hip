@@ -156,6 +156,14 @@ int mi_vec_destroy(mi_vec *v) {
   return MI_OK;
 }
 
+int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out) {
+  MI_REQUIRE(base && out, "null argument");
+  MI_REQUIRE(offset + n <= base->n, "view [%zu, %zu) exceeds the base vector (%zu)", offset, offset + n, base->n);
+  // an odd offset only costs alignment: gfx950 global 16-byte accesses need 4-byte alignment
+  *out = new mi_vec{base->ctx, n, base->d + offset, false};
+  return MI_OK;
+}
+
 int mi_vec_len(const mi_vec *v, size_t *n) {
   MI_REQUIRE(v && n, "null argument");
   *n = v->n;

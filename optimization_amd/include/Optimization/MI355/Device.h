@@ -155,10 +155,12 @@ class DeviceVector {
     check(mi_vec_axpby(z.v_, a, x.v_, b, y.v_));
     return z;
   }
-  static DeviceVector like(const DeviceVector &x) {
+  static DeviceVector like(const DeviceVector &x) { return on(x.ctx_, x.size()); }
+  // uninitialised vector of n doubles on the given raw context handle
+  static DeviceVector on(mi_ctx *ctx, size_t n) {
     DeviceVector z;
-    z.ctx_ = x.ctx_;
-    check(mi_vec_create(x.ctx_, x.size(), &z.v_));
+    z.ctx_ = ctx;
+    check(mi_vec_create(ctx, n, &z.v_));
     return z;
   }
 

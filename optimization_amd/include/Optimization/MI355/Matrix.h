@@ -1,0 +1,235 @@
+// Optimization/MI355/Matrix.h -- dense types for the LOBPCG drop-in:
+//   HostMatrix     small column-major dense matrix on the host (Gram matrices, Ritz coefficients)
+//   HostVectorD    small host vector (Ritz values, residual norms)
+//   DeviceMatrix   tall-skinny m x k COLUMN-MAJOR panel in HBM (ld = m), the layout of the reference's
+//                  Eigen dense matrices, with zero-copy column-block views (leftCols / middleCols /
+//                  rightCols) and the panel operations LOBPCG needs as free functions found by
+//                  argument-dependent lookup (gram, times_small, residual_and_norms, ...), each one
+//                  C-ABI call into optimization_amd/csrc/lobpcg.hip.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <utility>
+#include <vector>
+
+#include "Optimization/MI355/Device.h"
+
+namespace Optimization {
+namespace MI355 {
+
+class HostVectorD {
+ public:
+  HostVectorD() = default;
+  explicit HostVectorD(size_t n, double v = 0.0) : d_(n, v) {}
+  size_t size() const { return d_.size(); }
+  void resize(size_t n) { d_.resize(n); }
+  void conservativeResize(size_t n) { d_.resize(n); }
+  double &operator()(size_t i) { return d_[i]; }
+  double operator()(size_t i) const { return d_[i]; }
+  double &operator[](size_t i) { return d_[i]; }
+  double operator[](size_t i) const { return d_[i]; }
+  HostVectorD head(size_t k) const {
+    HostVectorD h(k);
+    for (size_t i = 0; i < k; ++i) h.d_[i] = d_[i];
+    return h;
+  }
+  double *data() { return d_.data(); }
+  const double *data() const { return d_.data(); }
+
+ private:
+  std::vector<double> d_;
+};
+
+class HostMatrix {
+ public:
+  HostMatrix() = default;
+  HostMatrix(size_t r, size_t c, double v = 0.0) : r_(r), c_(c), d_(r * c, v) {}
+  size_t rows() const { return r_; }
+  size_t cols() const { return c_; }
+  double &operator()(size_t i, size_t j) { return d_[i + j * r_]; }
+  double operator()(size_t i, size_t j) const { return d_[i + j * r_]; }
+  double *data() { return d_.data(); }
+  const double *data() const { return d_.data(); }
+
+ private:
+  size_t r_ = 0, c_ = 0;
+  std::vector<double> d_;
+};
+
+// The context used by DeviceMatrix::Random(m, nx), whose reference counterpart Matrix::Random
+// (LOBPCG.h:386) takes no context argument.
+inline mi_ctx *&current_context_slot() {
+  static mi_ctx *c = nullptr;
+  return c;
+}
+inline void make_current(const Context &ctx) { current_context_slot() = ctx.get(); }
+
+class DeviceMatrix {
+ public:
+  DeviceMatrix() = default;
+  DeviceMatrix(mi_ctx *ctx, size_t rows, size_t cols)
+      : buf_(std::make_shared<DeviceVector>(DeviceVector::on(ctx, rows * cols))), rows_(rows), cols_(cols) {
+    bind();
+  }
+  DeviceMatrix(const Context &ctx, size_t rows, size_t cols) : DeviceMatrix(ctx.get(), rows, cols) {}
+  // from a column-major host array
+  DeviceMatrix(const Context &ctx, size_t rows, size_t cols, const double *host) : DeviceMatrix(ctx, rows, cols) {
+    check(mi_vec_upload(buf_->handle(), host, rows * cols));
+  }
+  DeviceMatrix(const DeviceMatrix &o) : rows_(o.rows_), cols_(o.cols_) {  // deep copy (value semantics)
+    if (o.view_) {
+      buf_ = std::make_shared<DeviceVector>(DeviceVector::on(o.context(), rows_ * cols_));
+      bind();
+      check(mi_vec_copy(view_, o.view_));
+    }
+  }
+  DeviceMatrix(DeviceMatrix &&o) noexcept
+      : buf_(std::move(o.buf_)), off_(o.off_), rows_(o.rows_), cols_(o.cols_), view_(o.view_) {
+    o.view_ = nullptr;
+    o.rows_ = o.cols_ = 0;
+  }
+  DeviceMatrix &operator=(const DeviceMatrix &o) {
+    if (this != &o) {
+      DeviceMatrix tmp(o);
+      *this = std::move(tmp);
+    }
+    return *this;
+  }
+  DeviceMatrix &operator=(DeviceMatrix &&o) noexcept {
+    if (this != &o) {
+      unbind();
+      buf_ = std::move(o.buf_);
+      off_ = o.off_;
+      rows_ = o.rows_;
+      cols_ = o.cols_;
+      view_ = o.view_;
+      o.view_ = nullptr;
+      o.rows_ = o.cols_ = 0;
+    }
+    return *this;
+  }
+  ~DeviceMatrix() { unbind(); }
+
+  size_t rows() const { return rows_; }
+  size_t cols() const { return cols_; }
+  bool empty() const { return view_ == nullptr; }
+  mi_vec *handle() const { return view_; }
+  mi_ctx *context() const { return buf_ ? buf_->context() : nullptr; }
+
+  // columns [j0, j0 + k) as a view sharing this matrix's storage
+  DeviceMatrix cols_view(size_t j0, size_t k) const {
+    DeviceMatrix v;
+    v.buf_ = buf_;
+    v.off_ = off_ + j0 * rows_;
+    v.rows_ = rows_;
+    v.cols_ = k;
+    v.bind();
+    return v;
+  }
+  DeviceMatrix leftCols(size_t k) const { return cols_view(0, k); }
+  DeviceMatrix middleCols(size_t j0, size_t k) const { return cols_view(j0, k); }
+  DeviceMatrix rightCols(size_t k) const { return cols_view(cols_ - k, k); }
+  // this[:, j0 : j0+count) = src[:, i0 : i0+count)
+  void set_cols(size_t j0, const DeviceMatrix &src, size_t i0, size_t count) {
+    if (count == 0) return;
+    DeviceMatrix d = cols_view(j0, count), s = src.cols_view(i0, count);
+    check(mi_vec_copy(d.view_, s.view_));
+  }
+  void truncate_cols(size_t k) {  // X.conservativeResize(NoChange, nev)  LOBPCG.h:334
+    cols_ = k;
+    unbind();
+    bind();
+  }
+  double norm() const {  // Frobenius
+    double s = 0;
+    check(mi_vec_dot(view_, view_, &s));
+    return std::sqrt(s);
+  }
+  std::vector<double> to_host() const {  // column-major
+    std::vector<double> h(rows_ * cols_);
+    if (view_) check(mi_vec_download(view_, h.data(), h.size()));
+    return h;
+  }
+  // uniform [-1, 1] entries like Eigen's Matrix::Random, generated on the host (LOBPCG.h:386)
+  static DeviceMatrix Random(size_t m, size_t k) {
+    mi_ctx *ctx = current_context_slot();
+    if (!ctx) throw std::runtime_error("DeviceMatrix::Random: call MI355::make_current(ctx) first");
+    std::vector<double> h(m * k);
+    std::mt19937_64 gen(20260928);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    for (auto &x : h) x = u(gen);
+    DeviceMatrix M(ctx, m, k);
+    check(mi_vec_upload(M.buf_->handle(), h.data(), h.size()));
+    return M;
+  }
+
+ private:
+  void bind() {
+    if (buf_ && rows_ * cols_ > 0) check(mi_vec_view(buf_->handle(), off_, rows_ * cols_, &view_));
+  }
+  void unbind() {
+    if (view_) mi_vec_destroy(view_);
+    view_ = nullptr;
+  }
+  std::shared_ptr<DeviceVector> buf_;
+  size_t off_ = 0, rows_ = 0, cols_ = 0;
+  mi_vec *view_ = nullptr;
+};
+
+// ---- panel operations used by LOBPCG (found by ADL) ------------------------------------------------
+
+// G = S' T   (LOBPCG.h:223,271-272) -- fp64 MFMA kernel
+inline HostMatrix gram(const DeviceMatrix &S, const DeviceMatrix &T) {
+  HostMatrix G(S.cols(), T.cols());
+  check(mi_lobpcg_gram(S.context(), S.rows(), (int)S.cols(), (int)T.cols(), S.handle(), T.handle(), G.data()));
+  return G;
+}
+// Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
+inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size_t row0, size_t kc) {
+  DeviceMatrix Y(S.context(), S.rows(), kc);
+  check(mi_lobpcg_update(S.context(), S.rows(), (int)S.cols(), (int)kc, S.handle(), C.data() + row0,
+                         (int)C.rows(), Y.handle()));
+  return Y;
+}
+// R = AX - BX diag(theta); returns R and fills the column norms of R and X  (LOBPCG.h:230,285,293,302)
+inline DeviceMatrix residual_and_norms(const DeviceMatrix &AX, const DeviceMatrix &BX, const DeviceMatrix &X,
+                                       const HostVectorD &theta, HostVectorD &rnorm, HostVectorD &xnorm) {
+  const size_t nx = X.cols();
+  DeviceMatrix R(X.context(), X.rows(), nx);
+  rnorm.resize(nx);
+  xnorm.resize(nx);
+  check(mi_lobpcg_residual(X.context(), X.rows(), (int)nx, AX.handle(), BX.handle(), X.handle(), theta.data(),
+                           R.handle(), rnorm.data(), xnorm.data()));
+  return R;
+}
+// N(0,1) probe matrix drawn exactly like LOBPCG.h:205-211: default-seeded std::default_random_engine,
+// filled row by row (i outer, j inner) on the host, then uploaded
+inline DeviceMatrix gaussian_probe(const DeviceMatrix &like, size_t m, size_t nx) {
+  std::default_random_engine gen;
+  std::normal_distribution<double> normal(0, 1.0);
+  std::vector<double> h(m * nx);
+  for (size_t i = 0; i < m; ++i)
+    for (size_t j = 0; j < nx; ++j) h[i + j * m] = normal(gen);
+  DeviceMatrix Om(like.context(), m, nx);
+  check(mi_vec_upload(Om.handle(), h.data(), h.size()));
+  return Om;
+}
+inline DeviceMatrix empty_panel(const DeviceMatrix &like, size_t m, size_t k) {
+  return DeviceMatrix(like.context(), m, k);
+}
+
+// Rayleigh-Ritz on host matrices (LOBPCG.h:53-62)
+inline std::pair<HostVectorD, HostMatrix> rayleigh_ritz(const HostMatrix &A, const HostMatrix &B) {
+  const size_t n = A.rows();
+  HostVectorD theta(n);
+  HostMatrix C(n, n);
+  check(mi_rayleigh_ritz((int)n, A.data(), B.data(), theta.data(), C.data()));
+  return std::make_pair(std::move(theta), std::move(C));
+}
+
+}  // namespace MI355
+}  // namespace Optimization

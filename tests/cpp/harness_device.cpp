@@ -9,7 +9,9 @@
 #include <vector>
 
 #include "Optimization/LinearAlgebra/IterativeSolvers.h"
+#include "Optimization/LinearAlgebra/LOBPCG.h"
 #include "Optimization/MI355/Device.h"
+#include "Optimization/MI355/Matrix.h"
 #include "Optimization/MI355/SO3.h"
 #include "Optimization/MI355/Stiefel.h"
 #include "Optimization/Riemannian/GradientDescent.h"
@@ -259,6 +261,82 @@ extern "C" int hd_tnt_sphere(int with_precon, const double *x0, const orc_tnt_pa
   RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector, double, DeviceVector>(
       sp.F, sp.gradF, sp.HessCon, sp.metric, sp.retract, X0, P, pc, tp, uf);
   export_result(r, accepted, res);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// LOBPCG (tests/LOBPCG_unit_test.cpp:106-225): diagonal operators A, B, T on column-major device
+// panels, or a sparse A (BASELINE cfg5).  Adiag/Bdiag/Tdiag may be null; if rowptr != null the
+// operator A is the CSR matrix instead of diag(Adiag).  X0 == null -> the random-X0 overload.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_gaussian_probe(size_t m, size_t nx, double *out) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  MI355::DeviceMatrix like(ctx, 1, 1);
+  MI355::DeviceMatrix Om = MI355::gaussian_probe(like, m, nx);
+  const std::vector<double> h = Om.to_host();
+  std::memcpy(out, h.data(), h.size() * sizeof(double));
+  HD_GUARD_END
+}
+
+extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, const int32_t *rowptr,
+                         const int32_t *col, const double *val, const double *Bdiag, const double *Tdiag,
+                         const double *X0, size_t max_iters, double tau, double *Theta_out, double *X_out,
+                         size_t *num_iters, size_t *nc_out, double *resid_out) {
+  HD_GUARD_BEGIN
+  using MI355::DeviceMatrix;
+  using MI355::HostVectorD;
+  using Op = LA::SymmetricLinearOperator<DeviceMatrix>;
+  Context ctx(0);
+  MI355::make_current(ctx);
+  auto diag_op = [&](const double *d) -> Op {
+    auto dv = std::make_shared<DeviceVector>(ctx, d, m);
+    mi_ctx *c = ctx.get();
+    return [dv, c, m](const DeviceMatrix &X) {
+      DeviceMatrix Y(c, m, X.cols());
+      MI355::check(mi_panel_rowscale(c, m, (int)X.cols(), dv->handle(), X.handle(), Y.handle()));
+      return Y;
+    };
+  };
+  Op A;
+  mi_csr *csr = nullptr;
+  if (rowptr) {
+    MI355::check(mi_csr_create(ctx.get(), m, (size_t)rowptr[m], rowptr, col, val, &csr));
+    mi_ctx *c = ctx.get();
+    A = [csr, c, m](const DeviceMatrix &X) {
+      DeviceMatrix Y(c, m, X.cols());
+      MI355::check(mi_csr_spmm_colmajor(csr, (int)X.cols(), X.handle(), Y.handle()));
+      return Y;
+    };
+  } else {
+    A = diag_op(Adiag);
+  }
+  std::optional<Op> B, T;
+  if (Bdiag) B = diag_op(Bdiag);
+  if (Tdiag) T = diag_op(Tdiag);
+  size_t iters = 0, nc = 0;
+  std::vector<double> resid;
+  std::optional<LA::LOBPCGUserFunction<HostVectorD, DeviceMatrix>> uf =
+      [&](size_t, const Op &, const std::optional<Op> &, const std::optional<Op> &, size_t, const HostVectorD &,
+          const DeviceMatrix &, const HostVectorD &r, size_t) {
+        resid.assign(r.data(), r.data() + r.size());
+        return false;
+      };
+  std::pair<HostVectorD, DeviceMatrix> out;
+  if (X0) {
+    DeviceMatrix X0d(ctx, m, nx, X0);
+    out = LA::LOBPCG<HostVectorD, DeviceMatrix>(A, B, T, X0d, nev, max_iters, iters, nc, tau, uf);
+  } else {
+    out = LA::LOBPCG<HostVectorD, DeviceMatrix>(A, B, T, m, nx, nev, max_iters, iters, nc, tau, uf);
+  }
+  for (size_t i = 0; i < nev; ++i) Theta_out[i] = out.first(i);
+  const std::vector<double> xh = out.second.to_host();
+  std::memcpy(X_out, xh.data(), xh.size() * sizeof(double));
+  *num_iters = iters;
+  *nc_out = nc;
+  if (resid_out)
+    for (size_t i = 0; i < resid.size() && i < nx; ++i) resid_out[i] = resid[i];
+  if (csr) mi_csr_destroy(csr);
   HD_GUARD_END
 }
 

@@ -103,6 +103,42 @@ class DeviceHarness:
                                 _dp(R0), C.byref(params), int(with_precon), C.byref(res))
         return self._unpack(rc, bufs, res, self.err() if rc else "")
 
+    def gaussian_probe(self, m, nx):
+        out = np.zeros((m, nx), order="F")
+        self.L.hd_gaussian_probe.restype = C.c_int
+        self.L.hd_gaussian_probe.argtypes = [C.c_size_t, C.c_size_t, dp]
+        rc = self.L.hd_gaussian_probe(m, nx, _dp(out))
+        assert rc == 0, self.err()
+        return out
+
+    def lobpcg(self, m, nx, nev, Adiag=None, csr=None, Bdiag=None, Tdiag=None, X0=None, max_iters=1000,
+               tau=1e-6):
+        self.L.hd_lobpcg.restype = C.c_int
+        self.L.hd_lobpcg.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, dp, ip32, ip32, dp, dp, dp, dp,
+                                     C.c_size_t, C.c_double, dp, dp, sp, sp, dp]
+
+        def arr(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        Ad, Bd, Td = arr(Adiag), arr(Bdiag), arr(Tdiag)
+        X0f = None if X0 is None else np.asfortranarray(X0, dtype=np.float64)
+        rp = cl = vl = None
+        if csr is not None:
+            rp = np.ascontiguousarray(csr[0], dtype=np.int32)
+            cl = np.ascontiguousarray(csr[1], dtype=np.int32)
+            vl = np.ascontiguousarray(csr[2], dtype=np.float64)
+        th = np.zeros(nev)
+        X = np.zeros((m, nev), order="F")
+        it, nc = C.c_size_t(0), C.c_size_t(0)
+        res = np.zeros(nx)
+        rc = self.L.hd_lobpcg(m, nx, nev, _dp(Ad) if Ad is not None else None,
+                              rp.ctypes.data_as(ip32) if rp is not None else None,
+                              cl.ctypes.data_as(ip32) if cl is not None else None,
+                              _dp(vl) if vl is not None else None, _dp(Bd) if Bd is not None else None,
+                              _dp(Td) if Td is not None else None, _dp(X0f) if X0f is not None else None,
+                              max_iters, tau, _dp(th), _dp(X), C.byref(it), C.byref(nc), _dp(res))
+        return dict(rc=rc, err=self.err() if rc else "", Theta=th, X=X, num_iters=it.value, nc=nc.value,
+                    residuals=res)
+
     def tnt_sphere(self, with_precon, x0, params):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         bufs, res = self._result_buffers(3, params)

@@ -1,0 +1,167 @@
+"""GPU tests for the LOBPCG path (BASELINE cfg5): the panel kernels (fp64-MFMA Gram, small-matrix
+update, residual norms, column-major SpMM, host Rayleigh-Ritz) against numpy/scipy, and the drop-in
+LOBPCG template on MI355::DeviceMatrix against the known answers of the reference's own tests
+(tests/LOBPCG_unit_test.cpp) and against the CPU oracle run with identical inputs."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from conftest import rel_err
+from optimization_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def harness():
+    import harness_py
+    return harness_py.DeviceHarness()
+
+
+@pytest.mark.parametrize("m,ka,kb", [(1, 1, 1), (31, 3, 5), (32, 16, 16), (33, 17, 15), (1000, 10, 10),
+                                     (4097, 30, 20), (100_003, 60, 60), (50_000, 96, 72)])
+def test_gram_mfma_vs_numpy(ctx, m, ka, kb):
+    """G = S'T (LOBPCG.h:223,271-272) with ASYMMETRIC operands (catches a transposed C/D map)."""
+    rng = np.random.default_rng(m + ka)
+    S = rng.normal(size=(m, ka))
+    T = rng.normal(size=(m, kb)) + np.arange(kb)[None, :]
+    Sd, Td = ctx.upload(S.ravel(order="F")), ctx.upload(T.ravel(order="F"))
+    G = ctx.lobpcg_gram(m, Sd, ka, Td, kb)
+    ref = S.T @ T
+    assert np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max() * max(1, np.sqrt(m) / 10)
+    G2 = ctx.lobpcg_gram(m, Sd, ka, Sd, ka)  # S == T path stages one panel only
+    ref2 = S.T @ S
+    assert np.abs(G2 - ref2).max() <= 1e-12 * np.abs(ref2).max() * max(1, np.sqrt(m) / 10)
+    assert np.array_equal(ctx.lobpcg_gram(m, Sd, ka, Td, kb), G)  # deterministic
+
+
+def test_gram_identity_operand(ctx):
+    """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
+    m, k = 64, 16
+    S = np.zeros((m, k))
+    S[:k, :k] = np.eye(k)
+    T = np.arange(m * k, dtype=float).reshape(m, k)
+    G = ctx.lobpcg_gram(m, ctx.upload(S.ravel(order="F")), k, ctx.upload(T.ravel(order="F")), k)
+    assert np.array_equal(G, T[:k, :])
+
+
+@pytest.mark.parametrize("m,ks,kc", [(5, 3, 2), (1000, 30, 10), (100_001, 72, 24), (4096, 96, 32)])
+def test_panel_update_and_residual(ctx, m, ks, kc):
+    rng = np.random.default_rng(ks)
+    S = rng.normal(size=(m, ks))
+    Cm = rng.normal(size=(ks + 2, kc))  # leading dimension larger than ks
+    Y = ctx.lobpcg_update(m, ctx.upload(S.ravel(order="F")), ks, np.asfortranarray(Cm)[:ks + 2]).numpy()
+    ref = S @ Cm[:ks]
+    assert np.abs(Y.reshape(kc, m).T - ref).max() <= 1e-13 * np.abs(ref).max() * ks
+    nx = kc
+    AX, BX, X = rng.normal(size=(m, nx)), rng.normal(size=(m, nx)), rng.normal(size=(m, nx))
+    th = rng.normal(size=nx)
+    R, rn, xn = ctx.lobpcg_residual(m, nx, ctx.upload(AX.ravel(order="F")), ctx.upload(BX.ravel(order="F")),
+                                    ctx.upload(X.ravel(order="F")), th)
+    Rr = AX - BX * th[None, :]
+    assert np.abs(R.numpy().reshape(nx, m).T - Rr).max() <= 1e-14 * np.abs(Rr).max()
+    assert np.allclose(rn, np.linalg.norm(Rr, axis=0), rtol=1e-12)
+    assert np.allclose(xn, np.linalg.norm(X, axis=0), rtol=1e-12)
+
+
+def test_rayleigh_ritz_and_spmm_colmajor(ctx):
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 48, 72):  # tests/LOBPCG_unit_test.cpp:79-103
+        Q = rng.normal(size=(n, n))
+        A = Q + Q.T
+        Rm = rng.normal(size=(n, n))
+        B = Rm @ Rm.T + n * np.eye(n)
+        th, Cm = ctx.rayleigh_ritz(A, B)
+        assert np.linalg.norm(Cm.T @ A @ Cm - np.diag(th)) < 1e-8 * max(1, np.abs(th).max())
+        assert np.linalg.norm(Cm.T @ B @ Cm - np.eye(n)) < 1e-8
+        assert np.allclose(th, scipy.linalg.eigh(A, B, eigvals_only=True), rtol=1e-9, atol=1e-9)
+    nx, ny, nz, k = 9, 8, 7, 11
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    import scipy.sparse as sps
+    Asp = sps.csr_matrix((val, col, rowptr), shape=(n, n))
+    X = rng.normal(size=(n, k))
+    Y = ctx.csr(n, rowptr, col, val).spmm_colmajor(k, ctx.upload(X.ravel(order="F"))).numpy().reshape(k, n).T
+    assert np.abs(Y - Asp @ X).max() < 1e-12
+
+
+# ----------------------------------------------------------------------------------------------
+# the LOBPCG template on DeviceMatrix: reference test cases (tests/LOBPCG_unit_test.cpp:106-225)
+# ----------------------------------------------------------------------------------------------
+def test_lobpcg_small_eigenvalue_problem(harness):
+    d4 = np.arange(1.0, 5.0)
+    X0 = np.array([[1, 0], [0, 1], [1, 1], [.5, -.5]], dtype=float)
+    r = harness.lobpcg(4, 2, 2, Adiag=d4, X0=X0, max_iters=100, tau=1e-8)
+    assert r["rc"] == 0, r["err"]
+    assert r["nc"] == 2 and np.allclose(r["Theta"], [1, 2], atol=1e-3)
+
+
+@pytest.mark.parametrize("useB,useT", [(False, False), (False, True), (True, True), (True, False)])
+def test_lobpcg_reference_diagonal_problems(harness, oracle, useB, useT):
+    n, nx, nev = 1000, 10, 5
+    a = np.linspace(-500, 500, n)
+    b = np.arange(1.0, n + 1)
+    t = np.abs(a)  # the reference's T multiplies by |A| (tests/LOBPCG_unit_test.cpp:72-74)
+    lam = np.sort(a / b)[:nev] if useB else a[:nev]
+    max_iters = 10 * n
+    r = harness.lobpcg(n, nx, nev, Adiag=a, Bdiag=b if useB else None, Tdiag=t if useT else None, X0=None,
+                       max_iters=max_iters, tau=1e-8)
+    assert r["rc"] == 0, r["err"]
+    assert r["nc"] == nev
+    assert np.linalg.norm(r["Theta"] - lam) < 1e-4
+    X = r["X"]
+    Bx = X * b[:, None] if useB else X
+    assert np.abs(X.T @ Bx - np.eye(nev)).max() < 1e-6          # B-orthonormal Ritz vectors
+    # converged by the reference's criterion (LOBPCG.h:298-302) with the exact operator norms
+    res = np.linalg.norm(a[:, None] * X - Bx * r["Theta"][None, :], axis=0)
+    bound = 1e-8 * (500.0 + np.abs(r["Theta"]) * (1000.0 if useB else 1.0)) * np.linalg.norm(X, axis=0)
+    assert np.all(res <= 3 * bound)
+    # same inputs through the CPU oracle: identical iteration count and eigenvalues
+    X0 = None
+    import numpy.random as npr  # noqa: F401
+    # the random-X0 overload draws X0 inside the harness; repeat with an explicit X0 for the oracle comparison
+    rng = np.random.default_rng(7)
+    X0 = rng.uniform(-1, 1, size=(n, nx))
+    rd = harness.lobpcg(n, nx, nev, Adiag=a, Bdiag=b if useB else None, Tdiag=t if useT else None, X0=X0,
+                        max_iters=max_iters, tau=1e-8)
+    Om = harness.gaussian_probe(n, nx)
+    ro = oracle.lobpcg(lambda Z: a[:, None] * Z, (lambda Z: b[:, None] * Z) if useB else None,
+                       (lambda Z: t[:, None] * Z) if useT else None, X0, Om, nev, max_iters, tau=1e-8)
+    assert rd["nc"] == ro["nc"] == nev
+    assert abs(rd["num_iters"] - ro["num_iters"]) <= max(2, ro["num_iters"] // 50)
+    assert np.allclose(rd["Theta"], ro["Theta"], rtol=1e-7, atol=1e-7)
+
+
+def test_lobpcg_argument_checks(harness):
+    r = harness.lobpcg(10, 3, 4, Adiag=np.arange(10.0), X0=np.ones((10, 3)))
+    assert r["rc"] == -1 and "Block size nx must be greater" in r["err"]
+    r = harness.lobpcg(2, 3, 1, Adiag=np.arange(2.0), X0=np.ones((2, 3)))
+    assert r["rc"] == -1
+
+
+def test_lobpcg_cfg5_laplacian(harness):
+    """BASELINE cfg5 shape at reduced size for a converged answer (40^3 Laplacian, nev = 8, nx = 12,
+    Jacobi = constant diagonal so no preconditioner), then the full 126^3 = 2 000 376 size for a fixed
+    number of iterations with size-independent checks."""
+    nx_, ny_, nz_ = 20, 18, 16
+    n = nx_ * ny_ * nz_
+    csr = wl.laplacian_3d(nx_, ny_, nz_)
+    lams = np.sort([wl.laplacian_3d_eigvec(nx_, ny_, nz_, a, b, c)[1] + 0.1
+                    for a in range(1, 5) for b in range(1, 5) for c in range(1, 5)])
+    nev, nb = 6, 10
+    r = harness.lobpcg(n, nb, nev, csr=csr, X0=None, max_iters=400, tau=1e-7)
+    assert r["rc"] == 0, r["err"]
+    assert r["nc"] == nev
+    assert np.allclose(r["Theta"], lams[:nev], rtol=1e-6)
+    # full size: few iterations; Ritz values bound the true eigenvalues from above and X'X = I
+    g = 126
+    n = g ** 3
+    csr = wl.laplacian_3d(g, g, g)
+    lam_min = wl.laplacian_3d_eigvec(g, g, g, 1, 1, 1)[1] + 0.1
+    r = harness.lobpcg(n, 24, 20, csr=csr, X0=None, max_iters=6, tau=1e-6)
+    assert r["rc"] == 0, r["err"]
+    assert r["num_iters"] == 6 and r["nc"] < 20
+    assert np.all(np.diff(r["Theta"]) >= -1e-12) and r["Theta"][0] >= lam_min * (1 - 1e-12)
+    assert np.all(r["Theta"] < 12.2)
+    X = r["X"]
+    assert np.abs(X.T @ X - np.eye(20)).max() < 1e-10
