@@ -107,13 +107,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    # MI355OPT_BENCH_FORCE_COMM=1: run the multi-GPU code path (rendezvous, communicator, sharded matrix,
+    # slot-path kernels) even with one rank -- the dress rehearsal tests/test_gpu_comm.py runs on a 1-GPU box
+    use_comm = world > 1 or os.environ.get("MI355OPT_BENCH_FORCE_COMM") == "1"
     dist = None
-    if world > 1:
+    if use_comm:
         import torch.distributed as dist  # gloo: control plane only
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = capi.Context(local_rank)
-    if world > 1:
+    if use_comm:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
@@ -126,7 +129,7 @@ def main():
     n = nx * ny * (z1 - z0)
     Xb_glob, modes = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)
     Xb = np.ascontiguousarray(Xb_glob[nx * ny * z0: nx * ny * z1])
-    if world == 1:
+    if not use_comm:
         rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
         A = ctx.csr(n, rowptr, col, val)
     else:
@@ -208,7 +211,8 @@ def main():
                                    f"iterations at a near-optimal iterate (modes {modes})",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
                        "algorithmic_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
-                       "parallelism": f"row-sharded z-slabs x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"row-sharded z-slabs x{world}, RCCL comm (all-reduce of scalar slots, "
+                                       f"halo send/recv)") if use_comm else "single GPU",
                        "device": ctx.device_name()},
             "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
             "roofline": roofline, "cpu_baseline": cpu,

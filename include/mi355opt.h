@@ -255,6 +255,11 @@ MI_API int mi_comm_finalize(mi_ctx *ctx);
 MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
 /* halo description for a row-sharded sparse operator: rows [row_begin,row_end) of a global n x n
  * matrix are local; columns outside are fetched from the owning neighbour before each SpMM */
+/* host-only planning step of mi_csr_create_sharded (no GPU needed; also used by the CPU gloo tests):
+ * halo extents + local column indices ([0,n) local, then halo from rank-1, then halo from rank+1) */
+MI_API int mi_csr_shard_plan(size_t n_global, int world_size, int rank, const size_t *row_starts,
+                             size_t nnz_local, const int64_t *col_global, int32_t *col_local, size_t *need_lo,
+                             size_t *need_hi);
 MI_API int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t row_end,
                                  size_t nnz_local, const int32_t *rowptr, const int64_t *col_global,
                                  const double *val, const size_t *row_starts /*world_size+1*/,

@@ -156,6 +156,22 @@ def check(status):
         raise MiError(status, load().mi_last_error().decode())
 
 
+def csr_shard_plan(n_global, world_size, rank, row_starts, col_global):
+    """Host-only (no GPU): (col_local int32, need_lo, need_hi) for this rank's slab of a row-sharded matrix."""
+    L = load()
+    L.mi_csr_shard_plan.restype = C.c_int
+    L.mi_csr_shard_plan.argtypes = [C.c_size_t, C.c_int, C.c_int, c_size_p, C.c_size_t, c_int64_p, c_int32_p,
+                                    c_size_p, c_size_p]
+    col_global = np.ascontiguousarray(col_global, dtype=np.int64)
+    starts = (C.c_size_t * len(row_starts))(*[int(x) for x in row_starts])
+    col_local = np.zeros(col_global.size, dtype=np.int32)
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    check(L.mi_csr_shard_plan(n_global, world_size, rank, starts, col_global.size,
+                              col_global.ctypes.data_as(c_int64_p), col_local.ctypes.data_as(c_int32_p),
+                              C.byref(lo), C.byref(hi)))
+    return col_local, lo.value, hi.value
+
+
 def device_count():
     n = C.c_int(0)
     check(load().mi_device_count(C.byref(n)))

@@ -32,7 +32,9 @@ int nccl_fail(ncclResult_t r, const char *what) {
 namespace mi {
 
 int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
-  if (ctx->world_size <= 1 || !ctx->comm) return MI_OK;
+  // a communicator of size 1 still goes through RCCL: the single-GPU box then exercises exactly the
+  // calls the 8-GPU node makes (tests/test_gpu_comm.py)
+  if (!ctx->comm) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   MI_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, ctx->stream));
   return MI_OK;

@@ -309,7 +309,7 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
   }
   hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, (int)nb, nelem,
                      (const double *)partial, (double *)Gdev);
-  if (ctx->world_size > 1) {
+  if (ctx->comm) {
     for (int off = 0; off < nelem; off += 4096)  // all-reduce in chunks the comm layer accepts
       MI_TRY(comm_allreduce(ctx, (double *)Gdev + off, std::min(4096, nelem - off)));
   }

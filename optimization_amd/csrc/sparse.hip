@@ -138,6 +138,44 @@ int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W) {
   return csr_spmm_launch(A, p, V->d, W->d);
 }
 
+// Host-only planning step of a row-sharded matrix (no GPU needed): halo extents and the remap of
+// global column indices to local ones ([0,n) local rows, [n,n+need_lo) halo from rank-1,
+// [n+need_lo, n+need_lo+need_hi) halo from rank+1).  Columns outside the local range must belong to the
+// ADJACENT ranks (slab-partitioned stencils); anything else is rejected.
+int mi_csr_shard_plan(size_t n_global, int world_size, int rank, const size_t *row_starts, size_t nnz_local,
+                      const int64_t *col_global, int32_t *col_local, size_t *need_lo_out, size_t *need_hi_out) {
+  MI_REQUIRE(row_starts && (nnz_local == 0 || (col_global && col_local)) && need_lo_out && need_hi_out,
+             "null argument");
+  MI_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size/rank %d/%d", world_size, rank);
+  MI_REQUIRE(row_starts[0] == 0 && row_starts[world_size] == n_global, "row_starts must span [0, n_global]");
+  for (int r = 0; r < world_size; ++r)
+    MI_REQUIRE(row_starts[r] <= row_starts[r + 1], "row_starts must be non-decreasing");
+  const size_t row_begin = row_starts[rank], row_end = row_starts[rank + 1], n = row_end - row_begin;
+  size_t need_lo = 0, need_hi = 0;
+  for (size_t k = 0; k < nnz_local; ++k) {
+    const int64_t c = col_global[k];
+    MI_REQUIRE(c >= 0 && (size_t)c < n_global, "global column out of range at entry %zu", k);
+    if ((size_t)c < row_begin) need_lo = std::max(need_lo, row_begin - (size_t)c);
+    if ((size_t)c >= row_end) need_hi = std::max(need_hi, (size_t)c - row_end + 1);
+  }
+  if (need_lo)
+    MI_REQUIRE(rank > 0 && need_lo <= row_begin - row_starts[rank - 1],
+               "rank %d needs %zu rows below its range: not nearest-neighbour banded", rank, need_lo);
+  if (need_hi)
+    MI_REQUIRE(rank + 1 < world_size && need_hi <= row_starts[rank + 2] - row_end,
+               "rank %d needs %zu rows above its range: not nearest-neighbour banded", rank, need_hi);
+  MI_REQUIRE(n + need_lo + need_hi < (size_t)INT32_MAX, "local problem too large for int32 indices");
+  for (size_t k = 0; k < nnz_local; ++k) {
+    const size_t c = (size_t)col_global[k];
+    if (c < row_begin) col_local[k] = (int32_t)(n + (need_lo - (row_begin - c)));
+    else if (c >= row_end) col_local[k] = (int32_t)(n + need_lo + (c - row_end));
+    else col_local[k] = (int32_t)(c - row_begin);
+  }
+  *need_lo_out = need_lo;
+  *need_hi_out = need_hi;
+  return MI_OK;
+}
+
 int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t row_end,
                           size_t nnz_local, const int32_t *rowptr, const int64_t *col_global,
                           const double *val, const size_t *row_starts, mi_csr **out) {
@@ -148,26 +186,10 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   const int ws = ctx->world_size, rk = ctx->rank;
   MI_REQUIRE(row_starts[rk] == row_begin && row_starts[rk + 1] == row_end,
              "row_starts does not match this rank's range");
-  // halo extents: the columns outside [row_begin,row_end) must belong to the adjacent ranks
   size_t need_lo = 0, need_hi = 0;
-  for (size_t k = 0; k < nnz_local; ++k) {
-    const int64_t c = col_global[k];
-    MI_REQUIRE(c >= 0 && (size_t)c < n_global, "global column out of range at entry %zu", k);
-    if ((size_t)c < row_begin) need_lo = std::max(need_lo, row_begin - (size_t)c);
-    if ((size_t)c >= row_end) need_hi = std::max(need_hi, (size_t)c - row_end + 1);
-  }
-  if (need_lo) MI_REQUIRE(rk > 0 && need_lo <= row_begin - row_starts[rk - 1],
-                          "rank %d needs %zu rows below its range: not nearest-neighbour banded", rk, need_lo);
-  if (need_hi) MI_REQUIRE(rk + 1 < ws && need_hi <= row_starts[rk + 2] - row_end,
-                          "rank %d needs %zu rows above its range: not nearest-neighbour banded", rk, need_hi);
-  MI_REQUIRE(n + need_lo + need_hi < (size_t)INT32_MAX, "local problem too large for int32 indices");
   std::vector<int32_t> lcol(nnz_local);
-  for (size_t k = 0; k < nnz_local; ++k) {
-    const size_t c = (size_t)col_global[k];
-    if (c < row_begin) lcol[k] = (int32_t)(n + (need_lo - (row_begin - c)));  // [n, n+need_lo)
-    else if (c >= row_end) lcol[k] = (int32_t)(n + need_lo + (c - row_end));
-    else lcol[k] = (int32_t)(c - row_begin);
-  }
+  MI_TRY(mi_csr_shard_plan(n_global, ws, rk, row_starts, nnz_local, col_global, lcol.data(), &need_lo,
+                           &need_hi));
   mi_csr *A = nullptr;
   MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A));
   A->halo_lo = need_lo;

@@ -327,7 +327,7 @@ int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double 
                   const double *Vin, int count, double *M_out, double *out, bool dots, int *nparts) {
   const int grid = row_grid(n);
   double *slots = ctx->scalars + SLOT_GRAM;
-  const bool sharded = ctx->world_size > 1 || ctx->force_slot_path;
+  const bool sharded = ctx->comm != nullptr || ctx->force_slot_path;
   if (sharded) MI_TRY(sharded_reduce(ctx, count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
 #define FIN(D, F)                                                                                       \
@@ -442,7 +442,7 @@ int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
                                    (const double *)X->d, (const double *)V->d, (const double *)nullptr,
                                    Y->d, ctx->partials2));
   double *slots = ctx->scalars + SLOT_GRAM;
-  if (ctx->world_size > 1 || ctx->force_slot_path) {
+  if (ctx->comm != nullptr || ctx->force_slot_path) {
     MI_TRY(sharded_reduce(ctx, grid, nsym(p), slots));
     DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                      Y->d, (const double *)ctx->partials2, grid, (const double *)slots));

@@ -524,7 +524,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const size_t n = g->n;
   const int pre = !P ? PRE_NONE : (P->kind == 1 ? PRE_DIAG : (P->kind == 2 ? PRE_BLOCK3 : PRE_EXTERNAL));
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");
-  const bool sharded = ctx->world_size > 1 || ctx->force_slot_path;
+  const bool sharded = ctx->comm != nullptr || ctx->force_slot_path;
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
 
   mi_vec *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr;
