@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Side measurements for the other BASELINE.json configurations (the driver's bench line is bench.py =
+cfg2): cfg3 = block-Jacobi STPCG on SO(3)^N (N = 5e5), cfg5 = LOBPCG panel kernels at m = 2e6.
+Prints one JSON line per config.  Usage: python tools/bench_extra.py [cfg3] [cfg5]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+
+from optimization_amd import capi, workloads as wl  # noqa: E402
+
+
+def cfg3(ctx):
+    N = 500_000
+    ei, ej, Rt, w, Rtrue, Rinit = wl.pose_graph(N, seed=7)
+    prob = ctx.so3n(N, ei, ej, Rt, w)
+    R = ctx.upload(Rinit)
+    g, H, P = prob.model(R)
+    nnzb = 2 * ei.size
+    Nt = 3 * N
+    hvp_bytes = 72 * (nnzb + N) + 4 * nnzb + 8 * 2 * Nt          # blocks + diag blocks, indices, xi read, h written
+    step_bytes = 120 * Nt + hvp_bytes                              # 120 N for 3x3 block-Jacobi CG
+    s_out = ctx.vec(Nt)
+
+    def run(steps):
+        done = 0
+        while done < steps:
+            r = ctx.stpcg(g, H, P, Delta=1e6, max_iterations=min(50, steps - done), kappa_fgr=1e-14, theta=1.0,
+                          s_out=s_out)
+            if r["iterations"] == 0:
+                raise RuntimeError("no progress")
+            done += r["iterations"]
+    run(50)
+    ctx.sync()
+    t0 = time.perf_counter()
+    steps = 500
+    run(steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    for k in ("bsr3_spmv_dots", "cg_update", "cg_pupdate"):
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    run(100)
+    per = {k: ctx.ktime_read(k) for k in ("bsr3_spmv_dots", "cg_update", "cg_pupdate")}
+    print(json.dumps({"config": "cfg3 SO(3)^N N=5e5, ring + 2 chords/node (1.5e6 edges), 3x3 block-Jacobi STPCG",
+                      "us_per_step": 1e6 * dt / steps, "algorithmic_bytes_per_step": step_bytes,
+                      "GBps": steps * step_bytes / dt / 1e9, "frac_of_8TBps": steps * step_bytes / dt / 8e12,
+                      "kernels_avg_us": {k: 1e3 * v[1] / max(v[0], 1) for k, v in per.items()},
+                      "hvp_GBps": hvp_bytes / (1e3 * per["bsr3_spmv_dots"][1] / per["bsr3_spmv_dots"][0] * 1e-6) / 1e9}))
+
+
+def cfg5(ctx):
+    m, ns, nx = 126 ** 3, 60, 24
+    rng = np.random.default_rng(0)
+    S = ctx.upload(rng.normal(size=m * ns))
+    AS = ctx.upload(rng.normal(size=m * ns))
+    for k in ("lobpcg_gram", "lobpcg_update", "lobpcg_residual", "csr_spmm"):
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    for _ in range(5):
+        ctx.lobpcg_gram(m, S, ns, AS, ns)
+        ctx.lobpcg_gram(m, S, ns, S, ns)
+    Cm = rng.normal(size=(ns, nx))
+    for _ in range(5):
+        ctx.lobpcg_update(m, S, ns, Cm)
+    rowptr, col, val = wl.laplacian_3d(126, 126, 126)
+    A = ctx.csr(m, rowptr, col, val)
+    for _ in range(3):
+        A.spmm_colmajor(ns, S)
+    out = {}
+    n_g, ms_g = ctx.ktime_read("lobpcg_gram")
+    gram_us = 1e3 * ms_g / n_g
+    out["gram_avg_us(mixed S'AS and S'S)"] = gram_us
+    out["gram_TFLOPs"] = 2 * m * ns * ns / (gram_us * 1e-6) / 1e12
+    out["gram_GBps(2 panels)"] = 8 * m * 2 * ns / (gram_us * 1e-6) / 1e9
+    n_u, ms_u = ctx.ktime_read("lobpcg_update")
+    out["update_us_per_8col_launch"] = 1e3 * ms_u / n_u
+    out["update_GBps"] = (8 * m * (ns + 8)) / (1e3 * ms_u / n_u * 1e-6) / 1e9
+    n_s, ms_s = ctx.ktime_read("csr_spmm")
+    out["spmm_colmajor_us_per_8col_launch"] = 1e3 * ms_s / n_s
+    import harness_py
+    hz = harness_py.DeviceHarness()
+    t0 = time.perf_counter()
+    r = hz.lobpcg(m, nx, 20, csr=(rowptr, col, val), X0=None, max_iters=11, tau=1e-6)
+    dt = time.perf_counter() - t0
+    out["lobpcg_10_iterations_wall_s(incl. setup, upload, probe)"] = dt
+    out["config"] = "cfg5 LOBPCG m=126^3=2000376, nx=24, nev=20, ns<=72, 7-pt Laplacian, no preconditioner"
+    out["ritz_0"] = float(r["Theta"][0])
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg3", "cfg5"]
+    c = capi.Context(0)
+    if "cfg3" in which:
+        cfg3(c)
+    if "cfg5" in which:
+        cfg5(c)
+    c.close()

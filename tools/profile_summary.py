@@ -41,7 +41,14 @@ def main(tag):
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     g = os.path.join(ROOT, "gpurun_out")
-    stats_src = os.path.join(g, f"{tag}_trace", "bench_kernel_stats.csv")
+    import glob
+
+    def find(sub, suffix):
+        hits = sorted(glob.glob(os.path.join(g, f"{tag}_{sub}", "**", "*" + suffix), recursive=True))
+        if not hits:
+            raise SystemExit(f"no *{suffix} under gpurun_out/{tag}_{sub}")
+        return hits[-1]
+    stats_src = find("trace", "kernel_stats.csv")
     shutil.copy(stats_src, os.path.join(out, f"{tag}_kernel_stats.csv"))
     stats = {}
     with open(stats_src) as f:
@@ -51,7 +58,7 @@ def main(tag):
     pmc = collections.defaultdict(dict)
     for cnt, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         acc = collections.defaultdict(list)
-        with open(os.path.join(g, f"{tag}_{sub}", "bench_counter_collection.csv")) as f:
+        with open(find(sub, "counter_collection.csv")) as f:
             for row in csv.DictReader(f):
                 if row["Counter_Name"] == cnt:
                     acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
@@ -81,7 +88,9 @@ def main(tag):
         f.write(f"# {tag}: rocprofv3 summary of `python bench.py` (cfg2, Stiefel(1e6,3), 1x MI355X)\n\n")
         f.write("Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 500 "
                 "--warmup 50 --no-cpu-baseline --no-roofline`; PMC: two further runs with `--pmc FETCH_SIZE` and "
-                "`--pmc WRITE_SIZE` (100 steps).  Durations under the profiler are ~5 % longer than un-profiled.\n\n")
+                "`--pmc WRITE_SIZE` (100 steps).  bench.py's own per-kernel figures (HIP event pairs on the launch "
+                "stream) run 1-2 us above the profiler's kernel durations: an event pair also times the gap to "
+                "the event records.\n\n")
         if bench:
             f.write(f"Un-profiled bench line of the same build: value = {bench['value']:.1f} GB/s "
                     f"({bench['ms_per_step'] * 1e3:.2f} us/step), roofline.frac = {bench['roofline']['frac']:.3f} "
