@@ -8,14 +8,16 @@
 //   mi_rayleigh_ritz    small dense generalized symmetric-definite eigenproblem (host)   LOBPCG.h:53-62
 //   mi_csr_spmm_colmajor  Y = A X for a column-major panel (the user operator of cfg5)
 //
-// Gram kernel: a workgroup (4 waves) owns a contiguous range of rows; per 32-row tile both panels are
+// Gram kernel: a workgroup (8 waves) owns a contiguous range of rows; per 32-row tile both panels are
 // staged in LDS column-major with leading dimension 34 (== 2 mod 32, so the 16 columns x 2 rows that a
 // half-wave reads for one MFMA operand hit 32 distinct 8-byte bank pairs); each wave accumulates its
-// share of the (ka/16) x (kb/16) output tiles in registers over the whole row range; per-workgroup
-// partial Grams are then summed in fixed order by a second kernel (deterministic).
+// share (<= 5) of the (ka/16) x (kb/16) output tiles in registers over the whole row range, the next
+// tile's global loads in flight during the MFMA phase; per-workgroup partial Grams are then summed
+// in fixed order by a second kernel (deterministic).
 // Algorithmic bytes: 8 m (ka + kb)  (8 m ka when S == T); flops 2 m ka kb.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "mi_internal.h"
 
@@ -28,33 +30,82 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 constexpr int kGramRows = 32;       // rows per LDS tile
 constexpr int kGramLd = 34;         // LDS leading dimension
 constexpr int kGramMaxK = 96;       // max panel width
-constexpr int kGramThreads = 256;
-constexpr int kMaxTilesPerWave = 9;  // (96/16)^2 / 4
+constexpr int kGramThreads = 512;
+constexpr int kGramWaves = kGramThreads / 64;
+constexpr int kGramSegs = kGramThreads / 16;  // 16 threads x 16 B cover one 32-row column segment
+constexpr int kMaxTilesPerWave = 5;  // ceil((96/16)^2 / 8)
 
-// stage a 32-row x kpad-column tile (rows r0.., zero-filled past m and past k) into LDS
-__device__ __forceinline__ void stage_tile(const double *__restrict__ P, size_t m, int k, int kpad, size_t r0,
-                                           double *lds) {
-  // 16 threads (16 B each) cover one 32-row column segment
+constexpr int kColIters = kGramMaxK / kGramSegs;  // column segments a thread may own per panel
+
+// Global -> registers: the 32-row x k-column tile at rows r0.. (zero-filled past m and past k).
+// 16 threads (16 B each) cover one 32-row column segment; thread owns columns seg, seg+16, ...
+template <bool ALIGNED>
+__device__ __forceinline__ void load_tile(const double *__restrict__ P, size_t m, int k, size_t r0,
+                                          double2 (&reg)[kColIters]) {
   const int seg = threadIdx.x >> 4, part = threadIdx.x & 15;
-  for (int c = seg; c < kpad; c += kGramThreads / 16) {
-    const size_t r = r0 + 2 * (size_t)part;
+  const size_t r = r0 + 2 * (size_t)part;
+#pragma unroll
+  for (int i = 0; i < kColIters; ++i) {
+    // columns past k are clamped to k-1: their products land in output rows/columns that are never
+    // stored, and the loads stay branch-free (a load behind a divergent branch gets its own
+    // s_waitcnt at the merge, which serialises the whole tile fetch)
+    const int c = std::min(seg + kGramSegs * i, k - 1);
     double2 v = make_double2(0.0, 0.0);
-    if (c < k) {
+    {
       const double *src = P + (size_t)c * m + r;
-      if (r + 1 < m) {
-        // column starts are only 8-byte aligned in general (m odd): two scalar loads
-        v.x = src[0];
-        v.y = src[1];
+      if (ALIGNED && r0 + kGramRows <= m) {  // whole tile inside the panel (uniform test)
+        v = *reinterpret_cast<const double2 *>(src);
+      } else if (r + 1 < m) {
+        if (ALIGNED) {
+          v = *reinterpret_cast<const double2 *>(src);
+        } else {  // column starts are only 8-byte aligned in general (m odd)
+          v.x = src[0];
+          v.y = src[1];
+        }
       } else if (r < m) {
         v.x = src[0];
       }
     }
-    lds[c * kGramLd + 2 * part] = v.x;
-    lds[c * kGramLd + 2 * part + 1] = v.y;
+    reg[i] = v;
   }
 }
 
+// registers -> LDS (column-major, leading dimension kGramLd; 16-byte aligned because kGramLd is even)
+__device__ __forceinline__ void store_tile(double *lds, int kpad, const double2 (&reg)[kColIters]) {
+  const int seg = threadIdx.x >> 4, part = threadIdx.x & 15;
+#pragma unroll
+  for (int i = 0; i < kColIters; ++i) {
+    const int c = seg + kGramSegs * i;
+    if (c < kpad) *reinterpret_cast<double2 *>(lds + c * kGramLd + 2 * part) = reg[i];
+  }
+}
+
+// tile number -> (ti, tj).  SAME (G = S'S, symmetric): only tiles with ti <= tj are computed, the
+// reduce kernel mirrors them (the mirrored MFMA sums would be the same bits anyway).
 template <bool SAME>
+__device__ __forceinline__ void tile_decode(int tile, int tb, int &ti, int &tj) {
+  if (SAME) {
+    ti = 0;
+    int len = tb;
+    while (tile >= len) {
+      tile -= len;
+      ++ti;
+      --len;
+    }
+    tj = ti + tile;
+  } else {
+    ti = tile / tb;
+    tj = tile % tb;
+  }
+}
+
+// The next tile's global loads are issued into registers BEFORE the MFMA phase of the current tile,
+// so HBM latency overlaps the matrix pipe; 3 workgroups per CU (<= 52 KB LDS each) overlap each
+// other's barrier phases.
+// TPW = output tiles per wave = ceil(ntiles / 8), a compile-time constant so the MFMA phase is
+// branch-free and the LDS operand reads of step kk+1 are issued ahead of the MFMAs of step kk; a wave
+// whose last slot has no tile recomputes tile (0,0) there and discards it.
+template <bool SAME, bool ALIGNED, int TPW>
 __global__ __launch_bounds__(kGramThreads) void k_gram(size_t m, int ka, int kb, const double *__restrict__ S,
                                                        const double *__restrict__ T, size_t rows_per_block,
                                                        double *__restrict__ partial) {
@@ -63,65 +114,264 @@ __global__ __launch_bounds__(kGramThreads) void k_gram(size_t m, int ka, int kb,
   const int kapad = ta * 16, kbpad = tb * 16;
   double *ldsS = smem;
   double *ldsT = SAME ? smem : smem + (size_t)kapad * kGramLd;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int ntiles = ta * tb;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = SAME ? ta * (ta + 1) / 2 : ta * tb;
 
-  double4v acc[kMaxTilesPerWave];
+  const double *pa[TPW], *pb[TPW];
+  int row0[TPW], col0[TPW];
+  double4v acc[TPW];
+  const int loff = (lane & 15) * kGramLd + (lane >> 4);
 #pragma unroll
-  for (int t = 0; t < kMaxTilesPerWave; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
+    int ti = 0, tj = 0;
+    if (w + kGramWaves * t < ntiles) tile_decode<SAME>(w + kGramWaves * t, tb, ti, tj);
+    row0[t] = ti * 16;
+    col0[t] = tj * 16;
+    pa[t] = ldsS + ti * 16 * kGramLd + loff;
+    pb[t] = ldsT + tj * 16 * kGramLd + loff;
+  }
 
-  const size_t rb = (size_t)blockIdx.x * rows_per_block;
-  const size_t re = std::min(m, rb + rows_per_block);
-  for (size_t r0 = rb; r0 < re; r0 += kGramRows) {
+  // interleaved tiles: at step s the grid reads one contiguous band of 32 * gridDim rows of every
+  // column (DRAM-page friendly); workgroup b takes tile b of each band
+  (void)rows_per_block;
+  const size_t band = (size_t)kGramRows * gridDim.x;
+  const size_t rb = (size_t)blockIdx.x * kGramRows, re = m;
+  double2 ra[kColIters], rt[kColIters];
+  if (rb < re) {
+    load_tile<ALIGNED>(S, m, ka, rb, ra);
+    if (!SAME) load_tile<ALIGNED>(T, m, kb, rb, rt);
+  }
+  for (size_t r0 = rb; r0 < re; r0 += band) {
+    __syncthreads();  // everyone finished reading the previous tile
+    store_tile(ldsS, kapad, ra);
+    if (!SAME) store_tile(ldsT, kbpad, rt);
     __syncthreads();
-    stage_tile(S, m, ka, kapad, r0, ldsS);
-    if (!SAME) stage_tile(T, m, kb, kbpad, r0, ldsT);
-    __syncthreads();
+    if (r0 + band < re) {
+      load_tile<ALIGNED>(S, m, ka, r0 + band, ra);
+      if (!SAME) load_tile<ALIGNED>(T, m, kb, r0 + band, rt);
+    }
+    double av[2][TPW], bv[2][TPW];
 #pragma unroll
-    for (int t = 0; t < kMaxTilesPerWave; ++t) {
-      const int tile = w + 4 * t;
-      if (tile < ntiles) {
-        const int ti = tile / tb, tj = tile % tb;
-        const double *pa = ldsS + (ti * 16 + (lane & 15)) * kGramLd + (lane >> 4);
-        const double *pb = ldsT + (tj * 16 + (lane & 15)) * kGramLd + (lane >> 4);
+    for (int t = 0; t < TPW; ++t) {
+      av[0][t] = pa[t][0];
+      bv[0][t] = pb[t][0];
+    }
 #pragma unroll
-        for (int kk = 0; kk < kGramRows / 4; ++kk)
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[4 * kk], acc[t], 0, 0, 0);
+    for (int kk = 0; kk < kGramRows / 4; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < kGramRows / 4) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          av[nxt][t] = pa[t][4 * (kk + 1)];
+          bv[nxt][t] = pb[t][4 * (kk + 1)];
+        }
       }
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[cur][t], bv[cur][t], acc[t], 0, 0, 0);
     }
   }
   // partial Gram of this workgroup, column-major ka x kb; f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 j
   double *out = partial + (size_t)blockIdx.x * ka * kb;
 #pragma unroll
-  for (int t = 0; t < kMaxTilesPerWave; ++t) {
-    const int tile = w + 4 * t;
-    if (tile < ntiles) {
-      const int ti = tile / tb, tj = tile % tb;
-      const int col = tj * 16 + (lane & 15);
+  for (int t = 0; t < TPW; ++t) {
+    if (w + kGramWaves * t < ntiles) {
+      const int col = col0[t] + (lane & 15);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = ti * 16 + (lane >> 4) + 4 * j;
+        const int row = row0[t] + (lane >> 4) + 4 * j;
         if (row < ka && col < kb) out[(size_t)col * ka + row] = acc[t][j];
       }
     }
   }
 }
 
-// G[e] = sum over workgroups of partial[b][e], fixed order
-__global__ void k_gram_reduce(int nblocks, int nelem, const double *__restrict__ partial, double *__restrict__ G) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nelem) return;
-  double s = 0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * nelem + e];
-  G[e] = s;
+// ---- LDS-free Gram for square panels (ka == kb <= 80, m % 4 == 0, 32-byte aligned) ----------------
+// A wave owns every nrow-th 16-row step and a compile-time range [LO, HI) of the T x T output tiles
+// (all of them for T <= 4; for T = 5 two waves split them 13/12, so that the accumulators plus one
+// operand set stay under 256 registers and TWO waves fit on a SIMD).  Lane (i = l & 15, q = l >> 4)
+// loads the 4 consecutive rows r0 + 4q .. 4q+3 of column 16 t + i with one 32-byte load: a wave
+// instruction reads 16 whole 128-byte lines, every byte used, and those four values are the lane's
+// MFMA operands of the next four k-steps (step j contracts over the rows {r0 + 4q + j}; A and B use
+// the same row partition, so the sum over the 16 rows is complete).  No LDS, no barrier, no explicit
+// double buffering: the overlap of loads and MFMAs comes from the second wave on the SIMD.  (Explicit
+// register double-buffering was tried first: at 400+ registers the compiler either spilled or put
+// s_waitcnt vmcnt(0) in front of the first MFMA of every step, i.e. waited for the prefetch it had
+// just issued.)  Only whole 16-row steps are handled here; the m % 16 leftover rows go through
+// k_gram_tail.
+typedef double double4l __attribute__((ext_vector_type(4)));
+constexpr int kGdH = 1;  // 16-row blocks per pipeline step of k_gram_direct
+
+constexpr int gd_tile_index(int T, bool same, int a, int b) {  // a-major; upper triangle only when same
+  if (!same) return a * T + b;
+  int idx = 0;
+  for (int r = 0; r < a; ++r) idx += T - r;
+  return idx + (b - a);
+}
+constexpr bool gd_in(int T, bool same, int lo, int hi, int a, int b) {
+  return (!same || b >= a) && gd_tile_index(T, same, a, b) >= lo && gd_tile_index(T, same, a, b) < hi;
+}
+constexpr bool gd_need_row(int T, bool same, int lo, int hi, int a) {  // operand block a of S used as A?
+  for (int b = 0; b < T; ++b)
+    if (gd_in(T, same, lo, hi, a, b)) return true;
+  return false;
+}
+constexpr bool gd_need_col(int T, bool same, int lo, int hi, int b) {  // operand block b used as B?
+  for (int a = 0; a < T; ++a)
+    if (gd_in(T, same, lo, hi, a, b)) return true;
+  return false;
 }
 
-// Y[:, c0:c0+KC) = S (m x ks) C[:, c0:c0+KC); one thread per row, C chunk in LDS
+template <int T, bool SAME, int LO, int HI>
+__device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, const double *__restrict__ S,
+                                                 const double *__restrict__ Tm, size_t rowwave, size_t nrow,
+                                                 double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  // columns past k are clamped to column k-1: their products land in rows/columns that are never stored
+  const size_t lane_off = 4 * (size_t)(lane >> 4);
+  const double *ps[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) ps[t] = S + (size_t)std::min(16 * t + (lane & 15), k - 1) * m + lane_off;
+  const size_t dT = (size_t)(Tm - S);  // uniform: the T panel's operand addresses are ps[t] + dT
+  double4v acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b) acc[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
+  // Software pipeline inside the wave: a step is kGdH x 16 rows; the loads of step s+1 (into na/nb) are
+  // issued right after the operands of step s were moved to sa/sb, so they have the whole MFMA block of
+  // step s (kGdH x 4 x ntiles MFMAs, ~3.5 us at 13 tiles) to land.  Two identical waves on a SIMD WITHOUT
+  // such a pipeline run in lockstep (both wait for memory, then both want the matrix pipe): measured
+  // MfmaUtil 44 %, 89 % of wave cycles in s_waitcnt.
+  const size_t band = 16 * kGdH * nrow;
+  auto load = [&](double4l(&va)[kGdH][T], double4l(&vb)[kGdH][T], size_t r) {
+#pragma unroll
+    for (int h = 0; h < kGdH; ++h)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        // SAME: one operand set serves both sides
+        if (gd_need_row(T, SAME, LO, HI, t) || (SAME && gd_need_col(T, SAME, LO, HI, t)))
+          va[h][t] = *reinterpret_cast<const double4l *>(ps[t] + r + 16 * h);
+        if (!SAME && gd_need_col(T, SAME, LO, HI, t))
+          vb[h][t] = *reinterpret_cast<const double4l *>(ps[t] + dT + r + 16 * h);
+      }
+  };
+  auto mma = [&](const double4l(&va)[kGdH][T], const double4l(&vb)[kGdH][T]) {
+#pragma unroll
+    for (int h = 0; h < kGdH; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int b = 0; b < T; ++b)
+            if (gd_in(T, SAME, LO, HI, a, b))
+              acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[h][a][j], SAME ? va[h][b][j] : vb[h][b][j],
+                                                              acc[a][b], 0, 0, 0);
+  };
+  double4l sa[kGdH][T], sb[kGdH][T], na[kGdH][T], nb[kGdH][T];
+  size_t r0 = rowwave * 16 * kGdH;
+  if (r0 < mfull) load(na, nb, r0);
+  for (; r0 < mfull; r0 += band) {
+#pragma unroll
+    for (int h = 0; h < kGdH; ++h)
+#pragma unroll
+      for (int t = 0; t < T; ++t) {  // the one wait of the step: loads issued a whole MFMA block ago
+        sa[h][t] = na[h][t];
+        sb[h][t] = nb[h][t];
+      }
+    if (r0 + band < mfull) load(na, nb, r0 + band);
+    mma(sa, sb);
+  }
+  // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 j
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+      if (gd_in(T, SAME, LO, HI, a, b)) {
+        const int col = b * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = a * 16 + (lane >> 4) + 4 * j;
+          if (row < k && col < k) out[(size_t)col * k + row] = acc[a][b][j];
+        }
+      }
+}
+
+// amdgpu_waves_per_eu(1, 2): plan for at most two waves per SIMD.  Without a cap the scheduler chases
+// occupancy it cannot use: it shortens live ranges by re-loading operands in the middle of the MFMA
+// sequence, each reload behind an s_waitcnt vmcnt(0) (measured: 1200 us vs 640).
+template <int T, bool SAME, int NSPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_gram_direct(
+    size_t mfull, size_t m, int k, const double *__restrict__ S, const double *__restrict__ Tm,
+    double *__restrict__ partial) {
+  constexpr int NT = SAME ? T * (T + 1) / 2 : T * T;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t nrow = (size_t)gridDim.x * 4 / NSPLIT, rowwave = wave / NSPLIT;
+  double *out = partial + rowwave * (size_t)k * k;  // the waves of a split write disjoint tiles of one partial
+  if (NSPLIT == 1) {
+    gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, rowwave, nrow, out);
+  } else {
+    constexpr int MID = (NT + 1) / 2;
+    if (__builtin_amdgcn_readfirstlane((int)(wave % NSPLIT)) == 0)
+      gram_direct_body<T, SAME, 0, MID>(mfull, m, k, S, Tm, rowwave, nrow, out);
+    else
+      gram_direct_body<T, SAME, MID, NT>(mfull, m, k, S, Tm, rowwave, nrow, out);
+  }
+}
+
+// rows [r_begin, m) (fewer than 16) of S'T as one more partial Gram: one thread per output element
+__global__ __launch_bounds__(256) void k_gram_tail(size_t m, size_t r_begin, int ka, int kb,
+                                                   const double *__restrict__ S, const double *__restrict__ Tm,
+                                                   double *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ka * kb) return;
+  const int row = e % ka, col = e / ka;
+  double s = 0;
+  for (size_t r = r_begin; r < m; ++r) s += S[(size_t)row * m + r] * Tm[(size_t)col * m + r];
+  out[e] = s;
+}
+
+// G[e] = sum over workgroups of partial[b][e], fixed order; sym: element (row, col) below the block
+// diagonal is read from its mirror (col, row)
+// A workgroup handles kRedElems elements; group g of kRedGroups sums the workgroups b == g (mod
+// kRedGroups) in ascending order, then the groups are added in ascending order: fixed, launch-independent.
+constexpr int kRedElems = 32, kRedGroups = 8;
+__global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nblocks, int ka, int nelem, int sym,
+                                                                       const double *__restrict__ partial,
+                                                                       double *__restrict__ G) {
+  __shared__ double part[kRedGroups][kRedElems];
+  const int ex = threadIdx.x % kRedElems, g = threadIdx.x / kRedElems;
+  const int e = blockIdx.x * kRedElems + ex;
+  double s = 0;
+  if (e < nelem) {
+    int src = e;
+    if (sym) {
+      const int row = e % ka, col = e / ka;
+      if (row / 16 > col / 16) src = row * ka + col;
+    }
+    for (int b = g; b < nblocks; b += kRedGroups) s += partial[(size_t)b * nelem + src];
+  }
+  part[g][ex] = s;
+  __syncthreads();
+  if (g == 0 && e < nelem) {
+    double tot = part[0][ex];
+#pragma unroll
+    for (int q = 1; q < kRedGroups; ++q) tot += part[q][ex];
+    G[e] = tot;
+  }
+}
+
+// Y[:, c0:c0+KC) = S (m x ks) C[:, c0:c0+KC); one thread per row, KC accumulators in registers, the
+// C chunk in LDS (row-major by s, so one s needs KC consecutive broadcast reads).  KC = 24 covers a
+// whole nx = 24 block in ONE pass over S (the panel is the traffic: 8 m ks bytes per pass).
 template <int KC>
 __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const double *__restrict__ S,
                                                       const double *__restrict__ Cdev, int ldc, int c0, int kc,
                                                       double *__restrict__ Y) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // ks x KC, row-major by s
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // ks x KC
   for (int i = threadIdx.x; i < ks * KC; i += blockDim.x) {
     const int s = i / KC, c = i % KC;
     smem[i] = (c0 + c < kc) ? Cdev[(size_t)(c0 + c) * ldc + s] : 0.0;
@@ -132,8 +382,23 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
     double acc[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) acc[c] = 0;
-    for (int s = 0; s < ks; ++s) {
-      const double sv = S[(size_t)s * m + r];
+    const double *sp = S + r;
+    int s = 0;
+    for (; s + 4 <= ks; s += 4) {  // four independent column loads in flight
+      const double v0 = sp[(size_t)s * m], v1 = sp[(size_t)(s + 1) * m], v2 = sp[(size_t)(s + 2) * m],
+                   v3 = sp[(size_t)(s + 3) * m];
+      const double *cr = smem + s * KC;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] += v0 * cr[c];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] += v1 * cr[KC + c];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] += v2 * cr[2 * KC + c];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] += v3 * cr[3 * KC + c];
+    }
+    for (; s < ks; ++s) {
+      const double sv = sp[(size_t)s * m];
       const double *cr = smem + s * KC;
 #pragma unroll
       for (int c = 0; c < KC; ++c) acc[c] += sv * cr[c];
@@ -173,30 +438,38 @@ __global__ __launch_bounds__(kBlock) void k_residual(size_t m, int nx, int c0, c
   block_partials_store<16>(a, lds, partials);
 }
 
-// Y = A X for a column-major panel: one thread per row, columns in chunks of 8
+// Y = A X for a column-major panel: one thread per row, KC columns per pass over the matrix (the
+// matrix stream, 12 B/nnz, is re-read once per pass; X gathers of a wave are contiguous per column
+// for banded matrices).  Columns past k are clamped to the last valid one and not stored.
+template <int KC>
 __global__ __launch_bounds__(256) void k_spmm_colmajor(size_t n, size_t nslices, const long long *__restrict__ sp,
                                                        const int *__restrict__ col, const double *__restrict__ val,
                                                        int k, int c0, const double *__restrict__ X,
                                                        double *__restrict__ Y) {
   const int lane = threadIdx.x & 63;
-  const size_t slice = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // contiguous row ranges per XCD: the neighbour rows a stencil-like matrix gathers then live in
+  // the same XCD's L2 instead of being refetched by all eight
+  const size_t slice = (size_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (slice >= nslices) return;
   const size_t row = slice * 64 + lane;
-  double acc[8];
+  double acc[KC];
+  const double *xc[KC];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0;
+  for (int c = 0; c < KC; ++c) {
+    acc[c] = 0;
+    xc[c] = X + (size_t)std::min(c0 + c, k - 1) * n;
+  }
   const long long b0 = sp[slice], b1 = sp[slice + 1];
   for (long long kk = b0; kk < b1; ++kk) {
     const size_t e = (size_t)kk * 64 + lane;
     const double a = val[e];
     const size_t j = (size_t)col[e];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c0 + c < k) acc[c] += a * X[(size_t)(c0 + c) * n + j];
+    for (int c = 0; c < KC; ++c) acc[c] += a * xc[c][j];
   }
   if (row < n) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < KC; ++c)
       if (c0 + c < k) Y[(size_t)(c0 + c) * n + row] = acc[c];
   }
 }
@@ -226,39 +499,139 @@ int cholesky_lower(int n, std::vector<double> &A) {
   return 0;
 }
 
-void jacobi_eigh(int n, std::vector<double> &M, std::vector<double> &V, double *w) {
-  V.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; ++i) V[i + (size_t)i * n] = 1;
-  for (int sweep = 0; sweep < 100; ++sweep) {
-    double off = 0, diag = 0;
-    for (int j = 0; j < n; ++j)
-      for (int i = 0; i < n; ++i) (i != j ? off : diag) += M[i + (size_t)j * n] * M[i + (size_t)j * n];
-    if (off <= 1e-32 * (diag + off) || off == 0) break;
-    for (int p = 0; p + 1 < n; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = M[p + (size_t)q * n];
-        if (apq == 0) continue;
-        const double tau = (M[q + (size_t)q * n] - M[p + (size_t)p * n]) / (2 * apq);
-        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
-        const double c = 1 / std::sqrt(1 + t * t), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          const double a = M[k + (size_t)p * n], b = M[k + (size_t)q * n];
-          M[k + (size_t)p * n] = c * a - s * b;
-          M[k + (size_t)q * n] = s * a + c * b;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double a = M[p + (size_t)k * n], b = M[q + (size_t)k * n];
-          M[p + (size_t)k * n] = c * a - s * b;
-          M[q + (size_t)k * n] = s * a + c * b;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double a = V[k + (size_t)p * n], b = V[k + (size_t)q * n];
-          V[k + (size_t)p * n] = c * a - s * b;
-          V[k + (size_t)q * n] = s * a + c * b;
-        }
+// Symmetric eigen-decomposition of the ns x ns projected pencil (ns <= 96): Householder reduction to
+// tridiagonal form followed by implicit-shift QL with accumulated transformations (the classic
+// EISPACK tred2/tql2 pair).  O(n^3) with a small constant: 72 x 72 takes well under a millisecond
+// on one host core, so the device never waits long for the Ritz coefficients (a cyclic Jacobi here
+// cost 60 ms per LOBPCG iteration, 10x the whole device side of the iteration).
+// M is destroyed; on return V(:, j) is the eigenvector of w[j], ascending.
+void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, double *w) {
+  V = M;
+  std::vector<double> ev((size_t)n, 0.0);
+  double *d = w, *e = ev.data();
+#define VV(i, j) V[(size_t)(i) + (size_t)(j) * n]
+  // --- Householder tridiagonalisation, last row first
+  for (int j = 0; j < n; ++j) d[j] = VV(n - 1, j);
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0, h = 0;
+    for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+    if (scale == 0) {
+      e[i] = d[i - 1];
+      for (int j = 0; j < i; ++j) {
+        d[j] = VV(i - 1, j);
+        VV(i, j) = 0;
+        VV(j, i) = 0;
       }
+    } else {
+      for (int k = 0; k < i; ++k) {
+        d[k] /= scale;
+        h += d[k] * d[k];
+      }
+      double f = d[i - 1];
+      double g = f > 0 ? -std::sqrt(h) : std::sqrt(h);
+      e[i] = scale * g;
+      h -= f * g;
+      d[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0;
+      for (int j = 0; j < i; ++j) {  // e = (A u) / h, using the lower triangle only
+        f = d[j];
+        VV(j, i) = f;
+        g = e[j] + VV(j, j) * f;
+        for (int k = j + 1; k < i; ++k) {
+          g += VV(k, j) * d[k];
+          e[k] += VV(k, j) * f;
+        }
+        e[j] = g;
+      }
+      f = 0;
+      for (int j = 0; j < i; ++j) {
+        e[j] /= h;
+        f += e[j] * d[j];
+      }
+      const double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+      for (int j = 0; j < i; ++j) {  // rank-2 update of the leading block
+        f = d[j];
+        g = e[j];
+        for (int k = j; k < i; ++k) VV(k, j) -= f * e[k] + g * d[k];
+        d[j] = VV(i - 1, j);
+        VV(i, j) = 0;
+      }
+    }
+    d[i] = h;
   }
-  for (int i = 0; i < n; ++i) w[i] = M[i + (size_t)i * n];
+  // --- accumulate the reflectors
+  for (int i = 0; i + 1 < n; ++i) {
+    VV(n - 1, i) = VV(i, i);
+    VV(i, i) = 1;
+    const double h = d[i + 1];
+    if (h != 0) {
+      for (int k = 0; k <= i; ++k) d[k] = VV(k, i + 1) / h;
+      for (int j = 0; j <= i; ++j) {
+        double g = 0;
+        for (int k = 0; k <= i; ++k) g += VV(k, i + 1) * VV(k, j);
+        for (int k = 0; k <= i; ++k) VV(k, j) -= g * d[k];
+      }
+    }
+    for (int k = 0; k <= i; ++k) VV(k, i + 1) = 0;
+  }
+  for (int j = 0; j < n; ++j) {
+    d[j] = VV(n - 1, j);
+    VV(n - 1, j) = 0;
+  }
+  VV(n - 1, n - 1) = 1;
+  // --- implicit QL on (d, e)
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0;
+  double shift = 0, tst = 0;
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    tst = std::max(tst, std::fabs(d[l]) + std::fabs(e[l]));
+    int mm = l;
+    while (mm < n - 1 && std::fabs(e[mm]) > eps * tst) ++mm;
+    if (mm > l) {
+      int guard = 0;
+      do {
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2 * e[l]);
+        double r = std::hypot(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        shift += h;
+        p = d[mm];
+        double c = 1, c2 = 1, c3 = 1, s = 0, s2 = 0;
+        const double el1 = e[l + 1];
+        for (int i = mm - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = std::hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          for (int k = 0; k < n; ++k) {
+            h = VV(k, i + 1);
+            VV(k, i + 1) = s * VV(k, i) + c * h;
+            VV(k, i) = c * VV(k, i) - s * h;
+          }
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst && ++guard < 200);
+    }
+    d[l] += shift;
+    e[l] = 0;
+  }
+#undef VV
   for (int i = 0; i + 1 < n; ++i) {  // ascending
     int mn = i;
     for (int j = i + 1; j < n; ++j)
@@ -287,28 +660,86 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
   MI_TRY(check_panel(ctx, m, ka, S, "S"));
   MI_TRY(check_panel(ctx, m, kb, T, "T"));
   const bool same = (S->d == T->d) && ka == kb;
-  // rows per workgroup: a multiple of the 32-row tile, ~2 workgroups per CU
-  size_t nb = std::min<size_t>(2 * (size_t)ctx->num_cu, (m + kGramRows - 1) / kGramRows);
-  if (nb < 1) nb = 1;
-  size_t rpb = ((m + nb - 1) / nb + kGramRows - 1) / kGramRows * kGramRows;
-  nb = (m + rpb - 1) / rpb;
+  const bool aligned = (m % 2 == 0) && ((uintptr_t)S->d % 16 == 0) && ((uintptr_t)T->d % 16 == 0);
   const int nelem = ka * kb;
+  const int kapad = (ka + 15) / 16 * 16, kbpad = (kb + 15) / 16 * 16;
+  // square panels of up to 80 columns on 32-byte-aligned columns: the LDS-free one-wave-per-row-range kernel
+  const bool direct = ka == kb && ka <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T->d % 32 == 0 &&
+                      m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+  size_t nb, rpb = 0, nwaves = 0;
+  const size_t mfull = m - m % (16 * kGdH);  // rows k_gram_direct covers in whole pipeline steps
+  if (direct) {  // one partial per wave (4 per workgroup = one per SIMD) + one for the m % 16 leftover rows
+    const int occ = 2;                                         // waves per SIMD (amdgpu_waves_per_eu(2, 2))
+    const int nsplit = kapad / 16 >= 6 ? 2 : 1;               // waves sharing one row step (k_gram_direct)
+    nwaves = (std::min<size_t>(4 * (size_t)occ * ctx->num_cu, nsplit * (mfull / (16 * kGdH))) + 3) / 4 * 4;
+    nb = nwaves / nsplit + (mfull < m ? 1 : 0);
+  } else {  // rows per workgroup: a multiple of the 32-row tile, ~3 workgroups per CU
+    nb = std::min<size_t>(3 * (size_t)ctx->num_cu, (m + kGramRows - 1) / kGramRows);
+    if (nb < 1) nb = 1;
+    rpb = ((m + nb - 1) / nb + kGramRows - 1) / kGramRows * kGramRows;
+    nb = (m + rpb - 1) / rpb;
+  }
   void *partial = nullptr, *Gdev = nullptr;
   MI_TRY(pool_alloc(ctx, nb * (size_t)nelem * sizeof(double), &partial));
   MI_TRY(pool_alloc(ctx, (size_t)nelem * sizeof(double), &Gdev));
-  const int kapad = (ka + 15) / 16 * 16, kbpad = (kb + 15) / 16 * 16;
   const size_t lds = (size_t)(same ? kapad : kapad + kbpad) * kGramLd * sizeof(double);
-  {
+  if (direct) {
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
-    if (same)
-      hipLaunchKernelGGL(k_gram<true>, dim3((unsigned)nb), dim3(kGramThreads), lds, ctx->stream, m, ka, kb,
-                         (const double *)S->d, (const double *)T->d, rpb, (double *)partial);
-    else
-      hipLaunchKernelGGL(k_gram<false>, dim3((unsigned)nb), dim3(kGramThreads), lds, ctx->stream, m, ka, kb,
-                         (const double *)S->d, (const double *)T->d, rpb, (double *)partial);
+    if (mfull < m)
+      hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, ka, kb,
+                         (const double *)S->d, (const double *)T->d, (double *)partial + (nb - 1) * (size_t)nelem);
+#define GD(TT, SAME, NS)                                                                                         \
+  hipLaunchKernelGGL((k_gram_direct<TT, SAME, NS>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, \
+                     m, ka, (const double *)S->d, (const double *)T->d, (double *)partial)
+#define GD_T(SAME)                   \
+  switch (kapad / 16) {              \
+    case 1: GD(1, SAME, 1); break;   \
+    case 2: GD(2, SAME, 1); break;   \
+    case 3: GD(3, SAME, 1); break;   \
+    case 4: GD(4, SAME, 1); break;   \
+    default: GD(5, SAME, 1); break;  \
   }
-  hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, (int)nb, nelem,
-                     (const double *)partial, (double *)Gdev);
+    if (same) {
+      GD_T(true)
+    } else {
+      GD_T(false)
+    }
+#undef GD_T
+#undef GD
+  } else {
+    KScope ks(ctx, MI_K_LOBPCG_GRAM);
+    const int ta = kapad / 16, tb = kbpad / 16;
+    const int ntiles = same ? ta * (ta + 1) / 2 : ta * tb;
+    const int tpw = (ntiles + kGramWaves - 1) / kGramWaves;  // 1..5
+#define GRAM(SAME, AL, TPW)                                                                                        \
+  hipLaunchKernelGGL((k_gram<SAME, AL, TPW>), dim3((unsigned)nb), dim3(kGramThreads), lds, ctx->stream, m, ka, kb, \
+                     (const double *)S->d, (const double *)T->d, rpb, (double *)partial)
+#define GRAM_T(SAME, AL)        \
+  switch (tpw) {                \
+    case 1: GRAM(SAME, AL, 1); break; \
+    case 2: GRAM(SAME, AL, 2); break; \
+    case 3: GRAM(SAME, AL, 3); break; \
+    case 4: GRAM(SAME, AL, 4); break; \
+    default: GRAM(SAME, AL, 5); break; \
+  }
+    if (same) {
+      if (aligned) {
+        GRAM_T(true, true)
+      } else {
+        GRAM_T(true, false)
+      }
+    } else {
+      if (aligned) {
+        GRAM_T(false, true)
+      } else {
+        GRAM_T(false, false)
+      }
+    }
+#undef GRAM_T
+#undef GRAM
+  }
+  hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + kRedElems - 1) / kRedElems), dim3(kRedElems * kRedGroups), 0,
+                     ctx->stream, (int)nb, ka, nelem, (int)same, (const double *)partial, (double *)Gdev);
   if (ctx->comm) {
     for (int off = 0; off < nelem; off += 4096)  // all-reduce in chunks the comm layer accepts
       MI_TRY(comm_allreduce(ctx, (double *)Gdev + off, std::min(4096, nelem - off)));
@@ -335,9 +766,23 @@ int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, con
   MI_HIP(hipStreamSynchronize(ctx->stream));
   const int grid = (int)std::min<size_t>((m + 255) / 256, 2048);
   KScope ksc(ctx, MI_K_LOBPCG_UPDATE);
-  for (int c0 = 0; c0 < kc; c0 += 8)
-    hipLaunchKernelGGL(k_panel_update<8>, dim3(grid), dim3(256), (size_t)ks * 8 * sizeof(double), ctx->stream, m,
-                       ks, (const double *)S->d, (const double *)Cdev, ldc, c0, kc, Y->d);
+  for (int c0 = 0; c0 < kc;) {  // widest chunk that fits what is left: one pass over S per 24 output columns
+    const int left = kc - c0;
+#define UPD(KC)                                                                                                    \
+  hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), (size_t)ks * KC * sizeof(double), ctx->stream, m, \
+                     ks, (const double *)S->d, (const double *)Cdev, ldc, c0, kc, Y->d)
+    if (left > 16) {
+      UPD(24);
+      c0 += 24;
+    } else if (left > 8) {
+      UPD(16);
+      c0 += 16;
+    } else {
+      UPD(8);
+      c0 += 8;
+    }
+#undef UPD
+  }
   MI_HIP(hipGetLastError());
   pool_free(ctx, Cdev);  // stream-ordered reuse: later allocations are enqueued after these kernels
   return MI_OK;
@@ -410,7 +855,7 @@ int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, dou
       M[i + (size_t)j * n] = a;
       M[j + (size_t)i * n] = a;
     }
-  jacobi_eigh(n, M, Y, Theta);
+  sym_eigh(n, M, Y, Theta);
   for (int j = 0; j < n; ++j) {  // x = L^-T y ; C = D x  (:61)
     for (int i = n; i-- > 0;) {
       double s = Y[i + (size_t)j * n];
@@ -444,10 +889,24 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   mi_ctx *ctx = A->ctx;
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
-  for (int c0 = 0; c0 < k; c0 += 8)
-    hipLaunchKernelGGL(k_spmm_colmajor, dim3(grid), dim3(256), 0, ctx->stream, A->n, A->nslices,
-                       (const long long *)A->slice_ptr, (const int *)A->col, (const double *)A->val, k, c0,
-                       (const double *)X->d, Y->d);
+  for (int c0 = 0; c0 < k;) {
+    const int left = k - c0;
+#define SPMM(KC)                                                                                             \
+  hipLaunchKernelGGL(k_spmm_colmajor<KC>, dim3(grid), dim3(256), 0, ctx->stream, A->n, A->nslices,           \
+                     (const long long *)A->slice_ptr, (const int *)A->col, (const double *)A->val, k, c0,    \
+                     (const double *)X->d, Y->d)
+    if (left > 16) {
+      SPMM(24);
+      c0 += 24;
+    } else if (left > 8) {
+      SPMM(16);
+      c0 += 16;
+    } else {
+      SPMM(8);
+      c0 += 8;
+    }
+#undef SPMM
+  }
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -19,7 +19,10 @@ def harness():
 
 
 @pytest.mark.parametrize("m,ka,kb", [(1, 1, 1), (31, 3, 5), (32, 16, 16), (33, 17, 15), (1000, 10, 10),
-                                     (4097, 30, 20), (100_003, 60, 60), (50_000, 96, 72)])
+                                     (4097, 30, 20), (100_003, 60, 60), (50_000, 96, 72),
+                                     # m % 4 == 0 and square <= 80: the LDS-free one-wave-per-row-range kernel
+                                     (16, 5, 5), (20, 16, 16), (1000, 24, 24), (4100, 33, 33), (100_004, 48, 48),
+                                     (200_012, 72, 72), (65_536, 80, 80), (40_000, 96, 96)])
 def test_gram_mfma_vs_numpy(ctx, m, ka, kb):
     """G = S'T (LOBPCG.h:223,271-272) with ASYMMETRIC operands (catches a transposed C/D map)."""
     rng = np.random.default_rng(m + ka)
