@@ -285,7 +285,9 @@ __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, 
     if (r0 + band < mfull) load(na, nb, r0 + band);
     mma(sa, sb);
   }
-  // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 j
+  // One partial Gram per WAVE, straight from the accumulators (f64 C/D map: col = lane & 15,
+  // row = (lane >> 4) + 4 j).  Summing the four waves of a workgroup through LDS first was tried: the
+  // extra live ranges pushed the T = 5 kernel into scratch (1700 us instead of 560).
 #pragma unroll
   for (int a = 0; a < T; ++a)
 #pragma unroll
@@ -303,23 +305,13 @@ __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, 
 // amdgpu_waves_per_eu(1, 2): plan for at most two waves per SIMD.  Without a cap the scheduler chases
 // occupancy it cannot use: it shortens live ranges by re-loading operands in the middle of the MFMA
 // sequence, each reload behind an s_waitcnt vmcnt(0) (measured: 1200 us vs 640).
-template <int T, bool SAME, int NSPLIT>
+template <int T, bool SAME>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_gram_direct(
     size_t mfull, size_t m, int k, const double *__restrict__ S, const double *__restrict__ Tm,
     double *__restrict__ partial) {
   constexpr int NT = SAME ? T * (T + 1) / 2 : T * T;
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const size_t nrow = (size_t)gridDim.x * 4 / NSPLIT, rowwave = wave / NSPLIT;
-  double *out = partial + rowwave * (size_t)k * k;  // the waves of a split write disjoint tiles of one partial
-  if (NSPLIT == 1) {
-    gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, rowwave, nrow, out);
-  } else {
-    constexpr int MID = (NT + 1) / 2;
-    if (__builtin_amdgcn_readfirstlane((int)(wave % NSPLIT)) == 0)
-      gram_direct_body<T, SAME, 0, MID>(mfull, m, k, S, Tm, rowwave, nrow, out);
-    else
-      gram_direct_body<T, SAME, MID, NT>(mfull, m, k, S, Tm, rowwave, nrow, out);
-  }
+  gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, wave, (size_t)gridDim.x * 4, partial + wave * (size_t)k * k);
 }
 
 // rows [r_begin, m) (fewer than 16) of S'T as one more partial Gram: one thread per output element
@@ -338,7 +330,7 @@ __global__ __launch_bounds__(256) void k_gram_tail(size_t m, size_t r_begin, int
 // diagonal is read from its mirror (col, row)
 // A workgroup handles kRedElems elements; group g of kRedGroups sums the workgroups b == g (mod
 // kRedGroups) in ascending order, then the groups are added in ascending order: fixed, launch-independent.
-constexpr int kRedElems = 32, kRedGroups = 8;
+constexpr int kRedElems = 16, kRedGroups = 32;
 __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nblocks, int ka, int nelem, int sym,
                                                                        const double *__restrict__ partial,
                                                                        double *__restrict__ G) {
@@ -367,16 +359,14 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
 // Y[:, c0:c0+KC) = S (m x ks) C[:, c0:c0+KC); one thread per row, KC accumulators in registers, the
 // C chunk in LDS (row-major by s, so one s needs KC consecutive broadcast reads).  KC = 24 covers a
 // whole nx = 24 block in ONE pass over S (the panel is the traffic: 8 m ks bytes per pass).
+// The coefficients are wave-uniform: Ct (this chunk, ks x KC, row-major by s, zero-padded past kc) is
+// read with SCALAR loads (s_load_dwordx*, SGPR operand of v_fma_f64), not through LDS: with C in LDS
+// every FMA pair cost one broadcast ds_read and the kernel was LDS-issue bound (607 us for 72 x 48).
 template <int KC>
 __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const double *__restrict__ S,
-                                                      const double *__restrict__ Cdev, int ldc, int c0, int kc,
+                                                      const double *__restrict__ Ct, int c0, int kc,
                                                       double *__restrict__ Y) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // ks x KC
-  for (int i = threadIdx.x; i < ks * KC; i += blockDim.x) {
-    const int s = i / KC, c = i % KC;
-    smem[i] = (c0 + c < kc) ? Cdev[(size_t)(c0 + c) * ldc + s] : 0.0;
-  }
-  __syncthreads();
+  const double *__restrict__ smem = Ct;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
     double acc[KC];
@@ -388,14 +378,18 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
       const double v0 = sp[(size_t)s * m], v1 = sp[(size_t)(s + 1) * m], v2 = sp[(size_t)(s + 2) * m],
                    v3 = sp[(size_t)(s + 3) * m];
       const double *cr = smem + s * KC;
+      // column blocks of 8: 4 x 8 coefficients = 64 SGPRs live at a time (all 4 x KC at once spills)
 #pragma unroll
-      for (int c = 0; c < KC; ++c) acc[c] += v0 * cr[c];
+      for (int cb = 0; cb < KC; cb += 8) {
 #pragma unroll
-      for (int c = 0; c < KC; ++c) acc[c] += v1 * cr[KC + c];
+        for (int c = cb; c < cb + 8; ++c) acc[c] += v0 * cr[c];
 #pragma unroll
-      for (int c = 0; c < KC; ++c) acc[c] += v2 * cr[2 * KC + c];
+        for (int c = cb; c < cb + 8; ++c) acc[c] += v1 * cr[KC + c];
 #pragma unroll
-      for (int c = 0; c < KC; ++c) acc[c] += v3 * cr[3 * KC + c];
+        for (int c = cb; c < cb + 8; ++c) acc[c] += v2 * cr[2 * KC + c];
+#pragma unroll
+        for (int c = cb; c < cb + 8; ++c) acc[c] += v3 * cr[3 * KC + c];
+      }
     }
     for (; s < ks; ++s) {
       const double sv = sp[(size_t)s * m];
@@ -462,15 +456,17 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor(size_t n, size_t nslices,
   const long long b0 = sp[slice], b1 = sp[slice + 1];
   for (long long kk = b0; kk < b1; ++kk) {
     const size_t e = (size_t)kk * 64 + lane;
-    const double a = val[e];
-    const size_t j = (size_t)col[e];
+    // matrix stream and result are touched once: keep them from evicting the X lines that the
+    // neighbouring rows (one grid plane = 3 MB of X at 24 columns) are about to gather again
+    const double a = __builtin_nontemporal_load(val + e);
+    const size_t j = (size_t)__builtin_nontemporal_load(col + e);
 #pragma unroll
     for (int c = 0; c < KC; ++c) acc[c] += a * xc[c][j];
   }
   if (row < n) {
 #pragma unroll
     for (int c = 0; c < KC; ++c)
-      if (c0 + c < k) Y[(size_t)(c0 + c) * n + row] = acc[c];
+      if (c0 + c < k) __builtin_nontemporal_store(acc[c], Y + (size_t)(c0 + c) * n + row);
   }
 }
 
@@ -668,11 +664,11 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
                       m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
   size_t nb, rpb = 0, nwaves = 0;
   const size_t mfull = m - m % (16 * kGdH);  // rows k_gram_direct covers in whole pipeline steps
-  if (direct) {  // one partial per wave (4 per workgroup = one per SIMD) + one for the m % 16 leftover rows
-    const int occ = 2;                                         // waves per SIMD (amdgpu_waves_per_eu(2, 2))
-    const int nsplit = kapad / 16 >= 6 ? 2 : 1;               // waves sharing one row step (k_gram_direct)
-    nwaves = (std::min<size_t>(4 * (size_t)occ * ctx->num_cu, nsplit * (mfull / (16 * kGdH))) + 3) / 4 * 4;
-    nb = nwaves / nsplit + (mfull < m ? 1 : 0);
+  if (direct) {  // one partial per wave + one for the leftover rows
+    // two waves per SIMD where the registers allow it (k <= 48, and k <= 80 when S == T), else one
+    const int occ = (kapad <= 48 || same) ? 2 : 1;
+    nwaves = (std::min<size_t>(4 * (size_t)occ * ctx->num_cu, mfull / (16 * kGdH)) + 3) / 4 * 4;
+    nb = nwaves + (mfull < m ? 1 : 0);
   } else {  // rows per workgroup: a multiple of the 32-row tile, ~3 workgroups per CU
     nb = std::min<size_t>(3 * (size_t)ctx->num_cu, (m + kGramRows - 1) / kGramRows);
     if (nb < 1) nb = 1;
@@ -688,9 +684,9 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
     if (mfull < m)
       hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, ka, kb,
                          (const double *)S->d, (const double *)T->d, (double *)partial + (nb - 1) * (size_t)nelem);
-#define GD(TT, SAME, NS)                                                                                         \
-  hipLaunchKernelGGL((k_gram_direct<TT, SAME, NS>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, \
-                     m, ka, (const double *)S->d, (const double *)T->d, (double *)partial)
+#define GD(TT, SAME, NS)                                                                                  \
+  hipLaunchKernelGGL((k_gram_direct<TT, SAME>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, \
+                     mfull, m, ka, (const double *)S->d, (const double *)T->d, (double *)partial)
 #define GD_T(SAME)                   \
   switch (kapad / 16) {              \
     case 1: GD(1, SAME, 1); break;   \
@@ -759,27 +755,38 @@ int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, con
   MI_TRY(check_panel(ctx, m, ks, S, "S"));
   MI_TRY(check_panel(ctx, m, kc, Y, "Y"));
   MI_REQUIRE(S->d != Y->d, "in-place panel update is not supported");
+  // chunk plan (widest chunk that fits what is left: one pass over S per chunk) and the chunks'
+  // coefficient blocks, each ks x KC row-major by s, zero-padded past kc, packed back to back
+  struct Chunk { int c0, width; size_t off; };
+  std::vector<Chunk> chunks;
+  size_t total = 0;
+  for (int c0 = 0; c0 < kc;) {
+    const int left = kc - c0;
+    const int width = left > 32 ? 48 : (left > 16 ? 24 : (left > 8 ? 16 : 8));  // 48 = X and P of one iteration
+    chunks.push_back({c0, width, total});
+    total += (size_t)ks * width;
+    c0 += width;
+  }
+  std::vector<double> Ct(total, 0.0);
+  for (const Chunk &ch : chunks)
+    for (int s = 0; s < ks; ++s)
+      for (int c = 0; c < ch.width && ch.c0 + c < kc; ++c)
+        Ct[ch.off + (size_t)s * ch.width + c] = C_host[(size_t)(ch.c0 + c) * ldc + s];
   void *Cdev = nullptr;
-  MI_TRY(pool_alloc(ctx, (size_t)ldc * kc * sizeof(double), &Cdev));
-  MI_HIP(hipMemcpyAsync(Cdev, C_host, (size_t)ldc * kc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  // the host buffer may be reused by the caller right after we return
-  MI_HIP(hipStreamSynchronize(ctx->stream));
+  MI_TRY(pool_alloc(ctx, total * sizeof(double), &Cdev));
+  MI_HIP(hipMemcpyAsync(Cdev, Ct.data(), total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MI_HIP(hipStreamSynchronize(ctx->stream));  // Ct dies with this call
   const int grid = (int)std::min<size_t>((m + 255) / 256, 2048);
   KScope ksc(ctx, MI_K_LOBPCG_UPDATE);
-  for (int c0 = 0; c0 < kc;) {  // widest chunk that fits what is left: one pass over S per 24 output columns
-    const int left = kc - c0;
-#define UPD(KC)                                                                                                    \
-  hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), (size_t)ks * KC * sizeof(double), ctx->stream, m, \
-                     ks, (const double *)S->d, (const double *)Cdev, ldc, c0, kc, Y->d)
-    if (left > 16) {
-      UPD(24);
-      c0 += 24;
-    } else if (left > 8) {
-      UPD(16);
-      c0 += 16;
-    } else {
-      UPD(8);
-      c0 += 8;
+  for (const Chunk &ch : chunks) {
+#define UPD(KC)                                                                                       \
+  hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), 0, ctx->stream, m, ks, (const double *)S->d, \
+                     (const double *)Cdev + ch.off, ch.c0, kc, Y->d)
+    switch (ch.width) {
+      case 48: UPD(48); break;
+      case 24: UPD(24); break;
+      case 16: UPD(16); break;
+      default: UPD(8); break;
     }
 #undef UPD
   }
@@ -801,23 +808,30 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
   MI_HIP(hipMemcpyAsync(thdev, theta_host, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MI_HIP(hipStreamSynchronize(ctx->stream));
   const int grid = grid_for(m, 2);
-  double *slots = ctx->scalars + SLOT_GRAM;
-  for (int c0 = 0; c0 < nx; c0 += 8) {
+  // 8 columns per launch (16 reduction components); every chunk's sums land in their own 16 doubles of
+  // one device buffer, read back with ONE copy + sync after the last chunk
+  const int nchunks = (nx + 7) / 8;
+  void *sums = nullptr;
+  MI_TRY(pool_alloc(ctx, (size_t)nchunks * 16 * sizeof(double), &sums));
+  for (int ch = 0; ch < nchunks; ++ch) {
     {
       KScope ks(ctx, MI_K_LOBPCG_RESIDUAL);
-      hipLaunchKernelGGL(k_residual, dim3(grid), dim3(kBlock), 0, ctx->stream, m, nx, c0, (const double *)AX->d,
+      hipLaunchKernelGGL(k_residual, dim3(grid), dim3(kBlock), 0, ctx->stream, m, nx, 8 * ch, (const double *)AX->d,
                          (const double *)BX->d, (const double *)X->d, (const double *)thdev, R->d, ctx->partials2);
     }
-    MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, 16, slots));
-    MI_TRY(comm_allreduce(ctx, slots, 16));
-    double out[16];
-    MI_TRY(read_slots_sync(ctx, SLOT_GRAM, 16, out));
-    for (int c = 0; c < 8 && c0 + c < nx; ++c) {
-      rnorm[c0 + c] = std::sqrt(out[c]);
-      xnorm[c0 + c] = std::sqrt(out[8 + c]);
-    }
+    MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, 16, (double *)sums + 16 * ch));
+    MI_TRY(comm_allreduce(ctx, (double *)sums + 16 * ch, 16));
   }
+  std::vector<double> out((size_t)nchunks * 16);
+  hipError_t e = hipMemcpyAsync(out.data(), sums, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  pool_free(ctx, sums);
   pool_free(ctx, thdev);
+  if (e != hipSuccess) return hip_fail(e, "residual norms read-back", __FILE__, __LINE__);
+  for (int c = 0; c < nx; ++c) {
+    rnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + c % 8]);
+    xnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + 8 + c % 8]);
+  }
   return MI_OK;
 }
 

@@ -13,6 +13,7 @@
 // MI355::DeviceMatrix: column-major panels in HBM, Gram products on fp64 MFMA):
 //     gram(S, T) -> small host matrix S'T          times_small(S, C, row0, kc) -> S C[row0:, :kc]
 //     residual_and_norms(AX, BX, X, theta, r, xn)   gaussian_probe(like, m, nx)   rayleigh_ritz(A, B)
+//     ritz_update(S, C, nx, X, P) -> X = S C[:, :nx] and P = S[:, nx:] C[nx:, :nx] in one pass over S
 //   plus the members rows(), cols(), leftCols(k), middleCols(j,k), rightCols(k), set_cols(...),
 //   truncate_cols(k), norm().
 // As in the reference, the operators are invoked WITHOUT the Args pack (reference :213-219,247,267-282).
@@ -98,11 +99,11 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
   nc = 0;  // :233
 
   for (num_iters = 1; num_iters < max_iters; ++num_iters) {  // :237
-    W = T ? (*T)(R) : R;  // preconditioned residuals                               :247
+    if (T) W = (*T)(R);  // preconditioned residuals (T absent: W is R itself, no copy)   :247
 
     // S = [X, W(not converged), P(not converged)]  (soft locking drops the FIRST nc columns)  :254-264
     S.set_cols(0, X, 0, nx);
-    S.set_cols(nx, W, nc, nx - nc);
+    S.set_cols(nx, T ? W : R, nc, nx - nc);
     if (num_iters > 1) {
       S.set_cols(2 * nx - nc, P, nc, nx - nc);
       ns = 3 * nx - 2 * nc;
@@ -117,11 +118,11 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
     Theta = Vector(std::move(tc.first));
     const auto &C = tc.second;
 
-    X = times_small(Sns, C, 0, nx);  // :278
+    // X = S C[:, :nx] (:278) and P = S[:, nx:ns] C[nx:ns, :nx] (:288) read the same basis: one pass
+    ritz_update(Sns, C, nx, X, P);
     AX = A(X);                       // operators re-applied, not AS C               :281-282
-    BX = B ? (*B)(X) : X;
-    P = times_small(S.middleCols(nx, ns - nx), C, nx, nx);  // S[:, nx:ns] C[nx:ns, :nx]  :288
-    R = residual_and_norms(AX, BX, X, Theta.head(nx), r, xnorm);  // :285,293
+    if (B) BX = (*B)(X);             // B absent: BX is X itself, no copy
+    R = residual_and_norms(AX, B ? BX : X, X, Theta.head(nx), r, xnorm);  // :285,293
 
     // leading run of converged pairs among the first nev                           :298-318
     for (nc = 0; nc < nev; ++nc) {

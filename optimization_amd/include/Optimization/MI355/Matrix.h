@@ -195,6 +195,23 @@ inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size
                          (int)C.rows(), Y.handle()));
   return Y;
 }
+// X = S C[:, 0:nx]  and  P = S[:, nx:] C[nx:, 0:nx]  (LOBPCG.h:278 and :288) in ONE pass over the
+// search basis S: the two products become one m x 2nx panel Y = S [C(:, :nx) | C0(:, :nx)], C0 = C with
+// its first nx rows zeroed (the zero rows add exact +0.0 terms first, so P has the bits of the separate
+// product).  X and P are returned as the two column-block views of Y.
+inline void ritz_update(const DeviceMatrix &S, const HostMatrix &C, size_t nx, DeviceMatrix &X, DeviceMatrix &P) {
+  const size_t ns = S.cols();
+  HostMatrix C2(ns, 2 * nx);
+  for (size_t j = 0; j < nx; ++j)
+    for (size_t i = 0; i < ns; ++i) {
+      C2(i, j) = C(i, j);
+      C2(i, nx + j) = i < nx ? 0.0 : C(i, j);
+    }
+  DeviceMatrix Y(S.context(), S.rows(), 2 * nx);
+  check(mi_lobpcg_update(S.context(), S.rows(), (int)ns, (int)(2 * nx), S.handle(), C2.data(), (int)ns, Y.handle()));
+  X = Y.leftCols(nx);
+  P = Y.middleCols(nx, nx);
+}
 // R = AX - BX diag(theta); returns R and fills the column norms of R and X  (LOBPCG.h:230,285,293,302)
 inline DeviceMatrix residual_and_norms(const DeviceMatrix &AX, const DeviceMatrix &BX, const DeviceMatrix &X,
                                        const HostVectorD &theta, HostVectorD &rnorm, HostVectorD &xnorm) {

@@ -48,7 +48,8 @@ def test_gram_identity_operand(ctx):
     assert np.array_equal(G, T[:k, :])
 
 
-@pytest.mark.parametrize("m,ks,kc", [(5, 3, 2), (1000, 30, 10), (100_001, 72, 24), (4096, 96, 32)])
+@pytest.mark.parametrize("m,ks,kc", [(5, 3, 2), (1000, 30, 10), (100_001, 72, 24), (4096, 96, 32), (50_001, 72, 48),
+                                     (1000, 60, 40), (777, 96, 96)])
 def test_panel_update_and_residual(ctx, m, ks, kc):
     rng = np.random.default_rng(ks)
     S = rng.normal(size=(m, ks))

@@ -83,6 +83,9 @@ def cfg5(ctx):
     Cm = rng.normal(size=(ns, nx))
     us = timed("lobpcg_update", lambda: ctx.lobpcg_update(m, S, ns, Cm), 5)
     out["update_72x24"] = {"us": us, "GBps(one pass)": 8 * m * (ns + nx) / us / 1e3}
+    Cm2 = rng.normal(size=(ns, 2 * nx))
+    us = timed("lobpcg_update", lambda: ctx.lobpcg_update(m, S, ns, Cm2), 5)
+    out["update_72x48(X and P fused)"] = {"us": us, "GBps(one pass)": 8 * m * (ns + 2 * nx) / us / 1e3}
     rowptr, col, val = wl.laplacian_3d(126, 126, 126)
     A = ctx.csr(m, rowptr, col, val)
     Y = ctx.vec(m * nx)
@@ -93,11 +96,11 @@ def cfg5(ctx):
     import harness_py
     hz = harness_py.DeviceHarness()
     walls = {}
-    for iters in (2, 12):
+    for iters in (2, 2, 22):          # first call warms the harness up
         t0 = time.perf_counter()
         r = hz.lobpcg(m, nx, 20, csr=(rowptr, col, val), X0=None, max_iters=iters, tau=1e-12)
         walls[iters] = time.perf_counter() - t0
-    out["lobpcg_ms_per_iteration"] = 1e3 * (walls[12] - walls[2]) / 10
+    out["lobpcg_ms_per_iteration"] = 1e3 * (walls[22] - walls[2]) / 20
     out["lobpcg_setup_plus_2_iterations_s"] = walls[2]
     out["config"] = "cfg5 LOBPCG m=126^3=2000376, nx=24, nev=20, ns<=72, 7-pt Laplacian, no preconditioner"
     out["ritz_0"] = float(r["Theta"][0])
