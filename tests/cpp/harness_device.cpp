@@ -4,6 +4,7 @@
 // (tests/IterativeSolvers_unit_test.cpp STPCG cases, tests/TNT_unit_test.cpp sphere cases,
 // tests/GradientDescent_unit_test.cpp sphere case) plus the BASELINE cfg2 Stiefel problem.
 // Entry points hd_* are called from pytest (-m gpu) and compared with the oracle / golden fixtures.
+#include <chrono>
 #include <cstring>
 #include <optional>
 #include <vector>
@@ -279,6 +280,8 @@ extern "C" int hd_gaussian_probe(size_t m, size_t nx, double *out) {
   HD_GUARD_END
 }
 
+static std::vector<std::chrono::steady_clock::time_point> g_lobpcg_stamps;
+
 extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, const int32_t *rowptr,
                          const int32_t *col, const double *val, const double *Bdiag, const double *Tdiag,
                          const double *X0, size_t max_iters, double tau, double *Theta_out, double *X_out,
@@ -320,8 +323,10 @@ extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, c
       [&](size_t, const Op &, const std::optional<Op> &, const std::optional<Op> &, size_t, const HostVectorD &,
           const DeviceMatrix &, const HostVectorD &r, size_t) {
         resid.assign(r.data(), r.data() + r.size());
+        g_lobpcg_stamps.push_back(std::chrono::steady_clock::now());
         return false;
       };
+  g_lobpcg_stamps.clear();
   std::pair<HostVectorD, DeviceMatrix> out;
   if (X0) {
     DeviceMatrix X0d(ctx, m, nx, X0);
@@ -338,6 +343,14 @@ extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, c
     for (size_t i = 0; i < resid.size() && i < nx; ++i) resid_out[i] = resid[i];
   if (csr) mi_csr_destroy(csr);
   HD_GUARD_END
+}
+
+// mean wall time of one LOBPCG iteration of the last hd_lobpcg call, seconds (user-function to user-function,
+// first interval dropped); 0 if fewer than 3 iterations ran
+extern "C" double hd_lobpcg_seconds_per_iteration() {
+  if (g_lobpcg_stamps.size() < 3) return 0.0;
+  const std::chrono::duration<double> d = g_lobpcg_stamps.back() - g_lobpcg_stamps[1];
+  return d.count() / (double)(g_lobpcg_stamps.size() - 2);
 }
 
 // RiemannianGradientDescentSphere (tests/GradientDescent_unit_test.cpp:76-130) on the device
