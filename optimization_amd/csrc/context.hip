@@ -169,6 +169,7 @@ int mi_ctx_create(int device, mi_ctx **out) {
   memset((void *)ctx->status, 0, sizeof(HostStatus));
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
   { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
+  { const char *e = getenv("MI355OPT_FORCE_LOCKSTEP"); ctx->force_lockstep = e && e[0] == '1'; }
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
   *out = ctx;

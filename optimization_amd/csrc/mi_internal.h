@@ -56,8 +56,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 // Host-visible progress word written by the device (fine-grained pinned memory).
 struct HostStatus {
-  volatile uint64_t iters_done;  // completed STPCG iterations of the current solve
-  volatile uint32_t done;        // nonzero once the solve has reached a terminal state
+  // (B-step launches that did work in the current solve) << 1 | done.  ONE word, written with one store,
+  // so the host can never see "done" without the launch count it belongs to: with several ranks the
+  // number of speculatively enqueued iterations (each carries collectives) is derived from it and must
+  // be the same on every rank.
+  volatile uint64_t word;
   volatile uint32_t epoch;
 };
 
@@ -72,6 +75,7 @@ struct CgState {
   double M_norm;                   // update_step_M_norm
   double epsilon;
   unsigned long long k;            // num_iterations
+  unsigned long long launches;     // B-step launches that found the solve still running (progress word)
   unsigned long long max_iterations;
   int mode;                        // CgMode
   int exit_reason;
@@ -119,6 +123,7 @@ struct mi_ctx {
   void *comm = nullptr;
   int world_size = 1, rank = 0;
   bool force_slot_path = false;  // env MI355OPT_FORCE_SLOT_PATH=1: use the multi-GPU (reduce-kernel + slots) path on one GPU
+  bool force_lockstep = false;   // env MI355OPT_FORCE_LOCKSTEP=1: multi-rank enqueue rule of mi_stpcg on one GPU
 };
 
 struct mi_vec {

@@ -33,11 +33,11 @@ namespace {
 
 enum { PRE_NONE = 0, PRE_DIAG = 1, PRE_BLOCK3 = 2, PRE_EXTERNAL = 3 };
 
-__device__ __forceinline__ void publish(HostStatus *hs, unsigned long long k, int done) {
-  // relaxed system-scope stores: the host only looks at these two words (results are read after a
-  // stream synchronisation), so no release/write-back of the L2 is needed here
-  __hip_atomic_store(&hs->iters_done, (uint64_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (done) __hip_atomic_store(&hs->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void publish(HostStatus *hs, unsigned long long launches, int done) {
+  // one relaxed system-scope store: the host only looks at this word (results are read after a stream
+  // synchronisation), so no release/write-back of the L2 is needed here
+  __hip_atomic_store(&hs->word, (uint64_t)(launches << 1) | (uint64_t)(done ? 1 : 0), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Field-by-field state copies.  An aggregate copy (`*dst = cs`) makes the compiler keep the
@@ -45,7 +45,7 @@ __device__ __forceinline__ void publish(HostStatus *hs, unsigned long long k, in
 // tools/microbench/prologue.hip); explicit fields let SROA keep everything in registers.
 #define CG_FIELDS(X)                                                                               \
   X(sk_M_pk) X(sk_M_2) X(pk_M_2) X(Delta) X(Delta_2) X(target_rk_norm) X(rv) X(alpha) X(beta)      \
-  X(kappa) X(sigma) X(skplus1_M_2) X(M_norm) X(epsilon) X(k) X(max_iterations) X(mode) X(exit_reason)
+  X(kappa) X(sigma) X(skplus1_M_2) X(M_norm) X(epsilon) X(k) X(launches) X(max_iterations) X(mode) X(exit_reason)
 __device__ __forceinline__ CgState load_state(const CgState *__restrict__ src) {
   CgState s;
 #define X(f) s.f = src->f;
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
   s.M_norm = 0;
   s.epsilon = cfg.epsilon;
   s.k = 0;
+  s.launches = 0;
   s.max_iterations = cfg.max_iterations;
   s.exit_reason = MI_STPCG_EXIT_MAXIT;
   s.mode = CG_RUN;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
     else reduce_rows<1>(partials_b, nparts_b, red, lds);
   }
   step_b(cs, red[0]);
+  cs.launches = cs.launches + 1;
   if (leader) {
     store_state(st_out, cs);
     if (mode_in == CG_RUN && trace && cs.k - 1 < trace_cap) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
       trace[2 * trace_cap + k] = cs.kappa;
       trace[3 * trace_cap + k] = cs.rv;
     }
-    publish(hs, cs.k, cs.mode == CG_DONE);
+    publish(hs, cs.launches, cs.mode == CG_DONE);
   }
   if (mode_in == CG_KERNEL_PENDING) {
     const double sigma = cs.sigma;
@@ -526,6 +528,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");
   const bool sharded = ctx->comm != nullptr || ctx->force_slot_path;
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
+  const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
 
   mi_vec *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr;
   MI_TRY(mi_vec_create(ctx, n, &r));
@@ -546,8 +549,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
 
   ctx->epoch++;
-  ctx->status->iters_done = 0;
-  ctx->status->done = 0;
+  ctx->status->word = 0;
   ctx->status->epoch = ctx->epoch;
 
   CgSetup cfg{prm->Delta, prm->kappa_fgr, prm->theta, prm->epsilon,
@@ -611,9 +613,19 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   {
     size_t hvp = 0;
     for (size_t k = 0; k < prm->max_iterations; ++k) {
-      if (ctx->status->done) break;
-      while (!ctx->status->done && k > ctx->status->iters_done + (uint64_t)run_ahead) cpu_relax();
-      if (ctx->status->done) break;
+      // throttle: at most run_ahead launches ahead of the device
+      uint64_t w = ctx->status->word;
+      while (!(w & 1) && k > (w >> 1) + (uint64_t)run_ahead) {
+        cpu_relax();
+        w = ctx->status->word;
+      }
+      if (w & 1) {
+        // One rank: stop as soon as the exit is seen.  Several ranks: every enqueued iteration carries
+        // collectives, so all ranks must enqueue the SAME number -- exactly (launches at exit) + run_ahead,
+        // a function of the replicated device state only, not of when this host happened to look.  (No
+        // rank can get past that count unknowingly: the throttle holds it until the exit is published.)
+        if (!lockstep || k >= (w >> 1) + (uint64_t)run_ahead) break;
+      }
 
       // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials
       int nparts = 0;

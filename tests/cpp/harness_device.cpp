@@ -59,7 +59,12 @@ static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
   tp.Delta_tolerance = p->Delta_tolerance;
 }
 
+static double g_last_tnt_seconds = 0.0;
+// TNTResult::elapsed_time (TNT.h:608) of the last TNT run through this harness
+extern "C" double hd_last_tnt_seconds() { return g_last_tnt_seconds; }
+
 static void export_result(const RM::TNTResult<DeviceVector, double> &r, size_t accepted, orc_tnt_result *res) {
+  g_last_tnt_seconds = r.elapsed_time;
   const std::vector<double> x = r.x.to_host();
   std::memcpy(res->x, x.data(), x.size() * sizeof(double));
   res->f = r.f;

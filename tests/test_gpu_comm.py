@@ -76,3 +76,47 @@ def test_bench_dress_rehearsal_of_the_multi_gpu_launch():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 100 and d["value"] > 500
     assert "comm" in d["config"]["parallelism"]
+
+
+def test_lockstep_enqueue_count_is_a_function_of_the_device_state_only():
+    """With several ranks every speculatively enqueued STPCG iteration carries collectives, so all ranks must
+    enqueue the same number: (B-step launches at the exit) + run_ahead, whatever the host timing.  The rule is
+    forced on one GPU (MI355OPT_FORCE_LOCKSTEP=1); hvp_calls counts the enqueued iterations."""
+    code = r'''
+import json, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+from optimization_amd import capi
+c = capi.Context(0)
+rng = np.random.default_rng(3)
+n = 200_000
+D = rng.uniform(1.0, 50.0, n); g = rng.normal(size=n)
+G, H = c.upload(g), c.op_diag(c.upload(D))
+out = []
+for ra in (1, 3, 7):
+    for rep in range(3):
+        if rep == 2:
+            time.sleep(0.05)           # perturb host timing
+        for kw in (dict(Delta=1e9, max_iterations=200, kappa_fgr=1e-6, theta=1.0),     # residual exit
+                   dict(Delta=0.05, max_iterations=200, kappa_fgr=1e-12, theta=1.0),   # boundary exit
+                   dict(Delta=1e9, max_iterations=5, kappa_fgr=1e-12, theta=1.0)):     # iteration limit
+            r = c.stpcg(G, H, run_ahead=ra, **kw)
+            out.append((ra, r["iterations"], r["exit_reason"], r["hvp_calls"], float(r["M_norm"])))
+print(json.dumps(out))
+''' % ROOT
+    res = {}
+    for force in ("0", "1"):
+        env = dict(os.environ, MI355OPT_FORCE_LOCKSTEP=force)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[force] = json.loads(r.stdout.strip().splitlines()[-1])
+    # identical answers with and without the rule
+    assert [(a, b, c_, e) for a, b, c_, _, e in res["0"]] == [(a, b, c_, e) for a, b, c_, _, e in res["1"]]
+    # lockstep: the enqueue count depends only on (run_ahead, solve), never on the repetition / timing
+    seen = {}
+    for i, (ra, it, ex, hvp, _) in enumerate(res["1"]):
+        key = (ra, i % 3)
+        seen.setdefault(key, set()).add(hvp)
+        launches = it + (1 if ex == 3 else 0)          # a boundary exit spends one more B-step launch... at most
+        assert hvp <= min({0: 200, 1: 200, 2: 5}[i % 3], launches + 1 + ra), (ra, it, ex, hvp)
+    assert all(len(v) == 1 for v in seen.values()), seen

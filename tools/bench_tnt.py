@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Whole-TNT timing on cfg2 (Stiefel(1e6,3), drop-in template path on DeviceVector): how much of a solve
+is the fused inner loop (bench.py's metric) and how much the outer loop around it.  One JSON line."""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+from optimization_amd import workloads as wl
+import oracle_py as op
+import harness_py
+
+nx = ny = nz = 100
+n, p = nx * ny * nz, 3
+rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+X0, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-2, seed=7)
+hz = harness_py.DeviceHarness()
+O = op.Oracle()   # only for the default parameter struct (TNTParams defaults, TNT.h:76-128)
+hz.L.hd_last_tnt_seconds.restype = ctypes.c_double
+out = {}
+for tag, kw in (("warmup", dict(max_iterations=2)), ("run", dict(max_iterations=12))):
+    prm = O.default_params(max_TPCG_iterations=50, gradient_tolerance=1e-12, relative_decrease_tolerance=0.0,
+                           stepsize_tolerance=0.0, preconditioned_gradient_tolerance=0.0, **kw)
+    r = hz.tnt_stiefel(n, p, rowptr, col, val, X0, prm)
+    secs = hz.L.hd_last_tnt_seconds()
+    inner = int(np.sum(r["inner_iterations"]))
+    out[tag] = {"seconds": secs, "outer": int(r["outer_iterations"]), "inner_total": inner,
+                "ms_per_outer": 1e3 * secs / max(1, int(r["outer_iterations"])),
+                "us_per_inner_if_all_time_were_inner": 1e6 * secs / max(1, inner), "f": float(r["f"]),
+                "status": int(r["status"])}
+print(json.dumps(out))
