@@ -253,6 +253,12 @@ MI_API int mi_comm_init(mi_ctx *ctx, int world_size, int rank,
                         const unsigned char uid[MI_COMM_UID_BYTES]); /* sync */
 MI_API int mi_comm_finalize(mi_ctx *ctx);
 MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
+/* Verification hooks (used by tests/test_gpu_comm.py on a ONE-GPU box): pretend to be `rank` of
+ * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
+ * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in
+ * surface; with a communicator the halo is filled by the in-stream ncclSend/ncclRecv exchange. */
+MI_API int mi_debug_set_rank(mi_ctx *ctx, int world_size, int rank);
+MI_API int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host); /* (need_lo+need_hi) x p */
 /* halo description for a row-sharded sparse operator: rows [row_begin,row_end) of a global n x n
  * matrix are local; columns outside are fetched from the owning neighbour before each SpMM */
 /* host-only planning step of mi_csr_create_sharded (no GPU needed; also used by the CPU gloo tests):

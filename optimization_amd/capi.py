@@ -138,6 +138,8 @@ def load():
         "mi_comm_init": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
         "mi_comm_finalize": [vp],
         "mi_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mi_debug_set_rank": [vp, C.c_int, C.c_int],
+        "mi_debug_csr_set_halo": [vp, C.c_int, c_double_p],
         "mi_csr_create_sharded": [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
                                   c_int64_p, c_double_p, c_size_p, C.POINTER(vp)],
     }
@@ -400,6 +402,10 @@ class Context:
         buf = (C.c_ubyte * 128)(*uid)
         check(self.L.mi_comm_init(self.h, world_size, rank, buf))
 
+    def debug_set_rank(self, world_size, rank):
+        """verification hook: act as `rank` of `world_size` without a communicator (tests only)"""
+        check(self.L.mi_debug_set_rank(self.h, world_size, rank))
+
     def comm_finalize(self):
         check(self.L.mi_comm_finalize(self.h))
 
@@ -478,6 +484,10 @@ class Csr:
         W = W if W is not None else Vec(self.ctx, self.n * p)
         check(self.L.mi_csr_spmm(self.h, p, V.h, W.h))
         return W
+
+    def debug_set_halo(self, p, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        check(self.L.mi_debug_csr_set_halo(self.h, p, _dp(rows)))
 
     def spmm_colmajor(self, k, X, Y=None):
         Y = Y if Y is not None else Vec(self.ctx, self.n * k)

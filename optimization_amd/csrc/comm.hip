@@ -132,6 +132,24 @@ int mi_comm_finalize(mi_ctx *ctx) {
   return MI_OK;
 }
 
+int mi_debug_set_rank(mi_ctx *ctx, int world_size, int rank) {
+  MI_REQUIRE(ctx, "ctx is null");
+  MI_REQUIRE(!ctx->comm, "a communicator is attached: rank and size come from it");
+  MI_REQUIRE(world_size >= 1 && rank >= 0 && rank < world_size, "bad world_size/rank %d/%d", world_size, rank);
+  ctx->world_size = world_size;
+  ctx->rank = rank;
+  return MI_OK;
+}
+
+int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host) {
+  MI_REQUIRE(A && halo_rows_host, "null argument");
+  MI_REQUIRE(p >= 1 && p <= 4, "halo buffers hold at most 4 columns");
+  const size_t rows = A->halo_lo + A->halo_hi;
+  if (rows)
+    MI_HIP(hipMemcpy(A->halo, halo_rows_host, rows * (size_t)p * sizeof(double), hipMemcpyHostToDevice));
+  return MI_OK;
+}
+
 int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank) {
   MI_REQUIRE(ctx, "ctx is null");
   if (world_size) *world_size = ctx->world_size;

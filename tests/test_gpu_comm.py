@@ -120,3 +120,35 @@ print(json.dumps(out))
         launches = it + (1 if ex == 3 else 0)          # a boundary exit spends one more B-step launch... at most
         assert hvp <= min({0: 200, 1: 200, 2: 5}[i % 3], launches + 1 + ra), (ra, it, ex, hvp)
     assert all(len(v) == 1 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_addressing_of_the_sharded_spmm_against_the_global_product(world):
+    """Each rank's slab of a row-sharded matrix, with its halo rows filled by hand (what the in-stream
+    ncclSend/ncclRecv exchange delivers), must reproduce the corresponding rows of the global A V bit for bit:
+    checks the shard plan, the local column remap and the kernels' halo addressing on one GPU."""
+    from optimization_amd import capi
+    nx, ny, nz, p = 12, 10, 9, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    rng = np.random.default_rng(world)
+    V = rng.normal(size=(n, p))
+    c0 = capi.Context(0)
+    ref = c0.csr(n, rowptr, col, val).spmm(p, c0.upload(V)).numpy().reshape(n, p)
+    c0.close()
+    slabs = wl.shard_rows(nz, world)
+    starts = [nx * ny * a for a, _ in slabs] + [n]
+    for rank, (z0, z1) in enumerate(slabs):
+        c = capi.Context(0)
+        c.debug_set_rank(world, rank)
+        rp, colg, vl = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = c.csr_sharded(n, r0, r1, rp, colg, vl, starts)
+        _, need_lo, need_hi = capi.csr_shard_plan(n, world, rank, starts, colg)
+        assert (need_lo > 0) == (rank > 0) and (need_hi > 0) == (rank + 1 < world)
+        halo = np.concatenate([V[r0 - need_lo:r0], V[r1:r1 + need_hi]])      # rows the neighbours would send
+        A.debug_set_halo(p, halo)
+        Y = A.spmm(p, c.upload(V[r0:r1])).numpy().reshape(r1 - r0, p)
+        assert np.array_equal(Y, ref[r0:r1]), rank
+        # the fused Stiefel operator kernels read through the same view: objective/gradient pass on the slab
+        c.close()
