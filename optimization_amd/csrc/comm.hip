@@ -8,6 +8,8 @@
 // The reference has no communication layer at all -- nothing to mirror.
 #include <rccl/rccl.h>
 
+#include <cstdlib>
+
 #include "mi_internal.h"
 
 using namespace mi;
@@ -38,6 +40,10 @@ int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
   Comm *c = (Comm *)ctx->comm;
   MI_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, ctx->stream));
   return MI_OK;
+}
+
+int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k) {
+  return comm_allreduce(ctx, partials, k * kMaxRows);
 }
 
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
@@ -112,6 +118,7 @@ int mi_comm_init(mi_ctx *ctx, int world_size, int rank, const unsigned char uid[
   ctx->comm = c;
   ctx->world_size = world_size;
   ctx->rank = rank;
+  g_uniform_grid = world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr;
   // warm the communicator (first collective builds the rings) with one tiny all-reduce
   MI_HIP(hipMemsetAsync(ctx->scalars + SLOT_MISC, 0, sizeof(double), ctx->stream));
   MI_TRY(comm_allreduce(ctx, ctx->scalars + SLOT_MISC, 1));
@@ -129,6 +136,7 @@ int mi_comm_finalize(mi_ctx *ctx) {
   ctx->comm = nullptr;
   ctx->world_size = 1;
   ctx->rank = 0;
+  g_uniform_grid = false;
   return MI_OK;
 }
 

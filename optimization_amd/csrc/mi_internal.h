@@ -141,7 +141,20 @@ int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements
 // per grid-stride step
+// Set by mi_comm_init when world_size > 1 (one process per GPU, one context per process): every
+// reduction-producing kernel then runs with exactly kMaxGrid workgroups on EVERY rank, so that all
+// ranks leave the same number of partial rows and the component-major partial buffers can be
+// all-reduced row by row (comm_allreduce_rows) -- idle workgroups store zero partials.
+inline bool g_uniform_grid = false;
+inline int uniform_grid(size_t blocks) {
+  if (g_uniform_grid) return kMaxGrid;
+  if (blocks < 1) blocks = 1;
+  if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
+  return (int)blocks;
+}
+
 inline int grid_for(size_t n, int per_thread) {
+  if (g_uniform_grid) return kMaxGrid;
   size_t blocks = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
   if (blocks < 1) blocks = 1;
   if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
@@ -160,6 +173,12 @@ hipEvent_t event_get(mi_ctx *ctx);
 
 // all-reduce (sum) of `count` doubles at device pointer `buf`, in-stream; no-op when world_size==1
 int comm_allreduce(mi_ctx *ctx, double *buf, int count);
+// Multi-rank reduction of k components of a component-major partial buffer WITHOUT the one-workgroup
+// reduce kernel: all-reduce all k x kMaxRows doubles in place; the consumers keep the prologue
+// re-reduction of the single-GPU path (sum over ranks first, then over rows: fixed order, same bits on
+// every rank).  rows_mode(): a communicator is attached and the slot path is not forced.
+int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k);
+inline bool rows_mode(const mi_ctx *ctx) { return ctx->comm != nullptr && !ctx->force_slot_path; }
 
 // k <= 4 dot products -> ctx->scalars[slot0..slot0+k) on the device (all-reduced across ranks)
 int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double *const *y, size_t n,

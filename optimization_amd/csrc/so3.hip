@@ -285,7 +285,7 @@ int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int 
   mi_so3n *q = (mi_so3n *)self->impl;
   mi_ctx *ctx = q->ctx;
   const size_t ngroups = (q->nslices + kWaves - 1) / kWaves;
-  const int grid = (int)std::max<size_t>(1, std::min<size_t>(ngroups, kMaxGrid));
+  const int grid = uniform_grid(ngroups);
   KScope ks(ctx, MI_K_BSR3_SPMV_DOTS);
   if (dots)
     hipLaunchKernelGGL(k_bsr3_spmv<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), ctx->cg_live,

@@ -312,7 +312,7 @@ int sharded_reduce(mi_ctx *ctx, int count, int k, double *slots) {
 int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, const double *V,
                      const double *X, const double *S, double *Z, int *count) {
   const size_t ngroups = sell_groups(A);
-  const int grid = (int)std::max<size_t>(1, std::min<size_t>(ngroups, kMaxGrid));
+  const int grid = uniform_grid(ngroups);
   SellView view = sell_view(A);
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
@@ -327,7 +327,10 @@ int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double 
                   const double *Vin, int count, double *M_out, double *out, bool dots, int *nparts) {
   const int grid = row_grid(n);
   double *slots = ctx->scalars + SLOT_GRAM;
-  const bool sharded = ctx->comm != nullptr || ctx->force_slot_path;
+  // several ranks: all-reduce the Gram partial rows themselves and keep the prologue re-reduction
+  // (no one-workgroup reduce kernel); the slot variant stays reachable through MI355OPT_FORCE_SLOT_PATH
+  const bool sharded = ctx->force_slot_path;
+  if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
   if (sharded) MI_TRY(sharded_reduce(ctx, count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
 #define FIN(D, F)                                                                                       \

@@ -526,7 +526,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const size_t n = g->n;
   const int pre = !P ? PRE_NONE : (P->kind == 1 ? PRE_DIAG : (P->kind == 2 ? PRE_BLOCK3 : PRE_EXTERNAL));
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");
-  const bool sharded = ctx->comm != nullptr || ctx->force_slot_path;
+  // several ranks: the partial rows themselves are all-reduced (rows_mode) and the consumers keep
+  // their prologue re-reduction; the slot variants stay reachable through MI355OPT_FORCE_SLOT_PATH
+  const bool sharded = ctx->force_slot_path;
+  const bool rows = rows_mode(ctx);
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
   const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
 
@@ -601,6 +604,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
                        (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
   } else {
+    if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
     hipLaunchKernelGGL(k_cg_scalar_init<false>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
                        (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
   }
@@ -645,6 +649,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         KScope ks(ctx, MI_K_CG_UPDATE);
         LAUNCH_UPDATE(true);
       } else {
+        if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials, 3));
         KScope ks(ctx, MI_K_CG_UPDATE);
         LAUNCH_UPDATE(false);
       }
@@ -662,6 +667,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
                            (const double *)ctx->partials_b, grid, (const double *)slots_b,
                            (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
       } else {
+        if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
         hipLaunchKernelGGL(k_cg_pupdate<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
                            (const double *)ctx->partials_b, grid, (const double *)slots_b,

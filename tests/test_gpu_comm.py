@@ -152,3 +152,45 @@ def test_halo_addressing_of_the_sharded_spmm_against_the_global_product(world):
         assert np.array_equal(Y, ref[r0:r1]), rank
         # the fused Stiefel operator kernels read through the same view: objective/gradient pass on the slab
         c.close()
+
+
+def test_uniform_grid_rows_mode_runs_the_suite_subset():
+    """Several ranks all-reduce the partial ROWS (no one-workgroup reduce kernel); that needs every rank to
+    leave the same number of rows, so all reduction-producing kernels run kMaxGrid workgroups.  Forced here on
+    one GPU with a size-1 communicator: small problems then run mostly idle workgroups (zero partials) and must
+    still agree with the CPU oracle."""
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/oracle")
+from optimization_amd import capi, workloads as wl
+import oracle_py
+c = capi.Context(0)
+c.comm_init(1, 0, c.comm_unique_id())
+O = oracle_py.Oracle()
+nx, ny, nz, p = 9, 8, 7, 3
+n = nx * ny * nz
+rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+A = c.csr_sharded(n, 0, n, *wl.laplacian_3d(nx, ny, nz, z_range=(0, nz)), [0, n])
+prob = c.stiefel_rq(A, n, p)
+Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
+X = c.upload(Xb)
+g, H = prob.model(X)
+r = c.stpcg(g, H, Delta=1e3, max_iterations=30, kappa_fgr=1e-8, theta=.5)
+op = O.stiefel_rq(n, p, rowptr, col, val)
+go = O.eval_grad(op, Xb.ravel())
+ro = O.stpcg_problem(op, Xb.ravel(), go, 1e3, max_iterations=30, kappa_fgr=1e-8, theta=.5)
+assert np.abs(g.numpy() - go).max() <= 1e-12 * np.abs(go).max()
+assert r["iterations"] == ro["iterations"], (r["iterations"], ro["iterations"])
+assert np.abs(r["s"].numpy() - ro["s"]).max() <= 1e-9 * np.abs(ro["s"]).max()
+# diagonal operator + block-free preconditioned solve through the generic kernels
+D = np.linspace(1.0, 30.0, 5000); gg = np.cos(np.arange(5000.0))
+r2 = c.stpcg(c.upload(gg), c.op_diag(c.upload(D)), c.precon_diag(c.upload(1.0 / D)), Delta=1e9, max_iterations=50,
+             kappa_fgr=1e-10, theta=1.0)
+assert np.abs(r2["s"].numpy() + gg / D).max() < 1e-9
+c.comm_finalize(); c.close()
+print("ok")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, MI355OPT_FORCE_UNIFORM_GRID="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
