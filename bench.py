@@ -116,10 +116,15 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = capi.Context(local_rank)
+    peer_memory = False
     if use_comm:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
+        # tiny latency-bound exchanges (scalar all-reduces, halo rows) through mapped peer memory when every
+        # rank's bring-up + self-test succeeds (MI355OPT_COMM=rccl keeps them on RCCL)
+        peer_memory = ctx.enable_peer_memory(world, rank, dist)
+        dist.barrier()
 
     # ---- workload ------------------------------------------------------------------------------
     p = 3
@@ -135,6 +140,7 @@ def main():
     else:
         rowptr, col, val = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
         starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
+        dist.barrier()  # the first device-side exchange (halo extents) follows: no rank may be seconds behind
         A = ctx.csr_sharded(n_glob, nx * ny * z0, nx * ny * z1, rowptr, col, val, starts)
     nnz = int(rowptr[-1])
     prob = ctx.stiefel_rq(A, n, p)
@@ -211,8 +217,11 @@ def main():
                                    f"iterations at a near-optimal iterate (modes {modes})",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
                        "algorithmic_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
-                       "parallelism": (f"row-sharded z-slabs x{world}, RCCL comm (all-reduce of scalar slots, "
-                                       f"halo send/recv)") if use_comm else "single GPU",
+                       "parallelism": (f"row-sharded z-slabs x{world}, comm: " +
+                                       ("peer-memory layer (hipIpc-mapped arenas over xGMI: scalar all-reduce and "
+                                        "halo rows by peer stores), RCCL for bring-up" if peer_memory else
+                                        "RCCL (all-reduce of partial rows, halo send/recv)")) if use_comm
+                       else "single GPU",
                        "device": ctx.device_name()},
             "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
             "roofline": roofline, "cpu_baseline": cpu,

@@ -253,6 +253,19 @@ MI_API int mi_comm_init(mi_ctx *ctx, int world_size, int rank,
                         const unsigned char uid[MI_COMM_UID_BYTES]); /* sync */
 MI_API int mi_comm_finalize(mi_ctx *ctx);
 MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
+/* Peer-memory layer for the tiny, latency-bound exchanges of the STPCG path (scalar all-reduces, halo
+ * rows): every rank exports one fine-grained device arena (hipIpcGetMemHandle), the launcher gathers
+ * the handles, every rank maps all of them (hipIpcOpenMemHandle: plain xGMI peer stores), runs the
+ * collective self-test, and the layer is enabled only if EVERY rank passed (the launcher reduces the
+ * verdicts); otherwise RCCL keeps doing those exchanges.  Also works without RCCL (mi_comm_init not
+ * called): that is how several ranks on ONE GPU are tested (RCCL refuses duplicate devices). */
+#define MI_COMM_IPC_HANDLE_BYTES 64
+MI_API int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTES]);
+MI_API int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank,
+                              const unsigned char *handles /* world_size x MI_COMM_IPC_HANDLE_BYTES */);
+MI_API int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok);      /* collective, sync */
+MI_API int mi_comm_ipc_enable(mi_ctx *ctx, int on);
+MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounded wait timed out */
 /* Verification hooks (used by tests/test_gpu_comm.py on a ONE-GPU box): pretend to be `rank` of
  * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
  * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in

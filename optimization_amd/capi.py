@@ -138,6 +138,11 @@ def load():
         "mi_comm_init": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
         "mi_comm_finalize": [vp],
         "mi_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mi_comm_ipc_export": [vp, C.POINTER(C.c_ubyte)],
+        "mi_comm_ipc_attach": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
+        "mi_comm_ipc_selftest": [vp, C.POINTER(C.c_int)],
+        "mi_comm_ipc_enable": [vp, C.c_int],
+        "mi_comm_ipc_error": [vp, C.POINTER(C.c_int)],
         "mi_debug_set_rank": [vp, C.c_int, C.c_int],
         "mi_debug_csr_set_halo": [vp, C.c_int, c_double_p],
         "mi_csr_create_sharded": [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
@@ -401,6 +406,68 @@ class Context:
     def comm_init(self, world_size, rank, uid):
         buf = (C.c_ubyte * 128)(*uid)
         check(self.L.mi_comm_init(self.h, world_size, rank, buf))
+
+    # peer-memory exchange layer (include/mi355opt.h: mi_comm_ipc_*) -----------------------------
+    IPC_HANDLE_BYTES = 64
+
+    def comm_ipc_export(self):
+        buf = (C.c_ubyte * self.IPC_HANDLE_BYTES)()
+        check(self.L.mi_comm_ipc_export(self.h, buf))
+        return bytes(buf)
+
+    def comm_ipc_attach(self, world_size, rank, handles):
+        assert len(handles) == world_size * self.IPC_HANDLE_BYTES
+        buf = (C.c_ubyte * len(handles)).from_buffer_copy(handles)
+        check(self.L.mi_comm_ipc_attach(self.h, world_size, rank, buf))
+
+    def comm_ipc_selftest(self):
+        ok = C.c_int(0)
+        check(self.L.mi_comm_ipc_selftest(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    def comm_ipc_enable(self, on=True):
+        check(self.L.mi_comm_ipc_enable(self.h, int(on)))
+
+    def comm_ipc_error(self):
+        e = C.c_int(0)
+        check(self.L.mi_comm_ipc_error(self.h, C.byref(e)))
+        return e.value
+
+    def enable_peer_memory(self, world_size, rank, dist):
+        """Collective bring-up of the peer-memory layer over a torch.distributed (gloo) control plane: export,
+        gather handles, map, self-test; enabled only if EVERY rank succeeded at every step, else it stays off
+        (RCCL then does the small exchanges).  Returns True when enabled."""
+        import os
+
+        def all_ok(flag, payload=None):
+            lst = [None] * world_size
+            dist.all_gather_object(lst, (bool(flag), payload))
+            return all(f for f, _ in lst), [pl for _, pl in lst]
+
+        if os.environ.get("MI355OPT_COMM", "auto") == "rccl":
+            return False
+        try:
+            handle, ok = self.comm_ipc_export(), True
+        except MiError:
+            handle, ok = b"\0" * self.IPC_HANDLE_BYTES, False
+        ok, handles = all_ok(ok, handle)
+        if not ok:
+            return False
+        try:
+            self.comm_ipc_attach(world_size, rank, b"".join(handles))
+            ok = True
+        except MiError:
+            ok = False
+        ok, _ = all_ok(ok)
+        if not ok:
+            return False
+        try:
+            ok = self.comm_ipc_selftest()
+        except MiError:
+            ok = False
+        ok, _ = all_ok(ok)
+        self.comm_ipc_enable(ok)
+        return ok
 
     def debug_set_rank(self, world_size, rank):
         """verification hook: act as `rank` of `world_size` without a communicator (tests only)"""

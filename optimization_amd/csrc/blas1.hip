@@ -125,8 +125,7 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
       default: hipLaunchKernelGGL(k_dot<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a, ctx->partials_user); break;
     }
   }
-  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials_user, grid, k, ctx->scalars + slot0));
-  return comm_allreduce(ctx, ctx->scalars + slot0, k);
+  return reduce_rows_allreduce(ctx, ctx->partials_user, grid, k, ctx->scalars + slot0);
 }
 
 int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out) {

@@ -15,9 +15,44 @@
 using namespace mi;
 
 namespace {
+// ---- peer-memory ("IPC") exchange layer ------------------------------------------------------
+// RCCL's all-reduce of a handful of scalars costs a kernel launch plus ~15-25 us of protocol on an
+// 8-GPU xGMI node; the STPCG path needs three of them and one halo exchange per 85 us iteration.  For
+// these tiny, latency-bound exchanges every rank instead maps every other rank's ARENA (fine-grained
+// device memory, exported with hipIpcGetMemHandle / opened with hipIpcOpenMemHandle: plain xGMI peer
+// stores) and one workgroup does: reduce partial rows -> store my K values + a sequence-numbered flag
+// into every peer's mailbox -> wait for every peer's flag in MY mailbox -> sum in rank order.  Same
+// summation order on every rank => replicated, deterministic results.  Waits are bounded (timeout ->
+// error word, never a hang); the layer is switched on only after a collective self-test passed on
+// every rank, else RCCL stays in charge.
+constexpr int kIpcMaxRanks = 8;
+constexpr int kIpcRing = 4;            // mailbox slots in flight (2 would do: a rank is never >1 exchange ahead)
+constexpr int kIpcVals = 16;           // doubles per rank per exchange
+constexpr size_t kIpcMailboxBytes = 64 * 1024;
+constexpr size_t kIpcArenaBytes = 16u << 20;   // mailbox + halo regions
+constexpr uint64_t kIpcTimeoutTicks = 2000000000ull;  // 20 s of the 100 MHz wall clock
+
+struct IpcMailbox {  // lives at offset 0 of every arena
+  uint64_t flag[kIpcRing][kIpcMaxRanks];             // flag[q][r] == seq: rank r's values of exchange seq are in
+  double val[kIpcRing][kIpcMaxRanks][kIpcVals];
+  uint64_t halo_flag[2];                              // [0]: from rank-1, [1]: from rank+1
+  unsigned int halo_count;                            // "last workgroup" counter of k_ipc_halo_push
+  unsigned int pad;
+};
+static_assert(sizeof(IpcMailbox) <= kIpcMailboxBytes, "mailbox too large");
+
 struct Comm {
   ncclComm_t nccl = nullptr;
   double *scratch = nullptr;  // device, small all-gather buffer
+  // IPC layer
+  bool ipc_mapped = false, ipc_enabled = false;
+  char *arena = nullptr;                 // my arena (fine-grained device memory)
+  char *peer[kIpcMaxRanks] = {nullptr};  // mapped arenas, peer[rank] == arena
+  char **peer_dev = nullptr;             // device copy of peer[]
+  uint64_t seq = 0, halo_seq = 0;
+  size_t arena_top = kIpcMailboxBytes;   // bump allocator for halo regions
+  unsigned int *err_host = nullptr, *err_dev = nullptr;  // pinned, device-visible error word
+  double *vals_dev = nullptr;            // staging for value exchanges (kIpcMaxRanks * kIpcVals)
 };
 
 int nccl_fail(ncclResult_t r, const char *what) {
@@ -29,16 +64,155 @@ int nccl_fail(ncclResult_t r, const char *what) {
     ncclResult_t _r = (expr);                           \
     if (_r != ncclSuccess) return nccl_fail(_r, #expr); \
   } while (0)
+
+__device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err) {
+  const uint64_t t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+    if (wall_clock64() - t0 > kIpcTimeoutTicks) {
+      __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return true;
+}
+
+// One workgroup.  vals: K values per rank, either the fixed-order sums of `count` partial rows
+// (partials != null) or in_vals[0..K).  SUM: out[0..K) = sum over ranks in rank order; else
+// out[r * K + k] = value k of rank r (all-gather).
+template <int K, bool SUM>
+__global__ __launch_bounds__(kBlock) void k_ipc_exchange(const double *__restrict__ partials, int count,
+                                                         const double *__restrict__ in_vals, char *const *peers,
+                                                         int P, int rank, uint64_t seq, double *__restrict__ out,
+                                                         unsigned int *err) {
+  __shared__ double lds[K * (kWaves + 1)];
+  double v[K];
+  if (partials) {
+    reduce_rows<K>(partials, count, v, lds);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = in_vals[k];
+  }
+  const int q = (int)(seq % kIpcRing);
+  const int t = threadIdx.x;
+  if (t < P) {  // thread t serves peer t: push my values, then the flag (release)
+    IpcMailbox *mb = reinterpret_cast<IpcMailbox *>(peers[t]);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      __hip_atomic_store(&mb->val[q][rank][k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mb->flag[q][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ... and wait for peer t's flag in MY mailbox
+    IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(peers[rank]);
+    ipc_wait(&mine->flag[q][t], seq, err);
+  }
+  __syncthreads();
+  if (t < K) {
+    const IpcMailbox *mine = reinterpret_cast<const IpcMailbox *>(peers[rank]);
+    if (SUM) {
+      double s = 0;
+      for (int r = 0; r < P; ++r)
+        s += __hip_atomic_load(&mine->val[q][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      out[t] = s;
+    } else {
+      for (int r = 0; r < P; ++r)
+        out[r * K + t] = __hip_atomic_load(&mine->val[q][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// Halo exchange by peer stores: my first `send_lo` rows go into rank-1's upper halo, my last `send_hi`
+// rows into rank+1's lower halo (both inside the neighbour's arena); the last workgroup to finish
+// raises the neighbours' flags and waits for theirs, so the kernel's completion means "my halo is in".
+__global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict__ V, size_t n_doubles,
+                                                       size_t lo_doubles, size_t hi_doubles, char *const *peers,
+                                                       int P, int rank, size_t dst_lo_off, size_t dst_hi_off,
+                                                       int expect_lo, int expect_hi, uint64_t seq,
+                                                       unsigned int *err) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rank > 0 && lo_doubles) {
+    double *dst = reinterpret_cast<double *>(peers[rank - 1] + dst_lo_off);
+    for (size_t i = i0; i < lo_doubles; i += stride) dst[i] = V[i];
+  }
+  if (rank + 1 < P && hi_doubles) {
+    double *dst = reinterpret_cast<double *>(peers[rank + 1] + dst_hi_off);
+    const double *src = V + (n_doubles - hi_doubles);
+    for (size_t i = i0; i < hi_doubles; i += stride) dst[i] = src[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  __shared__ bool last;
+  IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(peers[rank]);
+  if (threadIdx.x == 0) {
+    const unsigned int done = __hip_atomic_fetch_add(&mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (done == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rank > 0 && lo_doubles)  // I am rank-1's upper neighbour: flag[1] there
+      __hip_atomic_store(&reinterpret_cast<IpcMailbox *>(peers[rank - 1])->halo_flag[1], seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (rank + 1 < P && hi_doubles)
+      __hip_atomic_store(&reinterpret_cast<IpcMailbox *>(peers[rank + 1])->halo_flag[0], seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (expect_lo) ipc_wait(&mine->halo_flag[0], seq, err);
+    if (expect_hi) ipc_wait(&mine->halo_flag[1], seq, err);
+  }
+}
+
+int ipc_exchange(mi_ctx *ctx, Comm *c, const double *partials, int count, const double *in_vals, int k, bool sum,
+                 double *out) {
+  const uint64_t seq = ++c->seq;
+#define IX(K)                                                                                              \
+  if (sum)                                                                                                 \
+    hipLaunchKernelGGL((k_ipc_exchange<K, true>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count,  \
+                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev); \
+  else                                                                                                     \
+    hipLaunchKernelGGL((k_ipc_exchange<K, false>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count, \
+                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev)
+  switch (k) {
+    case 1: IX(1); break;
+    case 2: IX(2); break;
+    case 3: IX(3); break;
+    case 4: IX(4); break;
+    case 6: IX(6); break;
+    case 9: IX(9); break;
+    case 10: IX(10); break;
+    case 16: IX(16); break;
+    default: set_error("unsupported exchange width %d", k); return MI_ERR_INTERNAL;
+  }
+#undef IX
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
 }  // namespace
 
 namespace mi {
+
+bool comm_ipc_enabled(const mi_ctx *ctx) { return ctx->comm && ((const Comm *)ctx->comm)->ipc_enabled; }
 
 int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
   // a communicator of size 1 still goes through RCCL: the single-GPU box then exercises exactly the
   // calls the 8-GPU node makes (tests/test_gpu_comm.py)
   if (!ctx->comm) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
-  MI_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, ctx->stream));
+  if (c->nccl) {
+    MI_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, ctx->stream));
+    return MI_OK;
+  }
+  // peer-memory layer only (no RCCL communicator): chunks of <= 16 values through the mailbox
+  MI_REQUIRE(c->ipc_enabled, "no RCCL communicator and the peer-memory layer is not enabled");
+  for (int off = 0; off < count; off += kIpcVals) {
+    const int k = std::min(kIpcVals, count - off);
+    // widths the exchange kernel is instantiated for: pad up through the staging buffer
+    const int kk = k <= 4 ? k : (k <= 6 ? 6 : (k <= 10 ? (k <= 9 ? 9 : 10) : 16));
+    MI_HIP(hipMemsetAsync(c->vals_dev, 0, sizeof(double) * kIpcVals, ctx->stream));
+    MI_HIP(hipMemcpyAsync(c->vals_dev, buf + off, sizeof(double) * k, hipMemcpyDeviceToDevice, ctx->stream));
+    MI_TRY(ipc_exchange(ctx, c, nullptr, 0, c->vals_dev, kk, true, c->vals_dev + kIpcVals));
+    MI_HIP(hipMemcpyAsync(buf + off, c->vals_dev + kIpcVals, sizeof(double) * k, hipMemcpyDeviceToDevice,
+                          ctx->stream));
+  }
   return MI_OK;
 }
 
@@ -46,11 +220,33 @@ int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k) {
   return comm_allreduce(ctx, partials, k * kMaxRows);
 }
 
+int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots) {
+  Comm *c = (Comm *)ctx->comm;
+  if (c && c->ipc_enabled && k <= kIpcVals)
+    return ipc_exchange(ctx, c, partials, count, nullptr, k, true, slots);
+  MI_TRY(launch_reduce_rows_to_slots(ctx, partials, count, k, slots));
+  return comm_allreduce(ctx, slots, k);
+}
+
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
   if (ctx->world_size <= 1 || !ctx->comm) return MI_OK;
   if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   const int rk = ctx->rank, ws = ctx->world_size;
+  if (c->ipc_enabled && A->halo_in_arena) {
+    const size_t lo = A->send_lo * p, hi = A->send_hi * p;
+    const size_t work = std::max(lo, hi);
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((work + 255) / 256, 64));
+    hipLaunchKernelGGL(k_ipc_halo_push, dim3(grid), dim3(256), 0, ctx->stream, V, A->n * (size_t)p, lo, hi,
+                       (char *const *)c->peer_dev, ws, rk,
+                       A->halo_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
+                       A->halo_off,                                          // rank+1's lower halo
+                       (int)(rk > 0 && A->halo_lo > 0), (int)(rk + 1 < ws && A->halo_hi > 0), ++c->halo_seq,
+                       c->err_dev);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
+  MI_REQUIRE(c->nccl, "halo exchange needs RCCL or the enabled peer-memory layer");
   MI_NCCL(ncclGroupStart());
   if (rk > 0) {
     if (A->send_lo) MI_NCCL(ncclSend(V, A->send_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream));
@@ -70,21 +266,56 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
 
 // Every rank learns how many rows its neighbours need from it: all-gather of (need_lo, need_hi).
 int comm_exchange_halo_counts(mi_ctx *ctx, size_t need_lo, size_t need_hi, size_t *send_lo,
-                              size_t *send_hi) {
-  *send_lo = *send_hi = 0;
+                              size_t *send_hi, size_t *peer_lo_rows, size_t *max_halo_rows) {
+  *send_lo = *send_hi = *peer_lo_rows = 0;
+  *max_halo_rows = need_lo + need_hi;
   if (ctx->world_size <= 1 || !ctx->comm) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   const int ws = ctx->world_size, rk = ctx->rank;
   std::vector<double> host(2 * (size_t)ws, 0.0);
   double mine[2] = {(double)need_lo, (double)need_hi};
-  MI_HIP(hipMemcpyAsync(c->scratch + 2 * rk, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
-  MI_NCCL(ncclAllGather(c->scratch + 2 * rk, c->scratch, 2, ncclDouble, c->nccl, ctx->stream));
-  MI_HIP(hipMemcpyAsync(host.data(), c->scratch, host.size() * sizeof(double), hipMemcpyDeviceToHost,
-                        ctx->stream));
+  if (c->nccl) {
+    MI_HIP(hipMemcpyAsync(c->scratch + 2 * rk, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    MI_NCCL(ncclAllGather(c->scratch + 2 * rk, c->scratch, 2, ncclDouble, c->nccl, ctx->stream));
+    MI_HIP(hipMemcpyAsync(host.data(), c->scratch, host.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+  } else {
+    MI_REQUIRE(c->ipc_enabled, "no RCCL communicator and the peer-memory layer is not enabled");
+    MI_HIP(hipMemcpyAsync(c->vals_dev, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    MI_TRY(ipc_exchange(ctx, c, nullptr, 0, c->vals_dev, 2, false, c->vals_dev + kIpcVals));
+    MI_HIP(hipMemcpyAsync(host.data(), c->vals_dev + kIpcVals, host.size() * sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+  }
   MI_HIP(hipStreamSynchronize(ctx->stream));
-  if (rk > 0) *send_lo = (size_t)host[2 * (rk - 1) + 1];       // rank-1 needs rows above its range
+  if (rk > 0) {
+    *send_lo = (size_t)host[2 * (rk - 1) + 1];       // rank-1 needs rows above its range
+    *peer_lo_rows = (size_t)host[2 * (rk - 1) + 0];  // ... and stores them behind its own lower halo
+  }
   if (rk + 1 < ws) *send_hi = (size_t)host[2 * (rk + 1) + 0];  // rank+1 needs rows below its range
+  for (int r = 0; r < ws; ++r) *max_halo_rows = std::max(*max_halo_rows, (size_t)(host[2 * r] + host[2 * r + 1]));
   return MI_OK;
+}
+
+int comm_halo_alloc(mi_ctx *ctx, size_t bytes, double **ptr, bool *in_arena, size_t *arena_off) {
+  *in_arena = false;
+  *arena_off = 0;
+  Comm *c = (Comm *)ctx->comm;
+  bytes = (std::max<size_t>(bytes, 8) + 255) / 256 * 256;
+  if (c && c->ipc_mapped && c->arena_top + bytes <= kIpcArenaBytes) {
+    *ptr = reinterpret_cast<double *>(c->arena + c->arena_top);
+    *arena_off = c->arena_top;
+    *in_arena = true;
+    c->arena_top += bytes;  // never reclaimed: a context holds a handful of sharded matrices
+    MI_HIP(hipMemsetAsync(*ptr, 0, bytes, ctx->stream));
+    return MI_OK;
+  }
+  MI_HIP(hipMalloc((void **)ptr, bytes));
+  MI_HIP(hipMemset(*ptr, 0, bytes));
+  return MI_OK;
+}
+
+void comm_halo_free(mi_ctx *, double *ptr, bool in_arena) {
+  if (!in_arena) (void)hipFree(ptr);
 }
 
 }  // namespace mi
@@ -126,11 +357,123 @@ int mi_comm_init(mi_ctx *ctx, int world_size, int rank, const unsigned char uid[
   return MI_OK;
 }
 
+// ---- peer-memory layer: setup ---------------------------------------------------------------------
+int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTES]) {
+  MI_REQUIRE(ctx && handle, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) <= MI_COMM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t too large");
+  Comm *c = (Comm *)ctx->comm;
+  if (!c) {  // peer-memory layer without RCCL (several ranks on ONE GPU in tests: RCCL refuses that)
+    c = new Comm();
+    ctx->comm = c;
+  }
+  MI_REQUIRE(!c->arena, "arena already exported");
+  MI_HIP(hipSetDevice(ctx->device));
+  MI_HIP(hipExtMallocWithFlags((void **)&c->arena, kIpcArenaBytes, hipDeviceMallocFinegrained));
+  MI_HIP(hipMemset(c->arena, 0, kIpcArenaBytes));
+  hipIpcMemHandle_t h;
+  MI_HIP(hipIpcGetMemHandle(&h, c->arena));
+  memset(handle, 0, MI_COMM_IPC_HANDLE_BYTES);
+  memcpy(handle, &h, sizeof(h));
+  return MI_OK;
+}
+
+int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank, const unsigned char *handles) {
+  MI_REQUIRE(ctx && handles, "null argument");
+  MI_REQUIRE(world_size >= 1 && world_size <= kIpcMaxRanks, "the peer-memory layer supports at most %d ranks",
+             kIpcMaxRanks);
+  MI_REQUIRE(rank >= 0 && rank < world_size, "bad rank");
+  Comm *c = (Comm *)ctx->comm;
+  MI_REQUIRE(c && c->arena, "call mi_comm_ipc_export first");
+  MI_REQUIRE(!c->ipc_mapped, "peer arenas already mapped");
+  if (c->nccl) MI_REQUIRE(ctx->world_size == world_size && ctx->rank == rank, "rank/size differ from the communicator");
+  MI_HIP(hipSetDevice(ctx->device));
+  for (int r = 0; r < world_size; ++r) {
+    if (r == rank) {
+      c->peer[r] = c->arena;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * MI_COMM_IPC_HANDLE_BYTES, sizeof(h));
+    void *ptr = nullptr;
+    MI_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    c->peer[r] = (char *)ptr;
+  }
+  MI_HIP(hipMalloc((void **)&c->peer_dev, sizeof(char *) * kIpcMaxRanks));
+  MI_HIP(hipMemcpy(c->peer_dev, c->peer, sizeof(char *) * kIpcMaxRanks, hipMemcpyHostToDevice));
+  MI_HIP(hipHostMalloc((void **)&c->err_host, sizeof(unsigned int), hipHostMallocMapped));
+  *c->err_host = 0;
+  MI_HIP(hipHostGetDevicePointer((void **)&c->err_dev, c->err_host, 0));
+  MI_HIP(hipMalloc((void **)&c->vals_dev, sizeof(double) * (kIpcVals + kIpcMaxRanks * kIpcVals)));
+  c->ipc_mapped = true;
+  ctx->world_size = world_size;
+  ctx->rank = rank;
+  return MI_OK;
+}
+
+// Collective: a few exchanges with known per-rank values; *ok = 1 iff every sum / gather came back
+// right and no wait timed out on THIS rank.  The caller combines the ranks' verdicts (min) and passes
+// the result to mi_comm_ipc_enable on every rank.
+int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok) {
+  MI_REQUIRE(ctx && ok, "null argument");
+  Comm *c = (Comm *)ctx->comm;
+  MI_REQUIRE(c && c->ipc_mapped, "peer arenas not mapped");
+  *ok = 0;
+  const int P = ctx->world_size, rk = ctx->rank;
+  bool good = true;
+  for (int round = 0; round < 6 && good; ++round) {
+    double in[kIpcVals], out[kIpcMaxRanks * kIpcVals];
+    for (int k = 0; k < kIpcVals; ++k) in[k] = (rk + 1) * 1000.0 + round * 16 + k;
+    MI_HIP(hipMemcpyAsync(c->vals_dev, in, sizeof(in), hipMemcpyHostToDevice, ctx->stream));
+    const bool sum = (round % 2 == 0);
+    MI_TRY(ipc_exchange(ctx, c, nullptr, 0, c->vals_dev, sum ? 16 : 4, sum, c->vals_dev + kIpcVals));
+    MI_HIP(hipMemcpyAsync(out, c->vals_dev + kIpcVals, sizeof(double) * (sum ? 16 : 4 * P), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+    if (*c->err_host) good = false;
+    if (sum) {
+      for (int k = 0; k < kIpcVals && good; ++k) {
+        double want = 0;
+        for (int r = 0; r < P; ++r) want += (r + 1) * 1000.0 + round * 16 + k;
+        if (out[k] != want) good = false;
+      }
+    } else {
+      for (int r = 0; r < P && good; ++r)
+        for (int k = 0; k < 4; ++k)
+          if (out[r * 4 + k] != (r + 1) * 1000.0 + round * 16 + k) good = false;
+    }
+  }
+  *ok = good ? 1 : 0;
+  return MI_OK;
+}
+
+int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
+  MI_REQUIRE(ctx, "ctx is null");
+  Comm *c = (Comm *)ctx->comm;
+  MI_REQUIRE(c && c->ipc_mapped, "peer arenas not mapped");
+  c->ipc_enabled = on != 0;
+  if (c->ipc_enabled) g_uniform_grid = false;  // slot path: rows never cross ranks
+  return MI_OK;
+}
+
+// 0: no error; nonzero: a wait inside the peer-memory layer timed out (results since then are invalid)
+int mi_comm_ipc_error(mi_ctx *ctx, int *err) {
+  MI_REQUIRE(ctx && err, "null argument");
+  Comm *c = (Comm *)ctx->comm;
+  *err = (c && c->err_host) ? (int)*c->err_host : 0;
+  return MI_OK;
+}
+
 int mi_comm_finalize(mi_ctx *ctx) {
   if (!ctx || !ctx->comm) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   (void)hipStreamSynchronize(ctx->stream);
   if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  for (int r = 0; r < kIpcMaxRanks; ++r)
+    if (c->peer[r] && c->peer[r] != c->arena) (void)hipIpcCloseMemHandle(c->peer[r]);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->peer_dev) (void)hipFree(c->peer_dev);
+  if (c->err_host) (void)hipHostFree(c->err_host);
+  if (c->vals_dev) (void)hipFree(c->vals_dev);
   (void)hipFree(c->scratch);
   delete c;
   ctx->comm = nullptr;

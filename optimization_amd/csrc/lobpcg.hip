@@ -819,8 +819,7 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
       hipLaunchKernelGGL(k_residual, dim3(grid), dim3(kBlock), 0, ctx->stream, m, nx, 8 * ch, (const double *)AX->d,
                          (const double *)BX->d, (const double *)X->d, (const double *)thdev, R->d, ctx->partials2);
     }
-    MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, 16, (double *)sums + 16 * ch));
-    MI_TRY(comm_allreduce(ctx, (double *)sums + 16 * ch, 16));
+    MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, 16, (double *)sums + 16 * ch));
   }
   std::vector<double> out((size_t)nchunks * 16);
   hipError_t e = hipMemcpyAsync(out.data(), sums, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);

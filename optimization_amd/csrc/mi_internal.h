@@ -178,7 +178,12 @@ int comm_allreduce(mi_ctx *ctx, double *buf, int count);
 // re-reduction of the single-GPU path (sum over ranks first, then over rows: fixed order, same bits on
 // every rank).  rows_mode(): a communicator is attached and the slot path is not forced.
 int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k);
-inline bool rows_mode(const mi_ctx *ctx) { return ctx->comm != nullptr && !ctx->force_slot_path; }
+bool comm_ipc_enabled(const mi_ctx *ctx);
+inline bool rows_mode(const mi_ctx *ctx) {
+  return ctx->comm != nullptr && !ctx->force_slot_path && !comm_ipc_enabled(ctx);
+}
+// slot variants (FROM_SLOTS kernels): forced, or the peer-memory layer delivers the sums into slots
+inline bool slot_mode(const mi_ctx *ctx) { return ctx->force_slot_path || comm_ipc_enabled(ctx); }
 
 // k <= 4 dot products -> ctx->scalars[slot0..slot0+k) on the device (all-reduced across ranks)
 int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double *const *y, size_t n,
@@ -188,6 +193,9 @@ int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out);
 int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts);
 // one-workgroup kernel: sum `count` partial rows of components [0,k) -> slots[0..k)
 int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
+// the same followed by the sum over ranks (one kernel with the peer-memory layer, else reduce kernel +
+// RCCL all-reduce); no-op beyond the local reduction without a communicator
+int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
 
 // scalar-file slot map
 enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GRAM_M = 32, SLOT_MISC = 48 };
@@ -283,13 +291,21 @@ struct mi_csr {
   size_t halo_lo = 0, halo_hi = 0;  // rows received from rank-1 / rank+1
   size_t send_lo = 0, send_hi = 0;  // rows sent to rank-1 (our first rows) / rank+1 (our last rows)
   double *halo = nullptr;           // device, (halo_lo + halo_hi) * 4 doubles (p <= 4)
+  // peer-memory (IPC) exchange: the halo lives in this rank's arena at byte offset halo_off (the same
+  // offset on every rank); peer_lo_rows = halo_lo of rank-1 (our first rows land behind them there)
+  bool halo_in_arena = false;
+  size_t halo_off = 0, peer_lo_rows = 0;
 };
 
 namespace mi {
 // In-stream halo exchange of the n x p field V into A->halo (no-op when not sharded).
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V);
 int comm_exchange_halo_counts(mi_ctx *ctx, size_t need_lo, size_t need_hi, size_t *send_lo,
-                              size_t *send_hi);
+                              size_t *send_hi, size_t *peer_lo_rows, size_t *max_halo_rows);
+// halo storage for a sharded matrix: inside the IPC arena when the peer-memory layer is mapped (bytes
+// must be the same on every rank), else an ordinary device allocation
+int comm_halo_alloc(mi_ctx *ctx, size_t bytes, double **ptr, bool *in_arena, size_t *arena_off);
+void comm_halo_free(mi_ctx *ctx, double *ptr, bool in_arena);
 // W = A V without the halo exchange (callers that fuse do it themselves)
 int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W);
 }  // namespace mi

@@ -429,8 +429,7 @@ int mi_so3n_objective(mi_so3n *q, const mi_vec *R, double *f) {
                      (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R->d,
                      ctx->partials2);
   double *slots = ctx->scalars + SLOT_MISC;
-  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, 1, slots));
-  MI_TRY(comm_allreduce(ctx, slots, 1));
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, 1, slots));
   double s = 0;
   MI_TRY(read_slots_sync(ctx, SLOT_MISC, 1, &s));
   *f = .5 * s;

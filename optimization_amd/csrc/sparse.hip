@@ -123,7 +123,7 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->slice_ptr);
   (void)hipFree(A->col);
   (void)hipFree(A->val);
-  (void)hipFree(A->halo);
+  if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;
   return MI_OK;
 }
@@ -194,10 +194,13 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A));
   A->halo_lo = need_lo;
   A->halo_hi = need_hi;
-  MI_HIP(hipMalloc((void **)&A->halo, std::max<size_t>(1, (need_lo + need_hi) * 4) * sizeof(double)));
-  MI_HIP(hipMemset(A->halo, 0, std::max<size_t>(1, (need_lo + need_hi) * 4) * sizeof(double)));
   // what we must SEND equals what the neighbours need; exchanged once through the communicator
-  MI_TRY(comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi));
+  size_t max_halo_rows = 0;
+  MI_TRY(comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi, &A->peer_lo_rows,
+                                   &max_halo_rows));
+  // same size on every rank, so that the arena offsets of the peer-memory layer agree
+  MI_TRY(comm_halo_alloc(ctx, std::max<size_t>(1, max_halo_rows * 4) * sizeof(double), &A->halo, &A->halo_in_arena,
+                         &A->halo_off));
   MI_REQUIRE(A->send_lo <= n && A->send_hi <= n, "neighbour halo request exceeds local rows");
   *out = A;
   return MI_OK;

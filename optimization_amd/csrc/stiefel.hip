@@ -305,8 +305,7 @@ inline int nsym(int p) { return p * (p + 1) / 2; }
 
 // sharded only: partial rows -> slots -> all-reduce
 int sharded_reduce(mi_ctx *ctx, int count, int k, double *slots) {
-  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, count, k, slots));
-  return comm_allreduce(ctx, slots, k);
+  return reduce_rows_allreduce(ctx, ctx->partials2, count, k, slots);
 }
 
 int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, const double *V,
@@ -329,7 +328,7 @@ int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double 
   double *slots = ctx->scalars + SLOT_GRAM;
   // several ranks: all-reduce the Gram partial rows themselves and keep the prologue re-reduction
   // (no one-workgroup reduce kernel); the slot variant stays reachable through MI355OPT_FORCE_SLOT_PATH
-  const bool sharded = ctx->force_slot_path;
+  const bool sharded = slot_mode(ctx);
   if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
   if (sharded) MI_TRY(sharded_reduce(ctx, count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
@@ -421,8 +420,7 @@ int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec 
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
   double *slots = ctx->scalars + SLOT_GRAM;
-  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, grid, p * p, slots));
-  MI_TRY(comm_allreduce(ctx, slots, p * p));
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, p * p, slots));
   return read_slots_sync(ctx, SLOT_GRAM, p * p, G_host);
 }
 
@@ -497,8 +495,7 @@ int mi_stiefel_rq_objective(mi_stiefel_rq *q, const mi_vec *X, double *f) {
   MI_TRY(launch_spmm_gram(ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Z->d, &count));
   double *slots = ctx->scalars + SLOT_GRAM;
   const int ns = nsym(q->p);
-  MI_TRY(launch_reduce_rows_to_slots(ctx, ctx->partials2, count, ns, slots));
-  MI_TRY(comm_allreduce(ctx, slots, ns));
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, count, ns, slots));
   double G[16];
   MI_TRY(read_slots_sync(ctx, SLOT_GRAM, ns, G));
   double tr = 0;

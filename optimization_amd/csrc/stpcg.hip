@@ -528,7 +528,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");
   // several ranks: the partial rows themselves are all-reduced (rows_mode) and the consumers keep
   // their prologue re-reduction; the slot variants stay reachable through MI355OPT_FORCE_SLOT_PATH
-  const bool sharded = ctx->force_slot_path;
+  const bool sharded = slot_mode(ctx);
   const bool rows = rows_mode(ctx);
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
   const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
@@ -599,8 +599,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
                        (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
   }
   if (sharded) {
-    CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials_b, grid, 1, slots_b));
-    CG_CHECK(comm_allreduce(ctx, slots_b, 1));
+    CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
     hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
                        (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
   } else {
@@ -644,8 +643,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   n, (const CgState *)st0, st1, (const double *)ctx->partials, nparts, (const double *)slots_a,      \
       (const double *)p->d, (const double *)Hp->d, pred, s_out->d, r->d, vd, ctx->partials_b
       if (sharded) {
-        CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials, nparts, 3, slots_a));
-        CG_CHECK(comm_allreduce(ctx, slots_a, 3));
+        CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, 3, slots_a));
         KScope ks(ctx, MI_K_CG_UPDATE);
         LAUNCH_UPDATE(true);
       } else {
@@ -660,8 +658,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
                            (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
       }
       if (sharded) {
-        CG_CHECK(launch_reduce_rows_to_slots(ctx, ctx->partials_b, grid, 1, slots_b));
-        CG_CHECK(comm_allreduce(ctx, slots_b, 1));
+        CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
         hipLaunchKernelGGL(k_cg_pupdate<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
                            (const double *)ctx->partials_b, grid, (const double *)slots_b,
@@ -682,6 +679,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
+    {
+      int ipc_err = 0;
+      (void)mi_comm_ipc_error(ctx, &ipc_err);
+      if (ipc_err) {
+        set_error("a wait in the peer-memory exchange layer timed out: the result of this solve is invalid");
+        ret = MI_ERR_COMM;
+        goto cleanup;
+      }
+    }
     const CgState &f = *ctx->cg_host;
     result->update_step_M_norm = f.M_norm;
     result->num_iterations = (size_t)f.k;

@@ -1,0 +1,100 @@
+"""One rank of the multi-process peer-memory test (tests/test_gpu_comm.py): W processes, ALL ON GPU 0 (RCCL
+refuses duplicate devices, the peer-memory layer does not care), gloo as control plane.  Exercises with real
+peers what a one-rank box otherwise cannot: the scalar all-reduces, the halo exchange, the sharded Stiefel
+operator, the lockstep enqueue rule of the fused STPCG.  Prints one JSON line per rank."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from optimization_amd import capi, workloads as wl  # noqa: E402  (ROCm before torch)
+
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = capi.Context(0)
+    enabled = c.enable_peer_memory(world, rank, dist)
+    out = {"rank": rank, "enabled": enabled}
+    if not enabled:
+        print(json.dumps(out))
+        return
+    nx, ny, nz, p = 16, 12, 4 * world + 1, 3          # uneven slabs
+    n = nx * ny * nz
+    slabs = wl.shard_rows(nz, world)
+    starts = [nx * ny * a for a, _ in slabs] + [n]
+    r0, r1 = starts[rank], starts[rank + 1]
+    rng = np.random.default_rng(11)
+    V = rng.normal(size=(n, p))
+    W = rng.normal(size=(n, p))
+
+    # A. dot products: local partial rows -> one exchange kernel -> identical sums everywhere
+    d = c.upload(V[r0:r1]).dot(c.upload(W[r0:r1]))
+    out["dot_err"] = abs(d - float(np.sum(V * W))) / abs(float(np.sum(V * W)))
+    out["dot"] = d
+
+    # B. sharded SpMM: halo rows arrive by peer stores
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    import scipy.sparse as sps
+    Ag = sps.csr_matrix((val, col, rowptr), shape=(n, n))
+    rp, colg, vl = wl.laplacian_3d(nx, ny, nz, z_range=slabs[rank])
+    A = c.csr_sharded(n, r0, r1, rp, colg, vl, starts)
+    Y = A.spmm(p, c.upload(V[r0:r1])).numpy().reshape(r1 - r0, p)
+    out["spmm_err"] = float(np.abs(Y - (Ag @ V)[r0:r1]).max())
+    Y2 = A.spmm(p, c.upload(W[r0:r1])).numpy().reshape(r1 - r0, p)   # second exchange: flags must advance
+    out["spmm2_err"] = float(np.abs(Y2 - (Ag @ W)[r0:r1]).max())
+
+    # C. sharded Stiefel model + fused STPCG against a single-process solve of the global problem
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
+    prob = c.stiefel_rq(A, r1 - r0, p)
+    X = c.upload(Xb[r0:r1])
+    out["f"] = prob.objective(X)
+    g, H = prob.model(X)
+    res = {}
+    for ra in (1, 5):
+        r = c.stpcg(g, H, Delta=1e3, max_iterations=25, kappa_fgr=1e-9, theta=1.0, run_ahead=ra)
+        res[ra] = r
+    r = res[1]
+    out.update(iters=r["iterations"], exit=r["exit_reason"], M=r["M_norm"], hvp1=res[1]["hvp_calls"],
+               hvp5=res[5]["hvp_calls"], same_s=bool(np.array_equal(res[1]["s"].numpy(), res[5]["s"].numpy())))
+    rb = c.stpcg(g, H, Delta=1e-3, max_iterations=25)      # boundary exit
+    out.update(b_iters=rb["iterations"], b_exit=rb["exit_reason"], b_M=rb["M_norm"])
+    Ynew = c.stiefel_retract(r1 - r0, p, X, rb["s"]).numpy().reshape(r1 - r0, p)
+    s_loc = r["s"].numpy().reshape(r1 - r0, p)
+    g_loc = g.numpy().reshape(r1 - r0, p)
+    out["ipc_error"] = c.comm_ipc_error()
+
+    # reference: the same problem on one plain context (every rank computes it: the GPU is shared anyway)
+    c1 = capi.Context(0)
+    A1 = c1.csr(n, rowptr, col, val)
+    prob1 = c1.stiefel_rq(A1, n, p)
+    X1 = c1.upload(Xb)
+    out["f_ref"] = prob1.objective(X1)
+    g1, H1 = prob1.model(X1)
+    r1s = c1.stpcg(g1, H1, Delta=1e3, max_iterations=25, kappa_fgr=1e-9, theta=1.0)
+    r1b = c1.stpcg(g1, H1, Delta=1e-3, max_iterations=25)
+    Y1 = c1.stiefel_retract(n, p, X1, r1b["s"]).numpy().reshape(n, p)
+    sref = r1s["s"].numpy().reshape(n, p)
+    gref = g1.numpy().reshape(n, p)
+    out.update(iters_ref=r1s["iterations"], exit_ref=r1s["exit_reason"], M_ref=r1s["M_norm"],
+               b_iters_ref=r1b["iterations"], b_exit_ref=r1b["exit_reason"],
+               g_err=float(np.abs(g_loc - gref[r0:r1]).max() / np.abs(gref).max()),
+               s_err=float(np.abs(s_loc - sref[r0:r1]).max() / np.abs(sref).max()),
+               retract_err=float(np.abs(Ynew - Y1[r0:r1]).max()))
+    c1.close()
+    dist.barrier()
+    c.comm_finalize()
+    c.close()
+    print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

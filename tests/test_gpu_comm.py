@@ -194,3 +194,26 @@ print("ok")
     env = dict(os.environ, MI355OPT_FORCE_UNIFORM_GRID="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_memory_layer_with_real_peers_on_one_gpu(world):
+    """W processes on GPU 0 talk through the peer-memory (hipIpc) layer: scalar all-reduces, halo exchange,
+    sharded Stiefel operator, fused STPCG with the lockstep enqueue rule -- against a single-process solve."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29560 + world), os.path.join(ROOT, "tests", "ipc_worker.py")]
+    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    outs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(outs) == world and all(o["enabled"] for o in outs), outs
+    for o in outs:
+        assert o["ipc_error"] == 0
+        assert o["dot_err"] < 1e-13 and o["spmm_err"] == 0.0 and o["spmm2_err"] == 0.0, o
+        assert abs(o["f"] - o["f_ref"]) <= 1e-12 * abs(o["f_ref"])
+        assert o["g_err"] < 1e-12 and o["s_err"] < 1e-9 and o["retract_err"] < 1e-12, o
+        assert (o["iters"], o["exit"]) == (o["iters_ref"], o["exit_ref"])
+        assert (o["b_iters"], o["b_exit"]) == (o["b_iters_ref"], o["b_exit_ref"])
+        assert abs(o["M"] - o["M_ref"]) <= 1e-10 * abs(o["M_ref"]) and o["same_s"]
+    # replicated scalars are bit-identical on all ranks, and so is the number of enqueued iterations
+    for k in ("dot", "f", "M", "b_M", "iters", "hvp1", "hvp5"):
+        assert len({o[k] for o in outs}) == 1, (k, [o[k] for o in outs])
