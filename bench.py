@@ -115,15 +115,21 @@ def main():
         import torch.distributed as dist  # gloo: control plane only
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    ctx = capi.Context(local_rank)
+    # MI355OPT_BENCH_ONE_GPU=1: functional rehearsal of the N-rank flow with all ranks on GPU 0 and WITHOUT RCCL
+    # (which refuses duplicate devices): the peer-memory layer carries every exchange.  Timings are meaningless.
+    one_gpu = os.environ.get("MI355OPT_BENCH_ONE_GPU") == "1"
+    ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
     if use_comm:
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        if not one_gpu:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(world, rank, uid[0])
         # tiny latency-bound exchanges (scalar all-reduces, halo rows) through mapped peer memory when every
         # rank's bring-up + self-test succeeds (MI355OPT_COMM=rccl keeps them on RCCL)
         peer_memory = ctx.enable_peer_memory(world, rank, dist)
+        if one_gpu and not peer_memory:
+            raise SystemExit("one-GPU rehearsal needs the peer-memory layer")
         dist.barrier()
 
     # ---- workload ------------------------------------------------------------------------------

@@ -217,3 +217,19 @@ def test_peer_memory_layer_with_real_peers_on_one_gpu(world):
     # replicated scalars are bit-identical on all ranks, and so is the number of enqueued iterations
     for k in ("dot", "f", "M", "b_M", "iters", "hvp1", "hvp5"):
         assert len({o[k] for o in outs}) == 1, (k, [o[k] for o in outs])
+
+
+def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
+    """bench.py's N = 2 flow end to end (weak-scaled 100x100x200 grid, z-slab sharding, uniform launches, barriers,
+    max-over-ranks timing, one JSON line from rank 0) with both ranks on GPU 0 through the peer-memory layer."""
+    env = dict(os.environ, MI355OPT_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100",
+           "--warmup", "10", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["rows_per_gpu"] == 1_000_000 and "peer-memory" in d["config"]["parallelism"]
