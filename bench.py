@@ -57,6 +57,47 @@ def run_steps(ctx, g, H, s_out, steps):
     return solves
 
 
+def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank):
+    """Cheap end-to-end checks of the N-rank data path before anything is timed (the 8-GPU node is the first
+    place the cross-device exchanges ever run).  Returns a list of failure strings (empty = all good), the same
+    on every rank."""
+    fails = []
+    n0, n1 = nx * ny * z0, nx * ny * z1
+    E, lam = [], []
+    for m in [(1, 1, 1), (1, 1, 2), (1, 2, 1)][:p]:
+        v, lm = wl.laplacian_3d_eigvec(nx, ny, nz, *m)
+        E.append(v[n0:n1])
+        lam.append(lm + 0.1)
+    E = np.ascontiguousarray(np.stack(E, axis=1))
+    Ed = ctx.upload(E)
+    # halo exchange: exact eigenvectors of the global grid operator must stay eigenvectors on every slab
+    Y = A.spmm(p, Ed).numpy().reshape(n1 - n0, p)
+    err = float(np.abs(Y - E * np.array(lam)[None, :]).max() / np.abs(E).max())
+    if not err < 1e-11:
+        fails.append(f"rank {rank}: sharded SpMM of exact eigenvectors off by {err:.3e} (halo exchange)")
+    # scalar all-reduce: the p unit vectors have squared norm p in total
+    d = Ed.dot(Ed)
+    if not abs(d - p) < 1e-11 * p:
+        fails.append(f"rank {rank}: all-reduced <E,E> = {d!r}, expected {p}")
+    # replicated control flow: a short fused solve must report the same bits everywhere
+    X = ctx.upload(np.ascontiguousarray(wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)[0][n0:n1]))
+    g, H = prob.model(X)
+    r = ctx.stpcg(g, H, Delta=1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0)
+    mine = (r["iterations"], r["exit_reason"], float(r["M_norm"]).hex(), r["hvp_calls"], ctx.comm_ipc_error())
+    every = [None] * world
+    dist.all_gather_object(every, (mine, fails))
+    if len({e[0] for e in every}) != 1:
+        fails.append(f"ranks disagree on a 10-iteration solve: {[e[0] for e in every]}")
+    if any(e[0][4] for e in every):
+        fails.append("a bounded wait of the peer-memory layer timed out")
+    for e in every:
+        fails.extend(x for x in e[1] if x not in fails)
+    fails = sorted(set(fails))
+    agree = [None] * world
+    dist.all_gather_object(agree, fails)
+    return sorted(set(x for a in agree for x in a))
+
+
 def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step):
     """The reference's own CPU path (oracle/_ref/libref.so = the reference templates compiled from
     /root/reference, single-threaded like the reference) on a bounded sample of the same workload;
@@ -150,6 +191,19 @@ def main():
         A = ctx.csr_sharded(n_glob, nx * ny * z0, nx * ny * z1, rowptr, col, val, starts)
     nnz = int(rowptr[-1])
     prob = ctx.stiefel_rq(A, n, p)
+    if use_comm:
+        fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank)
+        if peer_memory and os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1":
+            fails = fails + ["injected failure (test of the fallback path)"]
+        if fails and peer_memory and not one_gpu:
+            if rank == 0:
+                print("bench.py: peer-memory layer failed verification, falling back to RCCL:\n  " +
+                      "\n  ".join(fails), file=sys.stderr)
+            ctx.comm_ipc_enable(False)
+            peer_memory = False
+            fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank)
+        if fails:
+            raise SystemExit("bench.py: distributed data path failed verification:\n  " + "\n  ".join(fails))
     X = ctx.upload(Xb)
     g, H = prob.model(X)
     s_out = ctx.vec(n * p)

@@ -450,8 +450,10 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
   MI_REQUIRE(ctx, "ctx is null");
   Comm *c = (Comm *)ctx->comm;
   MI_REQUIRE(c && c->ipc_mapped, "peer arenas not mapped");
+  MI_REQUIRE(on || c->nccl, "no RCCL communicator to fall back to");
   c->ipc_enabled = on != 0;
-  if (c->ipc_enabled) g_uniform_grid = false;  // slot path: rows never cross ranks
+  // slot path (peer-memory): rows never cross ranks; RCCL rows mode needs the same row count everywhere
+  g_uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr);
   return MI_OK;
 }
 

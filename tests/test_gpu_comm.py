@@ -233,3 +233,15 @@ def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 1_000_000 and "peer-memory" in d["config"]["parallelism"]
+
+
+def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification():
+    env = dict(os.environ, MI355OPT_BENCH_FORCE_COMM="1", MI355OPT_BENCH_INJECT_VERIFY_FAILURE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29574", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100",
+           "--warmup", "10", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "falling back to RCCL" in r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "RCCL (all-reduce of partial rows" in d["config"]["parallelism"] and d["value"] > 500
