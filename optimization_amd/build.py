@@ -44,11 +44,27 @@ def _compile(src, force):
     return obj, True, r.stderr
 
 
+# Sources compiled as ONE translation unit = one code object: the four kernels of an STPCG iteration
+# (k_st_spmm_gram, k_st_finish, k_cg_update, k_cg_pupdate) then sit next to each other in device memory
+# instead of in separately loaded code objects at unrelated addresses.
+UNITY = ["stpcg.hip", "stiefel.hip"]
+
+
 def build(force=False, jobs=None, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     if not srcs:
         raise RuntimeError("no HIP sources found")
+    if os.environ.get("MI355OPT_NO_UNITY") != "1":
+        unity = os.path.join(OBJ, "hot_unity.hip")
+        text = "".join(f'#include "{os.path.join(CSRC, u)}"\n' for u in UNITY)
+        if not os.path.exists(unity) or open(unity).read() != text:
+            with open(unity, "w") as f:
+                f.write(text)
+        newest = max(os.path.getmtime(os.path.join(CSRC, u)) for u in UNITY)
+        if os.path.getmtime(unity) < newest:
+            os.utime(unity, (newest, newest))
+        srcs = [s_ for s_ in srcs if os.path.basename(s_) not in UNITY] + [unity]
     jobs = jobs or min(len(srcs), os.cpu_count() or 4)
     objs, rebuilt = [], False
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:

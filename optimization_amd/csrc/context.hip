@@ -149,19 +149,31 @@ int mi_ctx_create(int device, mi_ctx **out) {
            prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
   ctx->num_cu = prop.multiProcessorCount;
   MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  // All small control buffers (partial rows, scalar slots, the two CG states) come out of ONE 2 MB
+  // allocation (one translation for everything a kernel prologue touches).
   const size_t pbytes = sizeof(double) * kMaxComps * kMaxRows;
-  MI_HIP(hipMalloc((void **)&ctx->partials, pbytes));
-  MI_HIP(hipMalloc((void **)&ctx->partials_b, pbytes));
-  MI_HIP(hipMalloc((void **)&ctx->partials2, pbytes));
-  MI_HIP(hipMalloc((void **)&ctx->partials_user, pbytes));
-  MI_HIP(hipMemset(ctx->partials, 0, pbytes));
-  MI_HIP(hipMemset(ctx->partials_b, 0, pbytes));
-  MI_HIP(hipMemset(ctx->partials2, 0, pbytes));
-  MI_HIP(hipMemset(ctx->partials_user, 0, pbytes));
-  MI_HIP(hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots));
-  MI_HIP(hipMemset(ctx->scalars, 0, sizeof(double) * kScalarSlots));
-  MI_HIP(hipMalloc((void **)&ctx->cg, 2 * sizeof(CgState)));
-  MI_HIP(hipMemset(ctx->cg, 0, 2 * sizeof(CgState)));
+  const size_t slab_bytes = 2u << 20;
+  MI_HIP(hipMalloc((void **)&ctx->control_slab, slab_bytes));
+  MI_HIP(hipMemset(ctx->control_slab, 0, slab_bytes));
+  {
+    char *top = (char *)ctx->control_slab;
+    auto carve = [&](size_t bytes) {
+      char *p = top;
+      top += (bytes + 255) / 256 * 256;
+      return p;
+    };
+    ctx->cg = (CgState *)carve(2 * sizeof(CgState));
+    ctx->cg1 = ctx->cg + 1;
+    ctx->scalars = (double *)carve(sizeof(double) * kScalarSlots);
+    ctx->partials = (double *)carve(pbytes);
+    ctx->partials_b = (double *)carve(pbytes);
+    ctx->partials2 = (double *)carve(pbytes);
+    ctx->partials_user = (double *)carve(pbytes);
+    if ((size_t)(top - (char *)ctx->control_slab) > slab_bytes) {
+      set_error("control slab overflow");
+      return MI_ERR_INTERNAL;
+    }
+  }
   MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots, hipHostMallocDefault));
   MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState), hipHostMallocDefault));
   MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
@@ -190,12 +202,7 @@ int mi_ctx_destroy(mi_ctx *ctx) {
       (void)hipEventDestroy(pr.second);
     }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-  (void)hipFree(ctx->partials);
-  (void)hipFree(ctx->partials_b);
-  (void)hipFree(ctx->partials2);
-  (void)hipFree(ctx->partials_user);
-  (void)hipFree(ctx->scalars);
-  (void)hipFree(ctx->cg);
+  (void)hipFree(ctx->control_slab);
   (void)hipFree(ctx->trace_dev);
   (void)hipHostFree(ctx->host_scalars);
   (void)hipHostFree(ctx->cg_host);

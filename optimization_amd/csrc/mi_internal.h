@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <set>
 #include <vector>
 
 #include "mi355opt.h"
@@ -68,17 +69,21 @@ struct HostStatus {
 // a kernel reads st[i] and its workgroup 0 writes st[i^1] (no intra-kernel read/write race).
 struct CgState {
   double sk_M_pk, sk_M_2, pk_M_2;  // :259,263,266
-  double Delta, Delta_2, target_rk_norm;  // :171,271,278
+  double target_rk_norm;           // :278 (depends on the initial residual: computed on the device)
   double rv;                       // current <r,v>
   double alpha, beta, kappa, sigma;
   double skplus1_M_2;              // :344, carried from the A-step to the B-step
   double M_norm;                   // update_step_M_norm
-  double epsilon;
   unsigned long long k;            // num_iterations
   unsigned long long launches;     // B-step launches that found the solve still running (progress word)
-  unsigned long long max_iterations;
   int mode;                        // CgMode
   int exit_reason;
+};
+static_assert(sizeof(CgState) <= 128, "the CG state is meant to fit one 128-byte line");
+// Per-solve constants known on the host travel as kernel arguments (SGPRs), not through the state.
+struct CgConst {
+  double Delta, Delta_2, epsilon;  // :171,271,179
+  unsigned long long max_iterations;
 };
 enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_DONE = 3 };
 
@@ -101,13 +106,15 @@ struct mi_ctx {
   std::map<void *, size_t> pool_all;
   size_t pool_bytes = 0;
   // reductions: component-major partial buffers, kMaxComps x kMaxRows doubles each
+  void *control_slab = nullptr;     // one allocation holding everything below up to `cg`
   double *partials = nullptr;       // operator -> CG (curvature dots)
   double *partials_b = nullptr;     // CG update -> CG direction (<r,v>)
   double *partials2 = nullptr;      // operator-internal (e.g. Stiefel Gram)
   double *partials_user = nullptr;  // mi_vec_dot* (safe to call from callbacks)
   double *scalars = nullptr;        // kScalarSlots doubles
   double *host_scalars = nullptr;   // pinned staging for scalar read-backs
-  mi::CgState *cg = nullptr;        // device, 2 copies
+  mi::CgState *cg = nullptr;        // device, copy 0
+  mi::CgState *cg1 = nullptr;       // device, copy 1
   mi::CgState *cg_host = nullptr;   // pinned copy for read-back
   const mi::CgState *cg_live = nullptr;  // state copy operators may consult to skip work after exit
   mi::HostStatus *status = nullptr;      // pinned, device-visible

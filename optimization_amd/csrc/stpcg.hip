@@ -44,8 +44,8 @@ __device__ __forceinline__ void publish(HostStatus *hs, unsigned long long launc
 // per-thread struct in memory (promoted to 56 B/thread of LDS + scratch: +7-10 us per kernel,
 // tools/microbench/prologue.hip); explicit fields let SROA keep everything in registers.
 #define CG_FIELDS(X)                                                                               \
-  X(sk_M_pk) X(sk_M_2) X(pk_M_2) X(Delta) X(Delta_2) X(target_rk_norm) X(rv) X(alpha) X(beta)      \
-  X(kappa) X(sigma) X(skplus1_M_2) X(M_norm) X(epsilon) X(k) X(launches) X(max_iterations) X(mode) X(exit_reason)
+  X(sk_M_pk) X(sk_M_2) X(pk_M_2) X(target_rk_norm) X(rv) X(alpha) X(beta)                          \
+  X(kappa) X(sigma) X(skplus1_M_2) X(M_norm) X(k) X(launches) X(mode) X(exit_reason)
 __device__ __forceinline__ CgState load_state(const CgState *__restrict__ src) {
   CgState s;
 #define X(f) s.f = src->f;
@@ -65,18 +65,18 @@ __device__ __forceinline__ void store_state(CgState *__restrict__ dst, const CgS
 // ---------------------------------------------------------------------------------------------
 
 // after the operator: kappa, kernel test, alpha, boundary test (:300-362)
-__device__ __forceinline__ void step_a(CgState &s, double pHp, double HpHp, double pp) {
+__device__ __forceinline__ void step_a(CgState &s, const CgConst &c, double pHp, double HpHp, double pp) {
 #pragma clang fp contract(off)
   const double kappa = pHp;  // :300
   s.kappa = kappa;
-  if (sqrt(HpHp) / sqrt(pp) < s.epsilon) {  // :305-307
+  if (sqrt(HpHp) / sqrt(pp) < c.epsilon) {  // :305-307
     s.mode = CG_KERNEL_PENDING;              // needs <p,r> (:320): supplied by k_cg_update's body
     return;
   }
   const double alpha = s.rv / kappa;                                               // :341
   const double skplus1 = s.sk_M_2 + 2 * alpha * s.sk_M_pk + alpha * alpha * s.pk_M_2;  // :344-345
-  if ((kappa <= 0) || (skplus1 > s.Delta_2)) {                                     // :347
-    s.sigma = (-s.sk_M_pk + sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) /
+  if ((kappa <= 0) || (skplus1 > c.Delta_2)) {                                     // :347
+    s.sigma = (-s.sk_M_pk + sqrt(s.sk_M_pk * s.sk_M_pk + s.pk_M_2 * (c.Delta_2 - s.sk_M_2))) /
               s.pk_M_2;  // :355-357
     s.mode = CG_APPLY_SIGMA;
     s.exit_reason = MI_STPCG_EXIT_BOUNDARY;
@@ -87,10 +87,10 @@ __device__ __forceinline__ void step_a(CgState &s, double pHp, double HpHp, doub
 }
 
 // after the update: resolves every mode; returns true if a direction update p = -v + beta p follows
-__device__ __forceinline__ void step_b(CgState &s, double red) {
+__device__ __forceinline__ void step_b(CgState &s, const CgConst &c, double red) {
 #pragma clang fp contract(off)
   if (s.mode == CG_APPLY_SIGMA) {  // boundary step applied by k_cg_update (:359-361)
-    s.M_norm = s.Delta;
+    s.M_norm = c.Delta;
     s.mode = CG_DONE;
     return;
   }
@@ -99,10 +99,10 @@ __device__ __forceinline__ void step_b(CgState &s, double red) {
     const bool flip = red < 0;
     if (flip) sk_M_pk *= -1;  // :325
     const double sigma =
-        (-sk_M_pk + sqrt(sk_M_pk * sk_M_pk + s.pk_M_2 * (s.Delta_2 - s.sk_M_2))) / s.pk_M_2;  // :330
+        (-sk_M_pk + sqrt(sk_M_pk * sk_M_pk + s.pk_M_2 * (c.Delta_2 - s.sk_M_2))) / s.pk_M_2;  // :330
     s.sk_M_pk = sk_M_pk;
     s.sigma = flip ? -sigma : sigma;  // s += sigma * (-p)  ==  s += (-sigma) * p   (:324,336)
-    s.M_norm = s.Delta;               // :334
+    s.M_norm = c.Delta;               // :334
     s.exit_reason = MI_STPCG_EXIT_KERNEL;
     s.mode = CG_DONE;                 // k_cg_pupdate's body applies the step
     return;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void step_b(CgState &s, double red) {
   s.rv = rk_vk;
   s.beta = beta;
   s.k = s.k + 1;
-  if (s.k >= s.max_iterations) {  // :285
+  if (s.k >= c.max_iterations) {  // :285
     s.exit_reason = MI_STPCG_EXIT_MAXIT;
     s.M_norm = sqrt(s.sk_M_2);  // :424
     s.mode = CG_DONE;
@@ -255,18 +255,14 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
   s.sk_M_pk = 0;                        // :259
   s.sk_M_2 = 0;                         // :263
   s.pk_M_2 = rv0;                       // :266
-  s.Delta = cfg.Delta;
-  s.Delta_2 = cfg.Delta * cfg.Delta;    // :271
   const double r0_norm = sqrt(rv0);     // :275
   const double pw = pow(r0_norm, cfg.theta);
   s.target_rk_norm = r0_norm * ((pw < cfg.kappa_fgr) ? pw : cfg.kappa_fgr);  // :278-279 (std::min)
   s.rv = rv0;
   s.alpha = s.beta = s.kappa = s.sigma = s.skplus1_M_2 = 0;
   s.M_norm = 0;
-  s.epsilon = cfg.epsilon;
   s.k = 0;
   s.launches = 0;
-  s.max_iterations = cfg.max_iterations;
   s.exit_reason = MI_STPCG_EXIT_MAXIT;
   s.mode = CG_RUN;
   if (cfg.max_iterations == 0) {  // :285 body never runs
@@ -278,7 +274,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
     s.M_norm = sqrt(0.0);
   }
   store_state(st, s);
-  store_state(st + 1, s);
   publish(hs, 0, s.mode == CG_DONE);
 }
 
@@ -287,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
 //   CG_APPLY_SIGMA:    s += sigma p (:360)
 //   CG_KERNEL_PENDING: partial <p,r> (:320)
 template <int PRE, bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *__restrict__ st_in,
+__global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                       CgState *__restrict__ st_out,
                                                       const double *__restrict__ partials_a, int nparts_a,
                                                       const double *__restrict__ slots,
@@ -320,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
   } else {
     reduce_rows<3>(partials_a, nparts_a, d, lds);
   }
-  step_a(cs, d[0], d[1], d[2]);
+  step_a(cs, cc, d[0], d[1], d[2]);
   if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
 
   const int mode = cs.mode;
@@ -409,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, const CgState *_
 
 // B-step prologue + body:  CG_RUN: p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
 template <bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *__restrict__ st_in,
+__global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                        CgState *__restrict__ st_out,
                                                        const double *__restrict__ partials_b, int nparts_b,
                                                        const double *__restrict__ slots,
@@ -437,7 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, const CgState *
     if (FROM_SLOTS) red[0] = slots[0];
     else reduce_rows<1>(partials_b, nparts_b, red, lds);
   }
-  step_b(cs, red[0]);
+  step_b(cs, cc, red[0]);
   cs.launches = cs.launches + 1;
   if (leader) {
     store_state(st_out, cs);
@@ -557,10 +552,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
   CgSetup cfg{prm->Delta, prm->kappa_fgr, prm->theta, prm->epsilon,
               (unsigned long long)prm->max_iterations};
+  const CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations};
   hipStream_t st = ctx->stream;
   const int grid = (pre == PRE_BLOCK3) ? grid_for(n / 3, 2) : grid_for(n, 4);
   double *slots_a = ctx->scalars + SLOT_CG, *slots_b = ctx->scalars + SLOT_CG + 4;
-  CgState *st0 = ctx->cg, *st1 = ctx->cg + 1;
+  CgState *st0 = ctx->cg, *st1 = ctx->cg1;
   double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
   ctx->cg_live = st0;
@@ -640,7 +636,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       }
       ++hvp;
 #define UPD_ARGS                                                                                      \
-  n, (const CgState *)st0, st1, (const double *)ctx->partials, nparts, (const double *)slots_a,      \
+  n, cc, (const CgState *)st0, st1, (const double *)ctx->partials, nparts, (const double *)slots_a,  \
       (const double *)p->d, (const double *)Hp->d, pred, s_out->d, r->d, vd, ctx->partials_b
       if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, 3, slots_a));
@@ -660,13 +656,13 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL(k_cg_pupdate<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
+        hipLaunchKernelGGL(k_cg_pupdate<true>, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0,
                            (const double *)ctx->partials_b, grid, (const double *)slots_b,
                            (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
       } else {
         if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL(k_cg_pupdate<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1, st0,
+        hipLaunchKernelGGL(k_cg_pupdate<false>, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0,
                            (const double *)ctx->partials_b, grid, (const double *)slots_b,
                            (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
       }
