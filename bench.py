@@ -39,8 +39,8 @@ def kernel_bytes(n, nnz, p):
     return {
         "stiefel_spmm_gram": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,   # A; V gathered, X read; Z written
         "stiefel_finish_dots": 8 * 4 * N,                           # X, Z, V read; Hp written
-        "cg_update": 8 * 6 * N,                                     # s,p,r,Hp read; s,r written
-        "cg_pupdate": 8 * 3 * N,                                    # v(=r), p read; p written
+        "cg_update": 8 * 3 * N,                                     # r,Hp read; r written
+        "cg_pupdate": 8 * 5 * N,                                    # v(=r), p, s read; p, s written
     }
 
 

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
 }
 
 // A-step prologue + body:
-//   CG_RUN:            s = s + alpha p (:374); r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)
+//   CG_RUN:            r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)   [s += alpha p: see k_cg_pupdate]
 //   CG_APPLY_SIGMA:    s += sigma p (:360)
 //   CG_KERNEL_PENDING: partial <p,r> (:320)
 template <int PRE, bool FROM_SLOTS>
@@ -302,11 +302,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   // software prefetch of the first grid-stride step: its HBM latency overlaps the prologue's
   // reduction (tools/microbench/prologue.hip: hides the ~2.2 us prologue completely)
-  double2 pv0 = make_double2(0, 0), hv0 = pv0, sv0 = pv0, rv0 = pv0;
+  double2 hv0 = make_double2(0, 0), rv0 = hv0;
   if (PRE != PRE_BLOCK3 && i0 < n2) {
-    pv0 = reinterpret_cast<const double2 *>(p)[i0];
     hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
-    sv0 = reinterpret_cast<double2 *>(s)[i0];
     rv0 = reinterpret_cast<double2 *>(r)[i0];
   }
   double d[3];
@@ -347,7 +345,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const size_t i = 3 * b + c;
-          s[i] = s[i] + alpha * p[i];
           rr[c] = r[i] + alpha * Hp[i];
           r[i] = rr[c];
         }
@@ -360,19 +357,15 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
         }
       }
     } else {
-      double2 pv = pv0, hv = hv0, sv = sv0, rv = rv0;
+      double2 hv = hv0, rv = rv0;
       for (size_t i = i0; i < n2;) {
         const size_t inext = i + stride;
-        double2 pn = pv, hn = hv, sn = sv, rn = rv;
+        double2 hn = hv, rn = rv;
         if (inext < n2) {  // next step's operands are in flight while this one is computed
-          pn = reinterpret_cast<const double2 *>(p)[inext];
           hn = reinterpret_cast<const double2 *>(Hp)[inext];
-          sn = reinterpret_cast<double2 *>(s)[inext];
           rn = reinterpret_cast<double2 *>(r)[inext];
         }
-        sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
         rv.x += alpha * hv.x; rv.y += alpha * hv.y;
-        reinterpret_cast<double2 *>(s)[i] = sv;
         reinterpret_cast<double2 *>(r)[i] = rv;
         if (PRE != PRE_EXTERNAL) {
           double2 vv = rv;
@@ -383,11 +376,10 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
           }
           acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
         }
-        i = inext; pv = pn; hv = hn; sv = sn; rv = rn;
+        i = inext; hv = hn; rv = rn;
       }
       if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
-        s[i] = s[i] + alpha * p[i];
         const double rv = r[i] + alpha * Hp[i];
         r[i] = rv;
         if (PRE != PRE_EXTERNAL) {
@@ -402,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
   block_partials_store<1>(acc, lds, partials_b);
 }
 
-// B-step prologue + body:  CG_RUN: p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
+// B-step prologue + body:  CG_RUN: s = s + alpha p (:374), p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
 template <bool FROM_SLOTS>
 __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                        CgState *__restrict__ st_out,
@@ -422,10 +414,11 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
   const int mode_in = cs.mode;
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  double2 vv0 = make_double2(0, 0), pv0 = vv0;  // prefetch: overlaps the prologue's reduction
+  double2 vv0 = make_double2(0, 0), pv0 = vv0, sv0 = vv0;  // prefetch: overlaps the prologue's reduction
   if (i0 < n2) {
     vv0 = reinterpret_cast<const double2 *>(v)[i0];
     pv0 = reinterpret_cast<double2 *>(p)[i0];
+    sv0 = reinterpret_cast<double2 *>(s)[i0];
   }
   double red[1] = {0};
   if (mode_in != CG_APPLY_SIGMA) {
@@ -454,21 +447,33 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       reinterpret_cast<double2 *>(s)[i] = sv;
     }
     if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
-  } else if (mode_in == CG_RUN && cs.mode == CG_RUN) {
-    const double beta = cs.beta;
-    double2 vv = vv0, pv = pv0;
+  } else if (mode_in == CG_RUN) {
+    // s = s + alpha p (:374) is applied HERE, next to the direction update, not in k_cg_update: both need
+    // p, so p is read once per iteration instead of twice (8 N bytes saved; same arithmetic, same bits).
+    // It is applied whatever the B-step decided; p = -v + beta p (:420) only if the solve goes on.
+    const double alpha = cs.alpha, beta = cs.beta;
+    const bool dir = cs.mode == CG_RUN;
+    double2 vv = vv0, pv = pv0, sv = sv0;
     for (size_t i = i0; i < n2;) {
       const size_t inext = i + stride;
-      double2 vn = vv, pn = pv;
+      double2 vn = vv, pn = pv, sn = sv;
       if (inext < n2) {
         vn = reinterpret_cast<const double2 *>(v)[inext];
         pn = reinterpret_cast<double2 *>(p)[inext];
+        sn = reinterpret_cast<double2 *>(s)[inext];
       }
-      pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
-      reinterpret_cast<double2 *>(p)[i] = pv;
-      i = inext; vv = vn; pv = pn;
+      sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
+      reinterpret_cast<double2 *>(s)[i] = sv;
+      if (dir) {
+        pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
+        reinterpret_cast<double2 *>(p)[i] = pv;
+      }
+      i = inext; vv = vn; pv = pn; sv = sn;
     }
-    if ((n & 1) && leader) p[n - 1] = -v[n - 1] + beta * p[n - 1];
+    if ((n & 1) && leader) {
+      s[n - 1] = s[n - 1] + alpha * p[n - 1];
+      if (dir) p[n - 1] = -v[n - 1] + beta * p[n - 1];
+    }
   }
 }
 

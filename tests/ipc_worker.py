@@ -16,6 +16,16 @@ from optimization_amd import capi, workloads as wl  # noqa: E402  (ROCm before t
 import torch.distributed as dist  # noqa: E402
 
 
+def emit(out):
+    """one file per rank (stdout of several ranks may interleave)"""
+    d = os.environ.get("IPC_WORKER_OUT")
+    if d:
+        with open(os.path.join(d, f"rank{out['rank']}.json"), "w") as f:
+            json.dump(out, f)
+    else:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,7 +33,7 @@ def main():
     enabled = c.enable_peer_memory(world, rank, dist)
     out = {"rank": rank, "enabled": enabled}
     if not enabled:
-        print(json.dumps(out))
+        emit(out)
         return
     nx, ny, nz, p = 16, 12, 4 * world + 1, 3          # uneven slabs
     n = nx * ny * nz
@@ -91,7 +101,7 @@ def main():
     dist.barrier()
     c.comm_finalize()
     c.close()
-    print(json.dumps(out))
+    emit(out)
     dist.barrier()
     dist.destroy_process_group()
 

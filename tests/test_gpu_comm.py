@@ -202,9 +202,11 @@ def test_peer_memory_layer_with_real_peers_on_one_gpu(world):
     sharded Stiefel operator, fused STPCG with the lockstep enqueue rule -- against a single-process solve."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(29560 + world), os.path.join(ROOT, "tests", "ipc_worker.py")]
-    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    outs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run(cmd, env=dict(os.environ, IPC_WORKER_OUT=tmp), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs = [json.load(open(os.path.join(tmp, f))) for f in sorted(os.listdir(tmp))]
     assert len(outs) == world and all(o["enabled"] for o in outs), outs
     for o in outs:
         assert o["ipc_error"] == 0
