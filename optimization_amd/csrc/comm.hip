@@ -452,6 +452,7 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
   MI_REQUIRE(c && c->ipc_mapped, "peer arenas not mapped");
   MI_REQUIRE(on || c->nccl, "no RCCL communicator to fall back to");
   c->ipc_enabled = on != 0;
+  if (!c->ipc_enabled && c->err_host) *c->err_host = 0;  // a failed layer must not poison the RCCL path
   // slot path (peer-memory): rows never cross ranks; RCCL rows mode needs the same row count everywhere
   g_uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr);
   return MI_OK;
@@ -461,7 +462,7 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
 int mi_comm_ipc_error(mi_ctx *ctx, int *err) {
   MI_REQUIRE(ctx && err, "null argument");
   Comm *c = (Comm *)ctx->comm;
-  *err = (c && c->err_host) ? (int)*c->err_host : 0;
+  *err = (c && c->ipc_enabled && c->err_host) ? (int)*c->err_host : 0;
   return MI_OK;
 }
 
