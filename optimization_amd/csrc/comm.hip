@@ -30,7 +30,7 @@ constexpr int kIpcRing = 4;            // mailbox slots in flight (2 would do: a
 constexpr int kIpcVals = 16;           // doubles per rank per exchange
 constexpr size_t kIpcMailboxBytes = 64 * 1024;
 constexpr size_t kIpcArenaBytes = 16u << 20;   // mailbox + halo regions
-constexpr uint64_t kIpcTimeoutTicks = 2000000000ull;  // 20 s of the 100 MHz wall clock
+constexpr uint64_t kIpcTimeoutTicks = 2000000000ull;  // default: 20 s of the 100 MHz wall clock (MI355OPT_IPC_TIMEOUT_MS)
 
 struct IpcMailbox {  // lives at offset 0 of every arena
   uint64_t flag[kIpcRing][kIpcMaxRanks];             // flag[q][r] == seq: rank r's values of exchange seq are in
@@ -53,6 +53,7 @@ struct Comm {
   size_t arena_top = kIpcMailboxBytes;   // bump allocator for halo regions
   unsigned int *err_host = nullptr, *err_dev = nullptr;  // pinned, device-visible error word
   double *vals_dev = nullptr;            // staging for value exchanges (kIpcMaxRanks * kIpcVals)
+  uint64_t timeout = kIpcTimeoutTicks;   // bound of every device-side wait, in 100 MHz ticks
 };
 
 int nccl_fail(ncclResult_t r, const char *what) {
@@ -65,10 +66,10 @@ int nccl_fail(ncclResult_t r, const char *what) {
     if (_r != ncclSuccess) return nccl_fail(_r, #expr); \
   } while (0)
 
-__device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err) {
+__device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err, uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
-    if (wall_clock64() - t0 > kIpcTimeoutTicks) {
+    if (wall_clock64() - t0 > timeout) {
       __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
@@ -84,7 +85,7 @@ template <int K, bool SUM>
 __global__ __launch_bounds__(kBlock) void k_ipc_exchange(const double *__restrict__ partials, int count,
                                                          const double *__restrict__ in_vals, char *const *peers,
                                                          int P, int rank, uint64_t seq, double *__restrict__ out,
-                                                         unsigned int *err) {
+                                                         unsigned int *err, uint64_t timeout) {
   __shared__ double lds[K * (kWaves + 1)];
   double v[K];
   if (partials) {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_ipc_exchange(const double *__restric
     __hip_atomic_store(&mb->flag[q][rank], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ... and wait for peer t's flag in MY mailbox
     IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(peers[rank]);
-    ipc_wait(&mine->flag[q][t], seq, err);
+    ipc_wait(&mine->flag[q][t], seq, err, timeout);
   }
   __syncthreads();
   if (t < K) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
                                                        size_t lo_doubles, size_t hi_doubles, char *const *peers,
                                                        int P, int rank, size_t dst_lo_off, size_t dst_hi_off,
                                                        int expect_lo, int expect_hi, uint64_t seq,
-                                                       unsigned int *err) {
+                                                       unsigned int *err, uint64_t timeout) {
   const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (rank > 0 && lo_doubles) {
     double *dst = reinterpret_cast<double *>(peers[rank - 1] + dst_lo_off);
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
     if (rank + 1 < P && hi_doubles)
       __hip_atomic_store(&reinterpret_cast<IpcMailbox *>(peers[rank + 1])->halo_flag[0], seq, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    if (expect_lo) ipc_wait(&mine->halo_flag[0], seq, err);
-    if (expect_hi) ipc_wait(&mine->halo_flag[1], seq, err);
+    if (expect_lo) ipc_wait(&mine->halo_flag[0], seq, err, timeout);
+    if (expect_hi) ipc_wait(&mine->halo_flag[1], seq, err, timeout);
   }
 }
 
@@ -167,10 +168,10 @@ int ipc_exchange(mi_ctx *ctx, Comm *c, const double *partials, int count, const 
 #define IX(K)                                                                                              \
   if (sum)                                                                                                 \
     hipLaunchKernelGGL((k_ipc_exchange<K, true>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count,  \
-                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev); \
+                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev, c->timeout); \
   else                                                                                                     \
     hipLaunchKernelGGL((k_ipc_exchange<K, false>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count, \
-                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev)
+                       in_vals, (char *const *)c->peer_dev, ctx->world_size, ctx->rank, seq, out, c->err_dev, c->timeout)
   switch (k) {
     case 1: IX(1); break;
     case 2: IX(2); break;
@@ -242,7 +243,7 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
                        A->halo_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
                        A->halo_off,                                          // rank+1's lower halo
                        (int)(rk > 0 && A->halo_lo > 0), (int)(rk + 1 < ws && A->halo_hi > 0), ++c->halo_seq,
-                       c->err_dev);
+                       c->err_dev, c->timeout);
     MI_HIP(hipGetLastError());
     return MI_OK;
   }
@@ -367,6 +368,7 @@ int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTE
     ctx->comm = c;
   }
   MI_REQUIRE(!c->arena, "arena already exported");
+  if (const char *e = getenv("MI355OPT_IPC_TIMEOUT_MS")) c->timeout = (uint64_t)std::max(1L, atol(e)) * 100000ull;
   MI_HIP(hipSetDevice(ctx->device));
   MI_HIP(hipExtMallocWithFlags((void **)&c->arena, kIpcArenaBytes, hipDeviceMallocFinegrained));
   MI_HIP(hipMemset(c->arena, 0, kIpcArenaBytes));

@@ -247,3 +247,17 @@ def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification(
     assert "falling back to RCCL" in r.stderr
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "RCCL (all-reduce of partial rows" in d["config"]["parallelism"] and d["value"] > 500
+
+
+def test_peer_memory_wait_is_bounded_and_fails_loudly():
+    import tempfile
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "tests", "ipc_fault_worker.py")]
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, IPC_WORKER_OUT=tmp, MI355OPT_IPC_TIMEOUT_MS="300")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        o = json.load(open(os.path.join(tmp, "rank0.json")))
+    assert o["first"] == 2000.0
+    assert o["err"] != 0 and 0.2 < o["waited_s"] < 5.0, o
+    assert o["stpcg"].startswith("MiError"), o
