@@ -8,12 +8,14 @@
 //   mi_rayleigh_ritz    small dense generalized symmetric-definite eigenproblem (host)   LOBPCG.h:53-62
 //   mi_csr_spmm_colmajor  Y = A X for a column-major panel (the user operator of cfg5)
 //
-// Gram kernel: a workgroup (8 waves) owns a contiguous range of rows; per 32-row tile both panels are
-// staged in LDS column-major with leading dimension 34 (== 2 mod 32, so the 16 columns x 2 rows that a
-// half-wave reads for one MFMA operand hit 32 distinct 8-byte bank pairs); each wave accumulates its
-// share (<= 5) of the (ka/16) x (kb/16) output tiles in registers over the whole row range, the next
-// tile's global loads in flight during the MFMA phase; per-workgroup partial Grams are then summed
-// in fixed order by a second kernel (deterministic).
+// Gram kernels: square panels of <= 80 columns (every Gram inside the LOBPCG loop) take k_gram_direct --
+// no LDS, MFMA operands loaded straight from global memory in operand layout, one wave owning all output
+// tiles (see there).  Other shapes take k_gram: a workgroup (8 waves) takes every gridDim-th 32-row tile,
+// both panels staged in LDS column-major with leading dimension 34 (== 2 mod 32, so the 16 columns x 2
+// rows that a half-wave reads for one MFMA operand hit 32 distinct 8-byte bank pairs); each wave
+// accumulates its share (<= 5) of the (ka/16) x (kb/16) output tiles in registers, the next tile's
+// global loads in flight during the MFMA phase.  Partial Grams (one per wave / workgroup) are summed in
+// fixed order by k_gram_reduce (deterministic).
 // Algorithmic bytes: 8 m (ka + kb)  (8 m ka when S == T); flops 2 m ka kb.
 #include <algorithm>
 #include <cmath>
@@ -33,7 +35,6 @@ constexpr int kGramMaxK = 96;       // max panel width
 constexpr int kGramThreads = 512;
 constexpr int kGramWaves = kGramThreads / 64;
 constexpr int kGramSegs = kGramThreads / 16;  // 16 threads x 16 B cover one 32-row column segment
-constexpr int kMaxTilesPerWave = 5;  // ceil((96/16)^2 / 8)
 
 constexpr int kColIters = kGramMaxK / kGramSegs;  // column segments a thread may own per panel
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ void tile_decode(int tile, int tb, int &ti, int &tj) 
 // whose last slot has no tile recomputes tile (0,0) there and discards it.
 template <bool SAME, bool ALIGNED, int TPW>
 __global__ __launch_bounds__(kGramThreads) void k_gram(size_t m, int ka, int kb, const double *__restrict__ S,
-                                                       const double *__restrict__ T, size_t rows_per_block,
+                                                       const double *__restrict__ T,
                                                        double *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int ta = (ka + 15) / 16, tb = (kb + 15) / 16;
@@ -135,7 +136,6 @@ __global__ __launch_bounds__(kGramThreads) void k_gram(size_t m, int ka, int kb,
 
   // interleaved tiles: at step s the grid reads one contiguous band of 32 * gridDim rows of every
   // column (DRAM-page friendly); workgroup b takes tile b of each band
-  (void)rows_per_block;
   const size_t band = (size_t)kGramRows * gridDim.x;
   const size_t rb = (size_t)blockIdx.x * kGramRows, re = m;
   double2 ra[kColIters], rt[kColIters];
@@ -662,7 +662,7 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
   // square panels of up to 80 columns on 32-byte-aligned columns: the LDS-free one-wave-per-row-range kernel
   const bool direct = ka == kb && ka <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T->d % 32 == 0 &&
                       m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
-  size_t nb, rpb = 0, nwaves = 0;
+  size_t nb, nwaves = 0;
   const size_t mfull = m - m % (16 * kGdH);  // rows k_gram_direct covers in whole pipeline steps
   if (direct) {  // one partial per wave + one for the leftover rows
     // two waves per SIMD where the registers allow it (k <= 48, and k <= 80 when S == T), else one
@@ -672,8 +672,6 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
   } else {  // rows per workgroup: a multiple of the 32-row tile, ~3 workgroups per CU
     nb = std::min<size_t>(3 * (size_t)ctx->num_cu, (m + kGramRows - 1) / kGramRows);
     if (nb < 1) nb = 1;
-    rpb = ((m + nb - 1) / nb + kGramRows - 1) / kGramRows * kGramRows;
-    nb = (m + rpb - 1) / rpb;
   }
   void *partial = nullptr, *Gdev = nullptr;
   MI_TRY(pool_alloc(ctx, nb * (size_t)nelem * sizeof(double), &partial));
@@ -709,7 +707,7 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
     const int tpw = (ntiles + kGramWaves - 1) / kGramWaves;  // 1..5
 #define GRAM(SAME, AL, TPW)                                                                                        \
   hipLaunchKernelGGL((k_gram<SAME, AL, TPW>), dim3((unsigned)nb), dim3(kGramThreads), lds, ctx->stream, m, ka, kb, \
-                     (const double *)S->d, (const double *)T->d, rpb, (double *)partial)
+                     (const double *)S->d, (const double *)T->d, (double *)partial)
 #define GRAM_T(SAME, AL)        \
   switch (tpw) {                \
     case 1: GRAM(SAME, AL, 1); break; \
