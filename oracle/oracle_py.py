@@ -122,6 +122,11 @@ class _Lib:
                                      C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p,
                                      c_size_p]
             self.tnls_fn = getattr(L, prefix + "_tnls_sinfit")
+            self.tnls_affine_fn = getattr(L, prefix + "_tnls_affine")
+            self.tnls_affine_fn.restype = C.c_int
+            self.tnls_affine_fn.argtypes = [C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_double,
+                                            C.c_double, C.c_size_t, C.c_size_t, c_double_p, c_double_p,
+                                            c_double_p, C.POINTER(C.c_int), c_size_p, c_size_p]
             self.tnls_fn.restype = C.c_int
             self.tnls_fn.argtypes = [C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double,
                                      C.c_double, C.c_double, C.c_size_t, c_double_p, c_double_p, c_double_p,
@@ -278,6 +283,25 @@ class _Lib:
                           C.byref(gn), C.byref(st), C.byref(outer), C.byref(inner))
         return dict(rc=rc, beta=beta, f=f.value, gradfx_norm=gn.value, status=st.value, outer=outer.value,
                     inner_total=inner.value)
+
+
+def _tnls_affine(self, A, b, x0, root_tolerance=1e-9, gradient_tolerance=0.0, max_iterations=20,
+                 max_LSQR_iterations=1000):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    x = np.zeros(n)
+    f, gn = np.zeros(1), np.zeros(1)
+    st, outer, inner = C.c_int(-1), C.c_size_t(0), C.c_size_t(0)
+    rc = self.tnls_affine_fn(m, n, _dp(A), _dp(b), _dp(x0), root_tolerance, gradient_tolerance, max_iterations,
+                             max_LSQR_iterations, _dp(x), _dp(f), _dp(gn), C.byref(st), C.byref(outer),
+                             C.byref(inner))
+    return dict(rc=rc, x=x, f=float(f[0]), gradfx_norm=float(gn[0]), status=st.value, outer=outer.value,
+                inner_total=inner.value)
+
+
+_Lib.tnls_affine = _tnls_affine
 
 
 def _seq_dot(a, b):

@@ -16,6 +16,7 @@
 #include "Optimization/MI355/SO3.h"
 #include "Optimization/MI355/Stiefel.h"
 #include "Optimization/Riemannian/GradientDescent.h"
+#include "Optimization/Riemannian/TNLS.h"
 #include "Optimization/Riemannian/TNT.h"
 #include "oracle.h"  // result / parameter structs only (plain data)
 
@@ -379,5 +380,99 @@ extern "C" int hd_gd_sphere(const double *x0, double *x_out, double *f_out, doub
   *gradnorm_out = r.gradfx_norm;
   *status_out = static_cast<int>(r.status);
   *iterations_out = r.linesearch_iterations.size();
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSQR (IterativeSolvers.h:552-855) and TNLS (TNLS.h:265-729) on DeviceVector: the generic loops of the
+// drop-in headers running through the Vector concept on the GPU.  A and A' are two CSR matrices.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct CsrPair {
+  mi_csr *A = nullptr, *At = nullptr;
+  CsrPair(Context &ctx, size_t n, const int32_t *rp, const int32_t *cl, const double *vl, const int32_t *rpt,
+          const int32_t *clt, const double *vlt) {
+    MI355::check(mi_csr_create(ctx.get(), n, (size_t)rp[n], rp, cl, vl, &A));
+    MI355::check(mi_csr_create(ctx.get(), n, (size_t)rpt[n], rpt, clt, vlt, &At));
+  }
+  ~CsrPair() {
+    mi_csr_destroy(A);
+    mi_csr_destroy(At);
+  }
+  static DeviceVector apply(const mi_csr *M, const DeviceVector &x) {
+    DeviceVector y = DeviceVector::like(x);
+    MI355::check(mi_csr_spmm(M, 1, x.handle(), y.handle()));
+    return y;
+  }
+};
+}  // namespace
+
+extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const double *vl, const int32_t *rpt,
+                           const int32_t *clt, const double *vlt, const double *b, size_t max_iterations,
+                           double lambda, double btol, double Atol, double Acond_limit, double Delta, double *x_out,
+                           double *xnorm_out, size_t *iterations_out) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
+  LA::LinearOperator<DeviceVector, DeviceVector> Aop = [&](const DeviceVector &x) { return CsrPair::apply(M.A, x); };
+  LA::LinearOperator<DeviceVector, DeviceVector> Atop = [&](const DeviceVector &y) { return CsrPair::apply(M.At, y); };
+  LA::InnerProduct<DeviceVector, double> ip = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  DeviceVector bv(ctx, b, n);
+  double xnorm = 0;
+  size_t iters = 0;
+  DeviceVector x = LA::LSQR<DeviceVector, double>(Aop, Atop, bv, ip, xnorm, iters, max_iterations, lambda, btol, Atol,
+                                                 Acond_limit, Delta);
+  const std::vector<double> xh = x.to_host();
+  for (size_t j = 0; j < n; ++j) x_out[j] = j < xh.size() ? xh[j] : 0.0;
+  *xnorm_out = xnorm;
+  *iterations_out = iters;
+  HD_GUARD_END
+}
+
+extern "C" int hd_tnls_affine(size_t n, const int32_t *rp, const int32_t *cl, const double *vl, const int32_t *rpt,
+                              const int32_t *clt, const double *vlt, const double *b, const double *x0,
+                              double root_tolerance, double gradient_tolerance, size_t max_iterations,
+                              size_t max_LSQR_iterations, double *x_out, double *f_out, double *gradnorm_out,
+                              int *status_out, size_t *outer_out, size_t *inner_total_out) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
+  DeviceVector bv(ctx, b, n);
+  RM::Mapping<DeviceVector, DeviceVector> F = [&](const DeviceVector &x) { return CsrPair::apply(M.A, x) - bv; };
+  RM::JacobianPairFunction<DeviceVector, DeviceVector, DeviceVector> J = [&](const DeviceVector &) {
+    RM::Jacobian<DeviceVector, DeviceVector, DeviceVector> dF = [&](const DeviceVector &, const DeviceVector &v) {
+      return CsrPair::apply(M.A, v);
+    };
+    RM::JacobianAdjoint<DeviceVector, DeviceVector, DeviceVector> dFt = [&](const DeviceVector &,
+                                                                             const DeviceVector &w) {
+      return CsrPair::apply(M.At, w);
+    };
+    return std::make_pair(dF, dFt);
+  };
+  RM::RiemannianMetric<DeviceVector, DeviceVector, double> metric = [](const DeviceVector &, const DeviceVector &a,
+                                                                       const DeviceVector &c) { return a.dot(c); };
+  LA::InnerProduct<DeviceVector, double> ipY = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  RM::Retraction<DeviceVector, DeviceVector> retract = [](const DeviceVector &x, const DeviceVector &v) {
+    return x + v;
+  };
+  RM::TNLSParams<double> p;
+  p.relative_decrease_tolerance = 0;
+  p.stepsize_tolerance = 0;
+  p.gradient_tolerance = gradient_tolerance;
+  p.root_tolerance = root_tolerance;
+  p.max_iterations = max_iterations;
+  p.max_LSQR_iterations = max_LSQR_iterations;
+  DeviceVector xs(ctx, x0, n);
+  RM::TNLSResult<DeviceVector, double> r = RM::TNLS<DeviceVector, DeviceVector, DeviceVector, double>(
+      F, J, metric, ipY, retract, xs, std::optional<RM::TNLSPreconditioner<DeviceVector, DeviceVector>>(), p);
+  const std::vector<double> xh = r.x.to_host();
+  std::memcpy(x_out, xh.data(), n * sizeof(double));
+  *f_out = r.f;
+  *gradnorm_out = r.gradfx_norm;
+  *status_out = static_cast<int>(r.status);
+  *outer_out = r.inner_iterations.size();
+  size_t tot = 0;
+  for (size_t k : r.inner_iterations) tot += k;
+  *inner_total_out = tot;
   HD_GUARD_END
 }

@@ -145,6 +145,56 @@ class DeviceHarness:
         rc = self.L.hd_tnt_sphere(int(with_precon), _dp(x0), C.byref(params), C.byref(res))
         return self._unpack(rc, bufs, res, self.err() if rc else "")
 
+    @staticmethod
+    def _csr_pair(A):
+        """scipy CSR A -> (rowptr, col, val) of A and of A' as int32/float64 arrays"""
+        import scipy.sparse as sps
+        A = sps.csr_matrix(A)
+        At = sps.csr_matrix(A.T)
+        out = []
+        for M in (A, At):
+            M.sort_indices()
+            out += [np.ascontiguousarray(M.indptr, dtype=np.int32), np.ascontiguousarray(M.indices, dtype=np.int32),
+                    np.ascontiguousarray(M.data, dtype=np.float64)]
+        return out
+
+    def lsqr_csr(self, A, b, max_iterations=1000, lam=0.0, btol=1e-6, Atol=1e-6, Acond_limit=1e8, Delta=None):
+        """LinearAlgebra::LSQR on DeviceVector, A (square, scipy sparse) and A' as CSR operators"""
+        n = A.shape[0]
+        rp, cl, vl, rpt, clt, vlt = self._csr_pair(A)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if Delta is None:
+            Delta = float(np.sqrt(np.finfo(np.float64).max))
+        x = np.zeros(n)
+        xn, it = C.c_double(0), C.c_size_t(0)
+        self.L.hd_lsqr_csr.restype = C.c_int
+        self.L.hd_lsqr_csr.argtypes = [C.c_size_t, ip32, ip32, dp, ip32, ip32, dp, dp, C.c_size_t, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, dp, dp, sp]
+        rc = self.L.hd_lsqr_csr(n, rp.ctypes.data_as(ip32), cl.ctypes.data_as(ip32), _dp(vl), rpt.ctypes.data_as(ip32),
+                                clt.ctypes.data_as(ip32), _dp(vlt), _dp(b), max_iterations, lam, btol, Atol,
+                                Acond_limit, Delta, _dp(x), C.byref(xn), C.byref(it))
+        return dict(rc=rc, err=self.err() if rc else "", x=x, xnorm=xn.value, iterations=it.value)
+
+    def tnls_affine(self, A, b, x0, root_tolerance=1e-9, gradient_tolerance=0.0, max_iterations=20,
+                    max_LSQR_iterations=1000):
+        """Riemannian::TNLS on DeviceVector for F(x) = A x - b"""
+        n = A.shape[0]
+        rp, cl, vl, rpt, clt, vlt = self._csr_pair(A)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        x = np.zeros(n)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, outer, inner = C.c_int(-1), C.c_size_t(0), C.c_size_t(0)
+        self.L.hd_tnls_affine.restype = C.c_int
+        self.L.hd_tnls_affine.argtypes = [C.c_size_t, ip32, ip32, dp, ip32, ip32, dp, dp, dp, C.c_double, C.c_double,
+                                          C.c_size_t, C.c_size_t, dp, dp, dp, C.POINTER(C.c_int), sp, sp]
+        rc = self.L.hd_tnls_affine(n, rp.ctypes.data_as(ip32), cl.ctypes.data_as(ip32), _dp(vl),
+                                   rpt.ctypes.data_as(ip32), clt.ctypes.data_as(ip32), _dp(vlt), _dp(b), _dp(x0),
+                                   root_tolerance, gradient_tolerance, max_iterations, max_LSQR_iterations, _dp(x),
+                                   C.byref(f), C.byref(gn), C.byref(st), C.byref(outer), C.byref(inner))
+        return dict(rc=rc, err=self.err() if rc else "", x=x, f=f.value, gradfx_norm=gn.value, status=st.value,
+                    outer=outer.value, inner_total=inner.value)
+
     def gd_sphere(self, x0):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         x = np.zeros(3)

@@ -164,3 +164,64 @@ def test_tnt_stiefel_device_medium_vs_oracle(harness, oracle):
     assert np.allclose(r["gradient_norms"], o["gradient_norms"], rtol=1e-7, atol=1e-12)
     assert rel_err(r["x"], o["x"]) < 1e-9
     oracle.free(oprob)
+
+
+# ----------------------------------------------------------------------------------------------
+# LSQR and TNLS on DeviceVector (generic loops of the drop-in headers through the Vector concept)
+# ----------------------------------------------------------------------------------------------
+def _nonsym_sparse(n, seed):
+    import scipy.sparse as sps
+    rng = np.random.default_rng(seed)
+    A = sps.diags([np.full(n - 1, -1.0), np.full(n, 4.0), np.full(n - 1, 2.0)], [-1, 0, 1]).tolil()
+    for _ in range(3 * n):
+        i, j = rng.integers(0, n, size=2)
+        A[i, j] += rng.normal() * .3
+    return sps.csr_matrix(A)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7)])
+def test_lsqr_device_matches_host_template(harness, kw):
+    """IterativeSolvers.h:552-855 on DeviceVector vs the same template on a host vector (which equals the reference
+    bit for bit, tests/test_cpu_oracle_templates.py): iterates to 1e-9, same iteration count."""
+    import oracle_py
+    hz = oracle_py.TemplateHarness()
+    n = 300
+    A = _nonsym_sparse(n, 2)
+    b = np.random.default_rng(9).normal(size=n)
+    d = harness.lsqr_csr(A, b, **kw)
+    h = hz.lsqr_dense(A.toarray(), b, **kw)
+    assert d["rc"] == 0, d["err"]
+    assert d["iterations"] == h["iterations"]
+    assert np.abs(d["x"] - h["x"]).max() <= 1e-9 * max(1.0, np.abs(h["x"]).max())
+    assert abs(d["xnorm"] - h["xnorm"]) <= 1e-9 * max(1.0, h["xnorm"])
+
+
+def test_lsqr_device_large(harness):
+    """n = 1e6: residual reduction property of tests/IterativeSolvers_unit_test.cpp:254-310 style"""
+    import scipy.sparse as sps
+    n = 1_000_000
+    A = sps.diags([np.full(n - 1, -1.0), np.full(n, 3.0), np.full(n - 1, 1.5)], [-1, 0, 1], format="csr")
+    xs = np.sin(np.arange(n) * 1e-3)
+    b = A @ xs
+    d = harness.lsqr_csr(A, b, btol=1e-10, Atol=1e-10, max_iterations=200)
+    assert d["rc"] == 0, d["err"]
+    assert np.linalg.norm(A @ d["x"] - b) <= 1e-8 * np.linalg.norm(b)
+    assert np.abs(d["x"] - xs).max() < 1e-6
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(root_tolerance=0.0, gradient_tolerance=1e-9),
+                                dict(max_LSQR_iterations=3, max_iterations=8)])
+def test_tnls_device_matches_host_template(harness, kw):
+    """TNLS.h:265-729 on DeviceVector for F(x) = A x - b vs the host-vector run of the same template."""
+    import oracle_py
+    hz = oracle_py.TemplateHarness()
+    n = 200
+    A = _nonsym_sparse(n, 5)
+    rng = np.random.default_rng(6)
+    b, x0 = rng.normal(size=n), rng.normal(size=n)
+    d = harness.tnls_affine(A, b, x0, **kw)
+    h = hz.tnls_affine(A.toarray(), b, x0, **kw)
+    assert d["rc"] == 0, d["err"]
+    assert (d["status"], d["outer"], d["inner_total"]) == (h["status"], h["outer"], h["inner_total"])
+    assert np.abs(d["x"] - h["x"]).max() <= 1e-9 * max(1.0, np.abs(h["x"]).max())
+    assert abs(d["f"] - h["f"]) <= 1e-9 * max(1.0, abs(h["f"]))
