@@ -129,9 +129,13 @@ MI_API int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W);
 /* callback: must ENQUEUE out = Op(in) on the context stream and return MI_OK without synchronising */
 typedef int (*mi_apply_fn)(void *user, const mi_vec *in, mi_vec *out);
 MI_API int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_op **out);
+/* rectangular operator (n_in -> n_out), e.g. a Jacobian and its adjoint for LSQR / TNLS */
+MI_API int mi_op_create_callback_rect(mi_ctx *ctx, size_t n_in, size_t n_out, mi_apply_fn fn, void *user,
+                                      mi_op **out);
 MI_API int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out);           /* Hp = d .* p */
 MI_API int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out);     /* Hp = A p    */
 MI_API int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out);
+MI_API int mi_op_dims(const mi_op *op, size_t *n_in, size_t *n_out); /* either pointer may be null */
 MI_API int mi_op_destroy(mi_op *op);
 
 MI_API int mi_precon_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user,
@@ -183,6 +187,40 @@ MI_API void mi_stpcg_default_params(mi_stpcg_params *p);
 MI_API int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P /*nullable*/,
                     const mi_stpcg_params *params, mi_vec *s_out, mi_stpcg_result *result,
                     mi_stpcg_trace *trace /*nullable*/);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5b) fused LSQR  <->  LinearAlgebra::LSQR  IterativeSolvers.h:552-855 (Paige & Saunders, damped,
+ *      with the trust-region radius of :779-793 and the stopping rules S1-S4 of :825-837; the user
+ *      function S5 is only available through the generic template loop).  Device-resident like
+ *      mi_stpcg: no scalar reaches the host inside the loop.  A: n_x -> n_y, At: n_y -> n_x.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mi_lsqr_params {
+  size_t max_iterations; /* :558 (1000) */
+  double lambda;         /* :558 (0)    */
+  double btol, Atol;     /* :558-559 (1e-6) */
+  double Acond_limit;    /* :559 (1e8)  */
+  double Delta;          /* :559 (sqrt(DBL_MAX)) */
+  int run_ahead;         /* as in mi_stpcg_params */
+} mi_lsqr_params;
+enum {
+  MI_LSQR_EXIT_MAXIT = 0,   /* loop exhausted (:696) */
+  MI_LSQR_EXIT_S1 = 1,      /* :825 */
+  MI_LSQR_EXIT_S2 = 2,      /* :829 */
+  MI_LSQR_EXIT_S3 = 3,      /* :833 */
+  MI_LSQR_EXIT_S4 = 4,      /* :837 */
+  MI_LSQR_EXIT_TRIVIAL = 5  /* A'b = 0: x = 0 returned before the loop (:671-674) */
+};
+typedef struct mi_lsqr_result {
+  double xnorm;          /* :769-770,793 */
+  size_t num_iterations; /* :696 (not advanced by the pass that breaks) */
+  int exit_reason;
+  double rbar_norm, Arnorm, Anorm, Acond; /* :814,818,711,808 */
+  size_t operator_applications;           /* enqueued, incl. speculative ones past the exit */
+} mi_lsqr_result;
+MI_API void mi_lsqr_default_params(mi_lsqr_params *p);
+MI_API int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_params *params,
+                   mi_vec *x_out, mi_lsqr_result *result); /* sync at exit */
+
 
 /* ---------------------------------------------------------------------------------------------
  * (6) Stiefel manifold St(n,p), p in {1,2,3,4}, embedded metric -- the callables a client of

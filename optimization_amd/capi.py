@@ -47,6 +47,20 @@ class StpcgResult(C.Structure):
                 ("exit_reason", C.c_int), ("hvp_calls", C.c_size_t), ("rv_final", C.c_double)]
 
 
+class LsqrParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_size_t), ("lam", C.c_double), ("btol", C.c_double), ("Atol", C.c_double),
+                ("Acond_limit", C.c_double), ("Delta", C.c_double), ("run_ahead", C.c_int)]
+
+
+class LsqrResult(C.Structure):
+    _fields_ = [("xnorm", C.c_double), ("num_iterations", C.c_size_t), ("exit_reason", C.c_int),
+                ("rbar_norm", C.c_double), ("Arnorm", C.c_double), ("Anorm", C.c_double), ("Acond", C.c_double),
+                ("operator_applications", C.c_size_t)]
+
+
+LSQR_EXIT = ["MAXIT", "S1", "S2", "S3", "S4", "TRIVIAL"]
+
+
 class StpcgTrace(C.Structure):
     _fields_ = [("cap", C.c_size_t), ("len", C.c_size_t), ("alpha", c_double_p), ("beta", c_double_p),
                 ("kappa", c_double_p), ("rv", c_double_p)]
@@ -101,9 +115,13 @@ def load():
         "mi_csr_destroy": [vp],
         "mi_csr_spmm": [vp, C.c_int, vp, vp],
         "mi_op_create_callback": [vp, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
+        "mi_op_create_callback_rect": [vp, C.c_size_t, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
+        "mi_lsqr_default_params": [C.POINTER(LsqrParams)],
+        "mi_lsqr": [vp, vp, vp, vp, C.POINTER(LsqrParams), vp, C.POINTER(LsqrResult)],
         "mi_op_create_diag": [vp, vp, C.POINTER(vp)],
         "mi_op_create_csr": [vp, vp, C.c_int, C.POINTER(vp)],
         "mi_op_apply": [vp, vp, vp],
+        "mi_op_dims": [vp, c_size_p, c_size_p],
         "mi_op_destroy": [vp],
         "mi_precon_create_callback": [vp, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
         "mi_precon_create_diag": [vp, vp, C.POINTER(vp)],
@@ -153,6 +171,7 @@ def load():
         fn.restype = C.c_int
         fn.argtypes = args
     L.mi_stpcg_default_params.restype = None
+    L.mi_lsqr_default_params.restype = None
     L.mi_stpcg_default_params.argtypes = [C.POINTER(StpcgParams)]
     _lib = L
     return L
@@ -280,7 +299,9 @@ class Context:
     def op_csr(self, A, p):
         h = vp()
         check(self.L.mi_op_create_csr(self.h, A.h, p, C.byref(h)))
-        return Op(self, h, keep=[A])
+        op = Op(self, h, keep=[A])
+        op.n_in = A.n * p
+        return op
 
     def op_callback(self, n, fn):
         """fn(in_vec: Vec, out_vec: Vec) enqueues out = Op(in)."""
@@ -340,6 +361,22 @@ class Context:
         if tr:
             out["trace"] = {k: v[:tr.len].copy() for k, v in arrs.items()}
         return out
+
+    # fused LSQR ---------------------------------------------------------------------------------
+    def lsqr(self, A, At, b, x_out=None, **kw):
+        """mi_lsqr: A, At are Op handles (A: n_x -> n_y); kw: max_iterations, lam, btol, Atol, Acond_limit, Delta"""
+        prm = LsqrParams()
+        self.L.mi_lsqr_default_params(C.byref(prm))
+        for k, v in kw.items():
+            if not hasattr(prm, k):
+                raise AttributeError(k)
+            setattr(prm, k, v)
+        res = LsqrResult()
+        x = x_out if x_out is not None else Vec(self, kw_nx if (kw_nx := getattr(A, "n_in", None)) else b.n)
+        check(self.L.mi_lsqr(self.h, A.h, At.h, b.h, C.byref(prm), x.h, C.byref(res)))
+        return dict(x=x, xnorm=res.xnorm, iterations=res.num_iterations, exit_reason=res.exit_reason,
+                    rbar_norm=res.rbar_norm, Arnorm=res.Arnorm, Anorm=res.Anorm, Acond=res.Acond,
+                    operator_applications=res.operator_applications)
 
     # Stiefel ----------------------------------------------------------------------------------
     def stiefel_gram(self, n, p, X, Z):

@@ -320,7 +320,8 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W);
 // operator / preconditioner objects --------------------------------------------------------
 struct mi_op {
   mi_ctx *ctx = nullptr;
-  size_t n = 0;
+  size_t n = 0;      // input length
+  size_t n_out = 0;  // output length (0: same as n)
   // out = Op(in)
   int (*apply)(mi_op *self, const mi_vec *in, mi_vec *out) = nullptr;
   // out = Op(in) and per-workgroup partials of <in,out>, <out,out>, <in,in> in ctx->partials

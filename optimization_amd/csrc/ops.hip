@@ -126,6 +126,12 @@ int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_
   return MI_OK;
 }
 
+int mi_op_create_callback_rect(mi_ctx *ctx, size_t n_in, size_t n_out, mi_apply_fn fn, void *user, mi_op **out) {
+  MI_TRY(mi_op_create_callback(ctx, n_in, fn, user, out));
+  (*out)->n_out = n_out;
+  return MI_OK;
+}
+
 int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out) {
   MI_REQUIRE(ctx && d && out, "null argument");
   MI_REQUIRE(d->ctx == ctx, "vector belongs to another context");
@@ -156,9 +162,16 @@ int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out) {
 
 int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out) {
   MI_REQUIRE(op && in && out, "null argument");
-  MI_REQUIRE(in->n == op->n && out->n == op->n, "operator dimension mismatch");
+  MI_REQUIRE(in->n == op->n && out->n == (op->n_out ? op->n_out : op->n), "operator dimension mismatch");
   MI_REQUIRE(in->d != out->d, "operator input and output must not alias");
   return op->apply(op, in, out);
+}
+
+int mi_op_dims(const mi_op *op, size_t *n_in, size_t *n_out) {
+  MI_REQUIRE(op, "op is null");
+  if (n_in) *n_in = op->n;
+  if (n_out) *n_out = op->n_out ? op->n_out : op->n;
+  return MI_OK;
 }
 
 int mi_op_destroy(mi_op *op) {

@@ -97,6 +97,43 @@ bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args
     return true;
   }
 }
+
+// Fused device LSQR (mi_lsqr): both operators tagged DeviceOperator, both inner products Frobenius.
+template <typename VectorX, typename VectorY, typename Scalar, typename... Args>
+bool lsqr_on_device(const LinearOperator<VectorX, VectorY, Args...> &A,
+                    const LinearOperator<VectorY, VectorX, Args...> &At, const VectorY &b,
+                    const InnerProduct<VectorX, Scalar, Args...> &ipx,
+                    const InnerProduct<VectorY, Scalar, Args...> &ipy, size_t max_iterations, Scalar lambda,
+                    Scalar btol, Scalar Atol, Scalar Abar_cond_limit, Scalar Delta, VectorX &x_out, Scalar &xnorm,
+                    size_t &num_iterations) {
+  if constexpr (!MI355::is_device_vector<VectorX>::value || !MI355::is_device_vector<VectorY>::value ||
+                !std::is_same<Scalar, double>::value || sizeof...(Args) != 0) {
+    return false;
+  } else {
+    using namespace MI355;
+    if (b.empty()) return false;
+    if (!ipx.template target<FrobeniusInnerProduct>() || !ipy.template target<FrobeniusInnerProduct>()) return false;
+    const DeviceOperator *da = A.template target<DeviceOperator>();
+    const DeviceOperator *dat = At.template target<DeviceOperator>();
+    if (!da || !da->op || !dat || !dat->op) return false;
+    size_t nx = 0;
+    check(mi_op_dims(dat->op, nullptr, &nx));
+    mi_lsqr_params prm;
+    mi_lsqr_default_params(&prm);
+    prm.max_iterations = max_iterations;
+    prm.lambda = lambda;
+    prm.btol = btol;
+    prm.Atol = Atol;
+    prm.Acond_limit = Abar_cond_limit;
+    prm.Delta = Delta;
+    mi_lsqr_result res;
+    x_out = DeviceVector::on(b.context(), nx);
+    check(mi_lsqr(b.context(), da->op, dat->op, b.handle(), &prm, x_out.handle(), &res));
+    xnorm = res.xnorm;
+    num_iterations = res.num_iterations;
+    return true;
+  }
+}
 #endif
 
 }  // namespace detail
@@ -259,6 +296,16 @@ VectorX LSQR(const LinearOperator<VectorX, VectorY, Args...> &A,
     throw std::invalid_argument("Stopping tolerance Abar_cond_limit must be a positive real number");
   if (Delta <= 0)
     throw std::invalid_argument("Trust-region radius (Delta) must be a positive real value");
+
+#if OPTIMIZATION_HAVE_MI355
+  if (!user_function) {
+    VectorX x_dev;
+    if (detail::lsqr_on_device<VectorX, VectorY, Scalar, Args...>(A, At, b, inner_product_x, inner_product_y,
+                                                                  max_iterations, lambda, btol, Atol, Abar_cond_limit,
+                                                                  Delta, x_dev, xnorm, num_iterations))
+      return x_dev;
+  }
+#endif
 
   VectorX x;
   xnorm = 0;

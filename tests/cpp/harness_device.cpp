@@ -407,16 +407,29 @@ struct CsrPair {
 };
 }  // namespace
 
+// mode 0: operators / inner products as the tagged device callables => the template hands the solve to the
+// fused mi_lsqr; mode 1: plain lambdas => the generic loop of the template through the Vector concept
 extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const double *vl, const int32_t *rpt,
                            const int32_t *clt, const double *vlt, const double *b, size_t max_iterations,
-                           double lambda, double btol, double Atol, double Acond_limit, double Delta, double *x_out,
-                           double *xnorm_out, size_t *iterations_out) {
+                           double lambda, double btol, double Atol, double Acond_limit, double Delta, int mode,
+                           double *x_out, double *xnorm_out, size_t *iterations_out) {
   HD_GUARD_BEGIN
   Context ctx(0);
   CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
-  LA::LinearOperator<DeviceVector, DeviceVector> Aop = [&](const DeviceVector &x) { return CsrPair::apply(M.A, x); };
-  LA::LinearOperator<DeviceVector, DeviceVector> Atop = [&](const DeviceVector &y) { return CsrPair::apply(M.At, y); };
-  LA::InnerProduct<DeviceVector, double> ip = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  LA::LinearOperator<DeviceVector, DeviceVector> Aop, Atop;
+  LA::InnerProduct<DeviceVector, double> ip;
+  mi_op *opA = nullptr, *opAt = nullptr;
+  if (mode == 0) {
+    MI355::check(mi_op_create_csr(ctx.get(), M.A, 1, &opA));
+    MI355::check(mi_op_create_csr(ctx.get(), M.At, 1, &opAt));
+    Aop = MI355::DeviceOperator{opA};
+    Atop = MI355::DeviceOperator{opAt};
+    ip = MI355::FrobeniusInnerProduct{};
+  } else {
+    Aop = [&](const DeviceVector &x) { return CsrPair::apply(M.A, x); };
+    Atop = [&](const DeviceVector &y) { return CsrPair::apply(M.At, y); };
+    ip = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  }
   DeviceVector bv(ctx, b, n);
   double xnorm = 0;
   size_t iters = 0;
@@ -426,6 +439,8 @@ extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const
   for (size_t j = 0; j < n; ++j) x_out[j] = j < xh.size() ? xh[j] : 0.0;
   *xnorm_out = xnorm;
   *iterations_out = iters;
+  mi_op_destroy(opA);
+  mi_op_destroy(opAt);
   HD_GUARD_END
 }
 

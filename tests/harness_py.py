@@ -158,7 +158,8 @@ class DeviceHarness:
                     np.ascontiguousarray(M.data, dtype=np.float64)]
         return out
 
-    def lsqr_csr(self, A, b, max_iterations=1000, lam=0.0, btol=1e-6, Atol=1e-6, Acond_limit=1e8, Delta=None):
+    def lsqr_csr(self, A, b, max_iterations=1000, lam=0.0, btol=1e-6, Atol=1e-6, Acond_limit=1e8, Delta=None,
+                 mode=0):
         """LinearAlgebra::LSQR on DeviceVector, A (square, scipy sparse) and A' as CSR operators"""
         n = A.shape[0]
         rp, cl, vl, rpt, clt, vlt = self._csr_pair(A)
@@ -169,10 +170,10 @@ class DeviceHarness:
         xn, it = C.c_double(0), C.c_size_t(0)
         self.L.hd_lsqr_csr.restype = C.c_int
         self.L.hd_lsqr_csr.argtypes = [C.c_size_t, ip32, ip32, dp, ip32, ip32, dp, dp, C.c_size_t, C.c_double, C.c_double,
-                                       C.c_double, C.c_double, C.c_double, dp, dp, sp]
+                                       C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, sp]
         rc = self.L.hd_lsqr_csr(n, rp.ctypes.data_as(ip32), cl.ctypes.data_as(ip32), _dp(vl), rpt.ctypes.data_as(ip32),
                                 clt.ctypes.data_as(ip32), _dp(vlt), _dp(b), max_iterations, lam, btol, Atol,
-                                Acond_limit, Delta, _dp(x), C.byref(xn), C.byref(it))
+                                Acond_limit, Delta, mode, _dp(x), C.byref(xn), C.byref(it))
         return dict(rc=rc, err=self.err() if rc else "", x=x, xnorm=xn.value, iterations=it.value)
 
     def tnls_affine(self, A, b, x0, root_tolerance=1e-9, gradient_tolerance=0.0, max_iterations=20,

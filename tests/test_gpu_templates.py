@@ -179,8 +179,10 @@ def _nonsym_sparse(n, seed):
     return sps.csr_matrix(A)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7)])
-def test_lsqr_device_matches_host_template(harness, kw):
+@pytest.mark.parametrize("mode", [0, 1], ids=["fused", "generic"])
+@pytest.mark.parametrize("kw", [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7),
+                                dict(btol=1e-12, Atol=1e-12, Acond_limit=50.0)])
+def test_lsqr_device_matches_host_template(harness, kw, mode):
     """IterativeSolvers.h:552-855 on DeviceVector vs the same template on a host vector (which equals the reference
     bit for bit, tests/test_cpu_oracle_templates.py): iterates to 1e-9, same iteration count."""
     import oracle_py
@@ -188,7 +190,7 @@ def test_lsqr_device_matches_host_template(harness, kw):
     n = 300
     A = _nonsym_sparse(n, 2)
     b = np.random.default_rng(9).normal(size=n)
-    d = harness.lsqr_csr(A, b, **kw)
+    d = harness.lsqr_csr(A, b, mode=mode, **kw)
     h = hz.lsqr_dense(A.toarray(), b, **kw)
     assert d["rc"] == 0, d["err"]
     assert d["iterations"] == h["iterations"]
@@ -203,8 +205,10 @@ def test_lsqr_device_large(harness):
     A = sps.diags([np.full(n - 1, -1.0), np.full(n, 3.0), np.full(n - 1, 1.5)], [-1, 0, 1], format="csr")
     xs = np.sin(np.arange(n) * 1e-3)
     b = A @ xs
-    d = harness.lsqr_csr(A, b, btol=1e-10, Atol=1e-10, max_iterations=200)
+    d = harness.lsqr_csr(A, b, btol=1e-10, Atol=1e-10, max_iterations=200)     # fused mi_lsqr
     assert d["rc"] == 0, d["err"]
+    g = harness.lsqr_csr(A, b, btol=1e-10, Atol=1e-10, max_iterations=200, mode=1)
+    assert g["iterations"] == d["iterations"] and np.abs(g["x"] - d["x"]).max() < 1e-10
     assert np.linalg.norm(A @ d["x"] - b) <= 1e-8 * np.linalg.norm(b)
     assert np.abs(d["x"] - xs).max() < 1e-6
 
