@@ -169,6 +169,29 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
     return metric_X(x, a, b, aa...);
   };
 
+#if OPTIMIZATION_HAVE_MI355
+  // Device fast path: when the Jacobian pair handed back by J consists of tagged device operators (an
+  // mi_op each, bound to x: MI355::DeviceHessian) and the metric is the Frobenius one, LSQR receives the
+  // tagged callables it recognises and the whole inner solve runs in the fused mi_lsqr.  Redone after
+  // every linearisation because J may hand back new operators.
+  constexpr bool device_types = MI355::is_device_vector<TangentX>::value &&
+                                MI355::is_device_vector<VectorY>::value && sizeof...(Args) == 0;
+  auto retag_for_device = [&]() {
+    if constexpr (device_types) {
+      if (precon) return;
+      const auto *a = dF.template target<MI355::DeviceHessian>();
+      const auto *at = dFt.template target<MI355::DeviceHessian>();
+      if (!a || !at || !metric_X.template target<MI355::FrobeniusMetric>()) return;
+      A = MI355::DeviceOperator{a->op};
+      At = MI355::DeviceOperator{at->op};
+      inner_product_X = MI355::FrobeniusInnerProduct{};
+    }
+  };
+  retag_for_device();
+#else
+  auto retag_for_device = []() {};
+#endif
+
   Delta = params.Delta0;
   if (params.verbose) {
     std::cout << std::scientific;
@@ -267,6 +290,7 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
         break;
       }
       linearise();
+      retag_for_device();
     }
 
     if ((!std::isnan(rho)) && (rho >= params.eta2)) {  // :644-657

@@ -444,29 +444,42 @@ extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const
   HD_GUARD_END
 }
 
+// mode 0: Jacobian pair / metric / inner product as tagged device callables => TNLS hands every inner solve to the
+// fused mi_lsqr; mode 1: plain lambdas => generic loops
 extern "C" int hd_tnls_affine(size_t n, const int32_t *rp, const int32_t *cl, const double *vl, const int32_t *rpt,
                               const int32_t *clt, const double *vlt, const double *b, const double *x0,
                               double root_tolerance, double gradient_tolerance, size_t max_iterations,
-                              size_t max_LSQR_iterations, double *x_out, double *f_out, double *gradnorm_out,
-                              int *status_out, size_t *outer_out, size_t *inner_total_out) {
+                              size_t max_LSQR_iterations, int mode, double *x_out, double *f_out,
+                              double *gradnorm_out, int *status_out, size_t *outer_out, size_t *inner_total_out) {
   HD_GUARD_BEGIN
   Context ctx(0);
   CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
   DeviceVector bv(ctx, b, n);
+  mi_op *opA = nullptr, *opAt = nullptr;
+  MI355::check(mi_op_create_csr(ctx.get(), M.A, 1, &opA));
+  MI355::check(mi_op_create_csr(ctx.get(), M.At, 1, &opAt));
   RM::Mapping<DeviceVector, DeviceVector> F = [&](const DeviceVector &x) { return CsrPair::apply(M.A, x) - bv; };
   RM::JacobianPairFunction<DeviceVector, DeviceVector, DeviceVector> J = [&](const DeviceVector &) {
-    RM::Jacobian<DeviceVector, DeviceVector, DeviceVector> dF = [&](const DeviceVector &, const DeviceVector &v) {
-      return CsrPair::apply(M.A, v);
-    };
-    RM::JacobianAdjoint<DeviceVector, DeviceVector, DeviceVector> dFt = [&](const DeviceVector &,
-                                                                             const DeviceVector &w) {
-      return CsrPair::apply(M.At, w);
-    };
+    RM::Jacobian<DeviceVector, DeviceVector, DeviceVector> dF;
+    RM::JacobianAdjoint<DeviceVector, DeviceVector, DeviceVector> dFt;
+    if (mode == 0) {
+      dF = MI355::DeviceHessian{opA};
+      dFt = MI355::DeviceHessian{opAt};
+    } else {
+      dF = [&](const DeviceVector &, const DeviceVector &v) { return CsrPair::apply(M.A, v); };
+      dFt = [&](const DeviceVector &, const DeviceVector &w) { return CsrPair::apply(M.At, w); };
+    }
     return std::make_pair(dF, dFt);
   };
-  RM::RiemannianMetric<DeviceVector, DeviceVector, double> metric = [](const DeviceVector &, const DeviceVector &a,
-                                                                       const DeviceVector &c) { return a.dot(c); };
-  LA::InnerProduct<DeviceVector, double> ipY = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  RM::RiemannianMetric<DeviceVector, DeviceVector, double> metric;
+  LA::InnerProduct<DeviceVector, double> ipY;
+  if (mode == 0) {
+    metric = MI355::FrobeniusMetric{};
+    ipY = MI355::FrobeniusInnerProduct{};
+  } else {
+    metric = [](const DeviceVector &, const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+    ipY = [](const DeviceVector &a, const DeviceVector &c) { return a.dot(c); };
+  }
   RM::Retraction<DeviceVector, DeviceVector> retract = [](const DeviceVector &x, const DeviceVector &v) {
     return x + v;
   };
@@ -489,5 +502,7 @@ extern "C" int hd_tnls_affine(size_t n, const int32_t *rp, const int32_t *cl, co
   size_t tot = 0;
   for (size_t k : r.inner_iterations) tot += k;
   *inner_total_out = tot;
+  mi_op_destroy(opA);
+  mi_op_destroy(opAt);
   HD_GUARD_END
 }

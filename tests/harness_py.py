@@ -177,8 +177,8 @@ class DeviceHarness:
         return dict(rc=rc, err=self.err() if rc else "", x=x, xnorm=xn.value, iterations=it.value)
 
     def tnls_affine(self, A, b, x0, root_tolerance=1e-9, gradient_tolerance=0.0, max_iterations=20,
-                    max_LSQR_iterations=1000):
-        """Riemannian::TNLS on DeviceVector for F(x) = A x - b"""
+                    max_LSQR_iterations=1000, mode=0):
+        """Riemannian::TNLS on DeviceVector for F(x) = A x - b (mode 0: tagged callables => fused mi_lsqr)"""
         n = A.shape[0]
         rp, cl, vl, rpt, clt, vlt = self._csr_pair(A)
         b = np.ascontiguousarray(b, dtype=np.float64)
@@ -188,10 +188,10 @@ class DeviceHarness:
         st, outer, inner = C.c_int(-1), C.c_size_t(0), C.c_size_t(0)
         self.L.hd_tnls_affine.restype = C.c_int
         self.L.hd_tnls_affine.argtypes = [C.c_size_t, ip32, ip32, dp, ip32, ip32, dp, dp, dp, C.c_double, C.c_double,
-                                          C.c_size_t, C.c_size_t, dp, dp, dp, C.POINTER(C.c_int), sp, sp]
+                                          C.c_size_t, C.c_size_t, C.c_int, dp, dp, dp, C.POINTER(C.c_int), sp, sp]
         rc = self.L.hd_tnls_affine(n, rp.ctypes.data_as(ip32), cl.ctypes.data_as(ip32), _dp(vl),
                                    rpt.ctypes.data_as(ip32), clt.ctypes.data_as(ip32), _dp(vlt), _dp(b), _dp(x0),
-                                   root_tolerance, gradient_tolerance, max_iterations, max_LSQR_iterations, _dp(x),
+                                   root_tolerance, gradient_tolerance, max_iterations, max_LSQR_iterations, mode, _dp(x),
                                    C.byref(f), C.byref(gn), C.byref(st), C.byref(outer), C.byref(inner))
         return dict(rc=rc, err=self.err() if rc else "", x=x, f=f.value, gradfx_norm=gn.value, status=st.value,
                     outer=outer.value, inner_total=inner.value)

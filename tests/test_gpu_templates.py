@@ -213,9 +213,10 @@ def test_lsqr_device_large(harness):
     assert np.abs(d["x"] - xs).max() < 1e-6
 
 
+@pytest.mark.parametrize("mode", [0, 1], ids=["fused_lsqr", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(root_tolerance=0.0, gradient_tolerance=1e-6),
                                 dict(max_LSQR_iterations=3, max_iterations=8)])
-def test_tnls_device_matches_host_template(harness, kw):
+def test_tnls_device_matches_host_template(harness, kw, mode):
     """TNLS.h:265-729 on DeviceVector for F(x) = A x - b vs the host-vector run of the same template."""
     import oracle_py
     hz = oracle_py.TemplateHarness()
@@ -223,7 +224,7 @@ def test_tnls_device_matches_host_template(harness, kw):
     A = _nonsym_sparse(n, 5)
     rng = np.random.default_rng(6)
     b, x0 = rng.normal(size=n), rng.normal(size=n)
-    d = harness.tnls_affine(A, b, x0, **kw)
+    d = harness.tnls_affine(A, b, x0, mode=mode, **kw)
     h = hz.tnls_affine(A.toarray(), b, x0, **kw)
     assert d["rc"] == 0, d["err"]
     assert d["status"] == h["status"]
