@@ -61,6 +61,9 @@ static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
 }
 
 static double g_last_tnt_seconds = 0.0;
+static double g_last_solve_seconds = 0.0;
+// wall time of the last LSQR call through this harness (device drained before and after)
+extern "C" double hd_last_solve_seconds() { return g_last_solve_seconds; }
 // TNTResult::elapsed_time (TNT.h:608) of the last TNT run through this harness
 extern "C" double hd_last_tnt_seconds() { return g_last_tnt_seconds; }
 
@@ -433,8 +436,12 @@ extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const
   DeviceVector bv(ctx, b, n);
   double xnorm = 0;
   size_t iters = 0;
+  (void)bv.dot(bv);  // drain uploads before the clock starts
+  const auto t0 = std::chrono::steady_clock::now();
   DeviceVector x = LA::LSQR<DeviceVector, double>(Aop, Atop, bv, ip, xnorm, iters, max_iterations, lambda, btol, Atol,
                                                  Acond_limit, Delta);
+  (void)x.dot(x);    // ... and the solve before it stops
+  g_last_solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const std::vector<double> xh = x.to_host();
   for (size_t j = 0; j < n; ++j) x_out[j] = j < xh.size() ? xh[j] : 0.0;
   *xnorm_out = xnorm;

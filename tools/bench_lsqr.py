@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
 """LSQR on the GPU: fused mi_lsqr vs the generic template loop on DeviceVector (n = 3e6 unknowns, nonsymmetric
-tridiagonal operator, 100 passes).  Wall time of the whole harness call minus a 1-pass call = per-pass cost."""
+tridiagonal operator, 400 passes).  Time of the LSQR call (measured inside the harness, device drained) at 401 passes minus 1 pass = per-pass cost."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, scipy.sparse as sps
 import harness_py
 n = 3_000_000
-A = sps.diags([np.full(n - 1, -1.0), np.full(n, 3.0), np.full(n - 1, 1.5)], [-1, 0, 1], format="csr")
+A = sps.diags([np.full(n - 1, -1.0), np.full(n, 2.02), np.full(n - 1, -0.99)], [-1, 0, 1], format="csr")  # slow to converge
 b = A @ np.sin(np.arange(n) * 1e-3)
 hd = harness_py.DeviceHarness()
 out = {}
 for mode, tag in ((0, "fused_mi_lsqr"), (1, "generic_template_loop")):
+    import ctypes
+    hd.L.hd_last_solve_seconds.restype = ctypes.c_double
     t = {}
-    for iters in (1, 101):
-        hd.lsqr_csr(A, b, btol=0.0, Atol=0.0, Acond_limit=1e300, max_iterations=iters, mode=mode)  # warm
-        t0 = time.perf_counter()
-        r = hd.lsqr_csr(A, b, btol=0.0, Atol=0.0, Acond_limit=1e300, max_iterations=iters, mode=mode)
-        t[iters] = time.perf_counter() - t0
-        assert r["iterations"] == iters, r
-    us = 1e6 * (t[101] - t[1]) / 100
+    for iters in (1, 401):
+        best = 1e9
+        for rep in range(3):          # time of the LSQR call itself, measured inside the harness
+            r = hd.lsqr_csr(A, b, btol=0.0, Atol=0.0, Acond_limit=1e300, max_iterations=iters, mode=mode)
+            best = min(best, hd.L.hd_last_solve_seconds())
+            assert r["iterations"] == iters, r["iterations"]
+        t[iters] = best
+    us = 1e6 * (t[401] - t[1]) / 400
     # per pass: 2 SpMV (12 nnz + 16 n bytes each) + 17 n * 8 bytes of vector traffic (lsqr.hip)
     bytes_pass = 2 * (12 * A.nnz + 16 * n) + 17 * 8 * n
     out[tag] = {"us_per_pass": us, "GBps_algorithmic": bytes_pass / us / 1e3}
