@@ -22,6 +22,8 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <initializer_list>
+#include <utility>
 #include <vector>
 
 #include "mi355opt.h"
@@ -209,6 +211,20 @@ inline DeviceVector operator-(DeviceVector &&a) {
   return std::move(a);
 }
 inline double DeviceVector::norm() const { return std::sqrt(squaredNorm()); }
+
+// up to 4 inner products <x_i, y_i> with ONE device pass and ONE synchronisation (mi_vec_dot_batch)
+inline std::vector<double> dot_batch(std::initializer_list<std::pair<const DeviceVector *, const DeviceVector *>> pairs) {
+  std::vector<const mi_vec *> xs, ys;
+  mi_ctx *ctx = nullptr;
+  for (const auto &pr : pairs) {
+    xs.push_back(pr.first->handle());
+    ys.push_back(pr.second->handle());
+    ctx = pr.first->context();
+  }
+  std::vector<double> out(xs.size(), 0.0);
+  check(mi_vec_dot_batch(ctx, (int)xs.size(), xs.data(), ys.data(), out.data()));
+  return out;
+}
 
 template <typename T>
 struct is_device_vector : std::false_type {};

@@ -240,7 +240,24 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
     Tangent h = LA::STPCG<Tangent, Multiplier, Scalar, Args...>(
         grad, H, inner_product, args..., h_M_norm, inner_iterations, Delta, params.max_TPCG_iterations,
         params.kappa_fgr, params.theta, Pop);
-    h_norm = sqrt(metric(x, h, h, args...));
+    // Device path (Frobenius metric, tagged Hessian): the three step scalars |h|^2, <g,h>, <h,Hess h> of
+    // :496,:511-512 come from ONE pass and ONE synchronisation instead of three (the Hessian application is a
+    // pure device operation, so evaluating it before the retraction is unobservable).
+    bool step_scalars_batched = false;
+    Scalar gh = 0, hHh = 0;
+#if OPTIMIZATION_HAVE_MI355
+    if constexpr (device_types) {
+      if (metric.template target<MI355::FrobeniusMetric>() && Hess.template target<MI355::DeviceHessian>()) {
+        const Tangent Hh = Hess(x, h, args...);
+        const std::vector<double> d = MI355::dot_batch({{&h, &h}, {&grad, &h}, {&h, &Hh}});
+        h_norm = sqrt(d[0]);
+        gh = d[1];
+        hHh = d[2];
+        step_scalars_batched = true;
+      }
+    }
+#endif
+    if (!step_scalars_batched) h_norm = sqrt(metric(x, h, h, args...));
 
     if (params.verbose) {
       std::cout << ", Delta: " << Delta << ", inner iters: ";
@@ -252,7 +269,9 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
     fx_trial = f(x_trial, args...);     // :508
 
     // predicted vs. actual decrease                                                 :511-521
-    const Scalar dm = -metric(x, grad, h, args...) - .5 * metric(x, h, Hess(x, h, args...), args...);
+    const Scalar dm = step_scalars_batched
+                          ? -gh - .5 * hHh
+                          : -metric(x, grad, h, args...) - .5 * metric(x, h, Hess(x, h, args...), args...);
     const Scalar df = fx - fx_trial;
     relative_decrease = df / (sqrt_eps + fabs(fx));
     const Scalar rho = df / dm;
