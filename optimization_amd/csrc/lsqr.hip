@@ -453,17 +453,28 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
       wd = ctx->status->word;
     }
     if (wd & 1) break;
-    LQ_CHECK(A->apply(A, v, ty));
-    hipLaunchKernelGGL(k_lsqr_u, dim3(gy), dim3(kBlock), 0, stq, ny, (const LsqrState *)sa, (const double *)ty->d,
-                       u->d, pa);
+    // operators that can fold `out = Op(in) - scale out` and |out|^2 into their own pass (built-in CSR) save a
+    // kernel and a round trip of the product through memory per application
+    int nu = gy, nv = gx;
+    if (A->apply_sub_scaled) {
+      LQ_CHECK(A->apply_sub_scaled(A, v, &sa->alpha, &sa->mode, nullptr, u, pa, &nu));
+    } else {
+      LQ_CHECK(A->apply(A, v, ty));
+      hipLaunchKernelGGL(k_lsqr_u, dim3(gy), dim3(kBlock), 0, stq, ny, (const LsqrState *)sa, (const double *)ty->d,
+                         u->d, pa);
+    }
     hipLaunchKernelGGL(k_lsqr_unorm, dim3(gy), dim3(kBlock), 0, stq, ny, c, (const LsqrState *)sa, sb,
-                       (const double *)pa, gy, u->d);
-    LQ_CHECK(At->apply(At, u, tx));
+                       (const double *)pa, nu, u->d);
+    if (At->apply_sub_scaled) {
+      LQ_CHECK(At->apply_sub_scaled(At, u, &sb->beta, &sb->mode, &sb->beta_pos, v, pb, &nv));
+    } else {
+      LQ_CHECK(At->apply(At, u, tx));
+      hipLaunchKernelGGL(k_lsqr_v, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, (const double *)tx->d,
+                         v->d, pb);
+    }
     applies += 2;
-    hipLaunchKernelGGL(k_lsqr_v, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, (const double *)tx->d,
-                       v->d, pb);
     hipLaunchKernelGGL(k_lsqr_vnorm, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, sa,
-                       (const double *)pb, gx, v->d, (const double *)w->d, (const double *)x_out->d, p3);
+                       (const double *)pb, nv, v->d, (const double *)w->d, (const double *)x_out->d, p3);
     hipLaunchKernelGGL(k_lsqr_xw, dim3(gx), dim3(kBlock), 0, stq, nx, c, (const LsqrState *)sa, sb,
                        (const double *)p3, gx, (const double *)v->d, w->d, x_out->d, ctx->status_dev);
     std::swap(sa, sb);

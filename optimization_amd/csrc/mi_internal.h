@@ -305,6 +305,9 @@ struct mi_csr {
 };
 
 namespace mi {
+// W = A V - (*scale) W with partials of |W|^2 (p = 1): see mi_op::apply_sub_scaled
+int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, const int *mode, const int *gate,
+                        mi_vec *W, double *partials, int *nparts);
 // In-stream halo exchange of the n x p field V into A->halo (no-op when not sharded).
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V);
 int comm_exchange_halo_counts(mi_ctx *ctx, size_t need_lo, size_t need_hi, size_t *send_lo,
@@ -329,6 +332,12 @@ struct mi_op {
   // Implementations may consult ctx->cg_live (device CgState, may be null) to skip work once the
   // solve has left CG_RUN.
   int (*apply_dots)(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) = nullptr;
+  // inout = Op(in) - (*scale) inout, with per-workgroup partials of <inout,inout> in partials component 0
+  // (the bidiagonalisation step of LSQR, IterativeSolvers.h:707,712, folded into the operator's last pass).
+  // scale / mode / gate are DEVICE pointers: the kernel does nothing when *mode != 0 or (gate && !*gate).
+  // nullptr => the solver applies the operator and runs its own update kernel.
+  int (*apply_sub_scaled)(mi_op *self, const mi_vec *in, const double *scale, const int *mode, const int *gate,
+                          mi_vec *inout, double *partials, int *nparts) = nullptr;
   void (*destroy)(mi_op *self) = nullptr;
   void *impl = nullptr;
   bool borrowed = false;  // owned by a problem object; mi_op_destroy is a no-op

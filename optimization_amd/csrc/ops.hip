@@ -75,6 +75,11 @@ int op_csr_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
   CsrOpImpl *c = (CsrOpImpl *)self->impl;
   return mi_csr_spmm(c->A, c->p, in, out);
 }
+int op_csr_apply_sub_scaled(mi_op *self, const mi_vec *in, const double *scale, const int *mode, const int *gate,
+                            mi_vec *inout, double *partials, int *nparts) {
+  CsrOpImpl *c = (CsrOpImpl *)self->impl;
+  return csr_spmv_sub_scaled(c->A, in, scale, mode, gate, inout, partials, nparts);
+}
 void op_csr_destroy(mi_op *self) { delete (CsrOpImpl *)self->impl; }
 
 int precon_callback_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
@@ -154,6 +159,7 @@ int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out) {
   op->ctx = ctx;
   op->n = n * (size_t)p;
   op->apply = op_csr_apply;
+  if (p == 1) op->apply_sub_scaled = op_csr_apply_sub_scaled;
   op->destroy = op_csr_destroy;
   op->impl = new CsrOpImpl{A, p};
   *out = op;

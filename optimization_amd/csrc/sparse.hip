@@ -31,6 +31,36 @@ __global__ __launch_bounds__(kBlock) void k_spmm(SellView A, const double *__res
   }
 }
 
+// W = A V - s W (p = 1) and this workgroup's partial of |W|^2: LSQR's `u = A v - alpha u` / `v = A'u - beta v`
+// with the norm for the following normalisation, in the SpMV's own pass
+__global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled(SellView A, const double *__restrict__ V,
+                                                            const double *__restrict__ scale,
+                                                            const int *__restrict__ mode,
+                                                            const int *__restrict__ gate, double *__restrict__ W,
+                                                            double *__restrict__ partials) {
+  __shared__ double lds[kWaves + 1];
+  if (*mode != 0 || (gate && !*gate)) return;
+  const double sc = *scale;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t ngroups = (A.nslices + kSlicesPerGroup - 1) / kSlicesPerGroup;
+  size_t g0, g1;
+  group_range(ngroups, g0, g1);
+  double a[1] = {0};
+  for (size_t g = g0; g < g1; ++g) {
+    const size_t slice = g * kSlicesPerGroup + w;
+    if (slice >= A.nslices) continue;
+    const size_t row = slice * 64 + lane;
+    double acc[1];
+    sell_row_times<1>(A, slice, lane, V, acc);
+    if (row < A.n) {
+      const double out = acc[0] - sc * W[row];
+      W[row] = out;
+      a[0] += out * out;
+    }
+  }
+  block_partials_store<1>(a, lds, partials);
+}
+
 int upload(void **dst, const void *src, size_t bytes) {
   MI_HIP(hipMalloc(dst, bytes ? bytes : 8));
   if (bytes) MI_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -99,6 +129,19 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
     case 4: hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
     default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT;
   }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, const int *mode, const int *gate,
+                        mi_vec *W, double *partials, int *nparts) {
+  mi_ctx *ctx = A->ctx;
+  MI_TRY(comm_halo_exchange(ctx, A, 1, V->d));
+  const int grid = uniform_grid(sell_groups(A));
+  KScope ks(ctx, MI_K_SPMM);
+  hipLaunchKernelGGL(k_spmv_sub_scaled, dim3(grid), dim3(kBlock), 0, ctx->stream, sell_view(A), (const double *)V->d,
+                     scale, mode, gate, W->d, partials);
+  *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
