@@ -117,6 +117,18 @@ def build_harness(force=False):
             if r.returncode != 0:
                 raise RuntimeError("clang front-end check of the template layer failed:\n" + r.stderr[-6000:])
     out.append(dev_so)
+    # examples/*.cpp: stand-alone client programs of the drop-in headers (binaries under examples/bin/)
+    exdir = os.path.join(ROOT, "examples")
+    os.makedirs(os.path.join(exdir, "bin"), exist_ok=True)
+    for src in sorted(glob.glob(os.path.join(exdir, "*.cpp"))):
+        exe = os.path.join(exdir, "bin", os.path.splitext(os.path.basename(src))[0])
+        if force or _newer(src, exe, hdrs + [LIB]):
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall"] + inc + ["-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                   "-L", HERE, "-lmi355opt", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"example build failed ({src}):\n" + r.stderr[-6000:])
+        out.append(exe)
     return out
 
 

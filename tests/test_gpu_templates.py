@@ -234,3 +234,16 @@ def test_tnls_device_matches_host_template(harness, kw, mode):
     # number of no-progress passes (15 vs 13 here); the iterates agree to 1e-16
     assert np.abs(d["x"] - h["x"]).max() <= 1e-9 * max(1.0, np.abs(h["x"]).max())
     assert abs(d["f"] - h["f"]) <= 1e-9 * max(1.0, abs(h["f"]))
+
+
+def test_example_client_program_runs():
+    """examples/tnt_stiefel_device.cpp: a stand-alone client of the drop-in headers (random start on St(64000,3) ->
+    sum of the three smallest eigenvalues to 1e-6 relative; the program checks that itself)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "bin", "tnt_stiefel_device")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "smallest eigenvalues" in r.stdout
