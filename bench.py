@@ -36,12 +36,17 @@ TPCG = 50              # cfg2: max_TPCG_iterations
 def kernel_bytes(n, nnz, p):
     """Per-launch compulsory HBM bytes of each hot kernel (every operand streamed once)."""
     N = n * p
-    return {
+    fused = os.environ.get("MI355OPT_NO_DIRGRAM", "0") != "1"
+    kb = {
+        # A; V gathered, X read; Hp written (the projection matrix is known before the pass)
+        "stiefel_hess_fused": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,
         "stiefel_spmm_gram": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,   # A; V gathered, X read; Z written
         "stiefel_finish_dots": 8 * 4 * N,                           # X, Z, V read; Hp written
         "cg_update": 8 * 3 * N,                                     # r,Hp read; r written
-        "cg_pupdate": 8 * 5 * N,                                    # v(=r), p, s read; p, s written
+        # v(=r), p, s read; p, s written; fused: + X, Y read for the next direction's Gram rows
+        "cg_pupdate": 8 * (7 if fused else 5) * N,
     }
+    return kb
 
 
 def run_steps(ctx, g, H, s_out, steps):
@@ -245,6 +250,7 @@ def main():
             cnt, ms = ctx.ktime_read(k)
             per[k] = {"launches": cnt, "avg_us": 1e3 * ms / max(cnt, 1)}
             ctx.ktime_enable(k, False)
+        kb = {k: b for k, b in kb.items() if per[k]["launches"] > 0}
         dom = max(kb, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
         achieved = kb[dom] / (per[dom]["avg_us"] * 1e-6) / 1e9
         traffic = None

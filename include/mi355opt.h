@@ -73,7 +73,7 @@ enum {
   MI_K_CG_INIT, MI_K_CG_DOT3, MI_K_CG_SCALAR_A, MI_K_CG_UPDATE, MI_K_CG_SCALAR_B, MI_K_CG_PUPDATE,
   MI_K_SPMM, MI_K_STIEFEL_SPMM_GRAM, MI_K_STIEFEL_GRAM_REDUCE, MI_K_STIEFEL_FINISH_DOTS,
   MI_K_STIEFEL_RETRACT, MI_K_BSR3_SPMV_DOTS, MI_K_BLAS1, MI_K_LOBPCG_GRAM, MI_K_LOBPCG_UPDATE,
-  MI_K_LOBPCG_RESIDUAL, MI_K_COUNT
+  MI_K_LOBPCG_RESIDUAL, MI_K_STIEFEL_HESS_FUSED, MI_K_COUNT
 };
 MI_API int mi_ktime_enable(mi_ctx *ctx, int kernel_id, int on);
 MI_API int mi_ktime_reset(mi_ctx *ctx);

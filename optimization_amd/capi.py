@@ -18,7 +18,7 @@ STATUS = {0: "MI_OK", 1: "MI_ERR_INVALID_ARGUMENT", 2: "MI_ERR_HIP", 3: "MI_ERR_
 KERNELS = ["none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
            "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
            "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
-           "lobpcg_residual"]
+           "lobpcg_residual", "stiefel_hess_fused"]
 KID = {k: i for i, k in enumerate(KERNELS)}
 STPCG_EXIT = ["RESIDUAL", "MAXIT", "KERNEL", "BOUNDARY"]
 

@@ -119,7 +119,7 @@ static const char *kKernelNames[MI_K_COUNT] = {
     "none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
     "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
     "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
-    "lobpcg_residual"};
+    "lobpcg_residual", "stiefel_hess_fused"};
 const char *mi_kernel_name(int id) {
   if (id < 0 || id >= MI_K_COUNT) return "?";
   return kKernelNames[id];
@@ -182,6 +182,7 @@ int mi_ctx_create(int device, mi_ctx **out) {
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
   { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
   { const char *e = getenv("MI355OPT_FORCE_LOCKSTEP"); ctx->force_lockstep = e && e[0] == '1'; }
+  { const char *e = getenv("MI355OPT_NO_DIRGRAM"); ctx->no_dirgram = e && e[0] == '1'; }
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
   *out = ctx;

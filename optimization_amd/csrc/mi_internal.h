@@ -131,6 +131,7 @@ struct mi_ctx {
   int world_size = 1, rank = 0;
   bool force_slot_path = false;  // env MI355OPT_FORCE_SLOT_PATH=1: use the multi-GPU (reduce-kernel + slots) path on one GPU
   bool force_lockstep = false;   // env MI355OPT_FORCE_LOCKSTEP=1: multi-rank enqueue rule of mi_stpcg on one GPU
+  bool no_dirgram = false;       // env MI355OPT_NO_DIRGRAM=1: STPCG ignores mi_op::dirgram (two-pass Stiefel Hessian)
 };
 
 struct mi_vec {
@@ -338,9 +339,24 @@ struct mi_op {
   // nullptr => the solver applies the operator and runs its own update kernel.
   int (*apply_sub_scaled)(mi_op *self, const mi_vec *in, const double *scale, const int *mode, const int *gate,
                           mi_vec *inout, double *partials, int *nparts) = nullptr;
+  // Direction-Gram fusion (Stiefel Rayleigh-quotient Hessian): when `dirgram` is set, STPCG's direction
+  // kernel also leaves, in ctx->partials2, the partial rows of  sym(Y'p - (X'p) S)  of the NEW direction p
+  // (= sym(X'(A p - p S)) for symmetric A, Y = A X), and the solver calls apply_dir instead of apply_dots:
+  // out = Op(in) + the three curvature partials in ONE pass over the matrix, the projection's P x P
+  // matrix being re-reduced from those `gram_count` rows in the kernel's prologue.
+  const struct mi_dirgram *dirgram = nullptr;
+  int (*apply_dir)(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) = nullptr;
   void (*destroy)(mi_op *self) = nullptr;
   void *impl = nullptr;
   bool borrowed = false;  // owned by a problem object; mi_op_destroy is a no-op
+};
+
+struct mi_dirgram {
+  int p = 0;                  // columns of the n x p fields
+  size_t n = 0;               // rows
+  const double *X = nullptr;  // n x p, row-major
+  const double *Y = nullptr;  // A X
+  const double *S = nullptr;  // device, p x p
 };
 
 struct mi_precon {

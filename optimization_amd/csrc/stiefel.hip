@@ -15,6 +15,7 @@
 // so the three curvature inner products of STPCG (IterativeSolvers.h:300,305-306) cost no extra pass
 // and no scalar kernel sits between the passes.
 #include "spmm_core.h"
+#include "stiefel_core.h"
 
 #include <algorithm>
 
@@ -23,14 +24,6 @@ using namespace mi;
 namespace {
 
 enum { POST_SYM = 1, POST_INVSQRT = 2 };
-
-template <int P>
-struct SymIdx {
-  static constexpr int NS = P * (P + 1) / 2;
-  __host__ __device__ static constexpr int at(int a, int b) {  // a <= b
-    return a * P - a * (a - 1) / 2 + (b - a);
-  }
-};
 
 // ---- small dense helpers (device) --------------------------------------------------------
 template <int P>
@@ -73,42 +66,6 @@ __device__ void dev_sym_invsqrt(const double *G, double *out) {
       double acc = 0;
       for (int k = 0; k < P; ++k) acc += Q[i * P + k] * (1.0 / sqrt(M[k * P + k])) * Q[j * P + k];
       out[i * P + j] = acc;
-    }
-}
-
-// per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
-template <int P>
-__device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], double *lds,
-                                                   double *__restrict__ partials) {
-  constexpr int NS = SymIdx<P>::NS;
-  double Gs[NS];
-#pragma unroll
-  for (int a = 0; a < P; ++a)
-#pragma unroll
-    for (int b = a; b < P; ++b)
-      Gs[SymIdx<P>::at(a, b)] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
-  block_partials_store<NS>(Gs, lds, partials);
-}
-
-// every thread: full symmetric P x P matrix M from the reduced rows (or all-reduced slots)
-template <int P, bool FROM_SLOTS>
-__device__ __forceinline__ void load_sym(const double *__restrict__ partials, int count,
-                                         const double *__restrict__ slots, double (&M)[P * P],
-                                         double *lds) {
-  constexpr int NS = SymIdx<P>::NS;
-  double s[NS];
-  if (FROM_SLOTS) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) s[i] = slots[i];
-  } else {
-    reduce_rows<NS>(partials, count, s, lds);
-  }
-#pragma unroll
-  for (int a = 0; a < P; ++a)
-#pragma unroll
-    for (int b = a; b < P; ++b) {
-      M[a * P + b] = s[SymIdx<P>::at(a, b)];
-      M[b * P + a] = s[SymIdx<P>::at(a, b)];
     }
 }
 
@@ -159,6 +116,62 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
     }
   }
   store_sym_partials<P>(G, lds, partials);
+}
+
+// out = P_X(A V - V S) and the three curvature partials in ONE pass.  The projection's matrix
+// M = sym(X'(A V - V S)) is known before the pass: for symmetric A it equals sym(Y'V - (X'V) S) with
+// Y = A X fixed during the inner solve, and STPCG's direction kernel left its partial rows when it formed
+// V (mi_op::dirgram).  So no second pass over Z, X, V is needed (k_st_finish: 8 (4N) bytes saved).
+template <int P, bool FROM_SLOTS>
+__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgState *__restrict__ st,
+                                                          const double *__restrict__ V,
+                                                          const double *__restrict__ X,
+                                                          const double *__restrict__ S,
+                                                          const double *__restrict__ gram_partials, int count,
+                                                          const double *__restrict__ slots,
+                                                          double *__restrict__ out,
+                                                          double *__restrict__ partials) {
+  __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
+  if (st && st->mode != CG_RUN) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double Sm[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) Sm[i] = S[i];
+  double Mm[P * P];
+  load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
+  double a[3] = {0, 0, 0};
+  const size_t ngroups = (A.nslices + kSlicesPerGroup - 1) / kSlicesPerGroup;
+  size_t g0, g1;
+  group_range(ngroups, g0, g1);
+  for (size_t g = g0; g < g1; ++g) {
+    const size_t slice = g * kSlicesPerGroup + w;
+    if (slice >= A.nslices) continue;
+    const size_t row = slice * 64 + lane;
+    double acc[P];
+    sell_row_times<P>(A, slice, lane, V, acc);
+    if (row < A.n) {
+      double x[P], v[P];
+#pragma unroll
+      for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; v[c] = V[row * P + c]; }
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
+        acc[b] -= t;  // Z = A V - V S
+      }
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
+        const double o = acc[b] - t;  // Z - X M
+        out[row * P + b] = o;
+        a[0] += v[b] * o; a[1] += o * o; a[2] += v[b] * v[b];
+      }
+    }
+  }
+  block_partials_store<3>(a, lds, partials);
 }
 
 // Gram partial rows of two dense n x P fields.
@@ -368,6 +381,8 @@ struct mi_stiefel_rq {
   int p;
   double *S_dev;  // P*P: sym(X'AX) of the last model() call
   mi_vec *Z;      // n x p scratch
+  mi_vec *Y;      // A X of the last model() call (fixed during the inner solve; mi_op::dirgram)
+  mi_dirgram dg;
   mi_op hess;     // borrowed operator object bound to X
   const mi_vec *X;
 };
@@ -387,6 +402,33 @@ int rq_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
 }
 int rq_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
   return rq_apply_common(self, in, out, true, nparts);
+}
+
+// one-pass Hessian for STPCG: the direction kernel left `gram_count` partial rows of sym(Y'in - (X'in) S)
+int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
+  mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
+  mi_ctx *ctx = q->ctx;
+  const mi_csr *A = q->A;
+  const int p = q->p;
+  const int grid = uniform_grid(sell_groups(A));
+  SellView view = sell_view(A);
+  double *slots = ctx->scalars + SLOT_GRAM;
+  const bool sharded = slot_mode(ctx);
+  MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
+  if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
+  if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
+  KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
+#define HF(F)                                                                                              \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, view,  \
+                                   (const CgState *)ctx->cg_live, (const double *)in->d,                  \
+                                   (const double *)q->X->d, (const double *)q->S_dev,                     \
+                                   (const double *)ctx->partials2, gram_count, (const double *)slots,     \
+                                   out->d, ctx->partials))
+  if (sharded) { HF(true); } else { HF(false); }
+#undef HF
+  *nparts = grid;
+  MI_HIP(hipGetLastError());
+  return MI_OK;
 }
 
 struct RqPreconImpl {
@@ -468,10 +510,12 @@ int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stief
   MI_HIP(hipMalloc((void **)&q->S_dev, 16 * sizeof(double)));
   MI_HIP(hipMemset(q->S_dev, 0, 16 * sizeof(double)));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Z));
+  MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Y));
   q->hess.ctx = ctx;
   q->hess.n = n * (size_t)p;
   q->hess.apply = rq_apply;
   q->hess.apply_dots = rq_apply_dots;
+  q->hess.apply_dir = rq_apply_dir;
   q->hess.impl = q;
   q->hess.borrowed = true;
   *out = q;
@@ -483,6 +527,7 @@ int mi_stiefel_rq_destroy(mi_stiefel_rq *q) {
   (void)hipStreamSynchronize(q->ctx->stream);
   (void)hipFree(q->S_dev);
   mi_vec_destroy(q->Z);
+  mi_vec_destroy(q->Y);
   delete q;
   return MI_OK;
 }
@@ -511,11 +556,18 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   MI_REQUIRE(q && X && grad, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, grad, nullptr));
   int count = 0;
-  // Z = A X ; S = sym(X'AX) (kept on the device for the Hessian) ; grad = Z - X S
-  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Z->d, &count));
-  MI_TRY(launch_finish(q->ctx, q->n, q->p, nullptr, X->d, q->Z->d, nullptr, count, q->S_dev, grad->d, false,
+  // Y = A X (kept: the direction-Gram identity needs it) ; S = sym(X'AX) (kept on the device for the
+  // Hessian) ; grad = Y - X S
+  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Y->d, &count));
+  MI_TRY(launch_finish(q->ctx, q->n, q->p, nullptr, X->d, q->Y->d, nullptr, count, q->S_dev, grad->d, false,
                        nullptr));
   q->X = X;
+  q->dg.p = q->p;
+  q->dg.n = q->n;
+  q->dg.X = X->d;
+  q->dg.Y = q->Y->d;
+  q->dg.S = q->S_dev;
+  q->hess.dirgram = &q->dg;
   if (hess) *hess = &q->hess;
   return MI_OK;
 }

@@ -1,0 +1,52 @@
+// stiefel_core.h -- packed symmetric P x P helpers shared by the Stiefel kernels (stiefel.hip) and the
+// direction-Gram variant of STPCG's direction kernel (stpcg.hip).
+#pragma once
+#include "mi_internal.h"
+
+namespace mi {
+
+template <int P>
+struct SymIdx {
+  static constexpr int NS = P * (P + 1) / 2;
+  __host__ __device__ static constexpr int at(int a, int b) {  // a <= b
+    return a * P - a * (a - 1) / 2 + (b - a);
+  }
+};
+
+// per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
+template <int P>
+__device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], double *lds,
+                                                   double *__restrict__ partials) {
+  constexpr int NS = SymIdx<P>::NS;
+  double Gs[NS];
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = a; b < P; ++b)
+      Gs[SymIdx<P>::at(a, b)] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
+  block_partials_store<NS>(Gs, lds, partials);
+}
+
+// every thread: full symmetric P x P matrix M from the reduced rows (or all-reduced slots)
+template <int P, bool FROM_SLOTS>
+__device__ __forceinline__ void load_sym(const double *__restrict__ partials, int count,
+                                         const double *__restrict__ slots, double (&M)[P * P],
+                                         double *lds) {
+  constexpr int NS = SymIdx<P>::NS;
+  double s[NS];
+  if (FROM_SLOTS) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = slots[i];
+  } else {
+    reduce_rows<NS>(partials, count, s, lds);
+  }
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = a; b < P; ++b) {
+      M[a * P + b] = s[SymIdx<P>::at(a, b)];
+      M[b * P + a] = s[SymIdx<P>::at(a, b)];
+    }
+}
+
+}  // namespace mi

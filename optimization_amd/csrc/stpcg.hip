@@ -24,6 +24,7 @@
 //                 p = -v + beta p (:420)                                                [3N]
 // and the operator supplies <p,Hp>, <Hp,Hp>, <p,p> partials from its last pass (else k_cg_dot3, 2N).
 #include "mi_internal.h"
+#include "stiefel_core.h"
 
 #include <cmath>
 
@@ -395,7 +396,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
 }
 
 // B-step prologue + body:  CG_RUN: s = s + alpha p (:374), p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
-template <bool FROM_SLOTS>
+//   SP > 0 (mi_op::dirgram): the fields are rows of SP doubles and the kernel also leaves the partial rows of
+//   sym(Y'p - (X'p) S) of the NEW direction in dg.gpartials -- the projection matrix of the next Hessian pass.
+struct DirGramArgs {
+  const double *X, *Y, *S;
+  double *gpartials;
+};
+template <int SP>
+struct DirGramLds {
+  static constexpr int value = (SymIdx<SP>::NS * kWaves > kWaves + 1) ? SymIdx<SP>::NS * kWaves : kWaves + 1;
+};
+template <>
+struct DirGramLds<0> {
+  static constexpr int value = kWaves + 1;
+};
+
+template <bool FROM_SLOTS, int SP>
 __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                        CgState *__restrict__ st_out,
                                                        const double *__restrict__ partials_b, int nparts_b,
@@ -403,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
                                                        const double *__restrict__ v,
                                                        double *__restrict__ p, double *__restrict__ s,
                                                        HostStatus *hs, double *__restrict__ trace,
-                                                       size_t trace_cap) {
-  __shared__ double lds[kWaves + 1];
+                                                       size_t trace_cap, DirGramArgs dg) {
+  __shared__ double lds[DirGramLds<SP>::value];
   CgState cs = load_state(st_in);
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
   if (cs.mode == CG_DONE) {
@@ -415,7 +431,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   double2 vv0 = make_double2(0, 0), pv0 = vv0, sv0 = vv0;  // prefetch: overlaps the prologue's reduction
-  if (i0 < n2) {
+  constexpr int SPN = SP > 0 ? SP : 1;
+  double rv0[SPN], rp0[SPN], rs0[SPN], rx0[SPN], ry0[SPN];  // SP > 0: the same prefetch, one row per lane
+  if (SP > 0) {
+#pragma unroll
+    for (int c = 0; c < SPN; ++c) { rv0[c] = 0; rp0[c] = 0; rs0[c] = 0; rx0[c] = 0; ry0[c] = 0; }
+    if (mode_in == CG_RUN && i0 < n / SPN) {
+#pragma unroll
+      for (int c = 0; c < SPN; ++c) {
+        rv0[c] = v[i0 * SPN + c];
+        rp0[c] = p[i0 * SPN + c];
+        rs0[c] = s[i0 * SPN + c];
+        rx0[c] = dg.X[i0 * SPN + c];
+        ry0[c] = dg.Y[i0 * SPN + c];
+      }
+    }
+  } else if (i0 < n2) {
     vv0 = reinterpret_cast<const double2 *>(v)[i0];
     pv0 = reinterpret_cast<double2 *>(p)[i0];
     sv0 = reinterpret_cast<double2 *>(s)[i0];
@@ -453,6 +484,56 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
     // It is applied whatever the B-step decided; p = -v + beta p (:420) only if the solve goes on.
     const double alpha = cs.alpha, beta = cs.beta;
     const bool dir = cs.mode == CG_RUN;
+    if (SP > 0) {
+      const size_t nrows = n / SPN;
+      double Sm[SPN * SPN], G[SPN * SPN];
+#pragma unroll
+      for (int i = 0; i < SPN * SPN; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
+      double rv[SPN], rp[SPN], rs[SPN], x[SPN], y[SPN];
+#pragma unroll
+      for (int c = 0; c < SPN; ++c) { rv[c] = rv0[c]; rp[c] = rp0[c]; rs[c] = rs0[c]; x[c] = rx0[c]; y[c] = ry0[c]; }
+      for (size_t row = i0; row < nrows;) {
+        const size_t rnext = row + stride;
+        double vn[SPN], pn[SPN], sn[SPN], xn[SPN], yn[SPN];
+#pragma unroll
+        for (int c = 0; c < SPN; ++c) { vn[c] = rv[c]; pn[c] = rp[c]; sn[c] = rs[c]; xn[c] = x[c]; yn[c] = y[c]; }
+        if (rnext < nrows) {
+#pragma unroll
+          for (int c = 0; c < SPN; ++c) {
+            vn[c] = v[rnext * SPN + c];
+            pn[c] = p[rnext * SPN + c];
+            sn[c] = s[rnext * SPN + c];
+            xn[c] = dg.X[rnext * SPN + c];
+            yn[c] = dg.Y[rnext * SPN + c];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < SPN; ++c) {
+          rs[c] = rs[c] + alpha * rp[c];
+          s[row * SPN + c] = rs[c];
+        }
+        if (dir) {
+#pragma unroll
+          for (int c = 0; c < SPN; ++c) {
+            rp[c] = -rv[c] + beta * rp[c];
+            p[row * SPN + c] = rp[c];
+          }
+#pragma unroll
+          for (int b = 0; b < SPN; ++b) {
+            double t = 0;
+#pragma unroll
+            for (int a = 0; a < SPN; ++a) t += rp[a] * Sm[a * SPN + b];  // (p S)_b, as the Hessian pass forms it
+#pragma unroll
+            for (int a = 0; a < SPN; ++a) G[a * SPN + b] += y[a] * rp[b] - x[a] * t;
+          }
+        }
+        row = rnext;
+#pragma unroll
+        for (int c = 0; c < SPN; ++c) { rv[c] = vn[c]; rp[c] = pn[c]; rs[c] = sn[c]; x[c] = xn[c]; y[c] = yn[c]; }
+      }
+      if (dir) store_sym_partials<SPN>(G, lds, dg.gpartials);
+      return;
+    }
     double2 vv = vv0, pv = pv0, sv = sv0;
     for (size_t i = i0; i < n2;) {
       const size_t inext = i + stride;
@@ -475,6 +556,30 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       if (dir) p[n - 1] = -v[n - 1] + beta * p[n - 1];
     }
   }
+}
+
+// partial rows of sym(Y'p - (X'p) S) for the FIRST direction (p = -v, :256); later ones come from k_cg_pupdate
+template <int SP>
+__global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const double *__restrict__ p, DirGramArgs dg) {
+  __shared__ double lds[SymIdx<SP>::NS * kWaves];
+  double Sm[SP * SP], G[SP * SP];
+#pragma unroll
+  for (int i = 0; i < SP * SP; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    double x[SP], y[SP], pv[SP];
+#pragma unroll
+    for (int c = 0; c < SP; ++c) { x[c] = dg.X[row * SP + c]; y[c] = dg.Y[row * SP + c]; pv[c] = p[row * SP + c]; }
+#pragma unroll
+    for (int b = 0; b < SP; ++b) {
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < SP; ++a) t += pv[a] * Sm[a * SP + b];
+#pragma unroll
+      for (int a = 0; a < SP; ++a) G[a * SP + b] += y[a] * pv[b] - x[a] * t;
+    }
+  }
+  store_sym_partials<SP>(G, lds, dg.gpartials);
 }
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
@@ -530,6 +635,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // their prologue re-reduction; the slot variants stay reachable through MI355OPT_FORCE_SLOT_PATH
   const bool sharded = slot_mode(ctx);
   const bool rows = rows_mode(ctx);
+  // direction-Gram fusion (mi_op::dirgram): one-pass Hessian, the Gram rows come from the direction kernel
+  const mi_dirgram *dgp = (!ctx->no_dirgram && H->dirgram && H->apply_dir) ? H->dirgram : nullptr;
+  MI_REQUIRE(!dgp || (dgp->p >= 1 && dgp->p <= 4 && dgp->n * (size_t)dgp->p == g->n),
+             "operator's direction-Gram description does not match the problem dimension");
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
   const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
 
@@ -560,6 +669,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations};
   hipStream_t st = ctx->stream;
   const int grid = (pre == PRE_BLOCK3) ? grid_for(n / 3, 2) : grid_for(n, 4);
+  const DirGramArgs dga = dgp ? DirGramArgs{dgp->X, dgp->Y, dgp->S, ctx->partials2}
+                              : DirGramArgs{nullptr, nullptr, nullptr, nullptr};
+  const int sp = dgp ? dgp->p : 0;
   double *slots_a = ctx->scalars + SLOT_CG, *slots_b = ctx->scalars + SLOT_CG + 4;
   CgState *st0 = ctx->cg, *st1 = ctx->cg1;
   double *tr = tcap ? ctx->trace_dev : nullptr;
@@ -599,6 +711,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     hipLaunchKernelGGL(k_cg_dot_rv<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st0,
                        (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
   }
+  if (dgp) {
+    const size_t nrows = dgp->n;
+    switch (sp) {
+      case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+      case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+      case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+      default: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+    }
+  }
   if (sharded) {
     CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
     hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
@@ -633,7 +754,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
       // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials
       int nparts = 0;
-      if (H->apply_dots) {
+      if (dgp) {
+        CG_CHECK(H->apply_dir(H, p, Hp, grid, &nparts));
+      } else if (H->apply_dots) {
         CG_CHECK(H->apply_dots(H, p, Hp, &nparts));
       } else {
         CG_CHECK(H->apply(H, p, Hp));
@@ -658,19 +781,29 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         hipLaunchKernelGGL(k_cg_dot_rv<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1,
                            (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
       }
+#define PUPD(FS, SPV)                                                                                          \
+  hipLaunchKernelGGL((k_cg_pupdate<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0, \
+                     (const double *)ctx->partials_b, grid, (const double *)slots_b, (const double *)vd, p->d,  \
+                     s_out->d, ctx->status_dev, tr, tcap, dga)
+#define LAUNCH_PUPD(FS)                 \
+  switch (sp) {                         \
+    case 0: PUPD(FS, 0); break;         \
+    case 1: PUPD(FS, 1); break;         \
+    case 2: PUPD(FS, 2); break;         \
+    case 3: PUPD(FS, 3); break;         \
+    default: PUPD(FS, 4); break;        \
+  }
       if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL(k_cg_pupdate<true>, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0,
-                           (const double *)ctx->partials_b, grid, (const double *)slots_b,
-                           (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
+        LAUNCH_PUPD(true);
       } else {
         if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL(k_cg_pupdate<false>, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0,
-                           (const double *)ctx->partials_b, grid, (const double *)slots_b,
-                           (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap);
+        LAUNCH_PUPD(false);
       }
+#undef LAUNCH_PUPD
+#undef PUPD
     }
     result->hvp_calls = hvp;
   }

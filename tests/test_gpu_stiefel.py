@@ -228,3 +228,47 @@ def test_full_size_fused_stpcg_vs_oracle(ctx, oracle, full_rq):
     assert np.allclose(r["trace"]["beta"], o["trace"]["beta"], rtol=1e-8)
     assert rel_err(r["s"].numpy(), o["s"]) < 1e-10  # BASELINE.json: iterate match within 1e-10 relative
     oracle.free(oprob)
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
+    """STPCG's one-pass Stiefel Hessian (the direction kernel leaves the Gram rows of the next projection,
+    mi_op::dirgram) against the two-pass form (MI355OPT_NO_DIRGRAM=1) and the oracle, for every supported p."""
+    from optimization_amd import capi
+    nx, ny, nz = 9, 8, 7
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=11 + p)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
+                             trace_cap=64)
+    oracle.free(oprob)
+    res = {}
+    for mode in ("one-pass", "two-pass"):
+        monkeypatch.setenv("MI355OPT_NO_DIRGRAM", "1" if mode == "two-pass" else "0")
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            prob = c.stiefel_rq(A, n, p)
+            g, H = prob.model(c.upload(Xb))
+            names = ("stiefel_hess_fused", "stiefel_finish_dots")
+            for k in names:
+                c.ktime_enable(k, True)
+            c.ktime_reset()
+            r = c.stpcg(g, H, Delta=1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
+            launches = {k: c.ktime_read(k)[0] for k in names}
+            res[mode] = dict(r, s=r["s"].numpy().copy(), launches=launches)
+        finally:
+            c.close()
+    # the path under test really ran
+    assert res["one-pass"]["launches"]["stiefel_hess_fused"] > 0
+    assert res["one-pass"]["launches"]["stiefel_finish_dots"] == 0
+    assert res["two-pass"]["launches"]["stiefel_hess_fused"] == 0
+    assert res["two-pass"]["launches"]["stiefel_finish_dots"] > 0
+    for mode, r in res.items():
+        assert r["iterations"] == o["iterations"] and r["exit_reason"] == o["exit_reason"], mode
+        assert np.allclose(r["trace"]["alpha"], o["trace"]["alpha"], rtol=1e-9), mode
+        assert np.allclose(r["trace"]["beta"], o["trace"]["beta"], rtol=1e-8), mode
+        assert rel_err(r["s"], o["s"]) < 1e-10, mode
+    assert rel_err(res["one-pass"]["s"], res["two-pass"]["s"]) < 1e-11

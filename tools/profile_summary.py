@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_bytes  # noqa: E402
 
-SHORT = {"k_st_spmm_gram": "stiefel_spmm_gram", "k_st_finish": "stiefel_finish_dots", "k_cg_update": "cg_update",
+SHORT = {"k_st_hess_fused": "stiefel_hess_fused", "k_st_spmm_gram": "stiefel_spmm_gram", "k_st_finish": "stiefel_finish_dots", "k_cg_update": "cg_update",
          "k_cg_pupdate": "cg_pupdate", "k_cg_init": "cg_init", "k_cg_scalar_init": "cg_scalar_init",
          "k_cg_dot3": "cg_dot3", "k_reduce_rows_to_slots": "reduce_rows_to_slots"}
 
