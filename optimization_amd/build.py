@@ -22,6 +22,7 @@ CFLAGS = [
     "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", "/opt/rocm/include",
 ]
+CFLAGS += os.environ.get("MI355OPT_EXTRA_CFLAGS", "").split()  # experiments (e.g. -DMI_SPMM_CHUNK=8)
 LDFLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
 
 

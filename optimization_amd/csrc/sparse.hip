@@ -78,8 +78,11 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
     sp[s + 1] = sp[s] + w;
   }
   const size_t padded = (size_t)sp[nslices] * 64;
-  std::vector<int> pcol(padded);
-  std::vector<double> pval(padded, 0.0);
+  // at least one 64-entry chunk is always stored (zeros, column 0): the pipelined kernels park the loads of
+  // predicated-off entries of EMPTY slices there (spmm_core.h sell_stream)
+  const size_t stored = std::max<size_t>(padded, 64);
+  std::vector<int> pcol(stored, 0);
+  std::vector<double> pval(stored, 0.0);
   for (size_t s = 0; s < nslices; ++s) {
     const long long w = sp[s + 1] - sp[s];
     for (int lane = 0; lane < 64; ++lane) {
@@ -105,8 +108,8 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
   A->padded = padded;
   A->nslices = nslices;
   MI_TRY(upload((void **)&A->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
-  MI_TRY(upload((void **)&A->col, pcol.data(), padded * sizeof(int)));
-  MI_TRY(upload((void **)&A->val, pval.data(), padded * sizeof(double)));
+  MI_TRY(upload((void **)&A->col, pcol.data(), stored * sizeof(int)));
+  MI_TRY(upload((void **)&A->val, pval.data(), stored * sizeof(double)));
   *out = A;
   return MI_OK;
 }

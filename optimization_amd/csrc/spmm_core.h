@@ -49,7 +49,11 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
+#ifdef MI_DEBUG_NO_GATHER  // timing experiment only: every entry reads the lane's own row
+      const double *src = V + (slice * 64 + lane < A.n ? slice * 64 + lane : 0) * P + 0 * cidx[j];
+#else
       const double *src = (cidx[j] < A.n) ? (V + cidx[j] * P) : (A.halo + (cidx[j] - A.n) * P);
+#endif
 #pragma unroll
       for (int c = 0; c < P; ++c) {
         const double t = a[j] * src[c];
@@ -57,6 +61,100 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
       }
     }
   }
+}
+
+// Lean, software-pipelined form of the same product for a wave that owns the slices first, first + kWaves,
+// ... (< end); used by the one-pass Stiefel Hessian.
+//   * 32-bit byte offsets from scalar bases (global_load with saddr) instead of 64-bit multiply-adds per
+//     gathered entry: the caller guarantees that V, the halo, the value and the column arrays each span
+//     < 4 GiB (sell_stream_ok);
+//   * predication once per entry (the VALUE is zeroed), then one fma per component;
+//   * HALO is a template flag, so unsharded matrices carry no column-range select;
+//   * the value/column operands of the NEXT chunk -- of this slice or of the wave's next slice -- are
+//     requested right after the current chunk's gathers (unconditionally: behind a branch the compiler can no
+//     longer count outstanding loads and drains the queue), and the row epilogue's operands one slice ahead:
+//       epi.begin(slice)      issue the loads the epilogue of `slice` will need
+//       epi.end(slice, acc)   consume acc[0..P) = (A V)(row slice*64+lane, :)
+// `first` must be wave-uniform (readfirstlane): slice bounds then come from scalar loads.
+// What this does NOT buy on cfg2 is time: with wall_clock64 stamps inside the kernel the
+// main loop runs at ~6.4 TB/s, the practical HBM rate, in every variant tried -- ~3x fewer instructions (this
+// form), deeper prefetch, chunk sizes 2..8, L1-bypassing matrix loads, an LDS copy of the workgroup's rows of
+// V, a column-major V -- and the rest of the 33 us is the prologue reduction and the ramp-down.
+template <int P, bool HALO, class Epi>
+__device__ __forceinline__ void sell_stream(const SellView &A, size_t first, size_t end, int lane,
+                                            const double *__restrict__ V, Epi &epi) {
+  constexpr int CH = MI_SPMM_CHUNK;
+  if (first >= end) return;
+  size_t slice = first;
+  long long k = A.slice_ptr[slice], b1 = A.slice_ptr[slice + 1];
+  const unsigned lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
+  const unsigned nloc = (unsigned)A.n;
+  double a[CH];
+  unsigned ci[CH];
+  // entries beyond the slice width re-read the chunk's first entry -- or, for an empty slice, entry 0 of
+  // the matrix (mi_csr always stores >= 64 entries); their value is zeroed when the chunk is consumed
+  auto load_chunk = [&](double (&av)[CH], unsigned (&cv)[CH], long long kk, long long bb) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const long long kj = (kk + j < bb) ? kk + j : ((kk < bb) ? kk : 0);
+      const char *vb = reinterpret_cast<const char *>(A.val + (size_t)kj * 64);  // scalar bases
+      const char *cb = reinterpret_cast<const char *>(A.col + (size_t)kj * 64);
+      av[j] = *reinterpret_cast<const double *>(vb + lane8);
+      cv[j] = *reinterpret_cast<const unsigned *>(cb + lane4);
+    }
+  };
+  load_chunk(a, ci, k, b1);
+  epi.begin(slice);
+  double acc[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) acc[c] = 0;
+  for (;;) {
+    // the wave's next chunk: all selects on scalars, no branches
+    const bool row_done = k + CH >= b1;
+    const size_t cand = slice + kWaves;
+    const bool have_next = !row_done || cand < end;
+    const size_t nslice = row_done ? (cand < end ? cand : slice) : slice;
+    const long long p0 = A.slice_ptr[nslice], p1 = A.slice_ptr[nslice + 1];
+    const long long nk = row_done ? p0 : k + CH, nb1 = p1;
+    double g[CH][P];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const char *base = reinterpret_cast<const char *>(V);
+      unsigned boff = ci[j] * (unsigned)(P * 8);
+      if (HALO && ci[j] >= nloc) {
+        base = reinterpret_cast<const char *>(A.halo);
+        boff = (ci[j] - nloc) * (unsigned)(P * 8);
+      }
+      const double *src = reinterpret_cast<const double *>(base + boff);
+#pragma unroll
+      for (int c = 0; c < P; ++c) g[j][c] = src[c];
+    }
+    double an[CH];
+    unsigned cn[CH];
+    load_chunk(an, cn, nk, nb1);  // (re-reads the first chunk of the last slice when nothing follows)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const double aj = (k + j < b1) ? a[j] : 0.0;
+#pragma unroll
+      for (int c = 0; c < P; ++c) acc[c] = __builtin_fma(aj, g[j][c], acc[c]);
+    }
+    if (row_done) {
+      epi.end(slice, acc);
+#pragma unroll
+      for (int c = 0; c < P; ++c) acc[c] = 0;
+      if (have_next) epi.begin(nslice);
+    }
+    if (!have_next) break;
+    slice = nslice; k = nk; b1 = nb1;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { a[j] = an[j]; ci[j] = cn[j]; }
+  }
+}
+
+// sell_stream's 32-bit offsets: every array it indexes must span < 4 GiB
+inline bool sell_stream_ok(const mi_csr *A, int p) {
+  const size_t lim = (size_t)1 << 32;
+  return (A->n + A->halo_lo + A->halo_hi + 64) * (size_t)p * 8 < lim && A->padded * 8 < lim;
 }
 
 // Workgroup -> contiguous range of slice groups, XCD-aware: the workgroups of one XCD cover one

@@ -18,6 +18,7 @@
 #include "stiefel_core.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace mi;
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
 // M = sym(X'(A V - V S)) is known before the pass: for symmetric A it equals sym(Y'V - (X'V) S) with
 // Y = A X fixed during the inner solve, and STPCG's direction kernel left its partial rows when it formed
 // V (mi_op::dirgram).  So no second pass over Z, X, V is needed (k_st_finish: 8 (4N) bytes saved).
-template <int P, bool FROM_SLOTS>
+template <int P, bool FROM_SLOTS, bool HALO>
 __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
@@ -134,25 +135,37 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
   __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // a contiguous range of SLICES per workgroup (XCD-aware like group_range, but balanced to one slice)
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
   double Sm[P * P];
 #pragma unroll
   for (int i = 0; i < P * P; ++i) Sm[i] = S[i];
   double Mm[P * P];
   load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
   double a[3] = {0, 0, 0};
-  const size_t ngroups = (A.nslices + kSlicesPerGroup - 1) / kSlicesPerGroup;
-  size_t g0, g1;
-  group_range(ngroups, g0, g1);
-  for (size_t g = g0; g < g1; ++g) {
-    const size_t slice = g * kSlicesPerGroup + w;
-    if (slice >= A.nslices) continue;
-    const size_t row = slice * 64 + lane;
-    double acc[P];
-    sell_row_times<P>(A, slice, lane, V, acc);
-    if (row < A.n) {
-      double x[P], v[P];
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ X, *__restrict__ V;
+    double *__restrict__ out;
+    const double (&Sm)[P * P], (&Mm)[P * P];
+    double (&a)[3];
+    int lane;
+    double x[P], v[P];
+    // rows of the slice from a scalar base + a 32-bit lane offset (lanes past the last row read its first)
+    __device__ __forceinline__ unsigned lane_off(size_t slice) const {
+      return (slice * 64 + lane < A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+    }
+    __device__ __forceinline__ void begin(size_t slice) {
+      const unsigned off = lane_off(slice);
+      const double *xs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(X + slice * 64 * P) + off);
+      const double *vs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(V + slice * 64 * P) + off);
 #pragma unroll
-      for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; v[c] = V[row * P + c]; }
+      for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; }
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
+      if (slice * 64 + lane >= A.n) return;
+      double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out + slice * 64 * P) + lane_off(slice));
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
@@ -166,11 +179,14 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
         const double o = acc[b] - t;  // Z - X M
-        out[row * P + b] = o;
+        os[b] = o;
         a[0] += v[b] * o; a[1] += o * o; a[2] += v[b] * v[b];
       }
     }
-  }
+  } epi{A, X, V, out, Sm, Mm, a, lane, {}, {}};
+  // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
+  const size_t wfirst = s0 + (size_t)__builtin_amdgcn_readfirstlane(w);
+  sell_stream<P, HALO>(A, wfirst, s1, lane, V, epi);
   block_partials_store<3>(a, lds, partials);
 }
 
@@ -410,21 +426,30 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   mi_ctx *ctx = q->ctx;
   const mi_csr *A = q->A;
   const int p = q->p;
-  const int grid = uniform_grid(sell_groups(A));
+  // one workgroup per CU and one round (the kernel needs > 64 VGPRs: a second round would only repeat the
+  // prologue); the rows mode of several ranks needs the uniform 512-row partial layout instead
+  static const int cap = [] { const char *e = getenv("MI355OPT_HESS_GRID"); return e ? atoi(e) : 256; }();
+  int grid = uniform_grid(sell_groups(A));
+  if (!g_uniform_grid && grid > cap) grid = cap;
   SellView view = sell_view(A);
   double *slots = ctx->scalars + SLOT_GRAM;
   const bool sharded = slot_mode(ctx);
+  const bool halo = A->halo != nullptr;
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
   if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
   if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HF(F)                                                                                              \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, view,  \
-                                   (const CgState *)ctx->cg_live, (const double *)in->d,                  \
-                                   (const double *)q->X->d, (const double *)q->S_dev,                     \
-                                   (const double *)ctx->partials2, gram_count, (const double *)slots,     \
+#define HF(F, HL)                                                                                             \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL>), dim3(grid), dim3(kBlock), 0, ctx->stream, view, \
+                                   (const CgState *)ctx->cg_live, (const double *)in->d,                     \
+                                   (const double *)q->X->d, (const double *)q->S_dev,                        \
+                                   (const double *)ctx->partials2, gram_count, (const double *)slots,        \
                                    out->d, ctx->partials))
-  if (sharded) { HF(true); } else { HF(false); }
+  if (halo) {
+    if (sharded) { HF(true, true); } else { HF(false, true); }
+  } else {
+    if (sharded) { HF(true, false); } else { HF(false, false); }
+  }
 #undef HF
   *nparts = grid;
   MI_HIP(hipGetLastError());
@@ -567,7 +592,8 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   q->dg.X = X->d;
   q->dg.Y = q->Y->d;
   q->dg.S = q->S_dev;
-  q->hess.dirgram = &q->dg;
+  // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator
+  q->hess.dirgram = sell_stream_ok(q->A, q->p) ? &q->dg : nullptr;
   if (hess) *hess = &q->hess;
   return MI_OK;
 }
