@@ -36,15 +36,16 @@ TPCG = 50              # cfg2: max_TPCG_iterations
 def kernel_bytes(n, nnz, p):
     """Per-launch compulsory HBM bytes of each hot kernel (every operand streamed once)."""
     N = n * p
-    fused = os.environ.get("MI355OPT_NO_DIRGRAM", "0") != "1"
+    direct = os.environ.get("MI355OPT_DIRGRAM_DIRECT", "0") == "1"  # Gram rows formed by the direction kernel
     kb = {
-        # A; V gathered, X read; Hp written (the projection matrix is known before the pass)
-        "stiefel_hess_fused": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,
+        # A; V gathered, X read; Hp written (the projection matrix is known before the pass); recurrence
+        # form: + Y read for the Gram of the output
+        "stiefel_hess_fused": 12 * nnz + 4 * (n + 1) + 8 * (3 if direct else 4) * N,
         "stiefel_spmm_gram": 12 * nnz + 4 * (n + 1) + 8 * 3 * N,   # A; V gathered, X read; Z written
         "stiefel_finish_dots": 8 * 4 * N,                           # X, Z, V read; Hp written
         "cg_update": 8 * 3 * N,                                     # r,Hp read; r written
-        # v(=r), p, s read; p, s written; fused: + X, Y read for the next direction's Gram rows
-        "cg_pupdate": 8 * (7 if fused else 5) * N,
+        # v(=r), p, s read; p, s written; direct form: + X, Y read for the next direction's Gram rows
+        "cg_pupdate": 8 * (7 if direct else 5) * N,
     }
     return kb
 

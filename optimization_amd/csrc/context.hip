@@ -183,6 +183,7 @@ int mi_ctx_create(int device, mi_ctx **out) {
   { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
   { const char *e = getenv("MI355OPT_FORCE_LOCKSTEP"); ctx->force_lockstep = e && e[0] == '1'; }
   { const char *e = getenv("MI355OPT_NO_DIRGRAM"); ctx->no_dirgram = e && e[0] == '1'; }
+  { const char *e = getenv("MI355OPT_DIRGRAM_DIRECT"); ctx->dirgram_direct = e && e[0] == '1'; }
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
   *out = ctx;

@@ -30,7 +30,7 @@ constexpr int kMaxGrid = 512;
 constexpr int kMaxRows = kMaxGrid;      // partial rows per component
 constexpr int kMaxComps = 16;           // components per partial buffer (component-major layout)
 constexpr int kNumXCD = 8;
-constexpr int kScalarSlots = 64;        // device scalar file (doubles)
+constexpr int kScalarSlots = 96;        // device scalar file (doubles)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -132,6 +132,7 @@ struct mi_ctx {
   bool force_slot_path = false;  // env MI355OPT_FORCE_SLOT_PATH=1: use the multi-GPU (reduce-kernel + slots) path on one GPU
   bool force_lockstep = false;   // env MI355OPT_FORCE_LOCKSTEP=1: multi-rank enqueue rule of mi_stpcg on one GPU
   bool no_dirgram = false;       // env MI355OPT_NO_DIRGRAM=1: STPCG ignores mi_op::dirgram (two-pass Stiefel Hessian)
+  bool dirgram_direct = false;   // env MI355OPT_DIRGRAM_DIRECT=1: direction-kernel Gram rows even without a preconditioner
 };
 
 struct mi_vec {
@@ -206,7 +207,9 @@ int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, 
 int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
 
 // scalar-file slot map
-enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GRAM_M = 32, SLOT_MISC = 48 };
+// SLOT_GDIR: packed symmetric Gram of the CG residual [0,NS) and of the direction [16, 16+NS) (recurrence form of
+// mi_op::dirgram, stpcg.hip); SLOT_GRAM doubles as the 3+NS-component slot file of that form
+enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GDIR_P = 16 /* offset of G(p) inside SLOT_GDIR */, SLOT_MISC = 48, SLOT_GDIR = 64 };
 
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ double wave_reduce_sum(double v) {
@@ -344,6 +347,11 @@ struct mi_op {
   // (= sym(X'(A p - p S)) for symmetric A, Y = A X), and the solver calls apply_dir instead of apply_dots:
   // out = Op(in) + the three curvature partials in ONE pass over the matrix, the projection's P x P
   // matrix being re-reduced from those `gram_count` rows in the kernel's prologue.
+  // gram_count < 0 selects the recurrence form (no preconditioner): the Gram is LINEAR in the direction, and
+  // p' = -r' + beta p, r' = r + alpha Hp, so STPCG carries G(r), G(p) as 2 x P(P+1)/2 replicated scalars
+  // (ctx->scalars + SLOT_GDIR) and the operator pass itself leaves the rows of G(Hp) as components 3.. of
+  // ctx->partials next to the three dots; its prologue reads M = G(p) from there -- no Gram rows to reduce,
+  // no X/Y reads in the direction kernel, and one exchange fewer per iteration across ranks.
   const struct mi_dirgram *dirgram = nullptr;
   int (*apply_dir)(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) = nullptr;
   void (*destroy)(mi_op *self) = nullptr;

@@ -123,16 +123,23 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
 // M = sym(X'(A V - V S)) is known before the pass: for symmetric A it equals sym(Y'V - (X'V) S) with
 // Y = A X fixed during the inner solve, and STPCG's direction kernel left its partial rows when it formed
 // V (mi_op::dirgram).  So no second pass over Z, X, V is needed (k_st_finish: 8 (4N) bytes saved).
-template <int P, bool FROM_SLOTS, bool HALO>
+// RECUR (mi_op::apply_dir with gram_count < 0): M is read from gdir (packed symmetric, replicated scalars kept
+// by STPCG) and the packed symmetric Gram  sym(Y'out - (X'out) S)  of the OUTPUT rides along as components
+// 3.. of the partial row (DirComps<P>::value components in all).
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR>
 __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
+                                                          const double *__restrict__ Y,
                                                           const double *__restrict__ S,
                                                           const double *__restrict__ gram_partials, int count,
                                                           const double *__restrict__ slots,
+                                                          const double *__restrict__ gdir,
                                                           double *__restrict__ out,
                                                           double *__restrict__ partials) {
-  __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
+  constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
+  constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
+  __shared__ double lds[kLds];
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   // a contiguous range of SLICES per workgroup (XCD-aware like group_range, but balanced to one slice)
@@ -142,26 +149,46 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
 #pragma unroll
   for (int i = 0; i < P * P; ++i) Sm[i] = S[i];
   double Mm[P * P];
-  load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
-  double a[3] = {0, 0, 0};
+  if (RECUR) {
+#pragma unroll
+    for (int aa = 0; aa < P; ++aa)
+#pragma unroll
+      for (int b = aa; b < P; ++b) {
+        const double m = gdir[SLOT_GDIR_P + SymIdx<P>::at(aa, b)];
+        Mm[aa * P + b] = m;
+        Mm[b * P + aa] = m;
+      }
+  } else {
+    load_sym<P, FROM_SLOTS>(gram_partials, count, slots, Mm, lds);
+  }
+  double a[KC];
+#pragma unroll
+  for (int i = 0; i < KC; ++i) a[i] = 0;
   struct Epi {
     const SellView &A;
-    const double *__restrict__ X, *__restrict__ V;
+    const double *__restrict__ X, *__restrict__ Y, *__restrict__ V;
     double *__restrict__ out;
     const double (&Sm)[P * P], (&Mm)[P * P];
-    double (&a)[3];
+    double (&a)[KC];
     int lane;
-    double x[P], v[P];
+    double x[P], y[P], v[P];
     // rows of the slice from a scalar base + a 32-bit lane offset (lanes past the last row read its first)
     __device__ __forceinline__ unsigned lane_off(size_t slice) const {
       return (slice * 64 + lane < A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
     }
+    __device__ __forceinline__ const double *row_of(const double *F, size_t slice, unsigned off) const {
+      return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F + slice * 64 * P) + off);
+    }
     __device__ __forceinline__ void begin(size_t slice) {
       const unsigned off = lane_off(slice);
-      const double *xs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(X + slice * 64 * P) + off);
-      const double *vs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(V + slice * 64 * P) + off);
+      const double *xs = row_of(X, slice, off), *vs = row_of(V, slice, off);
 #pragma unroll
       for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; }
+      if (RECUR) {
+        const double *ys = row_of(Y, slice, off);
+#pragma unroll
+        for (int c = 0; c < P; ++c) y[c] = ys[c];
+      }
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
       if (slice * 64 + lane >= A.n) return;
@@ -173,21 +200,40 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
         for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
         acc[b] -= t;  // Z = A V - V S
       }
+      double o[P];
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
-        const double o = acc[b] - t;  // Z - X M
-        os[b] = o;
-        a[0] += v[b] * o; a[1] += o * o; a[2] += v[b] * v[b];
+        o[b] = acc[b] - t;  // Z - X M
+        os[b] = o[b];
+        a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
+      }
+      if (RECUR) {  // packed sym(y o' - x (o S)'): the Gram of this output row
+        double os_[P];
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+          double t = 0;
+#pragma unroll
+          for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
+          os_[b] = t;
+        }
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa)
+#pragma unroll
+          for (int b = aa; b < P; ++b) {
+            const double gab = y[aa] * o[b] - x[aa] * os_[b];
+            const double gba = y[b] * o[aa] - x[b] * os_[aa];
+            a[3 + SymIdx<P>::at(aa, b)] += (aa == b) ? gab : .5 * (gab + gba);
+          }
       }
     }
-  } epi{A, X, V, out, Sm, Mm, a, lane, {}, {}};
+  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
   const size_t wfirst = s0 + (size_t)__builtin_amdgcn_readfirstlane(w);
   sell_stream<P, HALO>(A, wfirst, s1, lane, V, epi);
-  block_partials_store<3>(a, lds, partials);
+  block_partials_store<KC>(a, lds, partials);
 }
 
 // Gram partial rows of two dense n x P fields.
@@ -433,22 +479,28 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   if (!g_uniform_grid && grid > cap) grid = cap;
   SellView view = sell_view(A);
   double *slots = ctx->scalars + SLOT_GRAM;
-  const bool sharded = slot_mode(ctx);
+  const bool recur = gram_count < 0;
+  const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
-  if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
-  if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
+  if (!recur) {
+    if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
+    if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
+  }
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HF(F, HL)                                                                                             \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL>), dim3(grid), dim3(kBlock), 0, ctx->stream, view, \
-                                   (const CgState *)ctx->cg_live, (const double *)in->d,                     \
-                                   (const double *)q->X->d, (const double *)q->S_dev,                        \
-                                   (const double *)ctx->partials2, gram_count, (const double *)slots,        \
+#define HF(F, HL, RC)                                                                                         \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
+                                   view, (const CgState *)ctx->cg_live, (const double *)in->d,               \
+                                   (const double *)q->X->d, (const double *)q->Y->d,                         \
+                                   (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
+                                   (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),        \
                                    out->d, ctx->partials))
-  if (halo) {
-    if (sharded) { HF(true, true); } else { HF(false, true); }
+  if (recur) {
+    if (halo) { HF(false, true, true); } else { HF(false, false, true); }
+  } else if (halo) {
+    if (sharded) { HF(true, true, false); } else { HF(false, true, false); }
   } else {
-    if (sharded) { HF(true, false); } else { HF(false, false); }
+    if (sharded) { HF(true, false, false); } else { HF(false, false, false); }
   }
 #undef HF
   *nparts = grid;

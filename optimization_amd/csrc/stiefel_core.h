@@ -13,6 +13,15 @@ struct SymIdx {
   }
 };
 
+// components the one-pass Hessian leaves per workgroup when the Gram of its OUTPUT rides along (recurrence
+// form of mi_op::dirgram): 3 curvature dots + NS packed symmetric entries, padded to a supported row count
+template <int P>
+struct DirComps {
+  static constexpr int NS = SymIdx<P>::NS;
+  static constexpr int value = (3 + NS <= 4) ? 4 : (3 + NS <= 6) ? 6 : (3 + NS <= 9) ? 9 : 16;
+};
+inline int dir_comps(int p) { return p == 1 ? 4 : p == 2 ? 6 : p == 3 ? 9 : 16; }
+
 // per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
 template <int P>
 __device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], double *lds,

@@ -278,11 +278,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup 
   publish(hs, 0, s.mode == CG_DONE);
 }
 
+// mi_op::dirgram plumbing.  Direct form: k_cg_pupdate<.,SP> forms the Gram rows of the new direction from X, Y.
+// Recurrence form (gdir != null, no preconditioner): the operator pass leaves the rows of G(Hp) as components
+// 3.. of its partial row; workgroup 0 of k_cg_update advances G(r) += alpha G(Hp) and workgroup 0 of
+// k_cg_pupdate G(p) = -G(r) + beta G(p) -- packed symmetric, ns = P(P+1)/2 doubles each at gdir[0..) / gdir[SLOT_GDIR_P..).
+struct DirGramArgs {
+  const double *X, *Y, *S;
+  double *gpartials;
+  double *gdir;
+  int ns;
+};
+
 // A-step prologue + body:
 //   CG_RUN:            r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)   [s += alpha p: see k_cg_pupdate]
 //   CG_APPLY_SIGMA:    s += sigma p (:360)
 //   CG_KERNEL_PENDING: partial <p,r> (:320)
-template <int PRE, bool FROM_SLOTS>
+template <int PRE, bool FROM_SLOTS, int KC = 3>
 __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                       CgState *__restrict__ st_out,
                                                       const double *__restrict__ partials_a, int nparts_a,
@@ -292,8 +303,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
                                                       const double *__restrict__ pre,
                                                       double *__restrict__ s, double *__restrict__ r,
                                                       double *__restrict__ v,
-                                                      double *__restrict__ partials_b) {
+                                                      double *__restrict__ partials_b, DirGramArgs dg) {
   __shared__ double lds[3 * (kWaves + 1)];
+  static_assert(KC >= 3 && KC <= kWaves, "3 curvature dots + at most 13 Gram components");
   CgState cs = load_state(st_in);
   if (cs.mode == CG_DONE) {
     if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
@@ -308,14 +320,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
     hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
     rv0 = reinterpret_cast<double2 *>(r)[i0];
   }
-  double d[3];
+  double d[KC];
   if (FROM_SLOTS) {
-    d[0] = slots[0]; d[1] = slots[1]; d[2] = slots[2];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) d[i] = slots[i];
   } else {
-    reduce_rows<3>(partials_a, nparts_a, d, lds);
+    reduce_rows<KC>(partials_a, nparts_a, d, lds);
   }
   step_a(cs, cc, d[0], d[1], d[2]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    store_state(st_out, cs);
+    if (KC > 3 && cs.mode == CG_RUN) {  // G(r) += alpha G(Hp)  (r += alpha Hp, :377)
+#pragma unroll
+      for (int i = 0; i < KC - 3; ++i)
+        if (i < dg.ns) dg.gdir[i] = dg.gdir[i] + cs.alpha * d[3 + i];
+    }
+  }
 
   const int mode = cs.mode;
   double acc[1] = {0};
@@ -398,10 +418,6 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
 // B-step prologue + body:  CG_RUN: s = s + alpha p (:374), p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
 //   SP > 0 (mi_op::dirgram): the fields are rows of SP doubles and the kernel also leaves the partial rows of
 //   sym(Y'p - (X'p) S) of the NEW direction in dg.gpartials -- the projection matrix of the next Hessian pass.
-struct DirGramArgs {
-  const double *X, *Y, *S;
-  double *gpartials;
-};
 template <int SP>
 struct DirGramLds {
   static constexpr int value = (SymIdx<SP>::NS * kWaves > kWaves + 1) ? SymIdx<SP>::NS * kWaves : kWaves + 1;
@@ -468,6 +484,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       trace[3 * trace_cap + k] = cs.rv;
     }
     publish(hs, cs.launches, cs.mode == CG_DONE);
+    if (SP == 0 && dg.gdir && mode_in == CG_RUN && cs.mode == CG_RUN) {  // G(p) = -G(r) + beta G(p)  (:420)
+      for (int i = 0; i < dg.ns; ++i) dg.gdir[SLOT_GDIR_P + i] = -dg.gdir[i] + cs.beta * dg.gdir[SLOT_GDIR_P + i];
+    }
   }
   if (mode_in == CG_KERNEL_PENDING) {
     const double sigma = cs.sigma;
@@ -582,6 +601,34 @@ __global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const doubl
   store_sym_partials<SP>(G, lds, dg.gpartials);
 }
 
+// recurrence form: G(p0) from the rows k_cg_dirgram left (or the all-reduced slots); G(r0) = -G(p0) (p0 = -r0)
+__global__ __launch_bounds__(kBlock) void k_cg_gdir_init(const double *__restrict__ partials, int count, int ns,
+                                                         const double *__restrict__ slots, int from_slots,
+                                                         double *__restrict__ gdir) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w >= ns) return;
+  double v;
+  if (from_slots) {
+    v = slots[w];
+  } else {
+    const double *src = partials + (size_t)w * kMaxRows;
+    double t[kMaxRows / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (r < count) ? src[r] : 0.0;
+    }
+    v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+  }
+  if (lane == 0) {
+    gdir[SLOT_GDIR_P + w] = v;
+    gdir[w] = -v;
+  }
+}
+
 inline void cpu_relax() { __builtin_ia32_pause(); }
 
 }  // namespace
@@ -669,9 +716,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations};
   hipStream_t st = ctx->stream;
   const int grid = (pre == PRE_BLOCK3) ? grid_for(n / 3, 2) : grid_for(n, 4);
-  const DirGramArgs dga = dgp ? DirGramArgs{dgp->X, dgp->Y, dgp->S, ctx->partials2}
-                              : DirGramArgs{nullptr, nullptr, nullptr, nullptr};
-  const int sp = dgp ? dgp->p : 0;
+  // recurrence form of the direction Gram: needs v == r (no preconditioner)
+  const bool recur = dgp && pre == PRE_NONE && !ctx->dirgram_direct;
+  const int gns = dgp ? dgp->p * (dgp->p + 1) / 2 : 0;
+  const DirGramArgs dga = dgp ? DirGramArgs{dgp->X, dgp->Y, dgp->S, ctx->partials2,
+                                            recur ? ctx->scalars + SLOT_GDIR : nullptr, gns}
+                              : DirGramArgs{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  const int sp = (dgp && !recur) ? dgp->p : 0;  // row form of k_cg_pupdate only in the direct form
+  const int kc = recur ? dir_comps(dgp->p) : 3;  // components of the operator's partial rows
+  double *slots_g = ctx->scalars + SLOT_GRAM;    // slot file of the recurrence form (kc <= 16 doubles)
   double *slots_a = ctx->scalars + SLOT_CG, *slots_b = ctx->scalars + SLOT_CG + 4;
   CgState *st0 = ctx->cg, *st1 = ctx->cg1;
   double *tr = tcap ? ctx->trace_dev : nullptr;
@@ -713,11 +766,17 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
   if (dgp) {
     const size_t nrows = dgp->n;
-    switch (sp) {
+    switch (dgp->p) {
       case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
       case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
       case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
       default: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+    }
+    if (recur) {
+      if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, gns, slots_g));
+      else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, gns));
+      hipLaunchKernelGGL(k_cg_gdir_init, dim3(1), dim3(kBlock), 0, st, (const double *)ctx->partials2, grid, gns,
+                         (const double *)slots_g, sharded ? 1 : 0, dga.gdir);
     }
   }
   if (sharded) {
@@ -755,7 +814,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials
       int nparts = 0;
       if (dgp) {
-        CG_CHECK(H->apply_dir(H, p, Hp, grid, &nparts));
+        CG_CHECK(H->apply_dir(H, p, Hp, recur ? -1 : grid, &nparts));
       } else if (H->apply_dots) {
         CG_CHECK(H->apply_dots(H, p, Hp, &nparts));
       } else {
@@ -764,9 +823,29 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       }
       ++hvp;
 #define UPD_ARGS                                                                                      \
-  n, cc, (const CgState *)st0, st1, (const double *)ctx->partials, nparts, (const double *)slots_a,  \
-      (const double *)p->d, (const double *)Hp->d, pred, s_out->d, r->d, vd, ctx->partials_b
-      if (sharded) {
+  n, cc, (const CgState *)st0, st1, (const double *)ctx->partials, nparts,                              \
+      (const double *)(recur ? slots_g : slots_a), (const double *)p->d, (const double *)Hp->d, pred,  \
+      s_out->d, r->d, vd, ctx->partials_b, dga
+      if (recur) {
+        // 3 dots + the Gram rows of Hp in one reduction (and one exchange across ranks)
+#define UPD_RECUR(FS)                                                                                      \
+  switch (kc) {                                                                                            \
+    case 4: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 4>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
+    case 6: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 6>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
+    case 9: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 9>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
+    default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 16>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break; \
+  }
+        if (sharded) {
+          CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, kc, slots_g));
+          KScope ks(ctx, MI_K_CG_UPDATE);
+          UPD_RECUR(true);
+        } else {
+          if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials, kc));
+          KScope ks(ctx, MI_K_CG_UPDATE);
+          UPD_RECUR(false);
+        }
+#undef UPD_RECUR
+      } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, 3, slots_a));
         KScope ks(ctx, MI_K_CG_UPDATE);
         LAUNCH_UPDATE(true);

@@ -232,8 +232,10 @@ def test_full_size_fused_stpcg_vs_oracle(ctx, oracle, full_rq):
 
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
 def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
-    """STPCG's one-pass Stiefel Hessian (the direction kernel leaves the Gram rows of the next projection,
-    mi_op::dirgram) against the two-pass form (MI355OPT_NO_DIRGRAM=1) and the oracle, for every supported p."""
+    """STPCG's one-pass Stiefel Hessian (mi_op::dirgram) in both forms -- Gram of the direction carried by
+    scalar recurrences (default without a preconditioner) and Gram rows formed by the direction kernel
+    (MI355OPT_DIRGRAM_DIRECT=1) -- against the two-pass operator (MI355OPT_NO_DIRGRAM=1) and the oracle, for
+    every supported p."""
     from optimization_amd import capi
     nx, ny, nz = 9, 8, 7
     n = nx * ny * nz
@@ -244,9 +246,11 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
     o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
                              trace_cap=64)
     oracle.free(oprob)
+    env = {"recurrence": ("0", "0"), "direct": ("0", "1"), "two-pass": ("1", "0")}
     res = {}
-    for mode in ("one-pass", "two-pass"):
-        monkeypatch.setenv("MI355OPT_NO_DIRGRAM", "1" if mode == "two-pass" else "0")
+    for mode, (no_dirgram, direct) in env.items():
+        monkeypatch.setenv("MI355OPT_NO_DIRGRAM", no_dirgram)
+        monkeypatch.setenv("MI355OPT_DIRGRAM_DIRECT", direct)
         c = capi.Context(0)
         try:
             A = c.csr(n, rowptr, col, val)
@@ -262,8 +266,9 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
         finally:
             c.close()
     # the path under test really ran
-    assert res["one-pass"]["launches"]["stiefel_hess_fused"] > 0
-    assert res["one-pass"]["launches"]["stiefel_finish_dots"] == 0
+    for mode in ("recurrence", "direct"):
+        assert res[mode]["launches"]["stiefel_hess_fused"] > 0
+        assert res[mode]["launches"]["stiefel_finish_dots"] == 0
     assert res["two-pass"]["launches"]["stiefel_hess_fused"] == 0
     assert res["two-pass"]["launches"]["stiefel_finish_dots"] > 0
     for mode, r in res.items():
@@ -271,4 +276,5 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
         assert np.allclose(r["trace"]["alpha"], o["trace"]["alpha"], rtol=1e-9), mode
         assert np.allclose(r["trace"]["beta"], o["trace"]["beta"], rtol=1e-8), mode
         assert rel_err(r["s"], o["s"]) < 1e-10, mode
-    assert rel_err(res["one-pass"]["s"], res["two-pass"]["s"]) < 1e-11
+    assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
+    assert rel_err(res["direct"]["s"], res["two-pass"]["s"]) < 1e-11
