@@ -296,6 +296,12 @@ struct mi_csr {
   long long *slice_ptr = nullptr;  // device, nslices + 1
   int *col = nullptr;              // device, padded
   double *val = nullptr;           // device, padded
+  // Value-indexed packed copy (lossless; built when the matrix has <= 256 distinct stored values and
+  // n + halo < 2^23): entry = (col - row) << 8 | index into vtab.  4 bytes per stored entry instead of 12:
+  // stencil / unit-weight Laplacian operators stream a third of the bytes (spmm_core.h sell_stream<.,.,true>).
+  uint32_t *pk = nullptr;          // device, padded (null: not representable)
+  double *vtab = nullptr;          // device, 256 doubles
+  int nvtab = 0;
   // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
   // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.

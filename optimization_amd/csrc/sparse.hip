@@ -5,6 +5,9 @@
 // Algorithmic bytes: 12*nnz + 4*(n+1) + 16*n*p.
 #include "spmm_core.h"
 
+#include <cstring>
+#include <unordered_map>
+
 #include <algorithm>
 
 using namespace mi;
@@ -110,6 +113,43 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
   MI_TRY(upload((void **)&A->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
   MI_TRY(upload((void **)&A->col, pcol.data(), stored * sizeof(int)));
   MI_TRY(upload((void **)&A->val, pval.data(), stored * sizeof(double)));
+  // value-indexed packed copy (mi_csr::pk): distinct stored values by BIT PATTERN (so -0.0, NaN payloads
+  // and denormals survive), column as a signed 24-bit offset from the row
+  static const bool no_pack = [] { const char *e = getenv("MI355OPT_NO_PACKED"); return e && e[0] == '1'; }();
+  if (!no_pack && ncols + 64 < ((size_t)1 << 23)) {
+    std::unordered_map<uint64_t, int> index;
+    std::vector<double> table;
+    std::vector<uint32_t> pk(stored, 0u);
+    bool ok = true;
+    for (size_t e = 0; e < stored && ok; ++e) {
+      uint64_t bits;
+      memcpy(&bits, &pval[e], sizeof bits);
+      auto it = index.find(bits);
+      int vi;
+      if (it == index.end()) {
+        if (table.size() == 256) { ok = false; break; }
+        vi = (int)table.size();
+        index.emplace(bits, vi);
+        table.push_back(pval[e]);
+      } else {
+        vi = it->second;
+      }
+      pk[e] = (uint32_t)vi;  // column part filled below, slice by slice
+    }
+    if (ok) {
+      for (size_t sl = 0; sl < nslices; ++sl)
+        for (long long k = sp[sl]; k < sp[sl + 1]; ++k)
+          for (int lane = 0; lane < 64; ++lane) {
+            const size_t e = (size_t)k * 64 + lane;
+            const long long delta = (long long)pcol[e] - (long long)(sl * 64 + lane);
+            pk[e] |= (uint32_t)((int32_t)delta) << 8;
+          }
+      table.resize(256, 0.0);
+      MI_TRY(upload((void **)&A->pk, pk.data(), stored * sizeof(uint32_t)));
+      MI_TRY(upload((void **)&A->vtab, table.data(), 256 * sizeof(double)));
+      A->nvtab = (int)index.size();
+    }
+  }
   *out = A;
   return MI_OK;
 }
@@ -169,6 +209,8 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->slice_ptr);
   (void)hipFree(A->col);
   (void)hipFree(A->val);
+  (void)hipFree(A->pk);
+  (void)hipFree(A->vtab);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;
   return MI_OK;

@@ -11,10 +11,12 @@ struct SellView {
   const int *__restrict__ col;
   const double *__restrict__ val;
   const double *__restrict__ halo;  // may be null
+  const uint32_t *__restrict__ pk;  // value-indexed packed entries (mi_csr::pk), may be null
+  const double *__restrict__ vtab;
 };
 
 inline SellView sell_view(const mi_csr *A) {
-  return SellView{A->n, A->nslices, A->slice_ptr, A->col, A->val, A->halo};
+  return SellView{A->n, A->nslices, A->slice_ptr, A->col, A->val, A->halo, A->pk, A->vtab};
 }
 
 #ifndef MI_SPMM_CHUNK
@@ -80,30 +82,41 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
 // main loop runs at ~6.4 TB/s, the practical HBM rate, in every variant tried -- ~3x fewer instructions (this
 // form), deeper prefetch, chunk sizes 2..8, L1-bypassing matrix loads, an LDS copy of the workgroup's rows of
 // V, a column-major V -- and the rest of the 33 us is the prologue reduction and the ramp-down.
-template <int P, bool HALO, class Epi>
+// PK: the matrix is read from its value-indexed packed copy (one dword per entry: (col - row) << 8 | value
+// index; `vt` = the 256-entry value table, staged in LDS by the caller) -- 4 instead of 12 bytes per entry.
+template <int P, bool HALO, bool PK, class Epi>
 __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, size_t end, int lane,
-                                            const double *__restrict__ V, Epi &epi) {
+                                            const double *__restrict__ V, const double *vt, Epi &epi) {
   constexpr int CH = MI_SPMM_CHUNK;
   if (first >= end) return;
   size_t slice = first;
   long long k = A.slice_ptr[slice], b1 = A.slice_ptr[slice + 1];
   const unsigned lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
   const unsigned nloc = (unsigned)A.n;
-  double a[CH];
-  unsigned ci[CH];
+  // operands of a chunk as loaded: PK: packed words (decoded when the chunk becomes current); else value + column
+  struct Ops {
+    double a[PK ? 1 : CH];
+    unsigned c[CH];
+  };
   // entries beyond the slice width re-read the chunk's first entry -- or, for an empty slice, entry 0 of
   // the matrix (mi_csr always stores >= 64 entries); their value is zeroed when the chunk is consumed
-  auto load_chunk = [&](double (&av)[CH], unsigned (&cv)[CH], long long kk, long long bb) {
+  auto load_chunk = [&](Ops &o, long long kk, long long bb) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const long long kj = (kk + j < bb) ? kk + j : ((kk < bb) ? kk : 0);
-      const char *vb = reinterpret_cast<const char *>(A.val + (size_t)kj * 64);  // scalar bases
-      const char *cb = reinterpret_cast<const char *>(A.col + (size_t)kj * 64);
-      av[j] = *reinterpret_cast<const double *>(vb + lane8);
-      cv[j] = *reinterpret_cast<const unsigned *>(cb + lane4);
+      if (PK) {
+        const char *pb = reinterpret_cast<const char *>(A.pk + (size_t)kj * 64);  // scalar base
+        o.c[j] = *reinterpret_cast<const unsigned *>(pb + lane4);
+      } else {
+        const char *vb = reinterpret_cast<const char *>(A.val + (size_t)kj * 64);
+        const char *cb = reinterpret_cast<const char *>(A.col + (size_t)kj * 64);
+        o.a[j] = *reinterpret_cast<const double *>(vb + lane8);
+        o.c[j] = *reinterpret_cast<const unsigned *>(cb + lane4);
+      }
     }
   };
-  load_chunk(a, ci, k, b1);
+  Ops cur;
+  load_chunk(cur, k, b1);
   epi.begin(slice);
   double acc[P];
 #pragma unroll
@@ -116,6 +129,19 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
     const size_t nslice = row_done ? (cand < end ? cand : slice) : slice;
     const long long p0 = A.slice_ptr[nslice], p1 = A.slice_ptr[nslice + 1];
     const long long nk = row_done ? p0 : k + CH, nb1 = p1;
+    double a[CH];
+    unsigned ci[CH];
+    if (PK) {
+      const unsigned row = (unsigned)(slice * 64) + (unsigned)lane;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        a[j] = vt[cur.c[j] & 255u];
+        ci[j] = row + (unsigned)((int)cur.c[j] >> 8);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { a[j] = cur.a[j]; ci[j] = cur.c[j]; }
+    }
     double g[CH][P];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -129,9 +155,8 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
 #pragma unroll
       for (int c = 0; c < P; ++c) g[j][c] = src[c];
     }
-    double an[CH];
-    unsigned cn[CH];
-    load_chunk(an, cn, nk, nb1);  // (re-reads the first chunk of the last slice when nothing follows)
+    Ops nxt;
+    load_chunk(nxt, nk, nb1);  // (re-reads the first chunk of the last slice when nothing follows)
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const double aj = (k + j < b1) ? a[j] : 0.0;
@@ -146,8 +171,7 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
     }
     if (!have_next) break;
     slice = nslice; k = nk; b1 = nb1;
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { a[j] = an[j]; ci[j] = cn[j]; }
+    cur = nxt;
   }
 }
 

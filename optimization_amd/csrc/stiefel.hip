@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
 // RECUR (mi_op::apply_dir with gram_count < 0): M is read from gdir (packed symmetric, replicated scalars kept
 // by STPCG) and the packed symmetric Gram  sym(Y'out - (X'out) S)  of the OUTPUT rides along as components
 // 3.. of the partial row (DirComps<P>::value components in all).
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR>
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK>
 __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
@@ -140,8 +140,13 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
   constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
   constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
   __shared__ double lds[kLds];
+  __shared__ double vt[PK ? 256 : 1];  // PK: the matrix's value table
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) {
+    if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
+    __syncthreads();
+  }
   // a contiguous range of SLICES per workgroup (XCD-aware like group_range, but balanced to one slice)
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
   const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
   } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
   const size_t wfirst = s0 + (size_t)__builtin_amdgcn_readfirstlane(w);
-  sell_stream<P, HALO>(A, wfirst, s1, lane, V, epi);
+  sell_stream<P, HALO, PK>(A, wfirst, s1, lane, V, vt, epi);
   block_partials_store<KC>(a, lds, partials);
 }
 
@@ -488,13 +493,15 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
     if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
   }
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HF(F, HL, RC)                                                                                         \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
-                                   view, (const CgState *)ctx->cg_live, (const double *)in->d,               \
+#define HF2(F, HL, RC, PKV)                                                                                   \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV>), dim3(grid), dim3(kBlock), 0,         \
+                                   ctx->stream, view, (const CgState *)ctx->cg_live, (const double *)in->d,  \
                                    (const double *)q->X->d, (const double *)q->Y->d,                         \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),        \
                                    out->d, ctx->partials))
+#define HF(F, HL, RC)                            \
+  if (A->pk) { HF2(F, HL, RC, true); } else { HF2(F, HL, RC, false); }
   if (recur) {
     if (halo) { HF(false, true, true); } else { HF(false, false, true); }
   } else if (halo) {
@@ -502,6 +509,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   } else {
     if (sharded) { HF(true, false, false); } else { HF(false, false, false); }
   }
+#undef HF2
 #undef HF
   *nparts = grid;
   MI_HIP(hipGetLastError());
