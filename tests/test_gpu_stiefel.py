@@ -278,3 +278,73 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
         assert rel_err(r["s"], o["s"]) < 1e-10, mode
     assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
     assert rel_err(res["direct"]["s"], res["two-pass"]["s"]) < 1e-11
+
+
+def _graph_laplacian(n, seed, weights):
+    """Connected random graph Laplacian + 0.1 I as CSR (symmetric, SPD).  weights: list to draw from, or None for
+    all-distinct random weights (then the matrix has far more than 256 distinct values)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    i = np.concatenate([np.arange(n - 1), rng.integers(0, n, size=2 * n)])
+    j = np.concatenate([np.arange(1, n), rng.integers(0, n, size=2 * n)])
+    keep = i != j
+    i, j = i[keep], j[keep]
+    w = rng.choice(weights, size=i.size) if weights is not None else rng.uniform(.5, 2.0, size=i.size)
+    W = sp.coo_matrix((w, (i, j)), shape=(n, n)).tocsr()
+    W = W.maximum(W.T)  # symmetric, duplicate edges collapsed
+    L = (sp.diags(np.asarray(W.sum(axis=1)).ravel() + .1) - W).tocsr()
+    L.sort_indices()
+    return L
+
+
+@pytest.mark.parametrize("kind", ["few-values", "signed-zero", "many-values"])
+def test_one_pass_hessian_random_graph_all_matrix_formats(oracle, monkeypatch, kind):
+    """The one-pass Hessian on an unstructured matrix (ragged rows): value-indexed packed entries (few distinct
+    values; one case stores an explicit -0.0 entry, which the table must keep apart from +0.0), the plain
+    value/column arrays (too many distinct values, and MI355OPT_NO_PACKED=1), against the two-pass operator and
+    the oracle."""
+    from optimization_amd import capi
+    n, p = 700, 3
+    L = _graph_laplacian(n, seed=5, weights=None if kind == "many-values" else [1.0, 2.0, .5])
+    rowptr, col, val = L.indptr.astype(np.int32), L.indices.astype(np.int32), L.data.astype(np.float64)
+    if kind == "signed-zero":  # one stored off-diagonal pair becomes an explicit -0.0
+        r = 3
+        k = next(k for k in range(rowptr[r], rowptr[r + 1]) if col[k] != r)
+        c = int(col[k])
+        k2 = next(k2 for k2 in range(rowptr[c], rowptr[c + 1]) if col[k2] == r)
+        val[k] = val[k2] = -0.0
+        L = L.copy()
+        L.data[:] = val
+        assert np.signbit(val[k]) and (val == 0).sum() == 2
+    distinct = np.unique(val.view(np.uint64)).size
+    assert (distinct > 256) == (kind == "many-values")
+    lam, U = np.linalg.eigh(L.toarray())
+    rng = np.random.default_rng(9)
+    Xb, _ = np.linalg.qr(U[:, :p] + 1e-2 * rng.normal(size=(n, p)))
+    Xb = np.ascontiguousarray(Xb)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=60, kappa_fgr=1e-9, theta=1.0,
+                             trace_cap=64)
+    oracle.free(oprob)
+    assert o["iterations"] >= 10
+    res = {}
+    for mode, envs in {"packed-or-plain": {}, "plain": {"MI355OPT_NO_PACKED": "1"},
+                       "two-pass": {"MI355OPT_NO_DIRGRAM": "1"}}.items():
+        for k in ("MI355OPT_NO_PACKED", "MI355OPT_NO_DIRGRAM"):
+            monkeypatch.setenv(k, envs.get(k, "0"))
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            prob = c.stiefel_rq(A, n, p)
+            g, H = prob.model(c.upload(Xb))
+            r = c.stpcg(g, H, Delta=1e3, max_iterations=60, kappa_fgr=1e-9, theta=1.0, trace_cap=64)
+            res[mode] = dict(r, s=r["s"].numpy().copy())
+        finally:
+            c.close()
+    for mode, r in res.items():
+        assert r["iterations"] == o["iterations"] and r["exit_reason"] == o["exit_reason"], mode
+        assert np.allclose(r["trace"]["alpha"], o["trace"]["alpha"], rtol=1e-9), mode
+        assert rel_err(r["s"], o["s"]) < 1e-10, mode
+    # same arithmetic per entry in both matrix formats: identical bits
+    assert np.array_equal(res["packed-or-plain"]["s"], res["plain"]["s"])
