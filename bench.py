@@ -302,6 +302,8 @@ def main():
             # reference schedule streams its operands once).  The fused kernels move fewer: the second pair
             # is the same step priced by the compulsory bytes of the kernels that actually ran.
             "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
+            "value_basis": "SURVEY 8(d) algorithmic bytes of the reference schedule per inner iteration; "
+                           "moved_* = compulsory bytes of the kernels that actually ran (fused, value-indexed A)",
             "moved_bytes_per_step_per_gpu": moved_bytes,
             "moved_GBps": (world * args.steps * moved_bytes / dt / 1e9) if moved_bytes else None,
             "roofline": roofline, "cpu_baseline": cpu,

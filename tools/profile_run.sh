@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/<tag>_* is made from, in one go on the GPU box (about 6 minutes):
+#   bash tools/profile_run.sh r01   then, back in the build container,   python tools/profile_summary.py r01
+# Counter passes run on their own (--pmc with --kernel-trace only), one counter per pass.
+set -u
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p "$OUT"
+python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+python tools/bench_extra.py cfg3 cfg5 > "$OUT/${TAG}_extra.json" 2> "$OUT/${TAG}_extra.err"
+python tools/bench_lsqr.py > "$OUT/${TAG}_lsqr.json" 2> "$OUT/${TAG}_lsqr.err"
+python tools/bench_tnt.py > "$OUT/${TAG}_tnt.json" 2> "$OUT/${TAG}_tnt.err"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- $BENCH --steps 500 --warmup 50 \
+  > "$OUT/${TAG}_trace.log" 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- $BENCH --steps 100 --warmup 10 \
+  > "$OUT/${TAG}_pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_write" -- $BENCH --steps 100 --warmup 10 \
+  > "$OUT/${TAG}_pmc_write.log" 2>&1
+cd "$REPO"
+tail -1 "$OUT/${TAG}_bench.json" | cut -c1-300
