@@ -115,6 +115,12 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
       }
     }
   };
+  // bounds of the wave's NEXT slice, requested a whole slice ahead: a scalar load issued where its result is
+  // needed costs a full memory latency per slice while the vector queue is saturated (measured: a young
+  // wave waited 4-6 us for its first pair)
+  size_t cand = slice + kWaves;
+  long long q0 = k, q1 = b1;
+  if (cand < end) { q0 = A.slice_ptr[cand]; q1 = A.slice_ptr[cand + 1]; }
   Ops cur;
   load_chunk(cur, k, b1);
   epi.begin(slice);
@@ -124,11 +130,11 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
   for (;;) {
     // the wave's next chunk: all selects on scalars, no branches
     const bool row_done = k + CH >= b1;
-    const size_t cand = slice + kWaves;
-    const bool have_next = !row_done || cand < end;
-    const size_t nslice = row_done ? (cand < end ? cand : slice) : slice;
-    const long long p0 = A.slice_ptr[nslice], p1 = A.slice_ptr[nslice + 1];
-    const long long nk = row_done ? p0 : k + CH, nb1 = p1;
+    const bool more_slices = cand < end;
+    const bool have_next = !row_done || more_slices;
+    const size_t nslice = (row_done && more_slices) ? cand : slice;
+    const long long nk = row_done ? (more_slices ? q0 : k) : k + CH;
+    const long long nb1 = (row_done && more_slices) ? q1 : b1;
     double a[CH];
     unsigned ci[CH];
     if (PK) {
@@ -170,6 +176,10 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
       if (have_next) epi.begin(nslice);
     }
     if (!have_next) break;
+    if (row_done) {  // moved on to `cand`: request the bounds of the slice after it
+      cand += kWaves;
+      if (cand < end) { q0 = A.slice_ptr[cand]; q1 = A.slice_ptr[cand + 1]; }
+    }
     slice = nslice; k = nk; b1 = nb1;
     cur = nxt;
   }
