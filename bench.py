@@ -264,9 +264,15 @@ def main():
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:  # noqa
                 traffic = None
+        # SURVEY 8(d) prices the whole Stiefel HVP (SpMM + Gram pass + finish pass, 12-byte matrix entries) at
+        # stiefel_hvp_bytes; the one-pass kernel performs all of it.  `achieved`/`frac` use the bytes THIS kernel
+        # must move (a fraction above 1 would say nothing); the 8(d) variant is reported next to it.
+        a8d = wl.stiefel_hvp_bytes(n, nnz, p) if dom == "stiefel_hess_fused" else kb[dom]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": kb[dom],
+                    "survey_8d_bytes_per_launch": a8d,
+                    "achieved_survey_8d": a8d / (per[dom]["avg_us"] * 1e-6) / 1e9,
                     "avg_launch_us": per[dom]["avg_us"],
                     "kernels": {k: dict(per[k], **({"GBps": kb[k] / (per[k]["avg_us"] * 1e-6) / 1e9,
                                                      "bytes": kb[k]} if k in kb else {}))
