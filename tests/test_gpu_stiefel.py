@@ -348,3 +348,42 @@ def test_one_pass_hessian_random_graph_all_matrix_formats(oracle, monkeypatch, k
         assert rel_err(r["s"], o["s"]) < 1e-10, mode
     # same arithmetic per entry in both matrix formats: identical bits
     assert np.array_equal(res["packed-or-plain"]["s"], res["plain"]["s"])
+
+
+@pytest.mark.parametrize("n", [40, 64, 300, 1000])
+def test_one_pass_hessian_empty_rows_and_ragged_tail(oracle, monkeypatch, n):
+    """Rows without entries (whole 64-row slices of width 0 when n is large enough) and a last slice that is
+    only partly filled: the one-pass kernel against the two-pass operator and the oracle over the first CG passes."""
+    from optimization_amd import capi
+    import scipy.sparse as sp
+    p = 3
+    L = _graph_laplacian(n, seed=n, weights=[1.0, 3.0]).tolil()
+    lo, hi = n // 5, n // 5 + max(n // 3, 3)   # rows/columns lo..hi-1 become empty (130+ rows at n = 1000)
+    L[lo:hi, :] = 0
+    L[:, lo:hi] = 0
+    L = sp.csr_matrix(L)
+    L.eliminate_zeros()
+    L.sort_indices()
+    rowptr, col, val = L.indptr.astype(np.int32), L.indices.astype(np.int32), L.data.astype(np.float64)
+    assert all(rowptr[r + 1] == rowptr[r] for r in range(lo, hi))
+    X0 = wl.random_stiefel(n, p, seed=n + 1)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, X0.ravel())
+    res = {}
+    for maxit in (1, 4):
+        o = oracle.stpcg_problem(oprob, X0.ravel(), go, 0.5, max_iterations=maxit, trace_cap=8)
+        for mode, nd in (("one-pass", "0"), ("two-pass", "1")):
+            monkeypatch.setenv("MI355OPT_NO_DIRGRAM", nd)
+            c = capi.Context(0)
+            try:
+                A = c.csr(n, rowptr, col, val)
+                prob = c.stiefel_rq(A, n, p)
+                g, H = prob.model(c.upload(X0))
+                r = c.stpcg(g, H, Delta=0.5, max_iterations=maxit, trace_cap=8)
+                res[mode] = r["s"].numpy().copy()
+                assert r["iterations"] == o["iterations"] and r["exit_reason"] == o["exit_reason"], (mode, maxit)
+                assert rel_err(res[mode], o["s"]) < 1e-10, (mode, maxit)
+            finally:
+                c.close()
+        assert rel_err(res["one-pass"], res["two-pass"]) < 1e-11
+    oracle.free(oprob)
