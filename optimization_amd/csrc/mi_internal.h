@@ -248,19 +248,26 @@ __device__ __forceinline__ void block_partials_store(const double (&acc)[K], dou
 // independent coalesced loads, then a single wave reduction; one barrier publishes the K totals.
 // (The earlier all-waves form cost K x 16 fp64 wave reductions = hundreds of ds_bpermute per
 // workgroup, ~2-4 us at the head of every consumer kernel.)
-template <int K>
+// after_issue(): called once the row loads are in the queue and before they are waited for -- the place for a
+// consumer's own first loads (they then return BEHIND the rows, in order, and do not delay the reduction).
+template <int K, class F>
 __device__ __forceinline__ void reduce_rows(const double *__restrict__ partials, int count,
-                                            double (&out)[K], double *lds) {
+                                            double (&out)[K], double *lds, F &&after_issue) {
   static_assert(K <= kWaves, "one wave per component");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double t[kMaxRows / 64];
+#pragma unroll
+  for (int j = 0; j < kMaxRows / 64; ++j) t[j] = 0.0;
   if (w < K) {
     const double *src = partials + (size_t)w * kMaxRows;
-    double t[kMaxRows / 64];
 #pragma unroll
     for (int j = 0; j < kMaxRows / 64; ++j) {
       const int r = lane + 64 * j;
-      t[j] = (r < count) ? src[r] : 0.0;
+      if (r < count) t[j] = src[r];
     }
+  }
+  after_issue();
+  if (w < K) {
     double v = 0;
 #pragma unroll
     for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
@@ -271,6 +278,11 @@ __device__ __forceinline__ void reduce_rows(const double *__restrict__ partials,
 #pragma unroll
   for (int k = 0; k < K; ++k) out[k] = lds[k];
   __syncthreads();
+}
+template <int K>
+__device__ __forceinline__ void reduce_rows(const double *__restrict__ partials, int count,
+                                            double (&out)[K], double *lds) {
+  reduce_rows<K>(partials, count, out, lds, [] {});
 }
 
 // XCD-aware workgroup remap (guide T1): consecutive logical tiles land on the same XCD so that a

@@ -315,17 +315,21 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   // software prefetch of the first grid-stride step: its HBM latency overlaps the prologue's
   // reduction (tools/microbench/prologue.hip: hides the ~2.2 us prologue completely)
+  // (issued BEHIND the prologue's row loads: loads return in order, so the reduction is not held up by them)
   double2 hv0 = make_double2(0, 0), rv0 = hv0;
-  if (PRE != PRE_BLOCK3 && i0 < n2) {
-    hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
-    rv0 = reinterpret_cast<double2 *>(r)[i0];
-  }
+  auto prefetch = [&] {
+    if (PRE != PRE_BLOCK3 && i0 < n2) {
+      hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
+      rv0 = reinterpret_cast<double2 *>(r)[i0];
+    }
+  };
   double d[KC];
   if (FROM_SLOTS) {
+    prefetch();
 #pragma unroll
     for (int i = 0; i < KC; ++i) d[i] = slots[i];
   } else {
-    reduce_rows<KC>(partials_a, nparts_a, d, lds);
+    reduce_rows<KC>(partials_a, nparts_a, d, lds, prefetch);
   }
   step_a(cs, cc, d[0], d[1], d[2]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -446,31 +450,37 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
   const int mode_in = cs.mode;
   const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
   const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  double2 vv0 = make_double2(0, 0), pv0 = vv0, sv0 = vv0;  // prefetch: overlaps the prologue's reduction
+  // prefetch of the first grid-stride step: overlaps the prologue's reduction, and is issued BEHIND the
+  // prologue's row loads (loads return in order, so the reduction is not held up by it)
+  double2 vv0 = make_double2(0, 0), pv0 = vv0, sv0 = vv0;
   constexpr int SPN = SP > 0 ? SP : 1;
   double rv0[SPN], rp0[SPN], rs0[SPN], rx0[SPN], ry0[SPN];  // SP > 0: the same prefetch, one row per lane
-  if (SP > 0) {
 #pragma unroll
-    for (int c = 0; c < SPN; ++c) { rv0[c] = 0; rp0[c] = 0; rs0[c] = 0; rx0[c] = 0; ry0[c] = 0; }
-    if (mode_in == CG_RUN && i0 < n / SPN) {
+  for (int c = 0; c < SPN; ++c) { rv0[c] = 0; rp0[c] = 0; rs0[c] = 0; rx0[c] = 0; ry0[c] = 0; }
+  auto prefetch = [&] {
+    if (SP > 0) {
+      if (mode_in == CG_RUN && i0 < n / SPN) {
 #pragma unroll
-      for (int c = 0; c < SPN; ++c) {
-        rv0[c] = v[i0 * SPN + c];
-        rp0[c] = p[i0 * SPN + c];
-        rs0[c] = s[i0 * SPN + c];
-        rx0[c] = dg.X[i0 * SPN + c];
-        ry0[c] = dg.Y[i0 * SPN + c];
+        for (int c = 0; c < SPN; ++c) {
+          rv0[c] = v[i0 * SPN + c];
+          rp0[c] = p[i0 * SPN + c];
+          rs0[c] = s[i0 * SPN + c];
+          rx0[c] = dg.X[i0 * SPN + c];
+          ry0[c] = dg.Y[i0 * SPN + c];
+        }
       }
+    } else if (i0 < n2) {
+      vv0 = reinterpret_cast<const double2 *>(v)[i0];
+      pv0 = reinterpret_cast<double2 *>(p)[i0];
+      sv0 = reinterpret_cast<double2 *>(s)[i0];
     }
-  } else if (i0 < n2) {
-    vv0 = reinterpret_cast<const double2 *>(v)[i0];
-    pv0 = reinterpret_cast<double2 *>(p)[i0];
-    sv0 = reinterpret_cast<double2 *>(s)[i0];
-  }
+  };
   double red[1] = {0};
-  if (mode_in != CG_APPLY_SIGMA) {
-    if (FROM_SLOTS) red[0] = slots[0];
-    else reduce_rows<1>(partials_b, nparts_b, red, lds);
+  if (mode_in != CG_APPLY_SIGMA && !FROM_SLOTS) {
+    reduce_rows<1>(partials_b, nparts_b, red, lds, prefetch);
+  } else {
+    prefetch();
+    if (mode_in != CG_APPLY_SIGMA) red[0] = slots[0];
   }
   step_b(cs, cc, red[0]);
   cs.launches = cs.launches + 1;
