@@ -47,7 +47,7 @@ def main(tag):
         hits = sorted(glob.glob(os.path.join(g, f"{tag}_{sub}", "**", "*" + suffix), recursive=True))
         if not hits:
             raise SystemExit(f"no *{suffix} under gpurun_out/{tag}_{sub}")
-        return hits[-1]
+        return max(hits, key=os.path.getmtime)  # gpurun merges calls: older runs' files stay around
     stats_src = find("trace", "kernel_stats.csv")
     shutil.copy(stats_src, os.path.join(out, f"{tag}_kernel_stats.csv"))
     stats = {}
