@@ -22,8 +22,21 @@ import os
 import sys
 import time
 
+# One launching thread per rank is all this benchmark needs on the host.  numpy's BLAS and torch's OpenMP pools
+# size themselves to the machine's 256 cores and spin after every parallel region; inside a container with a CPU
+# quota (16 CPUs on the GPU boxes of this pool) that throttles the whole cgroup and the kernel-launching thread
+# with it: measured 160-206 us/step instead of 68 in the multi-rank code path.  Must precede the imports.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# stdout carries exactly one line, the JSON result of rank 0: everything else that writes to file descriptor 1
+# (gloo's connection notice, RCCL's version banner at exit, stray prints) is sent to stderr instead
+_RESULT_FD = os.dup(1)
+os.dup2(2, 1)
+sys.stdout = sys.stderr
 
 import numpy as np  # noqa: E402
 
@@ -242,7 +255,9 @@ def main():
 
     # ---- roofline leg: same steps again with HIP-event pairs around every hot kernel ------------
     roofline = None
-    if not args.no_roofline and rank == 0:
+    # EVERY rank runs these steps (they contain the same exchanges as the timed ones: a rank running them alone
+    # would wait for peers that never come); rank 0's own kernel timings are the ones reported.
+    if not args.no_roofline:
         kb = kernel_bytes(n, nnz, p)
         names = list(kb) + ["stiefel_gram_reduce", "cg_scalar_a", "cg_scalar_b"]
         for k in names:
@@ -277,6 +292,9 @@ def main():
                     "kernels": {k: dict(per[k], **({"GBps": kb[k] / (per[k]["avg_us"] * 1e-6) / 1e9,
                                                      "bytes": kb[k]} if k in kb else {}))
                                 for k in names}}
+        barrier()
+        if rank != 0:
+            roofline = None
 
     moved_bytes = None
     if roofline is not None:
@@ -314,7 +332,7 @@ def main():
             "moved_GBps": (world * args.steps * moved_bytes / dt / 1e9) if moved_bytes else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         ctx.comm_finalize()

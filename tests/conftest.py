@@ -1,3 +1,8 @@
+import os as _os
+# worker processes started by the tests inherit this: BLAS / OpenMP pools sized to 256 cores spin past the
+# container's CPU quota and starve the kernel-launching threads (see bench.py)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    _os.environ.setdefault(_v, "1")
 import json
 import os
 import sys

@@ -227,14 +227,16 @@ def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
     env = dict(os.environ, MI355OPT_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100",
-           "--warmup", "10", "--no-cpu-baseline", "--no-roofline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+           "--warmup", "10"]  # exactly the driver's command line: the roofline leg runs too (on every rank)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    # stdout is the result line and nothing else (gloo / RCCL banners go to stderr)
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 1_000_000 and "peer-memory" in d["config"]["parallelism"]
+    assert d["roofline"]["kernel"] == "stiefel_hess_fused" and d["cpu_baseline"] is None
 
 
 def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification():
