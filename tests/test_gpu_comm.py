@@ -236,7 +236,8 @@ def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["rows_per_gpu"] == 1_000_000 and "peer-memory" in d["config"]["parallelism"]
-    assert d["roofline"]["kernel"] == "stiefel_hess_fused" and d["cpu_baseline"] is None
+    assert d["roofline"]["kernel"] in ("stiefel_hess_fused", "stiefel_spmm_gram", "cg_pupdate")  # by A/B switches
+    assert d["cpu_baseline"] is None
 
 
 def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification():
