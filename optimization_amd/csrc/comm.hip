@@ -68,7 +68,9 @@ int nccl_fail(ncclResult_t r, const char *what) {
 
 __device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err, uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+  // sequence numbers only grow: ">= want", so that a peer that is already one exchange further on (it may raise
+  // this flag again before a descheduled waiter has looked) still releases the wait
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
     if (wall_clock64() - t0 > timeout) {
       __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
@@ -235,13 +237,15 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
   Comm *c = (Comm *)ctx->comm;
   const int rk = ctx->rank, ws = ctx->world_size;
   if (c->ipc_enabled && A->halo_in_arena) {
+    // this exchange's buffer (mi_csr::halo_stride); every rank counts the exchanges of a matrix identically
+    const size_t buf_off = A->halo_off + (++A->halo_exchanges & 1) * A->halo_stride * sizeof(double);
     const size_t lo = A->send_lo * p, hi = A->send_hi * p;
     const size_t work = std::max(lo, hi);
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((work + 255) / 256, 64));
     hipLaunchKernelGGL(k_ipc_halo_push, dim3(grid), dim3(256), 0, ctx->stream, V, A->n * (size_t)p, lo, hi,
                        (char *const *)c->peer_dev, ws, rk,
-                       A->halo_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
-                       A->halo_off,                                          // rank+1's lower halo
+                       buf_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
+                       buf_off,                                          // rank+1's lower halo
                        (int)(rk > 0 && A->halo_lo > 0), (int)(rk + 1 < ws && A->halo_hi > 0), ++c->halo_seq,
                        c->err_dev, c->timeout);
     MI_HIP(hipGetLastError());
@@ -251,14 +255,14 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
   MI_NCCL(ncclGroupStart());
   if (rk > 0) {
     if (A->send_lo) MI_NCCL(ncclSend(V, A->send_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream));
-    if (A->halo_lo) MI_NCCL(ncclRecv(A->halo, A->halo_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream));
+    if (A->halo_lo) MI_NCCL(ncclRecv(const_cast<double *>(A->halo_cur()), A->halo_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream));
   }
   if (rk + 1 < ws) {
     if (A->send_hi)
       MI_NCCL(ncclSend(V + (A->n - A->send_hi) * p, A->send_hi * p, ncclDouble, rk + 1, c->nccl,
                        ctx->stream));
     if (A->halo_hi)
-      MI_NCCL(ncclRecv(A->halo + A->halo_lo * p, A->halo_hi * p, ncclDouble, rk + 1, c->nccl,
+      MI_NCCL(ncclRecv(const_cast<double *>(A->halo_cur()) + A->halo_lo * p, A->halo_hi * p, ncclDouble, rk + 1, c->nccl,
                        ctx->stream));
   }
   MI_NCCL(ncclGroupEnd());
@@ -502,7 +506,7 @@ int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host) {
   MI_REQUIRE(p >= 1 && p <= 4, "halo buffers hold at most 4 columns");
   const size_t rows = A->halo_lo + A->halo_hi;
   if (rows)
-    MI_HIP(hipMemcpy(A->halo, halo_rows_host, rows * (size_t)p * sizeof(double), hipMemcpyHostToDevice));
+    MI_HIP(hipMemcpy(const_cast<double *>(A->halo_cur()), halo_rows_host, rows * (size_t)p * sizeof(double), hipMemcpyHostToDevice));
   return MI_OK;
 }
 

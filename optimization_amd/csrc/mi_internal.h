@@ -324,6 +324,15 @@ struct mi_csr {
   // offset on every rank); peer_lo_rows = halo_lo of rank-1 (our first rows land behind them there)
   bool halo_in_arena = false;
   size_t halo_off = 0, peer_lo_rows = 0;
+  // The halo storage holds TWO buffers of halo_stride doubles; exchange number e of this matrix lands in
+  // buffer e & 1.  A peer-store push only waits for the neighbour's PUSH of the same exchange, not for the
+  // neighbour's kernels that read the halo afterwards, so with one buffer a fast rank's next push could
+  // overwrite rows a slow rank is still reading (two sharded SpMMs back to back, no scalar exchange in between:
+  // seen once in ~60 runs of tests/ipc_worker.py).  With two, a rank would have to be two pushes ahead, which
+  // the flag wait of the push in between rules out.
+  size_t halo_stride = 0;
+  mutable unsigned long long halo_exchanges = 0;
+  const double *halo_cur() const { return halo ? halo + (halo_exchanges & 1) * halo_stride : nullptr; }
 };
 
 namespace mi {

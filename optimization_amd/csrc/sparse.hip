@@ -287,8 +287,8 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   MI_TRY(comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi, &A->peer_lo_rows,
                                    &max_halo_rows));
   // same size on every rank, so that the arena offsets of the peer-memory layer agree
-  MI_TRY(comm_halo_alloc(ctx, std::max<size_t>(1, max_halo_rows * 4) * sizeof(double), &A->halo, &A->halo_in_arena,
-                         &A->halo_off));
+  A->halo_stride = std::max<size_t>(1, max_halo_rows * 4);  // doubles per buffer (p <= 4); two buffers
+  MI_TRY(comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo, &A->halo_in_arena, &A->halo_off));
   MI_REQUIRE(A->send_lo <= n && A->send_hi <= n, "neighbour halo request exceeds local rows");
   *out = A;
   return MI_OK;

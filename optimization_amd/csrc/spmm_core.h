@@ -16,7 +16,7 @@ struct SellView {
 };
 
 inline SellView sell_view(const mi_csr *A) {
-  return SellView{A->n, A->nslices, A->slice_ptr, A->col, A->val, A->halo, A->pk, A->vtab};
+  return SellView{A->n, A->nslices, A->slice_ptr, A->col, A->val, A->halo_cur(), A->pk, A->vtab};
 }
 
 #ifndef MI_SPMM_CHUNK

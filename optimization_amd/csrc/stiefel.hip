@@ -392,8 +392,8 @@ int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, con
                      const double *X, const double *S, double *Z, int *count) {
   const size_t ngroups = sell_groups(A);
   const int grid = uniform_grid(ngroups);
-  SellView view = sell_view(A);
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
+  SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
   DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
                                    X, S, Z, ctx->partials2));
@@ -482,12 +482,12 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   static const int cap = [] { const char *e = getenv("MI355OPT_HESS_GRID"); return e ? atoi(e) : 256; }();
   int grid = uniform_grid(sell_groups(A));
   if (!g_uniform_grid && grid > cap) grid = cap;
-  SellView view = sell_view(A);
   double *slots = ctx->scalars + SLOT_GRAM;
   const bool recur = gram_count < 0;
   const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
+  SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   if (!recur) {
     if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
     if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
