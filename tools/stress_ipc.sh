@@ -1,5 +1,7 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
+# Loops the 2- and 3-rank peer-memory worker (tests/ipc_worker.py) on one GPU and prints every run whose sharded
+# products / solves disagree with the single-process references.  Usage (GPU box): bash tools/stress_ipc.sh
+cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 fails=0
 for i in $(seq 1 16); do
   for w in 2 3; do
