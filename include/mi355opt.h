@@ -80,6 +80,11 @@ MI_API int mi_ktime_reset(mi_ctx *ctx);
 /* sync: resolves recorded event pairs; returns launches and total milliseconds for kernel_id */
 MI_API int mi_ktime_read(mi_ctx *ctx, int kernel_id, size_t *launches, double *total_ms);
 MI_API const char *mi_kernel_name(int kernel_id);
+/* Profiler ranges (SURVEY.md 8(b) group 9): roctx markers, visible to `rocprofv3 --marker-trace`.  The library
+ * brackets its own solves (mi_stpcg, mi_lsqr) with ranges of those names; callers may nest their own (e.g. one per
+ * TNT outer iteration, TNT.h:436-683).  No-ops (still MI_OK) when no ROCTx library (rocprofiler-sdk-roctx, else roctracer's libroctx64) is installed. */
+MI_API int mi_range_push(const char *name);
+MI_API int mi_range_pop(void);
 MI_API int mi_timer_start(mi_ctx *ctx);             /* records an event on the stream */
 MI_API int mi_timer_stop(mi_ctx *ctx, double *ms);  /* sync: records, waits, returns elapsed ms */
 

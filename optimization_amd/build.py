@@ -23,7 +23,7 @@ CFLAGS = [
     "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", "/opt/rocm/include",
 ]
 CFLAGS += os.environ.get("MI355OPT_EXTRA_CFLAGS", "").split()  # experiments (e.g. -DMI_SPMM_CHUNK=8)
-LDFLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
+LDFLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
 
 
 def _newer(src, dst, deps):

@@ -96,6 +96,8 @@ def load():
         "mi_ktime_enable": [vp, C.c_int, C.c_int],
         "mi_ktime_reset": [vp],
         "mi_ktime_read": [vp, C.c_int, c_size_p, c_double_p],
+        "mi_range_push": [C.c_char_p],
+        "mi_range_pop": [],
         "mi_timer_start": [vp],
         "mi_timer_stop": [vp, c_double_p],
         "mi_vec_create": [vp, C.c_size_t, C.POINTER(vp)],
@@ -259,6 +261,12 @@ class Context:
         ms = C.c_double(0)
         check(self.L.mi_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+    def range_push(self, name):
+        check(self.L.mi_range_push(name.encode()))
+
+    def range_pop(self):
+        check(self.L.mi_range_pop())
 
     def ktime_enable(self, name, on=True):
         check(self.L.mi_ktime_enable(self.h, KID[name], int(on)))

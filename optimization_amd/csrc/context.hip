@@ -1,6 +1,8 @@
 // context.hip -- context, stream, pooled allocator, event timing, error reporting.
 #include "mi_internal.h"
 
+#include <dlfcn.h>
+
 namespace mi {
 
 static thread_local char g_err[1024] = "";
@@ -277,6 +279,39 @@ int mi_ktime_read(mi_ctx *ctx, int id, size_t *launches, double *total_ms) {
   MI_TRY(ktime_resolve(ctx, id));
   if (launches) *launches = ctx->ktime[id].launches;
   if (total_ms) *total_ms = ctx->ktime[id].total_ms;
+  return MI_OK;
+}
+
+namespace {
+// roctx is looked up at run time: the library must load (and time nothing) where the tracer is absent
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    // rocprofv3 traces the markers of rocprofiler-sdk's ROCTx; the roctracer one (libroctx64) is the fallback
+    void *h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
+
+int mi_range_push(const char *name) {
+  MI_REQUIRE(name, "range name is null");
+  if (roctx().push) (void)roctx().push(name);
+  return MI_OK;
+}
+
+int mi_range_pop(void) {
+  if (roctx().pop) (void)roctx().pop();
   return MI_OK;
 }
 

@@ -170,6 +170,12 @@ inline int grid_for(size_t n, int per_thread) {
   return (int)blocks;
 }
 
+// Profiler range (roctx) for the lifetime of the object: one per solve
+struct RangeScope {
+  explicit RangeScope(const char *name) { (void)mi_range_push(name); }
+  ~RangeScope() { (void)mi_range_pop(); }
+};
+
 // Kernel-timing scope: brackets a launch with an event pair when enabled for `id`.
 struct KScope {
   mi_ctx *ctx;

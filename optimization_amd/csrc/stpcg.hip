@@ -685,6 +685,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
              "Relative norm tolerance for declaring a vector to lie in the kernel of H (epsilon) "
              "should be a small positive number in the range (0,1)");
 
+  RangeScope range("mi_stpcg");
   const size_t n = g->n;
   const int pre = !P ? PRE_NONE : (P->kind == 1 ? PRE_DIAG : (P->kind == 2 ? PRE_BLOCK3 : PRE_EXTERNAL));
   MI_REQUIRE(pre != PRE_BLOCK3 || n % 3 == 0, "block-Jacobi preconditioner needs n divisible by 3");

@@ -241,3 +241,15 @@ def test_stpcg_run_ahead_invariance(ctx):
             base = cur
         else:
             assert cur[0] == base[0] and cur[1] == base[1] and np.array_equal(cur[2], base[2])
+
+
+def test_profiler_ranges_nest_around_a_solve(ctx):
+    """mi_range_push/pop (roctx markers, SURVEY 8(b) group 9) are callable around and inside a solve; the solve
+    itself opens a range named mi_stpcg (checked with rocprofv3 --marker-trace in profiles/)."""
+    n = 4096
+    D = np.linspace(1.0, 9.0, n)
+    g = np.sin(np.arange(n, dtype=np.float64))
+    ctx.range_push("outer iteration")
+    r = ctx.stpcg(ctx.upload(g), ctx.op_diag(ctx.upload(D)), Delta=1e9, max_iterations=40, kappa_fgr=1e-10, theta=1.0)
+    ctx.range_pop()
+    assert np.abs(r["s"].numpy() + g / D).max() < 1e-8
