@@ -470,6 +470,44 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor(size_t n, size_t nslices,
   }
 }
 
+// The same product from the value-indexed packed copy of the matrix (mi_csr::pk: one dword per entry,
+// (col - row) << 8 | value index): a third of the matrix bytes per pass, which makes NARROW column chunks
+// affordable -- and narrow chunks are what keeps the gathered windows of X (KC columns x the rows a stencil
+// reaches, two grid planes for the 7-point operator) inside an XCD's 4 MB L2.
+template <int KC>
+__global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslices, const long long *__restrict__ sp,
+                                                          const uint32_t *__restrict__ pk,
+                                                          const double *__restrict__ vtab, int k, int c0,
+                                                          const double *__restrict__ X, double *__restrict__ Y) {
+  __shared__ double vt[256];
+  vt[threadIdx.x] = vtab[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t slice = (size_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const size_t row = slice * 64 + lane;
+  double acc[KC];
+  const double *xc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    acc[c] = 0;
+    xc[c] = X + (size_t)std::min(c0 + c, k - 1) * n;
+  }
+  const long long b0 = sp[slice], b1 = sp[slice + 1];
+  for (long long kk = b0; kk < b1; ++kk) {
+    const uint32_t w = __builtin_nontemporal_load(pk + (size_t)kk * 64 + lane);
+    const double a = vt[w & 255u];
+    const size_t j = (size_t)((long long)row + (long long)((int32_t)w >> 8));
+#pragma unroll
+    for (int c = 0; c < KC; ++c) acc[c] += a * xc[c][j];
+  }
+  if (row < n) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+      if (c0 + c < k) __builtin_nontemporal_store(acc[c], Y + (size_t)(c0 + c) * n + row);
+  }
+}
+
 // Y[r, c] = d[r] X[r, c]  (diagonal operators of the reference's LOBPCG tests, tests/LOBPCG_unit_test.cpp:56-74)
 __global__ __launch_bounds__(256) void k_rowscale(size_t m, size_t k, const double *__restrict__ d,
                                                   const double *__restrict__ X, double *__restrict__ Y) {
@@ -900,6 +938,25 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   mi_ctx *ctx = A->ctx;
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
+  if (A->pk) {
+    static const int chunk = [] { const char *e = getenv("MI355OPT_SPMM_PK_CHUNK"); return e ? atoi(e) : 24; }();
+    for (int c0 = 0; c0 < k;) {
+      const int left = k - c0;
+#define SPMMPK(KC)                                                                                            \
+  hipLaunchKernelGGL(k_spmm_colmajor_pk<KC>, dim3(grid), dim3(256), 0, ctx->stream, A->n, A->nslices,         \
+                     (const long long *)A->slice_ptr, (const uint32_t *)A->pk, (const double *)A->vtab, k,    \
+                     c0, (const double *)X->d, Y->d)
+      const int want = std::min(left, chunk);
+      if (want > 16) { SPMMPK(24); c0 += 24; }
+      else if (want > 8) { SPMMPK(16); c0 += 16; }
+      else if (want > 4) { SPMMPK(8); c0 += 8; }
+      else if (want > 2) { SPMMPK(4); c0 += 4; }
+      else { SPMMPK(2); c0 += 2; }
+#undef SPMMPK
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   for (int c0 = 0; c0 < k;) {
     const int left = k - c0;
 #define SPMM(KC)                                                                                             \
