@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Column-major SpMM (LOBPCG panel product) at cfg5 size: time per 24 columns; MI355OPT_SPMM_PK_CHUNK / MI355OPT_NO_PACKED select the variant."""
 import os, sys, time, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from optimization_amd import capi, workloads as wl
 ctx = capi.Context(0)
