@@ -5,6 +5,7 @@
 // Algorithmic bytes: 12*nnz + 4*(n+1) + 16*n*p.
 #include "spmm_core.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -32,6 +33,36 @@ __global__ __launch_bounds__(kBlock) void k_spmm(SellView A, const double *__res
       for (int c = 0; c < P; ++c) W[row * P + c] = acc[c];
     }
   }
+}
+
+// The same product on the lean pipelined core (spmm_core.h sell_stream): 32-bit offsets, one workgroup per CU,
+// the matrix from its value-indexed packed copy when it has one.  Same per-row arithmetic as k_spmm (bit-identical
+// results); used whenever the fields span < 4 GiB.
+template <int P, bool HALO, bool PK>
+__global__ __launch_bounds__(kBlock) void k_spmm_stream(SellView A, const double *__restrict__ V,
+                                                        double *__restrict__ W) {
+  __shared__ double vt[PK ? 256 : 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) {
+    if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
+    __syncthreads();
+  }
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  struct Epi {
+    const SellView &A;
+    double *__restrict__ W;
+    int lane;
+    __device__ __forceinline__ void begin(size_t) {}
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
+      if (slice * 64 + lane >= A.n) return;
+      double *ws = reinterpret_cast<double *>(reinterpret_cast<char *>(W + slice * 64 * P) +
+                                              (unsigned)lane * (unsigned)(P * 8));
+#pragma unroll
+      for (int c = 0; c < P; ++c) ws[c] = acc[c];
+    }
+  } epi{A, W, lane};
+  sell_stream<P, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
 }
 
 // W = A V - s W (p = 1) and this workgroup's partial of |W|^2: LSQR's `u = A v - alpha u` / `v = A'u - beta v`
@@ -165,6 +196,25 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
   const int grid = (int)std::min<size_t>(ngroups, kMaxGrid);
   SellView view = sell_view(A);
   KScope ks(ctx, MI_K_SPMM);
+  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  if (!no_stream && p >= 1 && p <= 4 && sell_stream_ok(A, p)) {
+    const int sgrid = (int)std::min<size_t>(ngroups, 256);  // one workgroup per CU, one round
+#define SS(PV, HL, PKV) \
+  hipLaunchKernelGGL((k_spmm_stream<PV, HL, PKV>), dim3(sgrid), dim3(kBlock), 0, ctx->stream, view, V, W)
+#define SSP(PV)                                                 \
+  if (A->halo) { if (A->pk) SS(PV, true, true); else SS(PV, true, false); } \
+  else { if (A->pk) SS(PV, false, true); else SS(PV, false, false); }
+    switch (p) {
+      case 1: SSP(1); break;
+      case 2: SSP(2); break;
+      case 3: SSP(3); break;
+      default: SSP(4); break;
+    }
+#undef SSP
+#undef SS
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   switch (p) {
     case 1: hipLaunchKernelGGL(k_spmm<1>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
     case 2: hipLaunchKernelGGL(k_spmm<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;

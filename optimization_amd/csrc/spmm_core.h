@@ -70,7 +70,7 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
 //   * 32-bit byte offsets from scalar bases (global_load with saddr) instead of 64-bit multiply-adds per
 //     gathered entry: the caller guarantees that V, the halo, the value and the column arrays each span
 //     < 4 GiB (sell_stream_ok);
-//   * predication once per entry (the VALUE is zeroed), then one fma per component;
+//   * predication once per entry (the VALUE is zeroed), then one multiply and one add per component;
 //   * HALO is a template flag, so unsharded matrices carry no column-range select;
 //   * the value/column operands of the NEXT chunk -- of this slice or of the wave's next slice -- are
 //     requested right after the current chunk's gathers (unconditionally: behind a branch the compiler can no
@@ -167,7 +167,13 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
     for (int j = 0; j < CH; ++j) {
       const double aj = (k + j < b1) ? a[j] : 0.0;
 #pragma unroll
-      for (int c = 0; c < P; ++c) acc[c] = __builtin_fma(aj, g[j][c], acc[c]);
+      for (int c = 0; c < P; ++c) {
+        // product and sum rounded separately, entry by entry in storage order: bit-identical to a plain CSR
+        // loop on the host (the checks of the sharded products rely on that)
+#pragma clang fp contract(off)
+        const double t = aj * g[j][c];
+        acc[c] = acc[c] + t;
+      }
     }
     if (row_done) {
       epi.end(slice, acc);
