@@ -101,6 +101,49 @@ int upload(void **dst, const void *src, size_t bytes) {
   return MI_OK;
 }
 
+// The same on the lean pipelined core (packed matrix when there is one)
+template <bool HALO, bool PK>
+__global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled_stream(SellView A, const double *__restrict__ V,
+                                                                   const double *__restrict__ scale,
+                                                                   const int *__restrict__ mode,
+                                                                   const int *__restrict__ gate,
+                                                                   double *__restrict__ W,
+                                                                   double *__restrict__ partials) {
+  __shared__ double lds[kWaves + 1];
+  __shared__ double vt[PK ? 256 : 1];
+  if (*mode != 0 || (gate && !*gate)) return;
+  const double sc = *scale;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) {
+    if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
+    __syncthreads();
+  }
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  double a[1] = {0};
+  struct Epi {
+    const SellView &A;
+    double *__restrict__ W;
+    double sc;
+    double (&a)[1];
+    int lane;
+    double wold;
+    __device__ __forceinline__ void begin(size_t slice) {
+      const size_t row = slice * 64 + lane;
+      wold = W[row < A.n ? row : slice * 64];
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[1]) {
+      const size_t row = slice * 64 + lane;
+      if (row >= A.n) return;
+      const double out = acc[0] - sc * wold;
+      W[row] = out;
+      a[0] += out * out;
+    }
+  } epi{A, W, sc, a, lane, 0.0};
+  sell_stream<1, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
+  block_partials_store<1>(a, lds, partials);
+}
+
 // Build the sliced-ELL image on the host from CSR with LOCAL column indices.
 int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *rowptr,
                const int32_t *col, const double *val, mi_csr **out) {
@@ -230,10 +273,21 @@ int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, c
                         mi_vec *W, double *partials, int *nparts) {
   mi_ctx *ctx = A->ctx;
   MI_TRY(comm_halo_exchange(ctx, A, 1, V->d));
-  const int grid = uniform_grid(sell_groups(A));
+  int grid = uniform_grid(sell_groups(A));
   KScope ks(ctx, MI_K_SPMM);
-  hipLaunchKernelGGL(k_spmv_sub_scaled, dim3(grid), dim3(kBlock), 0, ctx->stream, sell_view(A), (const double *)V->d,
-                     scale, mode, gate, W->d, partials);
+  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  if (!no_stream && sell_stream_ok(A, 1)) {
+    if (!g_uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
+#define SV(HL, PKV)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_sub_scaled_stream<HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, sell_view(A), \
+                     (const double *)V->d, scale, mode, gate, W->d, partials)
+    if (A->halo) { if (A->pk) SV(true, true); else SV(true, false); }
+    else { if (A->pk) SV(false, true); else SV(false, false); }
+#undef SV
+  } else {
+    hipLaunchKernelGGL(k_spmv_sub_scaled, dim3(grid), dim3(kBlock), 0, ctx->stream, sell_view(A),
+                       (const double *)V->d, scale, mode, gate, W->d, partials);
+  }
   *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
