@@ -123,6 +123,69 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
 // M = sym(X'(A V - V S)) is known before the pass: for symmetric A it equals sym(Y'V - (X'V) S) with
 // Y = A X fixed during the inner solve, and STPCG's direction kernel left its partial rows when it formed
 // V (mi_op::dirgram).  So no second pass over Z, X, V is needed (k_st_finish: 8 (4N) bytes saved).
+// k_st_spmm_gram on the lean pipelined core (packed matrix when there is one); same arithmetic per row
+template <int P, bool HALO, bool PK>
+__global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, const CgState *__restrict__ st,
+                                                                const double *__restrict__ V,
+                                                                const double *__restrict__ X,
+                                                                const double *__restrict__ S,
+                                                                double *__restrict__ Z,
+                                                                double *__restrict__ partials) {
+  __shared__ double lds[SymIdx<P>::NS * kWaves];
+  __shared__ double vt[PK ? 256 : 1];
+  if (st && st->mode != CG_RUN) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) {
+    if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
+    __syncthreads();
+  }
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  double Sm[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) Sm[i] = S ? S[i] : 0.0;
+  double G[P * P];
+#pragma unroll
+  for (int i = 0; i < P * P; ++i) G[i] = 0;
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ X, *__restrict__ V;
+    double *__restrict__ Z;
+    const double (&Sm)[P * P];
+    double (&G)[P * P];
+    int lane;
+    double x[P], v[P];
+    __device__ __forceinline__ unsigned lane_off(size_t slice) const {
+      return (slice * 64 + lane < A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+    }
+    __device__ __forceinline__ void begin(size_t slice) {
+      const unsigned off = lane_off(slice);
+      const double *xs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(X + slice * 64 * P) + off);
+      const double *vs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(V + slice * 64 * P) + off);
+#pragma unroll
+      for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; }
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
+      if (slice * 64 + lane >= A.n) return;
+      double *zs = reinterpret_cast<double *>(reinterpret_cast<char *>(Z + slice * 64 * P) + lane_off(slice));
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) t += v[a] * Sm[a * P + b];
+        acc[b] -= t;
+        zs[b] = acc[b];
+      }
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * acc[b];
+    }
+  } epi{A, X, V, Z, Sm, G, lane, {}, {}};
+  sell_stream<P, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
+  store_sym_partials<P>(G, lds, partials);
+}
+
 // RECUR (mi_op::apply_dir with gram_count < 0): M is read from gdir (packed symmetric, replicated scalars kept
 // by STPCG) and the packed symmetric Gram  sym(Y'out - (X'out) S)  of the OUTPUT rides along as components
 // 3.. of the partial row (DirComps<P>::value components in all).
@@ -391,12 +454,23 @@ int sharded_reduce(mi_ctx *ctx, int count, int k, double *slots) {
 int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, const double *V,
                      const double *X, const double *S, double *Z, int *count) {
   const size_t ngroups = sell_groups(A);
-  const int grid = uniform_grid(ngroups);
+  int grid = uniform_grid(ngroups);
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
-  DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
-                                   X, S, Z, ctx->partials2));
+  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  if (!no_stream && sell_stream_ok(A, p)) {
+    if (!g_uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
+#define SG(HL, PKV)                                                                                            \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_spmm_gram_stream<P, HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
+                                   view, st, V, X, S, Z, ctx->partials2))
+    if (A->halo) { if (A->pk) { SG(true, true); } else { SG(true, false); } }
+    else { if (A->pk) { SG(false, true); } else { SG(false, false); } }
+#undef SG
+  } else {
+    DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
+                                     X, S, Z, ctx->partials2));
+  }
   *count = grid;
   return MI_OK;
 }
