@@ -314,8 +314,8 @@ struct mi_csr {
   long long *slice_ptr = nullptr;  // device, nslices + 1
   int *col = nullptr;              // device, padded
   double *val = nullptr;           // device, padded
-  // Value-indexed packed copy (lossless; built when the matrix has <= 256 distinct stored values and
-  // n + halo < 2^23): entry = (col - row) << 8 | index into vtab.  4 bytes per stored entry instead of 12:
+  // Value-indexed packed copy (lossless; built when the matrix has <= 256 distinct stored values and every
+  // stored column lies within +-2^23 of its row): entry = (col - row) << 8 | index into vtab.  4 bytes per stored entry instead of 12:
   // stencil / unit-weight Laplacian operators stream a third of the bytes (spmm_core.h sell_stream<.,.,true>).
   uint32_t *pk = nullptr;          // device, padded (null: not representable)
   double *vtab = nullptr;          // device, 256 doubles

@@ -190,7 +190,7 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
   // value-indexed packed copy (mi_csr::pk): distinct stored values by BIT PATTERN (so -0.0, NaN payloads
   // and denormals survive), column as a signed 24-bit offset from the row
   static const bool no_pack = [] { const char *e = getenv("MI355OPT_NO_PACKED"); return e && e[0] == '1'; }();
-  if (!no_pack && ncols + 64 < ((size_t)1 << 23)) {
+  if (!no_pack) {
     std::unordered_map<uint64_t, int> index;
     std::vector<double> table;
     std::vector<uint32_t> pk(stored, 0u);
@@ -211,13 +211,16 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
       pk[e] = (uint32_t)vi;  // column part filled below, slice by slice
     }
     if (ok) {
-      for (size_t sl = 0; sl < nslices; ++sl)
+      for (size_t sl = 0; sl < nslices && ok; ++sl)
         for (long long k = sp[sl]; k < sp[sl + 1]; ++k)
           for (int lane = 0; lane < 64; ++lane) {
             const size_t e = (size_t)k * 64 + lane;
             const long long delta = (long long)pcol[e] - (long long)(sl * 64 + lane);
+            if (delta < -(1LL << 23) || delta >= (1LL << 23)) ok = false;  // 24-bit signed column offset
             pk[e] |= (uint32_t)((int32_t)delta) << 8;
           }
+    }
+    if (ok) {
       table.resize(256, 0.0);
       MI_TRY(upload((void **)&A->pk, pk.data(), stored * sizeof(uint32_t)));
       MI_TRY(upload((void **)&A->vtab, table.data(), 256 * sizeof(double)));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-pass vs two-pass Stiefel Hessian inside STPCG on an nx^3 grid (default 200^3 = 8e6 rows, beyond the Infinity Cache; 205^3 exceeds the 2^23-column limit of the packed matrix copy): agreement of the iterates and time per step."""
+"""One-pass vs two-pass Stiefel Hessian inside STPCG on an nx^3 grid (default 200^3 = 8e6 rows, beyond the Infinity Cache): agreement of the iterates and time per step."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
