@@ -345,6 +345,8 @@ namespace mi {
 // W = A V - (*scale) W with partials of |W|^2 (p = 1): see mi_op::apply_sub_scaled
 int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, const int *mode, const int *gate,
                         mi_vec *W, double *partials, int *nparts);
+// W = A V with the curvature partials <V,W>, <W,W>, <V,V> in ctx->partials (see mi_op::apply_dots)
+int csr_spmm_dots(const mi_csr *A, int p, const mi_vec *V, mi_vec *W, int *nparts, bool *unsupported);
 // In-stream halo exchange of the n x p field V into A->halo (no-op when not sharded).
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V);
 int comm_exchange_halo_counts(mi_ctx *ctx, size_t need_lo, size_t need_hi, size_t *send_lo,

@@ -75,6 +75,14 @@ int op_csr_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
   CsrOpImpl *c = (CsrOpImpl *)self->impl;
   return mi_csr_spmm(c->A, c->p, in, out);
 }
+int op_csr_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
+  CsrOpImpl *c = (CsrOpImpl *)self->impl;
+  bool unsupported = false;
+  MI_TRY(csr_spmm_dots(c->A, c->p, in, out, nparts, &unsupported));
+  if (!unsupported) return MI_OK;
+  MI_TRY(mi_csr_spmm(c->A, c->p, in, out));  // fields of 4 GiB or more: product, then the generic dot kernel
+  return launch_dot3_partials(self->ctx, in->n, in->d, out->d, nparts);
+}
 int op_csr_apply_sub_scaled(mi_op *self, const mi_vec *in, const double *scale, const int *mode, const int *gate,
                             mi_vec *inout, double *partials, int *nparts) {
   CsrOpImpl *c = (CsrOpImpl *)self->impl;
@@ -159,6 +167,7 @@ int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out) {
   op->ctx = ctx;
   op->n = n * (size_t)p;
   op->apply = op_csr_apply;
+  op->apply_dots = op_csr_apply_dots;
   if (p == 1) op->apply_sub_scaled = op_csr_apply_sub_scaled;
   op->destroy = op_csr_destroy;
   op->impl = new CsrOpImpl{A, p};

@@ -65,6 +65,53 @@ __global__ __launch_bounds__(kBlock) void k_spmm_stream(SellView A, const double
   sell_stream<P, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
 }
 
+// W = A V with the three curvature partials of STPCG, <V,W>, <W,W>, <V,V> (IterativeSolvers.h:300,305-306), in the
+// product's own pass: a plain CSR Hessian then needs no separate dot kernel (2N doubles re-read) per iteration
+template <int P, bool HALO, bool PK>
+__global__ __launch_bounds__(kBlock) void k_spmm_dots_stream(SellView A, const CgState *__restrict__ st,
+                                                             const double *__restrict__ V, double *__restrict__ W,
+                                                             double *__restrict__ partials) {
+  __shared__ double lds[3 * kWaves];
+  __shared__ double vt[PK ? 256 : 1];
+  if (st && st->mode != CG_RUN) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) {
+    if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
+    __syncthreads();
+  }
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  double a[3] = {0, 0, 0};
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ V;
+    double *__restrict__ W;
+    double (&a)[3];
+    int lane;
+    double v[P];
+    __device__ __forceinline__ unsigned lane_off(size_t slice) const {
+      return (slice * 64 + lane < A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+    }
+    __device__ __forceinline__ void begin(size_t slice) {
+      const double *vs = reinterpret_cast<const double *>(reinterpret_cast<const char *>(V + slice * 64 * P) +
+                                                          lane_off(slice));
+#pragma unroll
+      for (int c = 0; c < P; ++c) v[c] = vs[c];
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
+      if (slice * 64 + lane >= A.n) return;
+      double *ws = reinterpret_cast<double *>(reinterpret_cast<char *>(W + slice * 64 * P) + lane_off(slice));
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        ws[c] = acc[c];
+        a[0] += v[c] * acc[c]; a[1] += acc[c] * acc[c]; a[2] += v[c] * v[c];
+      }
+    }
+  } epi{A, V, W, a, lane, {}};
+  sell_stream<P, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
+  block_partials_store<3>(a, lds, partials);
+}
+
 // W = A V - s W (p = 1) and this workgroup's partial of |W|^2: LSQR's `u = A v - alpha u` / `v = A'u - beta v`
 // with the norm for the following normalisation, in the SpMV's own pass
 __global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled(SellView A, const double *__restrict__ V,
@@ -268,6 +315,37 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
     case 4: hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
     default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT;
   }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// W = A V + curvature partials into ctx->partials (mi_op::apply_dots of the CSR operator); MI_ERR_INTERNAL-free
+// fallback: returns 1 in *unsupported when the pipelined core cannot address the fields (the caller then uses
+// the product + k_cg_dot3)
+int csr_spmm_dots(const mi_csr *A, int p, const mi_vec *V, mi_vec *W, int *nparts, bool *unsupported) {
+  mi_ctx *ctx = A->ctx;
+  *unsupported = !(p >= 1 && p <= 4 && sell_stream_ok(A, p)) || A->n == 0;
+  if (*unsupported) return MI_OK;
+  MI_TRY(comm_halo_exchange(ctx, A, p, V->d));
+  int grid = uniform_grid(sell_groups(A));
+  if (!g_uniform_grid && grid > 256) grid = 256;
+  SellView view = sell_view(A);
+  KScope ks(ctx, MI_K_SPMM);
+#define SD(PV, HL, PKV)                                                                                       \
+  hipLaunchKernelGGL((k_spmm_dots_stream<PV, HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, view,       \
+                     (const CgState *)ctx->cg_live, (const double *)V->d, W->d, ctx->partials)
+#define SDP(PV)                                                                     \
+  if (A->halo) { if (A->pk) SD(PV, true, true); else SD(PV, true, false); }         \
+  else { if (A->pk) SD(PV, false, true); else SD(PV, false, false); }
+  switch (p) {
+    case 1: SDP(1); break;
+    case 2: SDP(2); break;
+    case 3: SDP(3); break;
+    default: SDP(4); break;
+  }
+#undef SDP
+#undef SD
+  *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
