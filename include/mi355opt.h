@@ -273,6 +273,11 @@ MI_API int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S
 /* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
 MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
                             const double *C_host, int ldc, mi_vec *Y);
+/* The same with two destinations: output columns [0, k1) -> Y (m x k1), [k1, kc) -> Y2 (m x (kc - k1)).  Lets the
+ * LOBPCG loop write X and P (LOBPCG.h:278,288) straight into the first and third block of the NEXT search basis
+ * instead of copying them there (:254-259). */
+MI_API int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const double *C_host, int ldc,
+                             mi_vec *Y, int k1, mi_vec *Y2);
 /* R = AX - BX diag(theta); rnorm[j] = |R_j|, xnorm[j] = |X_j| (host, sync) -- LOBPCG.h:230,285,293,302 */
 MI_API int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi_vec *BX,
                               const mi_vec *X, const double *theta_host, mi_vec *R, double *rnorm,

@@ -148,6 +148,7 @@ def load():
         "mi_so3n_retract": [vp, vp, vp, vp],
         "mi_lobpcg_gram": [vp, C.c_size_t, C.c_int, C.c_int, vp, vp, c_double_p],
         "mi_lobpcg_update": [vp, C.c_size_t, C.c_int, C.c_int, vp, c_double_p, C.c_int, vp],
+        "mi_lobpcg_update2": [vp, C.c_size_t, C.c_int, C.c_int, vp, c_double_p, C.c_int, vp, C.c_int, vp],
         "mi_lobpcg_residual": [vp, C.c_size_t, C.c_int, vp, vp, vp, c_double_p, vp, c_double_p,
                                c_double_p],
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],

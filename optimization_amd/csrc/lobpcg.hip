@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
 template <int KC>
 __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const double *__restrict__ S,
                                                       const double *__restrict__ Ct, int c0, int kc,
-                                                      double *__restrict__ Y) {
+                                                      double *__restrict__ Y, int k1, double *__restrict__ Y2) {
   const double *__restrict__ smem = Ct;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
@@ -397,9 +397,14 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
 #pragma unroll
       for (int c = 0; c < KC; ++c) acc[c] += sv * cr[c];
     }
+    // output columns [0, k1) go to Y, [k1, kc) to Y2 (two-destination form; k1 == kc: one panel)
 #pragma unroll
     for (int c = 0; c < KC; ++c)
-      if (c0 + c < kc) Y[(size_t)(c0 + c) * m + r] = acc[c];
+      if (c0 + c < kc) {
+        const int col = c0 + c;
+        if (col < k1) Y[(size_t)col * m + r] = acc[c];
+        else Y2[(size_t)(col - k1) * m + r] = acc[c];
+      }
   }
 }
 
@@ -786,11 +791,27 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
 
 int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const double *C_host, int ldc,
                      mi_vec *Y) {
+  return mi_lobpcg_update2(ctx, m, ks, kc, S, C_host, ldc, Y, kc, nullptr);
+}
+
+int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const double *C_host, int ldc,
+                      mi_vec *Y, int k1, mi_vec *Y2) {
   MI_REQUIRE(ctx && C_host, "null argument");
   MI_REQUIRE(ks >= 1 && ks <= kGramMaxK && kc >= 1 && kc <= kGramMaxK && ldc >= ks, "bad small-matrix shape");
+  MI_REQUIRE(k1 >= 1 && k1 <= kc && (k1 == kc || Y2), "bad split of the output columns");
   MI_TRY(check_panel(ctx, m, ks, S, "S"));
-  MI_TRY(check_panel(ctx, m, kc, Y, "Y"));
-  MI_REQUIRE(S->d != Y->d, "in-place panel update is not supported");
+  MI_TRY(check_panel(ctx, m, k1, Y, "Y"));
+  if (k1 < kc) MI_TRY(check_panel(ctx, m, kc - k1, Y2, "Y2"));
+  {  // neither destination may overlap the basis: the update reads S while other rows' results are written
+    const double *s0 = S->d, *s1 = S->d + (size_t)ks * m;
+    const double *y0 = Y->d, *y1 = Y->d + (size_t)k1 * m;
+    MI_REQUIRE(y1 <= s0 || y0 >= s1, "in-place panel update is not supported");
+    if (k1 < kc) {
+      const double *z0 = Y2->d, *z1 = Y2->d + (size_t)(kc - k1) * m;
+      MI_REQUIRE(z1 <= s0 || z0 >= s1, "in-place panel update is not supported");
+      MI_REQUIRE(z1 <= y0 || z0 >= y1, "the two destination panels overlap");
+    }
+  }
   // chunk plan (widest chunk that fits what is left: one pass over S per chunk) and the chunks'
   // coefficient blocks, each ks x KC row-major by s, zero-padded past kc, packed back to back
   struct Chunk { int c0, width; size_t off; };
@@ -817,7 +838,7 @@ int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, con
   for (const Chunk &ch : chunks) {
 #define UPD(KC)                                                                                       \
   hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), 0, ctx->stream, m, ks, (const double *)S->d, \
-                     (const double *)Cdev + ch.off, ch.c0, kc, Y->d)
+                     (const double *)Cdev + ch.off, ch.c0, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr)
     switch (ch.width) {
       case 48: UPD(48); break;
       case 24: UPD(24); break;

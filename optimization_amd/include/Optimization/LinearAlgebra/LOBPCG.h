@@ -73,7 +73,12 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
 
   Matrix X = X0;  // :162
   Matrix AX, BX, R, W, P;
-  Matrix S = empty_panel(X0, m, 3 * nx);  // search basis [X, W, P], allocated at full width  :185
+  // search basis [X, W, P], allocated at full width (:185) -- twice: iteration k reads one panel and writes the
+  // X, R and P of iteration k+1 straight into the blocks of the other, so that while no pair is locked (nc == 0,
+  // no preconditioner) the column copies of :254-259 disappear (2.3 GB per iteration at cfg5)
+  Matrix Sa = empty_panel(X0, m, 3 * nx), Sb = empty_panel(X0, m, 3 * nx);
+  Matrix *Scur = &Sa, *Snext = &Sb;
+  bool in_basis = false;  // X, R, P are views of *Scur's blocks 0, 1, 2
   Vector Theta, r, xnorm;
   size_t ns = 0;
 
@@ -102,10 +107,28 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
     if (T) W = (*T)(R);  // preconditioned residuals (T absent: W is R itself, no copy)   :247
 
     // S = [X, W(not converged), P(not converged)]  (soft locking drops the FIRST nc columns)  :254-264
-    S.set_cols(0, X, 0, nx);
-    S.set_cols(nx, T ? W : R, nc, nx - nc);
+    Matrix &S = *Scur;
+    const bool in_place = in_basis && nc == 0;  // [X | R | P] already sit where the basis wants them
+    if (!in_basis) S.set_cols(0, X, 0, nx);
+    if (T) {
+      S.set_cols(nx, W, nc, nx - nc);
+    } else if (!in_place) {
+      if (in_basis) {  // R is a view of S itself: shift its unlocked columns through a copy
+        const Matrix Rc = R;
+        S.set_cols(nx, Rc, nc, nx - nc);
+      } else {
+        S.set_cols(nx, R, nc, nx - nc);
+      }
+    }
     if (num_iters > 1) {
-      S.set_cols(2 * nx - nc, P, nc, nx - nc);
+      if (!in_place) {
+        if (in_basis) {
+          const Matrix Pc = P;
+          S.set_cols(2 * nx - nc, Pc, nc, nx - nc);
+        } else {
+          S.set_cols(2 * nx - nc, P, nc, nx - nc);
+        }
+      }
       ns = 3 * nx - 2 * nc;
     } else {
       ns = 2 * nx - nc;
@@ -119,10 +142,16 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
     const auto &C = tc.second;
 
     // X = S C[:, :nx] (:278) and P = S[:, nx:ns] C[nx:ns, :nx] (:288) read the same basis: one pass
-    ritz_update(Sns, C, nx, X, P);
+    // ... written straight into the other panel's first and third block
+    X = Snext->leftCols(nx);
+    P = Snext->middleCols(2 * nx, nx);
+    ritz_update_into(Sns, C, nx, X, P);
     AX = A(X);                       // operators re-applied, not AS C               :281-282
     if (B) BX = (*B)(X);             // B absent: BX is X itself, no copy
-    R = residual_and_norms(AX, B ? BX : X, X, Theta.head(nx), r, xnorm);  // :285,293
+    R = Snext->middleCols(nx, nx);   // residuals into its second block
+    residual_and_norms_into(R, AX, B ? BX : X, X, Theta.head(nx), r, xnorm);  // :285,293
+    in_basis = true;
+    std::swap(Scur, Snext);
 
     // leading run of converged pairs among the first nev                           :298-318
     for (nc = 0; nc < nev; ++nc) {
@@ -137,7 +166,8 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
 
   Theta.conservativeResize(nev);  // :333-334
   X.truncate_cols(nev);
-  return std::make_pair(Theta, X);
+  Matrix Xout = X;  // own storage: X may be a view that keeps a whole 3 nx panel alive
+  return std::make_pair(Theta, std::move(Xout));
 }
 
 // Same, starting from a random m x nx block                                       (reference :376-390)

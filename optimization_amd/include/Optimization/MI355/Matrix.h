@@ -212,6 +212,29 @@ inline void ritz_update(const DeviceMatrix &S, const HostMatrix &C, size_t nx, D
   X = Y.leftCols(nx);
   P = Y.middleCols(nx, nx);
 }
+// The same straight into two caller-supplied panels (views of the NEXT search basis): no copy of X and P into the
+// basis afterwards (LOBPCG.h:254-259)
+inline void ritz_update_into(const DeviceMatrix &S, const HostMatrix &C, size_t nx, DeviceMatrix &X, DeviceMatrix &P) {
+  const size_t ns = S.cols();
+  HostMatrix C2(ns, 2 * nx);
+  for (size_t j = 0; j < nx; ++j)
+    for (size_t i = 0; i < ns; ++i) {
+      C2(i, j) = C(i, j);
+      C2(i, nx + j) = i < nx ? 0.0 : C(i, j);
+    }
+  check(mi_lobpcg_update2(S.context(), S.rows(), (int)ns, (int)(2 * nx), S.handle(), C2.data(), (int)ns, X.handle(),
+                          (int)nx, P.handle()));
+}
+// R = AX - BX diag(theta) into a caller-supplied panel (a view of the next basis' second block)
+inline void residual_and_norms_into(DeviceMatrix &R, const DeviceMatrix &AX, const DeviceMatrix &BX,
+                                    const DeviceMatrix &X, const HostVectorD &theta, HostVectorD &rnorm,
+                                    HostVectorD &xnorm) {
+  const size_t nx = X.cols();
+  rnorm.resize(nx);
+  xnorm.resize(nx);
+  check(mi_lobpcg_residual(X.context(), X.rows(), (int)nx, AX.handle(), BX.handle(), X.handle(), theta.data(),
+                           R.handle(), rnorm.data(), xnorm.data()));
+}
 // R = AX - BX diag(theta); returns R and fills the column norms of R and X  (LOBPCG.h:230,285,293,302)
 inline DeviceMatrix residual_and_norms(const DeviceMatrix &AX, const DeviceMatrix &BX, const DeviceMatrix &X,
                                        const HostVectorD &theta, HostVectorD &rnorm, HostVectorD &xnorm) {
