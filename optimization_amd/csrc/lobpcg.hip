@@ -571,6 +571,20 @@ static inline double fast_hypot(double a, double b) {
   return std::hypot(a, b);
 }
 
+// dot product on four independent accumulators (a single one is a chain of dependent fmas, ~4 cycles each)
+static inline double dot4(const double *a, const double *b, int n) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    s0 += a[k] * b[k];
+    s1 += a[k + 1] * b[k + 1];
+    s2 += a[k + 2] * b[k + 2];
+    s3 += a[k + 3] * b[k + 3];
+  }
+  for (; k < n; ++k) s0 += a[k] * b[k];
+  return (s0 + s1) + (s2 + s3);
+}
+
 void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, double *w) {
   V = M;
   std::vector<double> ev((size_t)n, 0.0);
@@ -634,8 +648,7 @@ void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, double *w) 
     if (h != 0) {
       for (int k = 0; k <= i; ++k) d[k] = VV(k, i + 1) / h;
       for (int j = 0; j <= i; ++j) {
-        double g = 0;
-        for (int k = 0; k <= i; ++k) g += VV(k, i + 1) * VV(k, j);
+        const double g = dot4(&VV(0, i + 1), &VV(0, j), i + 1);
         for (int k = 0; k <= i; ++k) VV(k, j) -= g * d[k];
       }
     }
