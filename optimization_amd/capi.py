@@ -422,6 +422,15 @@ class Context:
         check(self.L.mi_lobpcg_update(self.h, m, ks, kc, S.h, _dp(Cmat), Cmat.shape[0], Y.h))
         return Y
 
+    def lobpcg_update2(self, m, S, ks, Cmat, k1):
+        """columns [0, k1) of S C into one panel, the rest into another (mi_lobpcg_update2)"""
+        Cmat = np.asfortranarray(Cmat, dtype=np.float64)
+        kc = Cmat.shape[1]
+        Y1, Y2 = Vec(self, m * k1), Vec(self, m * max(kc - k1, 1))
+        check(self.L.mi_lobpcg_update2(self.h, m, ks, kc, S.h, _dp(Cmat), Cmat.shape[0], Y1.h, k1,
+                                       Y2.h if k1 < kc else None))
+        return Y1, Y2
+
     def lobpcg_residual(self, m, nx, AX, BX, X, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         R = Vec(self, m * nx)

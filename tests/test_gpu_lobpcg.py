@@ -169,3 +169,19 @@ def test_lobpcg_cfg5_laplacian(harness):
     assert np.all(r["Theta"] < 12.2)
     X = r["X"]
     assert np.abs(X.T @ X - np.eye(20)).max() < 1e-10
+
+
+@pytest.mark.parametrize("m,ks,kc,k1", [(1000, 72, 48, 24), (4097, 60, 40, 20), (333, 24, 24, 24), (5000, 30, 17, 5)])
+def test_panel_update_two_destinations_matches_one(ctx, m, ks, kc, k1):
+    """mi_lobpcg_update2 (X and P of a LOBPCG iteration written into two panels in one pass over S) gives the bits of
+    the one-panel product, for single- and multi-chunk widths."""
+    rng = np.random.default_rng(m + ks)
+    S = ctx.upload(np.asfortranarray(rng.normal(size=(m, ks))).ravel(order="F"))
+    Cm = rng.normal(size=(ks, kc))
+    Y = ctx.lobpcg_update(m, S, ks, Cm).numpy()
+    Y1, Y2 = ctx.lobpcg_update2(m, S, ks, Cm, k1)
+    assert np.array_equal(Y1.numpy(), Y[: m * k1])
+    if k1 < kc:
+        assert np.array_equal(Y2.numpy()[: m * (kc - k1)], Y[m * k1:])
+    ref = (np.asarray(S.numpy()).reshape(ks, m).T @ Cm).ravel(order="F")
+    assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max()
