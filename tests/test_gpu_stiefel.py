@@ -387,3 +387,36 @@ def test_one_pass_hessian_empty_rows_and_ragged_tail(oracle, monkeypatch, n):
                 c.close()
         assert rel_err(res["one-pass"], res["two-pass"]) < 1e-11
     oracle.free(oprob)
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 257, 5000])
+@pytest.mark.parametrize("p", [1, 3, 4])
+def test_spmm_packed_matrix_ragged_vs_plain_and_oracle(oracle, monkeypatch, n, p):
+    """mi_csr_spmm on a ragged random matrix (empty rows, explicit -0.0) whose values come from a small set, so
+    that the value-indexed packed copy is what the kernel reads: bit-identical to the plain arrays
+    (MI355OPT_NO_PACKED=1) and to the straight core (MI355OPT_NO_SPMM_STREAM=1), and equal to the oracle."""
+    import ctypes as C
+    from optimization_amd import capi
+    rowptr, col, val = _random_csr(n, seed=7 * n + p, empty_every=5 if n > 4 else 0)
+    rng = np.random.default_rng(n + p)
+    val = rng.choice(np.array([-1.0, .5, 2.0, -0.0]), size=val.size)
+    V = rng.normal(size=(n, p))
+    Wo = np.zeros((n, p))
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    Vc = np.ascontiguousarray(V)
+    oracle.lib.orc_csr_spmm(n, p, rowptr.ctypes.data_as(ip), col.ctypes.data_as(ip), val.ctypes.data_as(dp),
+                            Vc.ctypes.data_as(dp), Wo.ctypes.data_as(dp))
+    out = {}
+    for mode, envs in {"packed": {}, "plain": {"MI355OPT_NO_PACKED": "1"},
+                       "straight": {"MI355OPT_NO_SPMM_STREAM": "1"}}.items():
+        for k in ("MI355OPT_NO_PACKED", "MI355OPT_NO_SPMM_STREAM"):
+            monkeypatch.setenv(k, envs.get(k, "0"))
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            out[mode] = A.spmm(p, c.upload(V)).numpy().reshape(n, p).copy()
+        finally:
+            c.close()
+    assert np.array_equal(out["packed"], out["plain"])
+    assert np.array_equal(out["packed"], out["straight"])
+    assert np.array_equal(out["packed"], Wo)  # same per-row order, products and sums rounded separately
