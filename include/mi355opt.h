@@ -320,6 +320,10 @@ MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounde
  * surface; with a communicator the halo is filled by the in-stream ncclSend/ncclRecv exchange. */
 MI_API int mi_debug_set_rank(mi_ctx *ctx, int world_size, int rank);
 MI_API int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host); /* (need_lo+need_hi) x p */
+/* Measurement hook: average microseconds of `reps` back-to-back applications of the operator in the fused form
+ * mi_stpcg uses (the user HVP of IterativeSolvers.h:294 together with the dots of :300,305-306), timed with
+ * events on the context stream.  sync.  Not part of the drop-in surface (tools/time_op.py). */
+MI_API int mi_debug_time_fused_apply(mi_op *op, const mi_vec *in, mi_vec *out, int reps, double *us_per_call);
 /* halo description for a row-sharded sparse operator: rows [row_begin,row_end) of a global n x n
  * matrix are local; columns outside are fetched from the owning neighbour before each SpMM */
 /* host-only planning step of mi_csr_create_sharded (no GPU needed; also used by the CPU gloo tests):

@@ -12,8 +12,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libmi355opt.so")
+# MI355OPT_BUILD_TAG=x: an experiment build next to the product one (objects in _build_x/, library
+# libmi355opt_x.so; load it with MI355OPT_LIB=... -- same-call A/B runs on the GPU box)
+_TAG = os.environ.get("MI355OPT_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "_build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "libmi355opt" + ("_" + _TAG if _TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355opt.so")
+LIB_PATH = os.environ.get("MI355OPT_LIB") or os.path.join(_HERE, "libmi355opt.so")  # MI355OPT_LIB: experiment builds
 
 MI_OK = 0
 STATUS = {0: "MI_OK", 1: "MI_ERR_INVALID_ARGUMENT", 2: "MI_ERR_HIP", 3: "MI_ERR_OOM",
@@ -164,6 +164,7 @@ def load():
         "mi_comm_ipc_selftest": [vp, C.POINTER(C.c_int)],
         "mi_comm_ipc_enable": [vp, C.c_int],
         "mi_comm_ipc_error": [vp, C.POINTER(C.c_int)],
+        "mi_debug_time_fused_apply": [vp, vp, vp, C.c_int, c_double_p],
         "mi_debug_set_rank": [vp, C.c_int, C.c_int],
         "mi_debug_csr_set_halo": [vp, C.c_int, c_double_p],
         "mi_csr_create_sharded": [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, c_int32_p,
@@ -632,6 +633,12 @@ class Op:
         out = out if out is not None else Vec(self.ctx, x.n)
         check(self.L.mi_op_apply(self.h, x.h, out.h))
         return out
+
+    def time_fused_apply(self, x, out, reps=200):
+        """average us per application in the fused form mi_stpcg uses (mi_debug_time_fused_apply)"""
+        us = C.c_double(0)
+        check(self.L.mi_debug_time_fused_apply(self.h, x.h, out.h, reps, C.byref(us)))
+        return us.value
 
     def __del__(self):
         try:

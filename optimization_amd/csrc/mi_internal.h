@@ -320,6 +320,10 @@ struct mi_csr {
   uint32_t *pk = nullptr;          // device, padded (null: not representable)
   double *vtab = nullptr;          // device, 256 doubles
   int nvtab = 0;
+  // LDS-window form of the sparse kernels (spmm_core.h sell_window): entries whose column lies within
+  // 64 * win_chunks rows of their row are gathered from an LDS ring of the workgroup's rows of V instead of
+  // through L1/L2.  0: the matrix is not banded enough for that to pay (decided at creation).
+  int win_chunks = 0;
   // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
   // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.

@@ -182,6 +182,35 @@ int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out) {
   return op->apply(op, in, out);
 }
 
+// Measurement hook (tools/time_op.py): `reps` back-to-back applications of the operator's FUSED STPCG form --
+// apply_dir in its recurrence form when the operator has one (the projection matrix is whatever the scalar file
+// holds: timing only), else apply_dots, else apply -- between two events on the context stream.
+int mi_debug_time_fused_apply(mi_op *op, const mi_vec *in, mi_vec *out, int reps, double *us_per_call) {
+  MI_REQUIRE(op && in && out && us_per_call && reps > 0, "bad argument");
+  MI_REQUIRE(in->n == op->n && out->n == (op->n_out ? op->n_out : op->n), "operator dimension mismatch");
+  mi_ctx *ctx = op->ctx;
+  hipEvent_t e0, e1;
+  MI_HIP(hipEventCreate(&e0));
+  MI_HIP(hipEventCreate(&e1));
+  int nparts = 0;
+  auto once = [&]() -> int {
+    if (op->dirgram && op->apply_dir) return op->apply_dir(op, in, out, -1, &nparts);
+    if (op->apply_dots) return op->apply_dots(op, in, out, &nparts);
+    return op->apply(op, in, out);
+  };
+  for (int i = 0; i < 3; ++i) MI_TRY(once());
+  MI_HIP(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i) MI_TRY(once());
+  MI_HIP(hipEventRecord(e1, ctx->stream));
+  MI_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  MI_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_call = 1e3 * (double)ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return MI_OK;
+}
+
 int mi_op_dims(const mi_op *op, size_t *n_in, size_t *n_out) {
   MI_REQUIRE(op, "op is null");
   if (n_in) *n_in = op->n;

@@ -191,6 +191,44 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled_stream(SellView A, c
   block_partials_store<1>(a, lds, partials);
 }
 
+// Window of the LDS-ring kernels (mi_csr::win_chunks): the smallest wc in {1,2,4,8,16} that already serves (from
+// the ring) 90 % of the entries the widest window would serve -- provided that is at least one off-diagonal entry
+// per row on average; a matrix without such a band (random graphs) keeps the plain gather kernels.
+// MI355OPT_WIN_CHUNKS=k forces k (0 switches the window form off).
+int window_chunks(size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col) {
+  if (const char *e = getenv("MI355OPT_WIN_CHUNKS")) {
+    const int k = atoi(e);
+    return k < 0 ? 0 : (k > kMaxWinChunks ? kMaxWinChunks : k);
+  }
+  if (n == 0 || nnz == 0) return 0;
+  const int cand[5] = {1, 2, 4, 8, 16};
+  size_t near[5] = {0, 0, 0, 0, 0};
+  for (size_t r = 0; r < n; ++r)
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      if ((size_t)col[k] >= n) continue;  // halo column: never in the ring
+      const long long d = (long long)col[k] - (long long)r;
+      const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+      for (int i = 0; i < 5; ++i)
+        if (ad <= 64ull * cand[i]) ++near[i];
+    }
+  if (near[4] < n + n / 2 + 1) return 0;
+  int wc = cand[4];
+  for (int i = 0; i < 5; ++i)
+    if (near[i] * 10 >= near[4] * 9) { wc = cand[i]; break; }
+  // the window kernel's straight-line slice code (spmm_core.h sell_window): rows of at most kWinHead entries,
+  // at most kFarCap of them outside the window
+  for (size_t r = 0; r < n; ++r) {
+    if (rowptr[r + 1] - rowptr[r] > kWinHead) return 0;
+    int far = 0;
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const long long d = (long long)col[k] - (long long)r;
+      if ((size_t)col[k] >= n || (unsigned long long)(d < 0 ? -d : d) > 64ull * wc) ++far;
+    }
+    if (far > kFarCap) return 0;
+  }
+  return wc;
+}
+
 // Build the sliced-ELL image on the host from CSR with LOCAL column indices.
 int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *rowptr,
                const int32_t *col, const double *val, mi_csr **out) {
@@ -269,11 +307,13 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
     }
     if (ok) {
       table.resize(256, 0.0);
-      MI_TRY(upload((void **)&A->pk, pk.data(), stored * sizeof(uint32_t)));
+      pk.resize(stored + (size_t)kWinHead * 64, 0u);  // readable padding behind the last slice (sell_window's head loads)
+      MI_TRY(upload((void **)&A->pk, pk.data(), pk.size() * sizeof(uint32_t)));
       MI_TRY(upload((void **)&A->vtab, table.data(), 256 * sizeof(double)));
       A->nvtab = (int)index.size();
     }
   }
+  A->win_chunks = A->pk ? window_chunks(n, nnz, rowptr, col) : 0;  // (the window kernels read the packed copy)
   *out = A;
   return MI_OK;
 }

@@ -189,8 +189,10 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // RECUR (mi_op::apply_dir with gram_count < 0): M is read from gdir (packed symmetric, replicated scalars kept
 // by STPCG) and the packed symmetric Gram  sym(Y'out - (X'out) S)  of the OUTPUT rides along as components
 // 3.. of the partial row (DirComps<P>::value components in all).
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK>
-__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgState *__restrict__ st,
+// WIN (mi_csr::win_chunks > 0): the rows of V near the workgroup's own are staged in an LDS ring and the gathers
+// of near entries are ds_reads (spmm_core.h sell_window); same arithmetic, bit-identical results.
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, bool WIN_>
+__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
                                                           const double *__restrict__ Y,
@@ -200,15 +202,21 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
                                                           const double *__restrict__ gdir,
                                                           double *__restrict__ out,
                                                           double *__restrict__ partials) {
+  constexpr bool WIN = WIN_ && P <= 3;  // (P = 4: ring + parked rows would need 192 KB of LDS; never dispatched)
   constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
   constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
   __shared__ double lds[kLds];
   __shared__ double vt[PK ? 256 : 1];  // PK: the matrix's value table
+  __shared__ double ring[WIN ? kRingChunks * 64 * P : 1];
+  __shared__ double xy_park[WIN ? kWaves * 2 * 64 * P : 1];  // WIN: the epilogue's X, Y rows of each wave's slice
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef MI_WIN_STAMPS  // both forms: each wave's entry and exit on the constant 100 MHz clock (slots 56, 57)
+  const unsigned long long t_entry = wall_clock64();
+#endif
   if (PK) {
     if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
-    __syncthreads();
+    if (!WIN) __syncthreads();  // WIN: the barrier behind the ring fill publishes the table too
   }
   // a contiguous range of SLICES per workgroup (XCD-aware like group_range, but balanced to one slice)
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
@@ -241,26 +249,68 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
     int lane;
     double x[P], y[P], v[P];
     // rows of the slice from a scalar base + a 32-bit lane offset (lanes past the last row read its first)
+    // (32-bit arithmetic: the fields span < 4 GiB, sell_stream_ok)
     __device__ __forceinline__ unsigned lane_off(size_t slice) const {
-      return (slice * 64 + lane < A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+      return ((unsigned)slice * 64u + (unsigned)lane < (unsigned)A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
     }
     __device__ __forceinline__ const double *row_of(const double *F, size_t slice, unsigned off) const {
-      return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F + slice * 64 * P) + off);
+      return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F) + (unsigned)slice * (unsigned)(64 * P * 8) +
+                                              off);
     }
     __device__ __forceinline__ void begin(size_t slice) {
       const unsigned off = lane_off(slice);
-      const double *xs = row_of(X, slice, off), *vs = row_of(V, slice, off);
+      const double *xs = row_of(X, slice, off);
 #pragma unroll
-      for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; }
+      for (int c = 0; c < P; ++c) x[c] = xs[c];
+      if (!WIN) {  // WIN: the row of V comes from the ring (end(slice, acc, vrow))
+        const double *vs = row_of(V, slice, off);
+#pragma unroll
+        for (int c = 0; c < P; ++c) v[c] = vs[c];
+      }
       if (RECUR) {
         const double *ys = row_of(Y, slice, off);
 #pragma unroll
         for (int c = 0; c < P; ++c) y[c] = ys[c];
       }
     }
+    // sell_window's protocol: request(slice) loads the rows one slice ahead into xn/yn, park() moves them to the
+    // wave's private LDS area at the top of their slice (so the registers can take the next request), end(slice,
+    // acc, vrow) reads them back
+    double xn[WIN ? P : 1], yn[WIN ? P : 1];
+    double *xy_lds;  // this wave's 2 x 64 x P doubles
+    __device__ __forceinline__ void request(size_t slice) {  // pinned loads: see spmm_core.h
+      const unsigned off = lane_off(slice);
+      const double *xs = row_of(X, slice, off);
+#pragma unroll
+      for (int c = 0; c < P; ++c) xn[WIN ? c : 0] = pinned_load(xs + c);
+      if (RECUR) {
+        const double *ys = row_of(Y, slice, off);
+#pragma unroll
+        for (int c = 0; c < P; ++c) yn[WIN ? c : 0] = pinned_load(ys + c);
+      }
+    }
+    __device__ __forceinline__ void park() {
+      LdsDouble *l = (LdsDouble *)xy_lds + lane * P;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        l[c] = xn[WIN ? c : 0];
+        if (RECUR) l[64 * P + c] = yn[WIN ? c : 0];
+      }
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&vrow)[P]) {
+      const LdsDouble *l = (const LdsDouble *)xy_lds + lane * P;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        v[c] = vrow[c];
+        x[c] = l[c];
+        if (RECUR) y[c] = l[64 * P + c];
+      }
+      end(slice, acc);
+    }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
-      if (slice * 64 + lane >= A.n) return;
-      double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out + slice * 64 * P) + lane_off(slice));
+      if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
+      double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (unsigned)slice * (unsigned)(64 * P * 8) +
+                                              lane_off(slice));
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
@@ -297,11 +347,23 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, const CgSt
           }
       }
     }
-  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
+  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}, {}, {}, xy_park + (WIN ? (threadIdx.x >> 6) * (2 * 64 * P) : 0)};
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
-  const size_t wfirst = s0 + (size_t)__builtin_amdgcn_readfirstlane(w);
-  sell_stream<P, HALO, PK>(A, wfirst, s1, lane, V, vt, epi);
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  if constexpr (WIN) sell_window<P, HALO, PK>(A, wc, s0, s1, wu, lane, V, vt, ring, epi);
+  else sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+#ifdef MI_WIN_STAMPS
+  const unsigned long long t_body = wall_clock64();
+#endif
   block_partials_store<KC>(a, lds, partials);
+#ifdef MI_WIN_STAMPS
+  if (g_stamp_buf && lane == 0) {
+    unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * kWaves + w) * kStampSlots;
+    o[56] = t_entry;
+    o[57] = wall_clock64();
+    o[58] = t_body;
+  }
+#endif
 }
 
 // Gram partial rows of two dense n x P fields.
@@ -560,6 +622,14 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const bool recur = gram_count < 0;
   const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
+  // LDS-window form when the matrix is banded enough (decided at creation, sparse.hip: window_chunks)
+  // (work in progress: opt-in with MI355OPT_WINDOW=1 until it beats the streaming form)
+  static const bool no_win = [] { const char *e = getenv("MI355OPT_WINDOW"); return !(e && e[0] == '1'); }();
+  // (p = 4: ring + parked rows would need 192 KB of LDS)
+  int wc = (no_win || p > 3) ? 0 : A->win_chunks;
+#ifdef MI_WIN_DEBUG
+  if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wc |= atoi(e) << 8;
+#endif
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   if (!recur) {
@@ -567,15 +637,17 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
     if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
   }
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HF2(F, HL, RC, PKV)                                                                                   \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV>), dim3(grid), dim3(kBlock), 0,         \
-                                   ctx->stream, view, (const CgState *)ctx->cg_live, (const double *)in->d,  \
-                                   (const double *)q->X->d, (const double *)q->Y->d,                         \
+#define HF3(F, HL, RC, PKV, WN)                                                                               \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV, WN>), dim3(grid), dim3(kBlock), 0,     \
+                                   ctx->stream, view, wc, (const CgState *)ctx->cg_live,                     \
+                                   (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,  \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),        \
                                    out->d, ctx->partials))
-#define HF(F, HL, RC)                            \
-  if (A->pk) { HF2(F, HL, RC, true); } else { HF2(F, HL, RC, false); }
+#define HF(F, HL, RC)                                                          \
+  if (A->pk && wc > 0) { HF3(F, HL, RC, true, true); }                         \
+  else if (A->pk) { HF3(F, HL, RC, true, false); }                             \
+  else { HF3(F, HL, RC, false, false); }
   if (recur) {
     if (halo) { HF(false, true, true); } else { HF(false, false, true); }
   } else if (halo) {
@@ -583,7 +655,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   } else {
     if (sharded) { HF(true, false, false); } else { HF(false, false, false); }
   }
-#undef HF2
+#undef HF3
 #undef HF
   *nparts = grid;
   MI_HIP(hipGetLastError());
@@ -612,6 +684,14 @@ void rq_precon_destroy(mi_precon *self) { delete (RqPreconImpl *)self->impl; }
 }  // namespace
 
 extern "C" {
+
+#ifdef MI_WIN_STAMPS
+// experiment builds: (de)register the device buffer the window kernel dumps its stamps into
+__attribute__((visibility("default"))) int mi_debug_stamp_buffer(void *dev_ptr) {
+  MI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(mi::g_stamp_buf), &dev_ptr, sizeof(dev_ptr)));
+  return MI_OK;
+}
+#endif
 
 int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, double *G_host) {
   MI_TRY(check_np(ctx, n, p, X, Z, nullptr));
