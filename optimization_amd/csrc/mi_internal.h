@@ -247,6 +247,30 @@ __device__ __forceinline__ void block_partials_store(const double (&acc)[K], dou
   __syncthreads();
 }
 
+// The same for a workgroup of NW (a power of two <= 16) waves (the window kernels): fixed-order pairwise sum.
+template <int K, int NW>
+__device__ __forceinline__ void block_partials_store_nw(const double (&acc)[K], double *lds,
+                                                        double *__restrict__ partials) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = wave_reduce_sum(acc[k]);
+    if (lane == 0) lds[k * NW + w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double t[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t[i] = lds[threadIdx.x * NW + i];
+#pragma unroll
+    for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+      for (int i = 0; i + span < NW; i += 2 * span) t[i] = t[i] + t[i + span];
+    partials[(size_t)threadIdx.x * kMaxRows + blockIdx.x] = t[0];
+  }
+  __syncthreads();
+}
+
 // Every thread of the workgroup obtains the fixed-order sums over `count` (<= kMaxRows) partial rows
 // of components [0,K).  All workgroups of a kernel run identical code on identical data, so they
 // all obtain bit-identical totals.  lds: >= K * 17 doubles.  Contains barriers.
@@ -322,8 +346,14 @@ struct mi_csr {
   int nvtab = 0;
   // LDS-window form of the sparse kernels (spmm_core.h sell_window): entries whose column lies within
   // 64 * win_chunks rows of their row are gathered from an LDS ring of the workgroup's rows of V instead of
-  // through L1/L2.  0: the matrix is not banded enough for that to pay (decided at creation).
+  // through L1/L2.  0: the matrix does not qualify (decided at creation, sparse.hip build_window).
+  //   wk    one dword per stored entry (positions as pk): (LDS row index << 8) | value index
+  //   wfar  two columns per row, (slice * 2 + slot) * 64 + lane: the row's far entries (else the row itself)
   int win_chunks = 0;
+  int win_head = 0;        // widest slice (<= kWinHead)
+  uint32_t win_zero = 0;   // word of a non-entry: zero row, index of 0.0 in vtab
+  uint32_t *wk = nullptr;  // device, padded + kWinHead * 64
+  int32_t *wfar = nullptr; // device, (nslices + 1) * 2 * 64
   // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
   // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.

@@ -191,42 +191,97 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled_stream(SellView A, c
   block_partials_store<1>(a, lds, partials);
 }
 
-// Window of the LDS-ring kernels (mi_csr::win_chunks): the smallest wc in {1,2,4,8,16} that already serves (from
-// the ring) 90 % of the entries the widest window would serve -- provided that is at least one off-diagonal entry
-// per row on average; a matrix without such a band (random graphs) keeps the plain gather kernels.
-// MI355OPT_WIN_CHUNKS=k forces k (0 switches the window form off).
-int window_chunks(size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col) {
+// Window form of the matrix for the LDS-ring kernels (spmm_core.h sell_window; mi_csr::wk, wfar).
+// The window half-width wc (in 64-row chunks) is the smallest of {1, 2, 4} that already serves, from the ring,
+// 90 % of the entries the widest would -- provided that is at least one off-diagonal entry per row on average (a
+// matrix without such a band, e.g. a random graph, keeps the plain gather kernels), every slice is at most kWinHead
+// entries wide, every row has at most kFarCap entries outside the window, and 0.0 has (or can get) a place in the
+// value table.  MI355OPT_WIN_CHUNKS=k forces k (0 switches the window form off).
+int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col,
+                 const std::vector<long long> &sp, const std::vector<uint32_t> &pk, std::vector<double> &table,
+                 int ntable) {
+  if (n == 0 || nnz == 0) return MI_OK;
+  const int ncand = 3, cand[ncand] = {1, 2, 4};
+  static_assert(kMaxWinChunks <= 4, "candidates");
+  int wc = 0;
   if (const char *e = getenv("MI355OPT_WIN_CHUNKS")) {
-    const int k = atoi(e);
-    return k < 0 ? 0 : (k > kMaxWinChunks ? kMaxWinChunks : k);
+    wc = atoi(e);
+    if (wc <= 0) return MI_OK;
+    if (wc > kMaxWinChunks) wc = kMaxWinChunks;
+  } else {
+    size_t near[ncand] = {0, 0, 0};
+    for (size_t r = 0; r < n; ++r)
+      for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        if ((size_t)col[k] >= n) continue;  // halo column: never in the ring
+        const long long d = (long long)col[k] - (long long)r;
+        const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+        for (int i = 0; i < ncand; ++i)
+          if (cand[i] <= kMaxWinChunks && ad <= 64ull * cand[i]) ++near[i];
+      }
+    int last = 0;
+    for (int i = 0; i < ncand; ++i)
+      if (cand[i] <= kMaxWinChunks) last = i;
+    if (near[last] < n + n / 2 + 1) return MI_OK;
+    wc = cand[last];
+    for (int i = 0; i <= last; ++i)
+      if (near[i] * 10 >= near[last] * 9) { wc = cand[i]; break; }
   }
-  if (n == 0 || nnz == 0) return 0;
-  const int cand[5] = {1, 2, 4, 8, 16};
-  size_t near[5] = {0, 0, 0, 0, 0};
-  for (size_t r = 0; r < n; ++r)
-    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-      if ((size_t)col[k] >= n) continue;  // halo column: never in the ring
-      const long long d = (long long)col[k] - (long long)r;
-      const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
-      for (int i = 0; i < 5; ++i)
-        if (ad <= 64ull * cand[i]) ++near[i];
-    }
-  if (near[4] < n + n / 2 + 1) return 0;
-  int wc = cand[4];
-  for (int i = 0; i < 5; ++i)
-    if (near[i] * 10 >= near[4] * 9) { wc = cand[i]; break; }
-  // the window kernel's straight-line slice code (spmm_core.h sell_window): rows of at most kWinHead entries,
-  // at most kFarCap of them outside the window
-  for (size_t r = 0; r < n; ++r) {
-    if (rowptr[r + 1] - rowptr[r] > kWinHead) return 0;
-    int far = 0;
-    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-      const long long d = (long long)col[k] - (long long)r;
-      if ((size_t)col[k] >= n || (unsigned long long)(d < 0 ? -d : d) > 64ull * wc) ++far;
-    }
-    if (far > kFarCap) return 0;
+  const size_t nslices = A->nslices;
+  int head = 0;
+  for (size_t s_ = 0; s_ < nslices; ++s_) head = std::max<int>(head, (int)(sp[s_ + 1] - sp[s_]));
+  if (head > kWinHead) return MI_OK;
+  // index of 0.0 (bit pattern +0.0) in the value table
+  int zidx = -1;
+  for (int i = 0; i < ntable; ++i) {
+    uint64_t bits;
+    memcpy(&bits, &table[i], sizeof bits);
+    if (bits == 0) { zidx = i; break; }
   }
-  return wc;
+  if (zidx < 0) {
+    if (ntable >= 256) return MI_OK;
+    zidx = ntable;  // (the table is zero-filled up to 256 entries)
+  }
+  const int nc = 2 * kWinWaves + 2 * wc;
+  const uint32_t zrow = (uint32_t)nc * 64u;
+  const uint32_t zw = (zrow << 8) | (uint32_t)zidx;
+  const size_t stored = pk.size();
+  std::vector<uint32_t> wk(stored + (size_t)kWinHead * 64, zw);
+  std::vector<int32_t> wfar((nslices + 1) * kFarCap * 64, 0);
+  for (size_t sl = 0; sl < nslices; ++sl) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const size_t r = sl * 64 + lane;
+      const int32_t self = (int32_t)std::min(r, n - 1);
+      for (int f = 0; f < kFarCap; ++f) wfar[(sl * kFarCap + f) * 64 + lane] = self;
+      if (r >= n) continue;  // (its words stay zw)
+      const int len = rowptr[r + 1] - rowptr[r];
+      int nfar = 0;
+      for (int k = 0; k < len; ++k) {
+        const size_t e = (size_t)(sp[sl] + k) * 64 + lane;
+        const uint32_t vi = pk[e] & 255u;
+        const long long c = col[rowptr[r] + k];
+        const long long d = c - (long long)r;
+        const bool nearj = (size_t)c < n && (unsigned long long)(d < 0 ? -d : d) <= 64ull * wc;
+        uint32_t rowidx;
+        if (nearj) {
+          rowidx = (uint32_t)(((size_t)c >> 6) % (size_t)nc) * 64u + (uint32_t)(c & 63);
+        } else {
+          if (nfar == kFarCap) return MI_OK;  // a row with a third far entry: not eligible
+          rowidx = zrow + 1u + (uint32_t)(sl % kWinWaves) * (uint32_t)(kFarCap * 64) + (uint32_t)nfar * 64u +
+                   (uint32_t)lane;
+          wfar[(sl * kFarCap + nfar) * 64 + lane] = (int32_t)c;
+          ++nfar;
+        }
+        wk[e] = (rowidx << 8) | vi;
+      }
+      // padding entries inside the slice (k >= len): zw already
+    }
+  }
+  MI_TRY(upload((void **)&A->wk, wk.data(), wk.size() * sizeof(uint32_t)));
+  MI_TRY(upload((void **)&A->wfar, wfar.data(), wfar.size() * sizeof(int32_t)));
+  A->win_chunks = wc;
+  A->win_head = head;
+  A->win_zero = zw;
+  return MI_OK;
 }
 
 // Build the sliced-ELL image on the host from CSR with LOCAL column indices.
@@ -306,14 +361,15 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
           }
     }
     if (ok) {
+      const int ntable = (int)table.size();
       table.resize(256, 0.0);
-      pk.resize(stored + (size_t)kWinHead * 64, 0u);  // readable padding behind the last slice (sell_window's head loads)
       MI_TRY(upload((void **)&A->pk, pk.data(), pk.size() * sizeof(uint32_t)));
       MI_TRY(upload((void **)&A->vtab, table.data(), 256 * sizeof(double)));
       A->nvtab = (int)index.size();
+      // the window form of the same matrix, when it qualifies (local columns only: col, not pcol)
+      MI_TRY(build_window(A, n, nnz, rowptr, col, sp, pk, table, ntable));
     }
   }
-  A->win_chunks = A->pk ? window_chunks(n, nnz, rowptr, col) : 0;  // (the window kernels read the packed copy)
   *out = A;
   return MI_OK;
 }
@@ -436,6 +492,8 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->val);
   (void)hipFree(A->pk);
   (void)hipFree(A->vtab);
+  (void)hipFree(A->wk);
+  (void)hipFree(A->wfar);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;
   return MI_OK;

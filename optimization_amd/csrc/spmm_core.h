@@ -201,65 +201,74 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
 }
 
 // ---- LDS-window form of sell_stream ---------------------------------------------------------------------------
-// What bounds the one-pass Hessian on cfg2 (in-kernel shader-clock stamps, tools/stamps.py): not
-// bytes and not the gathers themselves but EXPOSED LATENCY.  A wave of sell_stream keeps one 4-entry chunk of
-// matrix words in flight; they take ~2100 cycles from request to arrival and the wave needs them twice per
-// slice, and because vector loads return in order every wait for a just-issued gather also waits for every
-// prefetch issued before it.  This form removes the dependent global loads from the steady state:
-//   * the rows of V NEAR the workgroup's own are staged once per workgroup in an LDS ring (coalesced 512-byte
-//     loads) and near entries are gathered from there (conflict-free ds_reads, no vector-memory queue);
-//   * each row's few FAR entries (the +-nx*ny neighbours of a 3-D stencil, halo columns; at most kFarCap per
-//     row on the fast path) are gathered first thing in a slice -- and only THEN are the next slice's matrix
-//     words and epilogue rows requested, so the wait for the gathers (s_waitcnt vmcnt(#later loads)) never
-//     waits for a prefetch, and every prefetched operand has a whole slice time (~10k cycles at the bandwidth
-//     bound) to arrive;
-//   * the per-slice code is straight-line (branch-free selects between the gathered and the staged value), so
-//     the compiler's s_waitcnt counts are exact instead of the conservative vmcnt(0) a loop back-edge forces.
-// The arithmetic per row is unchanged: same entries, same order, same separately rounded products and sums --
-// results are bit-identical to sell_stream / sell_row_times.
+// What bounds the one-pass Hessian on cfg2 (in-kernel stamps, tools/stamps.py) is not bytes but
+// EXPOSED LATENCY: a wave of sell_stream keeps one 4-entry chunk of matrix words in flight, they take ~2100 cycles
+// from request to arrival, the wave needs them twice per slice, and because vector loads return in order every wait
+// for a just-issued gather also waits for every prefetch issued before it.  The first window form (gathers from an
+// LDS ring, decoded on the fly) removed those waits and ran SLOWER: with the loads out of the way it was bound by its
+// own ~700 VALU instructions per slice (classifying entries, unpacking, selecting between gathered and staged
+// values).  This form therefore moves every decision to the HOST, once per matrix (sparse.hip build_window):
 //
-//   ring     kRingChunks chunks of 64 rows x P doubles; chunk q (rows 64q..64q+63) lives at slot q & 63, so
-//            row c is at ring[(c & 4095) * P].
-//   tiles    the workgroup's slices [s0, s1) are taken 16 at a time (wave w owns slice s0 + 16 t + w of tile t);
-//            tile t needs the chunks [s0 + 16 t - wc, s0 + 16 t + 16 + wc).  Behind tile t every wave stages ONE
-//            more chunk (loads issued before its slice, LDS write after it), then one LDS-only barrier
-//            (s_waitcnt lgkmcnt + s_barrier: global loads stay in flight across it).  Waves that wait at the
-//            barrier have their next slice's 6 KB in flight, so the memory system does not run dry meanwhile.
-//   hazards  the write behind tile t overwrites chunk q - 64 with q < s0 + 16 (t + 2) + wc, i.e. below
-//            s0 + 16 t - wc as long as wc <= kMaxWinChunks = 16: nothing a wave still in tile t can need.
-//   near     entry (row r, column c) is served from the ring iff |c - r| <= 64 wc (then chunk(c) is within wc
-//            chunks of the wave's own slice, hence staged) and c is a local row (halo columns are not in V).
-//   eligible only matrices whose slices are all at most kWinHead entries wide, whose rows have at most kFarCap far
-//            entries each, and which have a packed copy (mi_csr::pk) take this form (decided at creation,
-//            sparse.hip window_chunks): that keeps a slice's code free of loops and branches, and the two sets
-//            of prefetched operands small enough for 128 registers.  Every other matrix keeps sell_stream.
-// `w` must be wave-uniform (readfirstlane).  Epilogue protocol: epi.request(slice) issues the loads the epilogue
-// of `slice` needs (one slice ahead), epi.park() moves them from registers to wave-private LDS at the top of that
-// slice, epi.end(slice, acc, vrow) consumes them together with acc = (A V)(row,:) and vrow = V(row,:) (read from
-// the ring: no global read of the row).
-#ifndef MI_WIN_LDS_BATCH
-#define MI_WIN_LDS_BATCH 4
+//   wk      one dword per stored entry, the same sliced-ELL positions as mi_csr::pk: (LDS row index << 8) | value
+//           index.  The row index says where the kernel will find the entry's row of V in LDS: a ring position for
+//           a NEAR entry (|col - row| <= 64 wc, a local column), one of the wave's two FAR SLOTS otherwise.
+//   wfar    two columns per row (slice-major, 64 lanes contiguous): the far entries' columns (the row itself when
+//           it has fewer), gathered first thing in a slice and written to the far slots.
+//   per entry the kernel does: word -> two LDS addresses (5 integer instructions), one value read, one row read,
+//           P multiplies and P adds.  No compare, no select, no per-lane case distinction.
+//
+//   waves    a workgroup of the window kernels has kWinWaves = 8 waves (512 threads) and two of them share a CU:
+//            the per-tile barrier keeps a workgroup's waves in the same phase (all waiting for memory, then all
+//            computing), so with ONE workgroup per CU loads and arithmetic add up instead of overlapping (measured:
+//            17.8 us with every load removed + 11.5 us of loads = the 29.4 us of the 16-wave version).
+//   ring     nc = 2 kWinWaves + 2 wc chunks of 64 rows; chunk q lives at slot q % nc.  Row index nc * 64 is the ZERO ROW
+//            (zeros): the word of an entry beyond a slice's width is replaced by `zw` (zero row, index of 0.0).
+//   far      row index nc * 64 + 1 + (slice % kWinWaves) * 128 + slot * 64 + lane: wave-private, so no barrier is
+//            needed between writing and reading them.
+//   tiles    aligned groups of NW = kWinWaves slices; wave w owns slice NW T + w of tile T, a workgroup owns a
+//            contiguous run of whole tiles (every wave of every workgroup but the last does the same number of
+//            slices).  Tile T needs the chunks [NW T - wc, NW T + NW + wc); during tile T every wave stages ONE chunk of tile T + 1
+//            (pinned loads at the top, LDS write behind the entries), then one LDS-only barrier (s_waitcnt lgkmcnt
+//            + s_barrier: global loads stay in flight across it).
+//   hazards  staging chunk q <= NW T + 2 NW - 1 + wc overwrites chunk q - nc <= NW T - 1 - wc, below everything a wave
+//            in tile T can need (all waves are in tile T between the barriers).
+//   queue    per slice, in this order and kept so by pinned (wavefront-scope atomic = plain, but ordered) loads:
+//            far gathers; next slice's words and far columns; this slice's epilogue rows (epi.request); s_waitcnt
+//            for the gathers only (vmcnt(#later loads)); entries; staged chunk -> ring; epilogue.  No wait covers a
+//            load issued after the one it needs, except the epilogue's (the rows it waits for are the newest).
+//   eligible matrices with a packed copy, every slice at most kWinHead entries wide, every row at most kFarCap far
+//            entries, wc <= kMaxWinChunks (decided at creation); every other matrix keeps sell_stream.
+// Same entries, same order, same separately rounded products and sums as sell_stream / sell_row_times: results are
+// bit-identical.  `w` must be wave-uniform (readfirstlane).  Epilogue protocol: epi.request(slice) issues the loads
+// the epilogue of `slice` needs, epi.end(slice, acc, vrow) consumes them with acc = (A V)(row,:), vrow = V(row,:).
+#ifdef MI_WIN_STAMPS
+constexpr int kMaxWinChunks = 2;  // (the stamp area needs the LDS of the wider rings)
+#else
+constexpr int kMaxWinChunks = 4;
 #endif
-constexpr int kRingChunks = 64;
-constexpr int kMaxWinChunks = 16;
 constexpr int kFarCap = 2;
 constexpr int kWinHead = 8;
+#ifndef MI_WIN_WAVES
+#define MI_WIN_WAVES 8
+#endif
+constexpr int kWinWaves = MI_WIN_WAVES;  // waves per workgroup of the window kernels = slices per tile
+constexpr int kWinBlock = kWinWaves * 64;
+constexpr int kWinRingRowsMax = (2 * kWinWaves + 2 * kMaxWinChunks) * 64;  // ring rows at the widest window
+constexpr int kWinFarRows = kWinWaves * kFarCap * 64;                       // far slots of a workgroup
+constexpr int kWinLdsRows = kWinRingRowsMax + 1 + kWinFarRows;   // ring, zero row, far slots
 
 // In-kernel timeline (experiment builds only, -DMI_WIN_STAMPS): shader-clock stamps taken once a given value has
 // arrived, kept in LDS per wave and dumped by the kernel at its end (tools/stamps.py).
 #ifdef MI_WIN_STAMPS
-constexpr int kStampSlots = 64;
+constexpr int kStampSlots = 64;     // per wave in the dump buffer
+constexpr int kStampLdsSlots = 48;  // of which the window core uses the first ones (kept in LDS until the end)
 __device__ unsigned long long *g_stamp_buf = nullptr;
 __device__ __forceinline__ void stamp_put(unsigned long long *area, int slot, double dep) {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
-  if (slot < kStampSlots && (threadIdx.x & 63) == 0) area[slot] = t;
+  if (slot < kStampLdsSlots && (threadIdx.x & 63) == 0) area[slot] = t;
 }
 #define MI_STAMP(slot, dep) stamp_put(stamp_area, (slot), (double)(dep))
-__device__ __forceinline__ void stamp_real(unsigned long long *area, int slot) {  // the constant 100 MHz clock
-  const unsigned long long t = wall_clock64();
-  if ((threadIdx.x & 63) == 0) area[slot] = t;
-}
 #else
 #define MI_STAMP(slot, dep) ((void)0)
 #endif
@@ -267,15 +276,13 @@ __device__ __forceinline__ void stamp_real(unsigned long long *area, int slot) {
 // A load the compiler keeps where it is written: a relaxed atomic load at wavefront scope is a plain global_load
 // (no cache-policy bits at that scope) but "ordered" -- neither the IR passes (which sink ordinary loads to their
 // first use and hoist address-ready ones) nor the machine scheduler move memory operations across it.  The window
-// kernels' queue discipline (what is issued before what, so that s_waitcnt vmcnt(N) never waits for a prefetch)
-// rests on it.
+// kernels' queue discipline rests on it.
 template <class T>
 __device__ __forceinline__ T pinned_load(const T *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 typedef __attribute__((address_space(3))) double LdsDouble;
-typedef __attribute__((address_space(1))) double GlobalDouble;
 
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -283,38 +290,40 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int P, bool HALO, bool PK, class Epi>
-__device__ __forceinline__ void sell_window(const SellView &A, int wc, size_t s0_, size_t s1_, int w, int lane,
-                                            const double *__restrict__ V, const double *vt, double *ring,
+// the window-form matrix arrays (mi_csr::wk, wfar) and constants
+struct WinView {
+  const uint32_t *__restrict__ wk;
+  const int32_t *__restrict__ wfar;
+  int wc, nc;     // window half-width in chunks; ring chunks (2 kWinWaves + 2 wc)
+  uint32_t zw;    // word of a non-entry: zero row, index of 0.0
+};
+
+// Tiles [t0, t1) of kWinWaves slices for this workgroup; `lds_rows` = kWinLdsRows x P doubles (ring, zero row, far slots).
+template <int P, int HW, bool HALO, class Epi>
+__device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
+                                            const double *__restrict__ V, const double *vt, double *lds_rows,
                                             Epi &epi) {
-  static_assert(PK, "the window form reads the packed matrix copy");
+  static_assert(HW <= kWinHead, "head width");
+  constexpr int NW = kWinWaves;
+  const int nchunks = (int)A.nslices;
 #ifdef MI_WIN_DEBUG  // timing experiments only (wrong results): flags in the high bits of wc
-  const int dbg = wc >> 8;
-  wc &= 255;
+  const int dbg = W.wc >> 8;
+  const int wc = W.wc & 255, nc = W.nc;
 #else
   constexpr int dbg = 0;
+  const int wc = W.wc, nc = W.nc;
 #endif
-  constexpr int HW = kWinHead;  // entries per slice (raw operands of TWO slices are held in registers)
-  // 32-bit indices throughout (sell_stream_ok: < 2^29 stored entries, < 2^26 slices): 64-bit slice numbers and
-  // bounds cost a register pair each, and the scalar file is what overflows first in this kernel
-  const int nchunks = (int)A.nslices;
-  const int s0 = (int)s0_, s1 = (int)s1_;
-  const int ntiles = (s1 - s0 + kWaves - 1) / kWaves;
   const unsigned nloc = (unsigned)A.n;
   const unsigned nPbytes = (unsigned)(A.n * P * 8);
   const unsigned lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
-  const unsigned wr = 64u * (unsigned)wc;
-  constexpr unsigned kRingMask = (unsigned)(kRingChunks * 64 - 1);
+  LdsDouble *const L = (LdsDouble *)lds_rows;
 #ifdef MI_WIN_STAMPS
-  __shared__ unsigned long long stamp_lds[kWaves * kStampSlots];
-  unsigned long long *stamp_area = stamp_lds + w * kStampSlots;
-  if (lane == 0)
-    for (int i = 0; i < kStampSlots; ++i) stamp_area[i] = 0;
+  __shared__ unsigned long long stamp_lds[NW * kStampLdsSlots];
+  unsigned long long *stamp_area = stamp_lds + w * kStampLdsSlots;
+  if (lane < kStampLdsSlots) stamp_area[lane] = 0;
 #endif
   MI_STAMP(0, 0.0);
-#ifdef MI_WIN_STAMPS
-  stamp_real(stamp_area, kStampSlots - 3);
-#endif
+  if (t0 >= t1) return;
   // chunk q of V: lane l takes the doubles l, 64 + l, ... of its 64 P doubles (P coalesced 512-byte loads)
   auto chunk_load = [&](int q, double (&buf)[P]) {
     const unsigned b0 = (unsigned)q * (unsigned)(64 * P * 8) + lane8;
@@ -325,42 +334,27 @@ __device__ __forceinline__ void sell_window(const SellView &A, int wc, size_t s0
       buf[c] = pinned_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(V) + bs));
     }
   };
-  auto chunk_store = [&](int q, const double (&buf)[P]) {
-    double *dst = ring + ((unsigned)q & (unsigned)(kRingChunks - 1)) * (unsigned)(64 * P) + lane;
+  auto chunk_store = [&](int slot, const double (&buf)[P]) {
+    LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * P) + lane;
 #pragma unroll
     for (int c = 0; c < P; ++c) dst[c * 64] = buf[c];
   };
-  // chunk staged behind tile i (tile i + 1 needs it); -1: none for this wave
-  auto job_chunk = [&](int i) -> int {
-    const int q = s0 + kWaves * (i + 1) + wc + w;
-    return (i + 1 < ntiles && q < nchunks && q < s1 + wc) ? q : -1;
-  };
-  // raw operands of a slice's head entries; entries beyond the slice width re-read its first entry (or entry 0
-  // of the matrix for an empty slice: mi_csr always stores >= 64 entries) and are zeroed when consumed
+  // raw operands of a slice: its words (ONE scalar base + immediate offsets j * 256: the words behind a narrower
+  // slice belong to the next slice or to the padding mi_csr keeps behind the array, and are replaced by zw when
+  // consumed) and its two far columns
   struct Head {
     unsigned c[HW];
+    unsigned f[kFarCap];
   };
-  // ONE scalar base + immediate offsets j * 256: the words behind a narrower slice belong to the next slice (or to
-  // the kWinHead rows of zero padding mi_csr keeps behind the packed copy) and are masked off when consumed
-  auto load_head = [&](Head &h, int kk) {
-    const char *pb = reinterpret_cast<const char *>(A.pk) + (unsigned)kk * 256u + lane4;
+  auto load_head = [&](Head &h, int kk, int sl) {
+    const char *pb = reinterpret_cast<const char *>(W.wk) + (unsigned)kk * 256u + lane4;
 #pragma unroll
     for (int j = 0; j < HW; ++j) h.c[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
-  };
-  // row `c` of V (or of the halo) through the vector-memory path
-  auto far_row = [&](unsigned c, double (&out)[P]) {
-    const char *base = reinterpret_cast<const char *>(V);
-    unsigned boff = c * (unsigned)(P * 8);
-    if (HALO && c >= nloc) {
-      base = reinterpret_cast<const char *>(A.halo);
-      boff = (c - nloc) * (unsigned)(P * 8);
-    }
-    const GlobalDouble *src = (const GlobalDouble *)reinterpret_cast<const double *>(base + boff);
+    const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
 #pragma unroll
-    for (int cc = 0; cc < P; ++cc) out[cc] = src[cc];
+    for (int j = 0; j < kFarCap; ++j) h.f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
   };
-  // the same with pinned loads (the far gathers of the slice loop)
-  auto far_row_pinned = [&](unsigned c, double (&out)[P]) {
+  auto far_row = [&](unsigned c, double (&out)[P]) {
     const char *base = reinterpret_cast<const char *>(V);
     unsigned boff = c * (unsigned)(P * 8);
     if (HALO && c >= nloc) {
@@ -371,155 +365,110 @@ __device__ __forceinline__ void sell_window(const SellView &A, int wc, size_t s0
 #pragma unroll
     for (int cc = 0; cc < P; ++cc) out[cc] = pinned_load(src + cc);
   };
-  auto near_row = [&](unsigned c, double (&out)[P]) {
-    const LdsDouble *l = (const LdsDouble *)ring + (c & kRingMask) * (unsigned)P;
-#pragma unroll
-    for (int cc = 0; cc < P; ++cc) out[cc] = l[cc];
-  };
 
-  // the wave's first slice: matrix operands and epilogue rows requested before the ring is filled
-  int slice = s0 + w;
-  bool have = slice < s1;
+  const int zrow = nc * 64;
+  const unsigned far_base = (unsigned)(zrow + 1 + w * (kFarCap * 64) + lane) * (unsigned)P;  // this lane's slot 0
+  int slice = t0 * NW + w;               // (tiles are aligned: slice % NW == w)
+  bool have = slice < nchunks;
   int k = 0, b1 = 0;
   if (have) {
     k = (int)slice_bound(A.slice_ptr, slice);
     b1 = (int)slice_bound(A.slice_ptr, slice + 1);
   }
-  // ONE register set for the prefetched operands (raw matrix words here, epilogue rows in the Epi), loop-carried:
-  // at the top of a slice they are turned into something else (columns + packed value indices; the rows are parked
-  // in wave-private LDS by epi.park()) -- work that needs the data and therefore stays at the top, where the loads
-  // are a slice old -- and the same registers then receive the next slice's loads.  (A plain copy `cur = next`
-  // is placed by the compiler at the BOTTOM of the previous slice, right behind the loads' issue: a wait for the
-  // whole prefetch in every slice.)
   Head h;
-  load_head(h, k);  // (no slice: entry 0 of the matrix, never consumed)
-  epi.request(have ? slice : s0);
+  load_head(h, k, have ? slice : 0);
+  // ring: the first tile's window, the zero row
+  int slot_own;  // ring slot of the wave's own chunk (= slice % nc), advanced by 16 per tile
   {
-    const int lo = s0 - wc;
-    int hi = s0 + kWaves + wc;
+    const int lo = t0 * NW - wc;
+    int hi = t0 * NW + NW + wc;
     if (hi > nchunks) hi = nchunks;
-    if (hi > s1 + wc) hi = s1 + wc;
-    for (int q = lo + w; q < hi; q += kWaves) {
+    for (int q = lo + w; q < hi; q += NW) {
       if (q < 0) continue;
       double b[P];
       chunk_load(q, b);
-      chunk_store(q, b);
+      chunk_store(q % nc, b);
     }
+    if (threadIdx.x < P) L[zrow * P + threadIdx.x] = 0.0;
+    slot_own = (t0 * NW + w) % nc;
   }
+  int slot_job = (t0 * NW + NW + wc + w) % nc;  // slot of the chunk this wave stages during the first tile
   lds_barrier();
   MI_STAMP(1, 0.0);
 
-  for (int t = 0; t < ntiles; ++t) {
-    MI_STAMP(2 + 8 * t, 0.0);
-    const int qj = job_chunk(t);
+  for (int t = t0; t < t1; ++t) {
+    MI_STAMP(2 + 8 * (t - t0), 0.0);
+    const int qj = (t + 1) * NW + wc + w;  // staged for tile t + 1 (its last wc chunks included)
+    const bool job = t + 1 < t1 && qj < nchunks;
     double pre[P] = {};
-    if (!(dbg & 16)) chunk_load(qj >= 0 ? qj : 0, pre);  // unconditional: the s_waitcnt counts below stay exact on every path
+    if (!(dbg & 16)) chunk_load(job ? qj : 0, pre);  // unconditional: the s_waitcnt counts below stay exact on every path
     if (have) {
-      const int nslice = slice + kWaves;
-      const bool more = nslice < s1;
+      const int nslice = slice + NW;
+      const bool more = t + 1 < t1 && nslice < nchunks;
       int q0 = k, q1 = b1;  // nothing follows: the prefetch re-reads this slice
       if (more) { q0 = (int)slice_bound(A.slice_ptr, nslice); q1 = (int)slice_bound(A.slice_ptr, nslice + 1); }
-      const unsigned row = (unsigned)(slice * 64) + (unsigned)lane;
-      // ---- the slice's words -> columns, packed value indices, this lane's (<= kFarCap) far entries ----------
-      // what stays of the eight words: per entry a 16-bit row offset into the ring (0 for far entries and beyond
-      // the slice width: the lane's own row, read and discarded / multiplied by a zero value) and an 8-bit value
-      // index, packed two and four to a register; the columns of the (<= 2) far entries
-      unsigned dpk[HW / 2], vix[HW / 4];
-      int f0 = HW, f1 = HW, nf = 0;
-      unsigned cf0 = row < nloc ? row : 0u, cf1 = cf0;  // lanes without a far entry re-read their own row
+      // ---- this slice's operands become LDS contents and addresses; the registers take the next slice's -------
+      double gf[kFarCap][P];
 #pragma unroll
-      for (int j = 0; j < HW / 4; ++j) vix[j] = 0;
+      for (int s = 0; s < kFarCap; ++s) far_row((dbg & 1) ? (unsigned)(slice * 64 + lane) : h.f[s], gf[s]);
+      unsigned wd[HW];
 #pragma unroll
-      for (int j = 0; j < HW / 2; ++j) dpk[j] = 0;
-      static_assert(kFarCap == 2, "two far slots per row (f0, f1)");
+      for (int j = 0; j < HW; ++j) wd[j] = (k + j < b1) ? h.c[j] : W.zw;  // (wave-uniform condition)
+      MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
+      if (!(dbg & 8)) load_head(h, q0, more ? nslice : slice);
+      if (!(dbg & 2)) epi.request(slice);  // the epilogue rows of THIS slice: the entries' work lies between here and their use
+      // the gathers (and only they: 2 P + HW + 2 + 2 P pinned loads were issued behind them) -> far slots
 #pragma unroll
-      for (int j = 0; j < HW; ++j) {
-        const int d = (int)h.c[j] >> 8;
-        vix[j / 4] |= (h.c[j] & 255u) << (8 * (j % 4));
-        const bool valid = k + j < b1;  // wave-uniform
-        const bool nearj = (unsigned)(d + (int)wr) <= 2u * wr && (!HALO || row + (unsigned)d < nloc);
-        const bool far = valid && !nearj;
-        const bool first = far && nf == 0, second = far && nf == 1;
-        f0 = first ? j : f0;
-        f1 = second ? j : f1;
-        cf0 = first ? row + (unsigned)d : cf0;
-        cf1 = second ? row + (unsigned)d : cf1;
-        nf += far ? 1 : 0;
-        const unsigned dn = (valid && nearj) ? ((unsigned)d & 0xffffu) : 0u;  // |d| <= 64 wc <= 1024
-        dpk[j / 2] |= dn << (16 * (j % 2));
-      }
-      epi.park();  // the epilogue rows of THIS slice: registers -> wave-private LDS
-      if (dbg & 1) { cf0 = row; cf1 = row; }  // (experiment: no far gathers)
-      double gf0[P], gf1[P];
-      far_row_pinned(cf0, gf0);
-      far_row_pinned(cf1, gf1);
-      MI_STAMP(2 + 8 * t + 1, (double)vix[0]);  // this slice's matrix words were there
-      // ---- only now the next slice's operands (newer than the gathers: waiting for those never waits for these)
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(dbg & 8)) load_head(h, q0);
-      if (!(dbg & 2)) epi.request(more ? nslice : slice);
-      // ---- consume the entries in storage order (straight-line: no branch, no loop up to the epilogue) -----
+      for (int s = 0; s < kFarCap; ++s)
+#pragma unroll
+        for (int c = 0; c < P; ++c) L[far_base + (unsigned)(s * 64 * P + c)] = gf[s][c];
+      MI_STAMP(2 + 8 * (t - t0) + 2, gf[kFarCap - 1][P - 1]);
+      // ---- entries in storage order ----------------------------------------------------------------------------
       double acc[P];
 #pragma unroll
       for (int c = 0; c < P; ++c) acc[c] = 0;
-      // Every product below depends on the gathers (through the selects), so the compiler would issue ALL ring
-      // reads and value lookups first and only then wait (64 registers: the accumulators spill).  Tie the ring
-      // addresses to the gathers' arrival instead: an opaque zero that exists once both have landed.  The ring
-      // reads are then issued MI_WIN_LDS_BATCH entries at a time, right where they are consumed.
-      unsigned rowz;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(rowz) : "v"(row), "v"(gf0[P - 1]), "v"(gf1[P - 1]));
 #pragma unroll
       for (int j = 0; j < HW; ++j) {
-        const double aj = (k + j < b1) ? vt[(vix[j / 4] >> (8 * (j % 4))) & 255u] : 0.0;
-        double g[P];
-        near_row(rowz + (unsigned)(int)(short)(dpk[j / 2] >> (16 * (j % 2))), g);
-#pragma unroll
-        for (int c = 0; c < P; ++c) {
-          g[c] = (j == f0) ? gf0[c] : g[c];
-          g[c] = (j == f1) ? gf1[c] : g[c];
-        }
+        const double aj = vt[wd[j] & 255u];
+        const LdsDouble *l = L + (wd[j] >> 8) * (unsigned)P;
 #pragma unroll
         for (int c = 0; c < P; ++c) {
 #pragma clang fp contract(off)
-          const double tt = aj * g[c];
+          const double tt = aj * l[c];
           acc[c] = acc[c] + tt;
         }
-        if (j == 0) MI_STAMP(2 + 8 * t + 2, acc[0]);  // the far gathers have arrived
-        if ((j % MI_WIN_LDS_BATCH) == MI_WIN_LDS_BATCH - 1 && j + 1 < HW) {
-          // the next batch's ring addresses "depend" on this batch's sums
-          asm volatile("v_mov_b32 %0, %1" : "=v"(rowz) : "v"(rowz), "v"(acc[0]), "v"(acc[P - 1]));
-        }
       }
-      MI_STAMP(2 + 8 * t + 4, acc[0]);
-      // the staged chunk goes into the ring here: its loads are the oldest in the queue (eighteen newer ones),
-      // and its slot holds a chunk no wave still in this tile can need (hazards, above)
-      if (qj >= 0) chunk_store(qj, pre);
+      MI_STAMP(2 + 8 * (t - t0) + 4, acc[0]);
+      // the staged chunk goes into the ring here: its loads are the oldest in the queue
+      if (job) chunk_store(slot_job, pre);
       {
         double vrow[P];
-        near_row(row, vrow);
+        const LdsDouble *l = L + (unsigned)(slot_own * 64 + lane) * (unsigned)P;
+#pragma unroll
+        for (int c = 0; c < P; ++c) vrow[c] = l[c];
         if (!(dbg & 4)) epi.end(slice, acc, vrow);
-        MI_STAMP(2 + 8 * t + 5, acc[0]);  // epilogue done, stores issued
+        MI_STAMP(2 + 8 * (t - t0) + 5, acc[0]);  // epilogue done, stores issued
       }
       have = more;
       slice = nslice;
       k = q0;
       b1 = q1;
+    } else if (job) {
+      chunk_store(slot_job, pre);  // a wave without a slice in this tile
     }
-    else if (qj >= 0) {
-      chunk_store(qj, pre);  // a wave without a slice in this tile
-    }
-    if (t + 1 < ntiles) {
-      MI_STAMP(2 + 8 * t + 6, 0.0);
+    slot_own += NW;
+    slot_own = slot_own >= nc ? slot_own - nc : slot_own;
+    slot_job += NW;
+    slot_job = slot_job >= nc ? slot_job - nc : slot_job;
+    if (t + 1 < t1) {
+      MI_STAMP(2 + 8 * (t - t0) + 6, 0.0);
       lds_barrier();
-      MI_STAMP(2 + 8 * t + 7, 0.0);  // barrier passed
+      MI_STAMP(2 + 8 * (t - t0) + 7, 0.0);  // barrier passed
     }
   }
 #ifdef MI_WIN_STAMPS
-  MI_STAMP(kStampSlots - 1, 0.0);
-  stamp_real(stamp_area, kStampSlots - 2);
-  if (g_stamp_buf && (lane < 56 || lane > 58))
-    g_stamp_buf[((size_t)blockIdx.x * kWaves + w) * kStampSlots + lane] = stamp_area[lane];
+  if (g_stamp_buf && lane < kStampLdsSlots)
+    g_stamp_buf[((size_t)blockIdx.x * NW + w) * kStampSlots + lane] = stamp_area[lane];
 #endif
 }
 

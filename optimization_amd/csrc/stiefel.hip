@@ -189,10 +189,11 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // RECUR (mi_op::apply_dir with gram_count < 0): M is read from gdir (packed symmetric, replicated scalars kept
 // by STPCG) and the packed symmetric Gram  sym(Y'out - (X'out) S)  of the OUTPUT rides along as components
 // 3.. of the partial row (DirComps<P>::value components in all).
-// WIN (mi_csr::win_chunks > 0): the rows of V near the workgroup's own are staged in an LDS ring and the gathers
-// of near entries are ds_reads (spmm_core.h sell_window); same arithmetic, bit-identical results.
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, bool WIN_>
-__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, const CgState *__restrict__ st,
+// HW > 0 (mi_csr::win_chunks > 0): the window form -- the rows of V near the workgroup's own are staged in an LDS
+// ring and every entry's row is read from LDS at an address the host worked out (spmm_core.h sell_window); HW = the
+// entries per slice.  Same arithmetic, bit-identical results.
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW>
+__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
                                                           const double *__restrict__ Y,
@@ -202,13 +203,12 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, co
                                                           const double *__restrict__ gdir,
                                                           double *__restrict__ out,
                                                           double *__restrict__ partials) {
-  constexpr bool WIN = WIN_ && P <= 3;  // (P = 4: ring + parked rows would need 192 KB of LDS; never dispatched)
+  constexpr bool WIN = HW > 0 && P <= 3;  // (P = 4: ring + parked rows would need > 160 KB of LDS; never dispatched)
   constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
   constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
   __shared__ double lds[kLds];
   __shared__ double vt[PK ? 256 : 1];  // PK: the matrix's value table
-  __shared__ double ring[WIN ? kRingChunks * 64 * P : 1];
-  __shared__ double xy_park[WIN ? kWaves * 2 * 64 * P : 1];  // WIN: the epilogue's X, Y rows of each wave's slice
+  __shared__ double ring[WIN ? kWinLdsRows * P : 1];  // WIN: ring, zero row, far slots
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #ifdef MI_WIN_STAMPS  // both forms: each wave's entry and exit on the constant 100 MHz clock (slots 56, 57)
@@ -273,12 +273,10 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, co
         for (int c = 0; c < P; ++c) y[c] = ys[c];
       }
     }
-    // sell_window's protocol: request(slice) loads the rows one slice ahead into xn/yn, park() moves them to the
-    // wave's private LDS area at the top of their slice (so the registers can take the next request), end(slice,
-    // acc, vrow) reads them back
+    // sell_window's protocol: request(slice) issues the loads of the slice's rows (pinned: see spmm_core.h),
+    // end(slice, acc, vrow) consumes them
     double xn[WIN ? P : 1], yn[WIN ? P : 1];
-    double *xy_lds;  // this wave's 2 x 64 x P doubles
-    __device__ __forceinline__ void request(size_t slice) {  // pinned loads: see spmm_core.h
+    __device__ __forceinline__ void request(size_t slice) {
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off);
 #pragma unroll
@@ -289,21 +287,12 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, co
         for (int c = 0; c < P; ++c) yn[WIN ? c : 0] = pinned_load(ys + c);
       }
     }
-    __device__ __forceinline__ void park() {
-      LdsDouble *l = (LdsDouble *)xy_lds + lane * P;
-#pragma unroll
-      for (int c = 0; c < P; ++c) {
-        l[c] = xn[WIN ? c : 0];
-        if (RECUR) l[64 * P + c] = yn[WIN ? c : 0];
-      }
-    }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&vrow)[P]) {
-      const LdsDouble *l = (const LdsDouble *)xy_lds + lane * P;
 #pragma unroll
       for (int c = 0; c < P; ++c) {
         v[c] = vrow[c];
-        x[c] = l[c];
-        if (RECUR) y[c] = l[64 * P + c];
+        x[c] = xn[WIN ? c : 0];
+        if (RECUR) y[c] = yn[WIN ? c : 0];
       }
       end(slice, acc);
     }
@@ -347,18 +336,25 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, int wc, co
           }
       }
     }
-  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}, {}, {}, xy_park + (WIN ? (threadIdx.x >> 6) * (2 * 64 * P) : 0)};
+  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}, {}, {}};
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  if constexpr (WIN) sell_window<P, HALO, PK>(A, wc, s0, s1, wu, lane, V, vt, ring, epi);
-  else sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+  if constexpr (WIN) {
+    // a contiguous run of whole TILES (16 slices) per workgroup, the same number for every workgroup but the last
+    const int ntiles = (int)((A.nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + (int)nb - 1) / (int)nb;
+    const int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    sell_window<P, HW, HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
+  } else {
+    sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+  }
 #ifdef MI_WIN_STAMPS
   const unsigned long long t_body = wall_clock64();
 #endif
-  block_partials_store<KC>(a, lds, partials);
+  if constexpr (WIN) block_partials_store_nw<KC, kWinWaves>(a, lds, partials);
+  else block_partials_store<KC>(a, lds, partials);
 #ifdef MI_WIN_STAMPS
   if (g_stamp_buf && lane == 0) {
-    unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * kWaves + w) * kStampSlots;
+    unsigned long long *o = g_stamp_buf + ((size_t)blockIdx.x * (WIN ? kWinWaves : kWaves) + w) * kStampSlots;
     o[56] = t_entry;
     o[57] = wall_clock64();
     o[58] = t_body;
@@ -622,14 +618,20 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const bool recur = gram_count < 0;
   const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
-  // LDS-window form when the matrix is banded enough (decided at creation, sparse.hip: window_chunks)
-  // (work in progress: opt-in with MI355OPT_WINDOW=1 until it beats the streaming form)
-  static const bool no_win = [] { const char *e = getenv("MI355OPT_WINDOW"); return !(e && e[0] == '1'); }();
-  // (p = 4: ring + parked rows would need 192 KB of LDS)
-  int wc = (no_win || p > 3) ? 0 : A->win_chunks;
+  // the window form when the matrix qualifies (decided at creation, sparse.hip build_window); p = 4 does not fit
+  static const bool no_win = [] { const char *e = getenv("MI355OPT_NO_WINDOW"); return e && e[0] == '1'; }();
+  const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
+  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero};
 #ifdef MI_WIN_DEBUG
-  if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wc |= atoi(e) << 8;
+  if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
+  const bool win = recur && wc > 0;
+  if (win && !g_uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
+    const int wgs = cap * (kWaves / kWinWaves) <= kMaxGrid ? cap * (kWaves / kWinWaves) : kMaxGrid;
+    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + wgs - 1) / wgs;
+    grid = (ntiles + per - 1) / per;
+  }
+  const int block = win ? kWinBlock : kBlock;
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   if (!recur) {
@@ -637,18 +639,23 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
     if (sharded) MI_TRY(sharded_reduce(ctx, gram_count, nsym(p), slots));
   }
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HF3(F, HL, RC, PKV, WN)                                                                               \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV, WN>), dim3(grid), dim3(kBlock), 0,     \
-                                   ctx->stream, view, wc, (const CgState *)ctx->cg_live,                     \
+#define HF3(F, HL, RC, PKV, HWV)                                                                              \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV, HWV>), dim3(grid), dim3(block), 0,     \
+                                   ctx->stream, view, wv, (const CgState *)ctx->cg_live,                     \
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,  \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),        \
                                    out->d, ctx->partials))
 #define HF(F, HL, RC)                                                          \
-  if (A->pk && wc > 0) { HF3(F, HL, RC, true, true); }                         \
-  else if (A->pk) { HF3(F, HL, RC, true, false); }                             \
-  else { HF3(F, HL, RC, false, false); }
-  if (recur) {
+  if (A->pk) { HF3(F, HL, RC, true, 0); }                                      \
+  else { HF3(F, HL, RC, false, 0); }
+  if (win) {  // the window form (recurrence form only: the unpreconditioned solve)
+    if (A->win_head <= 7) {
+      if (halo) { HF3(false, true, true, true, 7); } else { HF3(false, false, true, true, 7); }
+    } else {
+      if (halo) { HF3(false, true, true, true, 8); } else { HF3(false, false, true, true, 8); }
+    }
+  } else if (recur) {
     if (halo) { HF(false, true, true); } else { HF(false, false, true); }
   } else if (halo) {
     if (sharded) { HF(true, true, false); } else { HF(false, true, false); }
