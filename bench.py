@@ -9,10 +9,17 @@ on BASELINE cfg2: Stiefel(1e6 x world_size, 3), f(X) = .5 tr(X'AX), A = 7-point 
 iterations).  Steps are executed as STPCG solves of max_TPCG_iterations = 50 (cfg2), i.e. the timed
 region also contains each solve's initialisation and final read-back.
 
-value = steps * algorithmic_bytes_per_step / time, algorithmic bytes per SURVEY.md 8(d):
-88*N (CG) + 12*nnz + 4*(n+1) + 16*n*p + 56*N (Stiefel HVP), inputs resident in HBM.
+value = steps x (compulsory HBM bytes of the three kernels an iteration runs) / time: a bandwidth that can be
+held against the 8 TB/s HBM peak (hbm_roofline_frac_whole_step = value / n_gpus / 8000).  The fused kernels
+move far fewer bytes than SURVEY.md 8(d)'s accounting of the reference schedule (88 N + 12 nnz + 4 (n+1) +
+16 n p + 56 N per iteration); the same time priced by those bytes is reported as survey_8d_equivalent_GBps.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+Extra legs (rank 0 of a 1-GPU run, each with its own moved-bytes fraction): the same workload with the
+matrix in plain 12-byte entries instead of the 4-byte value-indexed copy (`plain_matrix_leg`), St(8e6,3) on
+one GPU -- beyond the 256 MiB Infinity Cache -- (`beyond_cache_leg`), and the CPU baselines: the reference's
+own single-threaded path and the oracle's OpenMP build on all host cores this process may use.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-roofline] [--no-legs]
        (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL for the data path,
         torch.distributed/gloo only for rendezvous, barriers and the max-over-ranks time.)
 """
@@ -46,13 +53,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8
 TPCG = 50              # cfg2: max_TPCG_iterations
 
 
-def kernel_bytes(n, nnz, p):
+def kernel_bytes(n, nnz, p, packed=True):
     """Per-launch compulsory HBM bytes of each hot kernel (every operand streamed once)."""
     N = n * p
     direct = os.environ.get("MI355OPT_DIRGRAM_DIRECT", "0") == "1"  # Gram rows formed by the direction kernel
     # the one-pass Hessian streams the value-indexed packed copy of A (4 B per entry: the bench matrix has 2
     # distinct values) unless that format is switched off
-    a_fused = (4 if os.environ.get("MI355OPT_NO_PACKED", "0") != "1" else 12) * nnz + 4 * (n + 1)
+    a_fused = (4 if packed else 12) * nnz + 4 * (n + 1)
     kb = {
         # A; V gathered, X read; Hp written (the projection matrix is known before the pass); recurrence
         # form: + Y read for the Gram of the output
@@ -64,6 +71,77 @@ def kernel_bytes(n, nnz, p):
         "cg_pupdate": 8 * (7 if direct else 5) * N,
     }
     return kb
+
+
+HOT = ["stiefel_hess_fused", "stiefel_spmm_gram", "stiefel_finish_dots", "cg_update", "cg_pupdate"]
+AUX = ["stiefel_gram_reduce", "cg_scalar_a", "cg_scalar_b"]
+
+
+def timed_kernels(ctx, g, H, s_out, steps, kb):
+    """`steps` more iterations with a HIP-event pair around every hot kernel (on the stream they are launched on).
+    Returns (per-kernel dict, moved bytes per step)."""
+    names = HOT + AUX
+    for k in names:
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    run_steps(ctx, g, H, s_out, steps)
+    per = {}
+    for k in names:
+        cnt, ms = ctx.ktime_read(k)
+        per[k] = {"launches": cnt, "avg_us": 1e3 * ms / max(cnt, 1)}
+        ctx.ktime_enable(k, False)
+    for k in HOT:
+        if per[k]["launches"]:
+            per[k]["bytes"] = kb[k]
+            per[k]["GBps"] = kb[k] / (per[k]["avg_us"] * 1e-6) / 1e9
+    moved = sum(kb[k] * per[k]["launches"] for k in HOT) / steps
+    return per, moved
+
+
+def wall_steps(ctx, g, H, s_out, steps, warmup):
+    """time `steps` iterations (after `warmup`): seconds"""
+    if warmup:
+        run_steps(ctx, g, H, s_out, warmup)
+    ctx.sync()
+    t0 = time.perf_counter()
+    run_steps(ctx, g, H, s_out, steps)
+    ctx.sync()
+    return time.perf_counter() - t0
+
+
+def extra_leg(ctx, nx, p, steps, warmup, packed, label):
+    """One more single-GPU leg: St(nx^3, p), matrix packed or plain, its own moved-bytes bandwidth."""
+    n = nx ** 3
+    prev = os.environ.get("MI355OPT_NO_PACKED")
+    os.environ["MI355OPT_NO_PACKED"] = "0" if packed else "1"
+    try:
+        rowptr, col, val = wl.laplacian_3d(nx, nx, nx)
+        A = ctx.csr(n, rowptr, col, val)
+    finally:
+        if prev is None:
+            os.environ.pop("MI355OPT_NO_PACKED", None)
+        else:
+            os.environ["MI355OPT_NO_PACKED"] = prev
+    nnz = int(rowptr[-1])
+    del rowptr, col, val
+    prob = ctx.stiefel_rq(A, n, p)
+    Xb, _ = wl.stiefel_bench_iterate(nx, nx, nx, p, eps=1e-3, seed=7)
+    X = ctx.upload(Xb)
+    del Xb
+    g, H = prob.model(X)
+    s_out = ctx.vec(n * p)
+    dt = wall_steps(ctx, g, H, s_out, steps, warmup)
+    kb = kernel_bytes(n, nnz, p, packed=packed)
+    per, moved = timed_kernels(ctx, g, H, s_out, min(steps, 100), kb)
+    N = n * p
+    ws = 6 * 8 * N + (4 if packed else 12) * nnz
+    out = {"workload": label, "rows": n, "nnz": nnz, "packed_matrix": packed, "steps": steps,
+           "us_per_step": 1e6 * dt / steps, "moved_bytes_per_step": moved,
+           "moved_GBps": steps * moved / dt / 1e9, "hbm_roofline_frac": steps * moved / dt / 1e9 / HBM_PEAK_GBS,
+           "working_set_MB": ws / 1e6, "infinity_cache_MB": 268.4,
+           "kernels": {k: v for k, v in per.items() if v["launches"]}}
+    del g, H, s_out, X, prob, A
+    return out
 
 
 def run_steps(ctx, g, H, s_out, steps):
@@ -120,39 +198,81 @@ def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank):
     return sorted(set(x for a in agree for x in a))
 
 
-def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step):
-    """The reference's own CPU path (oracle/_ref/libref.so = the reference templates compiled from
-    /root/reference, single-threaded like the reference) on a bounded sample of the same workload;
-    falls back to the plain-C oracle ("port") if the reference build is absent."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_py
-    O = oracle_py.Oracle()
-    lib, kind = (oracle_py.Reference(), "reference") if oracle_py.have_reference() else (O, "port")
-    n = nx * ny * nz
-    prob = O.stiefel_rq(n, p, rowptr, col, val)
-    g = O.eval_grad(prob, Xb.ravel())
-    solves, iters = 3, 0
-    O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=2, kappa_fgr=1e-12, theta=1.0, lib=lib)
-    t0 = time.perf_counter()
-    for _ in range(solves):
-        r = O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=TPCG, kappa_fgr=1e-12, theta=1.0,
-                            lib=lib)
-        iters += r["iterations"]
-    dt = time.perf_counter() - t0
-    O.free(prob)
-    cpu = "?"
+def host_cpus():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256
+    cores to a container that has a quota of 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    cpu = line.split(":", 1)[1].strip()
-                    break
+                    return line.split(":", 1)[1].strip()
     except OSError:
         pass
-    return {"value": iters * bytes_per_step / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": kind,
-            "sample": f"{solves} STPCG solves x {TPCG} inner iterations of the same St(1e6,3) workload "
-                      f"({iters} steps, {dt:.1f} s)",
-            "ms_per_step": 1e3 * dt / max(iters, 1), "cpu": cpu, "host_cores_available": os.cpu_count()}
+    return "?"
+
+
+def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
+    """(a) The reference's own CPU path (oracle/_ref/libref.so = the reference templates compiled from
+    /root/reference, single-threaded like the reference; the plain-C oracle, "port", if that build is absent) and
+    (b) the oracle's OpenMP build (its vector and row loops as `omp parallel for`) on all the host CPUs this
+    process may use -- both on a bounded sample of the same workload, same iteration counts asserted.
+    `value` prices a CPU step with the same bytes as the GPU's `value` (so the ratio of the two is the ratio of
+    steps per second); the SURVEY 8(d) figure of the reference schedule is next to it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    n = nx * ny * nz
+    out = []
+    ncpu = host_cpus()
+    for omp in (False, True):
+        O = oracle_py.Oracle(omp=omp)
+        if omp:
+            threads = O.set_threads(ncpu)
+            lib, kind = O, "port"
+        else:
+            threads = 1
+            lib, kind = (oracle_py.Reference(), "reference") if oracle_py.have_reference() else (O, "port")
+        prob = O.stiefel_rq(n, p, rowptr, col, val)
+        g = O.eval_grad(prob, Xb.ravel())
+        solves, iters = (3 if not omp else 6), 0
+        O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=2, kappa_fgr=1e-12, theta=1.0, lib=lib)
+        t0 = time.perf_counter()
+        for _ in range(solves):
+            r = O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=TPCG, kappa_fgr=1e-12, theta=1.0,
+                                lib=lib)
+            if r["iterations"] != TPCG:
+                raise RuntimeError("CPU baseline: %d iterations instead of %d" % (r["iterations"], TPCG))
+            iters += r["iterations"]
+        dt = time.perf_counter() - t0
+        O.free(prob)
+        out.append({"value": iters * bytes_per_step / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": kind,
+                    "sample": f"{solves} STPCG solves x {TPCG} inner iterations of the same St({n},{p}) workload "
+                              f"({iters} steps, {dt:.1f} s)" + (", OpenMP loops (oracle/liboracle_omp.so)" if omp else ""),
+                    "ms_per_step": 1e3 * dt / max(iters, 1),
+                    "survey_8d_GBps": iters * bytes_8d / dt / 1e9,
+                    "cpu": cpu_model(), "host_cores_visible": os.cpu_count(), "host_cores_usable": ncpu})
+    return out[0], out[1]
 
 
 def main():
@@ -162,6 +282,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the plain-matrix and beyond-cache legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,9 +309,10 @@ def main():
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(world, rank, uid[0])
-        # tiny latency-bound exchanges (scalar all-reduces, halo rows) through mapped peer memory when every
-        # rank's bring-up + self-test succeeds (MI355OPT_COMM=rccl keeps them on RCCL)
-        peer_memory = ctx.enable_peer_memory(world, rank, dist)
+        # RCCL carries every exchange by default.  MI355OPT_COMM=peer opts into the peer-memory layer (scalar
+        # all-reduces and halo rows by xGMI peer stores), enabled only when every rank's bring-up + self-test
+        # succeeds; the one-GPU rehearsal needs it (RCCL refuses duplicate devices).
+        peer_memory = ctx.enable_peer_memory(world, rank, dist, force=one_gpu)
         if one_gpu and not peer_memory:
             raise SystemExit("one-GPU rehearsal needs the peer-memory layer")
         dist.barrier()
@@ -251,26 +373,24 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    value = world * args.steps * bytes_per_step / dt / 1e9
+    packed = os.environ.get("MI355OPT_NO_PACKED", "0") != "1"
+    kb = kernel_bytes(n, nnz, p, packed=packed)
+    # compulsory bytes of the three kernels a completed iteration launches (the per-solve initialisation kernels,
+    # ~2 % of the time at 50 iterations per solve, are inside the timed region but not counted)
+    recur = os.environ.get("MI355OPT_NO_DIRGRAM", "0") != "1"
+    moved_model = (kb["stiefel_hess_fused"] if recur else kb["stiefel_spmm_gram"] + kb["stiefel_finish_dots"]) + \
+        kb["cg_update"] + kb["cg_pupdate"]
 
     # ---- roofline leg: same steps again with HIP-event pairs around every hot kernel ------------
     roofline = None
+    moved_bytes = moved_model
     # EVERY rank runs these steps (they contain the same exchanges as the timed ones: a rank running them alone
     # would wait for peers that never come); rank 0's own kernel timings are the ones reported.
     if not args.no_roofline:
-        kb = kernel_bytes(n, nnz, p)
-        names = list(kb) + ["stiefel_gram_reduce", "cg_scalar_a", "cg_scalar_b"]
-        for k in names:
-            ctx.ktime_enable(k, True)
-        ctx.ktime_reset()
-        run_steps(ctx, g, H, s_out, min(args.steps, 200))
-        per = {}
-        for k in names:
-            cnt, ms = ctx.ktime_read(k)
-            per[k] = {"launches": cnt, "avg_us": 1e3 * ms / max(cnt, 1)}
-            ctx.ktime_enable(k, False)
-        kb = {k: b for k, b in kb.items() if per[k]["launches"] > 0}
-        dom = max(kb, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
+        per, moved_measured = timed_kernels(ctx, g, H, s_out, min(args.steps, 200), kb)
+        moved_bytes = moved_measured
+        ran = [k for k in HOT if per[k]["launches"]]
+        dom = max(ran, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
         achieved = kb[dom] / (per[dom]["avg_us"] * 1e-6) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -281,7 +401,7 @@ def main():
                 traffic = None
         # SURVEY 8(d) prices the whole Stiefel HVP (SpMM + Gram pass + finish pass, 12-byte matrix entries) at
         # stiefel_hvp_bytes; the one-pass kernel performs all of it.  `achieved`/`frac` use the bytes THIS kernel
-        # must move (a fraction above 1 would say nothing); the 8(d) variant is reported next to it.
+        # must move; the 8(d) variant is reported next to it.
         a8d = wl.stiefel_hvp_bytes(n, nnz, p) if dom == "stiefel_hess_fused" else kb[dom]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -289,21 +409,26 @@ def main():
                     "survey_8d_bytes_per_launch": a8d,
                     "achieved_survey_8d": a8d / (per[dom]["avg_us"] * 1e-6) / 1e9,
                     "avg_launch_us": per[dom]["avg_us"],
-                    "kernels": {k: dict(per[k], **({"GBps": kb[k] / (per[k]["avg_us"] * 1e-6) / 1e9,
-                                                     "bytes": kb[k]} if k in kb else {}))
-                                for k in names}}
+                    "kernels": per}
         barrier()
         if rank != 0:
             roofline = None
+    value = world * args.steps * moved_bytes / dt / 1e9
 
-    moved_bytes = None
-    if roofline is not None:
-        per_solve = {k: v["launches"] for k, v in roofline["kernels"].items()}
-        steps_timed = min(args.steps, 200)
-        moved_bytes = sum(kernel_bytes(n, nnz, p).get(k, 0) * c for k, c in per_solve.items()) / steps_timed
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step)
+    # ---- extra legs and CPU baselines: rank 0 of a single-GPU run -------------------------------------------
+    plain_leg = big_leg = cpu = cpu_all = None
+    if rank == 0 and world == 1 and not use_comm:
+        if not args.no_legs:
+            try:
+                plain_leg = extra_leg(ctx, nx, p, min(args.steps, 200), 20, packed=not packed,
+                                      label=f"cfg2 St({n},{p}) with the matrix in " +
+                                            ("plain 12-byte entries" if packed else "4-byte value-indexed entries"))
+                big_leg = extra_leg(ctx, 200, p, 50, 10, packed=packed,
+                                    label=f"St(8000000,{p}), 200^3 grid, one GPU: beyond the Infinity Cache")
+            except capi.MiError as e:  # an extra leg must never take the headline down with it
+                print("bench.py: extra leg failed: %s" % e, file=sys.stderr)
+        if not args.no_cpu_baseline:
+            cpu, cpu_all = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, moved_bytes, bytes_per_step)
 
     if rank == 0:
         out = {
@@ -315,22 +440,28 @@ def main():
                                    f"{nx}x{ny}x{nz}+0.1I, fused device STPCG in solves of {TPCG} inner "
                                    f"iterations at a near-optimal iterate (modes {modes})",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
-                       "algorithmic_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
+                       "moved_bytes_per_step_per_gpu": moved_bytes,
+                       "survey_8d_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
+                       "packed_matrix": packed,
                        "parallelism": (f"row-sharded z-slabs x{world}, comm: " +
                                        ("peer-memory layer (hipIpc-mapped arenas over xGMI: scalar all-reduce and "
                                         "halo rows by peer stores), RCCL for bring-up" if peer_memory else
                                         "RCCL (all-reduce of partial rows, halo send/recv)")) if use_comm
                        else "single GPU",
                        "device": ctx.device_name()},
-            # `value` counts SURVEY 8(d)'s algorithmic bytes (the metric's definition: every phase of the
-            # reference schedule streams its operands once).  The fused kernels move fewer: the second pair
-            # is the same step priced by the compulsory bytes of the kernels that actually ran.
+            # `value` = compulsory HBM bytes of the kernels that ran / time: comparable with the 8 TB/s peak.
             "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
-            "value_basis": "SURVEY 8(d) algorithmic bytes of the reference schedule per inner iteration; "
-                           "moved_* = compulsory bytes of the kernels that actually ran (fused, value-indexed A)",
-            "moved_bytes_per_step_per_gpu": moved_bytes,
-            "moved_GBps": (world * args.steps * moved_bytes / dt / 1e9) if moved_bytes else None,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "value_basis": "compulsory HBM bytes of the three kernels of an iteration (one-pass Hessian: "
+                           "4 nnz + 4 (n+1) + 32 N with the value-indexed matrix, 12 nnz + ... without; "
+                           "cg_update 24 N; cg_pupdate 40 N) per second; working set "
+                           f"{(6 * 8 * N + (4 if packed else 12) * nnz) / 1e6:.0f} MB per GPU (Infinity Cache: 268 MB)",
+            "packed_matrix": packed,
+            "survey_8d_equivalent_GBps": world * args.steps * bytes_per_step / dt / 1e9,
+            "survey_8d_basis": "the same time priced by SURVEY.md 8(d)'s bytes of the reference schedule "
+                               "(88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration): exceeds the HBM peak "
+                               "because the fused kernels never move those bytes",
+            "roofline": roofline, "plain_matrix_leg": plain_leg, "beyond_cache_leg": big_leg,
+            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
         }
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:

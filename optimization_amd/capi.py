@@ -489,10 +489,13 @@ class Context:
         check(self.L.mi_comm_ipc_error(self.h, C.byref(e)))
         return e.value
 
-    def enable_peer_memory(self, world_size, rank, dist):
+    def enable_peer_memory(self, world_size, rank, dist, force=False):
         """Collective bring-up of the peer-memory layer over a torch.distributed (gloo) control plane: export,
         gather handles, map, self-test; enabled only if EVERY rank succeeded at every step, else it stays off
-        (RCCL then does the small exchanges).  Returns True when enabled."""
+        (RCCL then does the small exchanges).  Returns True when enabled.
+        OPT-IN: RCCL is the default exchange layer; the peer-memory layer is only brought up with
+        MI355OPT_COMM=peer (or force=True: the one-GPU multi-process tests, where RCCL cannot run) -- it has never
+        executed across real xGMI links yet."""
         import os
 
         def all_ok(flag, payload=None):
@@ -500,7 +503,7 @@ class Context:
             dist.all_gather_object(lst, (bool(flag), payload))
             return all(f for f, _ in lst), [pl for _, pl in lst]
 
-        if os.environ.get("MI355OPT_COMM", "auto") == "rccl":
+        if not force and os.environ.get("MI355OPT_COMM", "rccl") != "peer":
             return False
         try:
             handle, ok = self.comm_ipc_export(), True

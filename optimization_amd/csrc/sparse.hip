@@ -329,7 +329,9 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
   MI_TRY(upload((void **)&A->val, pval.data(), stored * sizeof(double)));
   // value-indexed packed copy (mi_csr::pk): distinct stored values by BIT PATTERN (so -0.0, NaN payloads
   // and denormals survive), column as a signed 24-bit offset from the row
-  static const bool no_pack = [] { const char *e = getenv("MI355OPT_NO_PACKED"); return e && e[0] == '1'; }();
+  // (read at every creation, not once: bench.py builds the same matrix both ways in one process)
+  const char *no_pack_env = getenv("MI355OPT_NO_PACKED");
+  const bool no_pack = no_pack_env && no_pack_env[0] == '1';
   if (!no_pack) {
     std::unordered_map<uint64_t, int> index;
     std::vector<double> table;

@@ -11,6 +11,20 @@
 #include <string.h>
 #include <time.h>
 
+/* Optional all-cores leg (liboracle_omp.so, -fopenmp -DORC_OMP): the vector statements of STPCG run as OpenMP
+ * loops.  The default liboracle.so is built WITHOUT it and stays the sequential restatement that is compared
+ * bit for bit with the real reference. */
+#if defined(ORC_OMP) && defined(_OPENMP)
+#include <omp.h>
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static)")
+void orc_set_threads(int n) { omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+#define ORC_PAR_FOR
+void orc_set_threads(int n) { (void)n; }
+int orc_max_threads(void) { return 1; }
+#endif
+
 /* ------------------------------------------------------------------------------------------- */
 void orc_problem_free(orc_problem *p) {
   if (!p) return;
@@ -38,6 +52,7 @@ int orc_stpcg(size_t n, const double *g, orc_apply_fn H, void *H_user, orc_inner
   int reason = ORC_STPCG_EXIT_MAXIT;
   if (trace) trace->len = 0;
 
+  ORC_PAR_FOR
   for (i = 0; i < n; ++i) s[i] = 0 * g[i]; /* :211 */
   memcpy(r, g, n * sizeof(double));        /* :214 */
   if (!P)
@@ -45,6 +60,7 @@ int orc_stpcg(size_t n, const double *g, orc_apply_fn H, void *H_user, orc_inner
   else
     P(P_user, r, v); /* :234 */
 
+  ORC_PAR_FOR
   for (i = 0; i < n; ++i) p[i] = -v[i]; /* :256 */
 
   double sk_M_pk = 0;                   /* :259 */
@@ -95,7 +111,9 @@ int orc_stpcg(size_t n, const double *g, orc_apply_fn H, void *H_user, orc_inner
       return 0;
     }
 
+    ORC_PAR_FOR
     for (i = 0; i < n; ++i) s[i] = s[i] + alpha_k * p[i]; /* :374 */
+    ORC_PAR_FOR
     for (i = 0; i < n; ++i) r[i] += alpha_k * Hp[i];      /* :377 */
     if (!P)
       memcpy(v, r, n * sizeof(double)); /* :383 */
@@ -109,6 +127,7 @@ int orc_stpcg(size_t n, const double *g, orc_apply_fn H, void *H_user, orc_inner
     sk_M_pk = beta_k * (sk_M_pk + alpha_k * pk_M_2); /* :416 */
     pk_M_2 = rk_vk + beta_k * beta_k * pk_M_2;       /* :417 */
 
+    ORC_PAR_FOR
     for (i = 0; i < n; ++i) p[i] = -v[i] + beta_k * p[i]; /* :420 */
 
     if (trace && trace->len < trace->cap) {

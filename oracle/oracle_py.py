@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
+_LIB_OMP = os.path.join(_HERE, "liboracle_omp.so")  # same sources, OpenMP loops: bench.py's all-cores CPU leg only
 _REF = os.path.join(_HERE, "_ref", "libref.so")
 
 c_double_p = C.POINTER(C.c_double)
@@ -25,14 +26,14 @@ MATOP_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, c_double_p, c_d
 
 def build(force=False):
     """Compile liboracle.so (and _ref/libref.so when /root/reference is mounted)."""
-    if force or not os.path.exists(_LIB) or _stale():
+    if force or not os.path.exists(_LIB) or not os.path.exists(_LIB_OMP) or _stale():
         subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
     return _LIB
 
 
 def _stale():
     try:
-        t = os.path.getmtime(_LIB)
+        t = min(os.path.getmtime(_LIB), os.path.getmtime(_LIB_OMP))
         return any(os.path.getmtime(os.path.join(_HERE, f)) > t
                    for f in ("oracle.c", "problems.c", "oracle.h"))
     except OSError:
@@ -313,9 +314,16 @@ def _seq_dot(a, b):
 
 
 class Oracle(_Lib):
-    def __init__(self):
+    def __init__(self, omp=False):
+        """omp=True: the OpenMP build (vector loops and row loops in parallel; sums re-associated, so NOT the
+        bit-for-bit restatement -- used only as the all-cores CPU baseline)."""
         build()
-        super().__init__(_LIB, "orc", True)
+        super().__init__(_LIB_OMP if omp else _LIB, "orc", True)
+        self.lib.orc_max_threads.restype = C.c_int
+
+    def set_threads(self, n):
+        self.lib.orc_set_threads(int(n))
+        return self.lib.orc_max_threads()
 
     def default_params(self, **kw):
         p = TntParams()

@@ -12,10 +12,22 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Optional all-cores leg (liboracle_omp.so, -fopenmp -DORC_OMP; see oracle.c): the row loops of the Stiefel problem and
+ * the inner products run as OpenMP loops (the sums are then re-associated: the last bits differ from the sequential
+ * restatement, which is why the default build keeps them sequential). */
+#if defined(ORC_OMP) && defined(_OPENMP)
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static)")
+#define ORC_PAR_SUM(var) _Pragma("omp parallel for schedule(static) reduction(+ : s)")
+#else
+#define ORC_PAR_FOR
+#define ORC_PAR_SUM(var)
+#endif
+
 static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
 static double dotn(size_t n, const double *a, const double *b) {
   double s = 0;
   size_t i;
+  ORC_PAR_SUM(s)
   for (i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
@@ -199,6 +211,9 @@ void orc_csr_spmm(size_t n, size_t p, const int *rowptr, const int *col, const d
                   const double *V, double *W) {
   size_t i, c;
   int k;
+#if defined(ORC_OMP) && defined(_OPENMP)
+#pragma omp parallel for schedule(static) private(c, k)
+#endif
   for (i = 0; i < n; ++i) {
     double acc[16];
     for (c = 0; c < p; ++c) acc[c] = 0;
@@ -279,6 +294,19 @@ static void stiefel_destroy(void *u) {
 static void gram(size_t n, size_t p, const double *X, const double *Z, double *G) {
   size_t i, a, b;
   for (a = 0; a < p * p; ++a) G[a] = 0;
+#if defined(ORC_OMP) && defined(_OPENMP)
+  {
+    double Gl[256];
+    const size_t pp = p * p;
+    for (a = 0; a < 256; ++a) Gl[a] = 0;
+#pragma omp parallel for schedule(static) private(a, b) reduction(+ : Gl[:pp])
+    for (i = 0; i < n; ++i)
+      for (a = 0; a < p; ++a)
+        for (b = 0; b < p; ++b) Gl[a * p + b] += X[i * p + a] * Z[i * p + b];
+    for (a = 0; a < pp; ++a) G[a] = Gl[a];
+    return;
+  }
+#endif
   for (i = 0; i < n; ++i)
     for (a = 0; a < p; ++a)
       for (b = 0; b < p; ++b) G[a * p + b] += X[i * p + a] * Z[i * p + b];
@@ -296,6 +324,9 @@ static void symmetrize(size_t p, double *G) {
 static void sub_XM(size_t n, size_t p, const double *Z, const double *X, const double *M,
                    double *out) {
   size_t i, a, b;
+#if defined(ORC_OMP) && defined(_OPENMP)
+#pragma omp parallel for schedule(static) private(a, b)
+#endif
   for (i = 0; i < n; ++i)
     for (b = 0; b < p; ++b) {
       double s = 0;
@@ -320,6 +351,9 @@ static void stiefel_hess(void *u, const double *X, const double *V, double *hv) 
   size_t i, a, b, n = s->n, p = s->p;
   double M[256];
   orc_csr_spmm(n, p, s->rowptr, s->col, s->val, V, s->W);
+#if defined(ORC_OMP) && defined(_OPENMP)
+#pragma omp parallel for schedule(static) private(a, b)
+#endif
   for (i = 0; i < n; ++i) /* Z = A V - V S */
     for (b = 0; b < p; ++b) {
       double t = 0;
