@@ -27,7 +27,8 @@ constexpr int kWave = 64;
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / kWave;  // 16
 constexpr int kMaxGrid = 512;
-constexpr int kMaxRows = kMaxGrid;      // partial rows per component
+constexpr int kMaxRows = 1024;          // partial rows per component (the streaming kernels leave <= kMaxGrid; the
+                                        // window kernels, with their smaller workgroups, up to kMaxRows)
 constexpr int kMaxComps = 16;           // components per partial buffer (component-major layout)
 constexpr int kNumXCD = 8;
 constexpr int kScalarSlots = 96;        // device scalar file (doubles)

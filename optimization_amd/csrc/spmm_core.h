@@ -217,10 +217,11 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
 //   per entry the kernel does: word -> two LDS addresses (5 integer instructions), one value read, one row read,
 //           P multiplies and P adds.  No compare, no select, no per-lane case distinction.
 //
-//   waves    a workgroup of the window kernels has kWinWaves = 8 waves (512 threads) and two of them share a CU:
+//   waves    a workgroup of the window kernels has kWinWaves = 4 waves (256 threads) and four of them share a CU:
 //            the per-tile barrier keeps a workgroup's waves in the same phase (all waiting for memory, then all
 //            computing), so with ONE workgroup per CU loads and arithmetic add up instead of overlapping (measured:
-//            17.8 us with every load removed + 11.5 us of loads = the 29.4 us of the 16-wave version).
+//            17.8 us with every load removed + 11.5 us of loads = the 29.4 us of the 16-wave version; 8 waves x 2:
+//            26.3 us; 4 waves x 4: 26.0 us, and 210 instead of 235 us on St(8e6,3), beyond the Infinity Cache).
 //   ring     nc = 2 kWinWaves + 2 wc chunks of 64 rows; chunk q lives at slot q % nc.  Row index nc * 64 is the ZERO ROW
 //            (zeros): the word of an entry beyond a slice's width is replaced by `zw` (zero row, index of 0.0).
 //   far      row index nc * 64 + 1 + (slice % kWinWaves) * 128 + slot * 64 + lane: wave-private, so no barrier is
@@ -249,7 +250,7 @@ constexpr int kMaxWinChunks = 4;
 constexpr int kFarCap = 2;
 constexpr int kWinHead = 8;
 #ifndef MI_WIN_WAVES
-#define MI_WIN_WAVES 8
+#define MI_WIN_WAVES 4
 #endif
 constexpr int kWinWaves = MI_WIN_WAVES;  // waves per workgroup of the window kernels = slices per tile
 constexpr int kWinBlock = kWinWaves * 64;

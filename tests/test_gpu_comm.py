@@ -241,7 +241,9 @@ def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
 
 
 def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification():
-    env = dict(os.environ, MI355OPT_BENCH_FORCE_COMM="1", MI355OPT_BENCH_INJECT_VERIFY_FAILURE="1")
+    # (the peer-memory layer is opt-in: RCCL is the default exchange layer)
+    env = dict(os.environ, MI355OPT_BENCH_FORCE_COMM="1", MI355OPT_BENCH_INJECT_VERIFY_FAILURE="1",
+               MI355OPT_COMM="peer")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29574", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "100",
            "--warmup", "10", "--no-cpu-baseline", "--no-roofline"]
