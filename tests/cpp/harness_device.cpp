@@ -6,6 +6,7 @@
 // Entry points hd_* are called from pytest (-m gpu) and compared with the oracle / golden fixtures.
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <optional>
 #include <vector>
 
@@ -270,6 +271,113 @@ extern "C" int hd_tnt_sphere(int with_precon, const double *x0, const orc_tnt_pa
   if (with_precon) pc = sp.precon;
   RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector, double, DeviceVector>(
       sp.F, sp.gradF, sp.HessCon, sp.metric, sp.retract, X0, P, pc, tp, uf);
+  export_result(r, accepted, res);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// BASELINE cfg1: chained Rosenbrock (n = 100) through EuclideanTNT<DeviceVector> (reference
+// Riemannian/TNT.h:757-805).  The user callables evaluate f, grad f and the tridiagonal Hessian product on the HOST
+// from a downloaded copy of x (the same statements as the oracle's problem definition, oracle/problems.c --
+// user code may do what it likes), everything TNT and STPCG do with the vectors runs on the GPU.
+//   mode 0: Hessian handed over as a device operator (tridiagonal CSR rebuilt at every outer iterate)
+//   mode 1: Hessian product as a plain host lambda (download v, multiply, upload)
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_tnt_rosenbrock(size_t n, int precon_kind, const double *x0h, const orc_tnt_params *params, int mode,
+                                 orc_tnt_result *res) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  DeviceVector x0(ctx, x0h, n);
+  RM::TNTParams<double> tp;
+  fill_params(tp, params);
+  size_t accepted = 0;
+  Objective<DeviceVector> f = [n](const DeviceVector &X) {
+    const std::vector<double> x = X.to_host();
+    double s = 0;
+    for (size_t i = 0; i + 1 < n; ++i) {
+      const double a = 1 - x[i], b = x[i + 1] - x[i] * x[i];
+      s += a * a + 100 * b * b;
+    }
+    return s;
+  };
+  struct Tri {  // the Hessian at one iterate: CSR on the device, kept alive by the operator that uses it
+    mi_csr *A = nullptr;
+    mi_op *op = nullptr;
+    ~Tri() {
+      if (op) mi_op_destroy(op);
+      if (A) mi_csr_destroy(A);
+    }
+  };
+  std::shared_ptr<Tri> current;  // the Hessian of the latest model (TNT drops the previous one when it asks again)
+  RM::EuclideanQuadraticModel<DeviceVector> QM = [n, mode, &ctx, &current](
+                                                     const DeviceVector &X, DeviceVector &g,
+                                                     RM::EuclideanLinearOperator<DeviceVector> &Hs) {
+    auto xh = std::make_shared<std::vector<double>>(X.to_host());
+    const std::vector<double> &x = *xh;
+    std::vector<double> gh(n, 0.0);
+    for (size_t i = 0; i + 1 < n; ++i) {
+      const double b = x[i + 1] - x[i] * x[i];
+      gh[i] += -2 * (1 - x[i]) - 400 * x[i] * b;
+      gh[i + 1] += 200 * b;
+    }
+    g = DeviceVector(ctx, gh.data(), n);
+    if (mode == 1) {
+      Hs = [xh, n, &ctx](const DeviceVector &, const DeviceVector &V) {
+        const std::vector<double> &x = *xh;
+        const std::vector<double> v = V.to_host();
+        std::vector<double> hv(n, 0.0);
+        for (size_t i = 0; i + 1 < n; ++i) {
+          const double dii = 2 + 1200 * x[i] * x[i] - 400 * x[i + 1];
+          const double off = -400 * x[i];
+          hv[i] += dii * v[i] + off * v[i + 1];
+          hv[i + 1] += off * v[i] + 200 * v[i + 1];
+        }
+        return DeviceVector(ctx, hv.data(), n);
+      };
+      return;
+    }
+    // tridiagonal CSR: row i = [off_{i-1}, (200 if i > 0) + dii (if i < n-1), off_i]
+    std::vector<int32_t> rp(n + 1, 0), ci;
+    std::vector<double> va;
+    for (size_t i = 0; i < n; ++i) {
+      double d = 0;
+      if (i > 0) {
+        ci.push_back((int32_t)(i - 1));
+        va.push_back(-400 * x[i - 1]);
+        d += 200;
+      }
+      if (i + 1 < n) d += 2 + 1200 * x[i] * x[i] - 400 * x[i + 1];
+      ci.push_back((int32_t)i);
+      va.push_back(d);
+      if (i + 1 < n) {
+        ci.push_back((int32_t)(i + 1));
+        va.push_back(-400 * x[i]);
+      }
+      rp[i + 1] = (int32_t)ci.size();
+    }
+    auto tri = std::make_shared<Tri>();
+    MI355::check(mi_csr_create(ctx.get(), n, ci.size(), rp.data(), ci.data(), va.data(), &tri->A));
+    MI355::check(mi_op_create_csr(ctx.get(), tri->A, 1, &tri->op));
+    Hs = MI355::DeviceHessian{tri->op};
+    current = tri;
+  };
+  std::optional<RM::EuclideanLinearOperator<DeviceVector>> pc;
+  if (precon_kind) {
+    pc = [n, &ctx](const DeviceVector &X, const DeviceVector &V) {
+      const std::vector<double> x = X.to_host(), v = V.to_host();
+      std::vector<double> pv(n);
+      for (size_t i = 0; i < n; ++i) pv[i] = v[i] / (std::fabs(2 + 1200 * x[i] * x[i]) + 200);
+      return DeviceVector(ctx, pv.data(), n);
+    };
+  }
+  std::optional<RM::EuclideanTNTUserFunction<DeviceVector>> uf =
+      [&](size_t, double, const DeviceVector &, double, const DeviceVector &,
+          const RM::EuclideanLinearOperator<DeviceVector> &, double, size_t, const DeviceVector &, double, double,
+          bool acc) {
+        accepted += acc;
+        return false;
+      };
+  RM::TNTResult<DeviceVector, double> r = RM::EuclideanTNT<DeviceVector>(f, QM, x0, pc, tp, uf);
   export_result(r, accepted, res);
   HD_GUARD_END
 }

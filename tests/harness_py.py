@@ -89,6 +89,16 @@ class DeviceHarness:
                                    C.byref(params), mode, C.byref(res))
         return self._unpack(rc, bufs, res, self.err() if rc else "")
 
+    def tnt_rosenbrock(self, n, precon_kind, x0, params, mode=0):
+        """BASELINE cfg1 through EuclideanTNT<DeviceVector> (hd_tnt_rosenbrock)"""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64).ravel()
+        bufs, res = self._result_buffers(n, params)
+        self.L.hd_tnt_rosenbrock.restype = C.c_int
+        self.L.hd_tnt_rosenbrock.argtypes = [C.c_size_t, C.c_int, dp, C.POINTER(op.TntParams), C.c_int,
+                                             C.POINTER(op.TntResult)]
+        rc = self.L.hd_tnt_rosenbrock(n, precon_kind, _dp(x0), C.byref(params), mode, C.byref(res))
+        return self._unpack(rc, bufs, res, self.err() if rc else "")
+
     def tnt_so3n(self, N, ei, ej, Rt, w, R0, params, with_precon):
         ei = np.ascontiguousarray(ei, dtype=np.int32)
         ej = np.ascontiguousarray(ej, dtype=np.int32)

@@ -74,6 +74,36 @@ def test_tnt_sphere_device_golden(harness, oracle, golden, key, pre):
     assert np.linalg.norm(r["x"] - np.array([0, 0, 1.0])) < 1e-8
 
 
+@pytest.mark.parametrize("key,pk", [("plain", 0), ("jacobi", 1)])
+@pytest.mark.parametrize("mode", [0, 1], ids=["device-csr-hessian", "host-lambda-hessian"])
+def test_tnt_rosenbrock100_device_golden(harness, oracle, golden, key, pk, mode):
+    """BASELINE cfg1 on the HIP path: chained Rosenbrock n = 100 through EuclideanTNT<DeviceVector> (reference
+    Riemannian/TNT.h:757-805) against the trace of the REAL reference (tests/golden/tnt_rosenbrock100.json).
+    The outer loop, STPCG and every vector operation run on the GPU; the inner products are two-stage device
+    reductions, i.e. re-associated with respect to the reference's sequential sums, and this problem takes
+    ~370 outer iterations through a curved valley: the trace is compared while it agrees to rounding, the
+    end result by its own optimality and against the reference's minimiser."""
+    g = golden("tnt_rosenbrock100.json")[key]
+    p = oracle.default_params(gradient_tolerance=1e-8, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                              preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=500)
+    r = harness.tnt_rosenbrock(100, pk, 0.1 * np.ones(100), p, mode)
+    assert r["rc"] == 0, r.get("err")
+    assert r["status"] == g["status"] == 0  # TNTStatus::Gradient
+    assert r["gradfx_norm"] < 1e-8 and r["f"] < 1e-15
+    assert np.linalg.norm(r["x"] - np.array(g["x"])) < 1e-8
+    # the first iterations must follow the reference's trace step by step (same counts, same accept decisions,
+    # f to rounding): 40 outer iterations are ~250 inner ones
+    k = 40
+    assert list(r["inner_iterations"][:k]) == g["inner_iterations"][:k]
+    assert np.allclose(r["objective_values"][:k], g["objective_values"][:k], rtol=1e-9)
+    assert np.allclose(r["trust_region_radius"][:k], g["trust_region_radius"][:k], rtol=1e-9)
+    # ... and the whole run stays close to it in length
+    assert abs(r["outer_iterations"] - g["outer_iterations"]) <= max(4, g["outer_iterations"] // 20), \
+        (r["outer_iterations"], g["outer_iterations"])
+    print("rosenbrock100", key, mode, "outer", r["outer_iterations"], "ref", g["outer_iterations"], "inner",
+          int(np.sum(r["inner_iterations"])), "ref", int(np.sum(g["inner_iterations"])))
+
+
 def test_gd_sphere_device(harness):
     """tests/GradientDescent_unit_test.cpp:76-130 on the device."""
     r = harness.gd_sphere([-0.5, -0.5, -0.707107])
