@@ -313,6 +313,53 @@ def _seq_dot(a, b):
     return s
 
 
+def projected_stpcg_problem(case, n=1000, m=100):
+    """Seeded inputs of the reference's two equality-constrained STPCG tests
+    (tests/IterativeSolvers_unit_test.cpp:316-496; Eigen's Random -> numpy PCG64): g in [-1,1]^n, diagonal
+    Hessian and diagonal M in [1000,3000], constraint matrix 1000 * U(-1,1)^(m x n).
+    case "exact": kappa 1e-8; "truncated": kappa .1 (theta .7, Delta DBL_MAX, max 5 n iterations both)."""
+    rng = np.random.Generator(np.random.PCG64({"exact": 316, "truncated": 413}[case]))
+    g = rng.uniform(-1, 1, n)
+    P = 2000 + 1000 * rng.uniform(-1, 1, n)
+    M = 2000 + 1000 * rng.uniform(-1, 1, n)
+    A = np.ascontiguousarray(1000 * rng.uniform(-1, 1, (m, n)))
+    return dict(n=n, m=m, g=g, P=P, M=M, A=A, Delta=float(np.finfo(np.float64).max), max_iterations=5 * n,
+                kappa={"exact": 1e-8, "truncated": .1}[case], theta=.7)
+
+
+def stpcg_projected(lib, prefix, pr):
+    """<prefix>_stpcg_projected of a template-driver library (oracle/template_driver.inc)"""
+    fn = getattr(lib, prefix + "_stpcg_projected")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_size_t, C.c_size_t, c_double_p, c_double_p, c_double_p, c_double_p, C.c_double,
+                   C.c_size_t, C.c_double, C.c_double, c_double_p, c_double_p, c_size_p]
+    s = np.zeros(pr["n"])
+    mn, it = C.c_double(0), C.c_size_t(0)
+    rc = fn(pr["n"], pr["m"], _dp(pr["g"]), _dp(pr["P"]), _dp(pr["M"]), _dp(pr["A"]), pr["Delta"],
+            pr["max_iterations"], pr["kappa"], pr["theta"], _dp(s), C.byref(mn), C.byref(it))
+    return dict(rc=rc, s=s, M_norm=mn.value, iterations=it.value)
+
+
+def stpcg_stop_problem(n=200, seed=365):
+    """Seeded inputs of the user-function stop test: diagonal SPD Hessian, diagonal preconditioner."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return dict(n=n, g=rng.normal(size=n), D=rng.uniform(1.0, 100.0, n), Minv=1.0 / rng.uniform(1.0, 50.0, n))
+
+
+def stpcg_diag_stop(lib, prefix, g, D, Minv, stop_at, Delta=1e6, max_iterations=100, kappa=1e-10, theta=1.0):
+    """<prefix>_stpcg_diag_stop (template drivers: prefix ref / hz; device harness: prefix hd)"""
+    fn = getattr(lib, prefix + "_stpcg_diag_stop")
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_size_t, c_double_p, c_double_p, c_double_p, C.c_double, C.c_size_t, C.c_double, C.c_double,
+                   C.c_size_t, c_double_p, c_double_p, c_size_p, c_size_p]
+    n = g.size
+    s = np.zeros(n)
+    mn, it, calls = C.c_double(0), C.c_size_t(0), C.c_size_t(0)
+    rc = fn(n, _dp(g), _dp(D), _dp(Minv) if Minv is not None else None, Delta, max_iterations, kappa, theta,
+            stop_at, _dp(s), C.byref(mn), C.byref(it), C.byref(calls))
+    return dict(rc=rc, s=s, M_norm=mn.value, iterations=it.value, calls=calls.value)
+
+
 class Oracle(_Lib):
     def __init__(self, omp=False):
         """omp=True: the OpenMP build (vector loops and row loops in parallel; sums re-associated, so NOT the

@@ -19,6 +19,7 @@
 #include "Optimization/Riemannian/GradientDescent.h"
 #include "Optimization/Riemannian/TNLS.h"
 #include "Optimization/Riemannian/TNT.h"
+#include "kkt_dense.h"  // host-side dense KKT solves of the projected-STPCG user callables (test infrastructure)
 #include "oracle.h"  // result / parameter structs only (plain data)
 
 using namespace Optimization;
@@ -136,6 +137,98 @@ extern "C" int hd_stpcg_diag(size_t n, const double *g, const double *D, const d
   *iterations = it;
   mi_op_destroy(op);
   if (pc) mi_precon_destroy(pc);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// STPCG on DeviceVector with a user function that stops at iteration `stop_at` (IterativeSolvers.h:365-369): the
+// device callables are the tagged ones (which would select the fused solver), the user function forces the generic
+// loop -- every statement of it still runs on the GPU.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_stpcg_diag_stop(size_t n, const double *g, const double *D, const double *Minv, double Delta,
+                                  size_t max_iterations, double kappa, double theta, size_t stop_at, double *s_out,
+                                  double *M_norm, size_t *iterations, size_t *calls) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  DeviceVector gd(ctx, g, n), Dd(ctx, D, n);
+  mi_op *op = nullptr;
+  MI355::check(mi_op_create_diag(ctx.get(), Dd.handle(), &op));
+  mi_precon *pc = nullptr;
+  std::optional<DeviceVector> Mi;
+  if (Minv) {
+    Mi = DeviceVector(ctx, Minv, n);
+    MI355::check(mi_precon_create_diag(ctx.get(), Mi->handle(), &pc));
+  }
+  LA::SymmetricLinearOperator<DeviceVector> H = MI355::DeviceOperator{op};
+  LA::InnerProduct<DeviceVector> ip = MI355::FrobeniusInnerProduct{};
+  std::optional<LA::STPCGPreconditioner<DeviceVector, std::nullptr_t>> P;
+  if (pc) P = MI355::DeviceSTPCGPreconditioner<std::nullptr_t>{pc};
+  size_t ncalls = 0;
+  std::optional<LA::STPCGUserFunction<DeviceVector, std::nullptr_t>> uf =
+      LA::STPCGUserFunction<DeviceVector, std::nullptr_t>(
+          [&](size_t k, const DeviceVector &, const LA::SymmetricLinearOperator<DeviceVector> &,
+              const std::optional<LA::STPCGPreconditioner<DeviceVector, std::nullptr_t>> &,
+              const std::optional<LA::LinearOperator<std::nullptr_t, DeviceVector>> &, const DeviceVector &,
+              const DeviceVector &, const DeviceVector &, const DeviceVector &, double) {
+            ++ncalls;
+            return k == stop_at;
+          });
+  double mn = 0;
+  size_t it = 0;
+  const std::optional<LA::LinearOperator<std::nullptr_t, DeviceVector>> At_none;
+  DeviceVector s = LA::STPCG<DeviceVector, std::nullptr_t>(gd, H, ip, mn, it, Delta, max_iterations, kappa, theta, P,
+                                                           At_none, uf);
+  const std::vector<double> sh = s.to_host();
+  std::memcpy(s_out, sh.data(), n * sizeof(double));
+  *M_norm = mn;
+  *iterations = it;
+  *calls = ncalls;
+  mi_op_destroy(op);
+  if (pc) mi_precon_destroy(pc);
+  HD_GUARD_END
+}
+
+// ------------------------------------------------------------------------------------------------
+// Projected STPCG on DeviceVector (the `At` + constraint-preconditioner branch, IterativeSolvers.h:229-253,
+// 381-405; the reference's cases tests/IterativeSolvers_unit_test.cpp:316-496): diagonal Hessian as a device
+// operator, Frobenius inner product, Multiplier = DeviceVector; the user's constraint preconditioner and A'
+// do their dense algebra on the host (oracle/kkt_dense.h, the same code as the reference-side driver) and hand
+// device vectors back -- the solver's own work (every vector statement, the r -= A'lambda correction) is on the GPU.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const double *Pdiag, const double *Mdiag,
+                                  const double *A, double Delta, size_t max_iterations, double kappa_fgr,
+                                  double theta, double *s_out, double *M_norm, size_t *iterations) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  const KktDense K(n, m, A, Mdiag);
+  DeviceVector gd(ctx, g, n), Pd(ctx, Pdiag, n);
+  mi_op *op = nullptr;
+  MI355::check(mi_op_create_diag(ctx.get(), Pd.handle(), &op));
+  LA::SymmetricLinearOperator<DeviceVector> H = MI355::DeviceOperator{op};
+  LA::InnerProduct<DeviceVector> ip = MI355::FrobeniusInnerProduct{};
+  std::optional<LA::STPCGPreconditioner<DeviceVector, DeviceVector>> P =
+      LA::STPCGPreconditioner<DeviceVector, DeviceVector>([&](const DeviceVector &r) {
+        const std::vector<double> rh = r.to_host();
+        std::vector<double> x(n), l(m);
+        K.solve(rh.data(), x.data(), l.data());
+        return std::make_pair(DeviceVector(ctx, x.data(), n), DeviceVector(ctx, l.data(), m));
+      });
+  std::optional<LA::LinearOperator<DeviceVector, DeviceVector>> At =
+      LA::LinearOperator<DeviceVector, DeviceVector>([&](const DeviceVector &l) {
+        const std::vector<double> lh = l.to_host();
+        std::vector<double> out(n);
+        K.At(lh.data(), out.data());
+        return DeviceVector(ctx, out.data(), n);
+      });
+  double mn = 0;
+  size_t it = 0;
+  DeviceVector s = LA::STPCG<DeviceVector, DeviceVector>(gd, H, ip, mn, it, Delta, max_iterations, kappa_fgr, theta,
+                                                         P, At);
+  const std::vector<double> sh = s.to_host();
+  std::memcpy(s_out, sh.data(), n * sizeof(double));
+  *M_norm = mn;
+  *iterations = it;
+  mi_op_destroy(op);
   HD_GUARD_END
 }
 

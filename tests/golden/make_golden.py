@@ -57,6 +57,68 @@ def main():
                            alpha=lst(r["trace"]["alpha"]))
     json.dump(cases, open(os.path.join(OUT, "stpcg_small.json"), "w"), indent=1)
 
+    # --- projected STPCG (At + constraint preconditioner): tests/IterativeSolvers_unit_test.cpp:316-496 -----
+    # inputs are regenerated from their seed (oracle_py.projected_stpcg_problem); the fixture holds what the
+    # REAL reference returned, plus a checksum of the inputs
+    import ctypes
+    ref = ctypes.CDLL(oracle_py._REF)
+    out = {}
+    for case in ("exact", "truncated"):
+        pr = oracle_py.projected_stpcg_problem(case)
+        r = oracle_py.stpcg_projected(ref, "ref", pr)
+        assert r["rc"] == 0
+        out[case] = dict(n=pr["n"], m=pr["m"], kappa=pr["kappa"], theta=pr["theta"],
+                         input_checksum=float(pr["g"].sum() + pr["P"].sum() + pr["M"].sum() + pr["A"].sum()),
+                         iterations=int(r["iterations"]), M_norm=float(r["M_norm"]), s=lst(r["s"]))
+    json.dump(out, open(os.path.join(OUT, "stpcg_projected.json"), "w"), indent=1)
+
+    # --- STPCG stopped by its user function at iteration k (IterativeSolvers.h:365-369) ---------------------
+    pr = oracle_py.stpcg_stop_problem()
+    cases = []
+    for pre in (False, True):
+        for stop in (0, 3, 7, 1000):
+            r = oracle_py.stpcg_diag_stop(ref, "ref", pr["g"], pr["D"], pr["Minv"] if pre else None, stop)
+            assert r["rc"] == 0
+            cases.append(dict(precon=pre, stop_at=stop, iterations=int(r["iterations"]), calls=int(r["calls"]),
+                              M_norm=float(r["M_norm"]), s=lst(r["s"])))
+    json.dump(dict(n=pr["n"], seed=365, input_checksum=float(pr["g"].sum() + pr["D"].sum() + pr["Minv"].sum()),
+                   cases=cases), open(os.path.join(OUT, "stpcg_user_stop.json"), "w"), indent=1)
+
+    # --- LSQR / TNLS on the sparse test operators of tests/test_gpu_templates.py (reference
+    # IterativeSolvers.h:552-855, TNLS.h:265-729): what the REAL reference returns, so that the GPU tests do not
+    # depend on the CPU suite having compared the host templates with it
+    import scipy.sparse as sps
+
+    def nonsym_sparse(n, seed):
+        rng = np.random.default_rng(seed)
+        A = sps.diags([np.full(n - 1, -1.0), np.full(n, 4.0), np.full(n - 1, 2.0)], [-1, 0, 1]).tolil()
+        for _ in range(3 * n):
+            i, j = rng.integers(0, n, size=2)
+            A[i, j] += rng.normal() * .3
+        return sps.csr_matrix(A)
+
+    out = {"lsqr": [], "tnls": []}
+    n = 300
+    A = nonsym_sparse(n, 2)
+    b = np.random.default_rng(9).normal(size=n)
+    for kw in [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7),
+               dict(btol=1e-12, Atol=1e-12, Acond_limit=50.0)]:
+        r = R.lsqr_dense(A.toarray(), b, **kw)
+        assert r["rc"] == 0
+        out["lsqr"].append(dict(kw=kw, n=n, matrix_seed=2, b_seed=9, A_checksum=float(A.sum()),
+                                iterations=int(r["iterations"]), xnorm=float(r["xnorm"]), x=lst(r["x"])))
+    n = 200
+    A = nonsym_sparse(n, 5)
+    rng = np.random.default_rng(6)
+    b, x0 = rng.normal(size=n), rng.normal(size=n)
+    for kw in [dict(), dict(root_tolerance=0.0, gradient_tolerance=1e-6), dict(max_LSQR_iterations=3, max_iterations=8)]:
+        r = R.tnls_affine(A.toarray(), b, x0, **kw)
+        assert r["rc"] == 0
+        out["tnls"].append(dict(kw=kw, n=n, matrix_seed=5, rng_seed=6, A_checksum=float(A.sum()),
+                                status=int(r["status"]), outer=int(r["outer"]), inner_total=int(r["inner_total"]),
+                                f=float(r["f"]), x=lst(r["x"])))
+    json.dump(out, open(os.path.join(OUT, "lsqr_tnls.json"), "w"), indent=1)
+
     # --- TNT on the sphere: tests/TNT_unit_test.cpp:63-187 -----------------------------------------
     out = {}
     x0 = [-0.5, -0.5, -0.707107]

@@ -74,6 +74,43 @@ def test_tnt_sphere_device_golden(harness, oracle, golden, key, pre):
     assert np.linalg.norm(r["x"] - np.array([0, 0, 1.0])) < 1e-8
 
 
+def test_stpcg_user_function_stop_on_device_vectors(harness, golden):
+    """STPCG on DeviceVector with a user function that stops the solve at iteration k (reference
+    IterativeSolvers.h:365-369): tagged device callables + a user function take the generic loop (the fused solver
+    has no user hook); against the fixture of the REAL reference (tests/golden/stpcg_user_stop.json): same
+    iteration and call counts, s WITHOUT the interrupted iteration's step, M-norm from the recurrence (:424)."""
+    import oracle_py
+    fx = golden("stpcg_user_stop.json")
+    pr = oracle_py.stpcg_stop_problem(fx["n"], fx["seed"])
+    for c in fx["cases"]:
+        r = oracle_py.stpcg_diag_stop(harness.L, "hd", pr["g"], pr["D"], pr["Minv"] if c["precon"] else None,
+                                      c["stop_at"])
+        assert r["rc"] == 0, harness.err()
+        assert (r["iterations"], r["calls"]) == (c["iterations"], c["calls"]), c["stop_at"]
+        # (the never-stopped preconditioned case runs into the 100-iteration limit with the residual stagnating at
+        # rounding level 30 iterations earlier: from there on CG amplifies last-bit differences of the inner products)
+        tol = 1e-10 if c["iterations"] < 100 else 1e-5
+        assert np.abs(r["s"] - np.array(c["s"])).max() <= tol * max(1e-300, np.abs(c["s"]).max())
+        assert abs(r["M_norm"] - c["M_norm"]) <= tol * max(1e-300, c["M_norm"])
+
+
+@pytest.mark.parametrize("case", ["exact", "truncated"])
+def test_projected_stpcg_on_device_vectors(harness, golden, case):
+    """The `At` + constraint-preconditioner branch of STPCG (reference IterativeSolvers.h:229-253,381-405) with
+    Vector = Multiplier = DeviceVector, on the reference's two equality-constrained cases
+    (tests/IterativeSolvers_unit_test.cpp:316-496, n = 1000, 100 constraints), against the fixture the REAL
+    reference produced (tests/golden/stpcg_projected.json): same iteration count, iterate to 1e-10, |A s| < 1e-6."""
+    import oracle_py
+    pr = oracle_py.projected_stpcg_problem(case)
+    fx = golden("stpcg_projected.json")[case]
+    r = harness.stpcg_projected(pr)
+    assert r["rc"] == 0, r["err"]
+    assert r["iterations"] == fx["iterations"]
+    assert rel_err(r["s"], np.array(fx["s"])) < 1e-10
+    assert abs(r["M_norm"] - fx["M_norm"]) < 1e-10 * fx["M_norm"]
+    assert np.linalg.norm(pr["A"] @ r["s"]) < 1e-6
+
+
 @pytest.mark.parametrize("key,pk", [("plain", 0), ("jacobi", 1)])
 @pytest.mark.parametrize("mode", [0, 1], ids=["device-csr-hessian", "host-lambda-hessian"])
 def test_tnt_rosenbrock100_device_golden(harness, oracle, golden, key, pk, mode):
@@ -212,17 +249,23 @@ def _nonsym_sparse(n, seed):
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7),
                                 dict(btol=1e-12, Atol=1e-12, Acond_limit=50.0)])
-def test_lsqr_device_matches_host_template(harness, kw, mode):
-    """IterativeSolvers.h:552-855 on DeviceVector vs the same template on a host vector (which equals the reference
-    bit for bit, tests/test_cpu_oracle_templates.py): iterates to 1e-9, same iteration count."""
+def test_lsqr_device_matches_host_template(harness, golden, kw, mode):
+    """IterativeSolvers.h:552-855 on DeviceVector against (i) what the REAL reference returned on the same inputs
+    (tests/golden/lsqr_tnls.json, made by make_golden.py from oracle/_ref/libref.so) and (ii) the same template on a
+    host vector: iterates to 1e-9, same iteration count."""
     import oracle_py
     hz = oracle_py.TemplateHarness()
     n = 300
     A = _nonsym_sparse(n, 2)
     b = np.random.default_rng(9).normal(size=n)
     d = harness.lsqr_csr(A, b, mode=mode, **kw)
-    h = hz.lsqr_dense(A.toarray(), b, **kw)
+    fx = [c for c in golden("lsqr_tnls.json")["lsqr"] if c["kw"] == kw][0]
+    assert abs(float(A.sum()) - fx["A_checksum"]) < 1e-9
     assert d["rc"] == 0, d["err"]
+    assert d["iterations"] == fx["iterations"]
+    assert np.abs(d["x"] - np.array(fx["x"])).max() <= 1e-9 * max(1.0, np.abs(fx["x"]).max())
+    assert abs(d["xnorm"] - fx["xnorm"]) <= 1e-9 * max(1.0, fx["xnorm"])
+    h = hz.lsqr_dense(A.toarray(), b, **kw)
     assert d["iterations"] == h["iterations"]
     assert np.abs(d["x"] - h["x"]).max() <= 1e-9 * max(1.0, np.abs(h["x"]).max())
     assert abs(d["xnorm"] - h["xnorm"]) <= 1e-9 * max(1.0, h["xnorm"])
@@ -246,8 +289,9 @@ def test_lsqr_device_large(harness):
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused_lsqr", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(root_tolerance=0.0, gradient_tolerance=1e-6),
                                 dict(max_LSQR_iterations=3, max_iterations=8)])
-def test_tnls_device_matches_host_template(harness, kw, mode):
-    """TNLS.h:265-729 on DeviceVector for F(x) = A x - b vs the host-vector run of the same template."""
+def test_tnls_device_matches_host_template(harness, golden, kw, mode):
+    """TNLS.h:265-729 on DeviceVector for F(x) = A x - b against the REAL reference's result on the same inputs
+    (tests/golden/lsqr_tnls.json) and the host-vector run of the same template."""
     import oracle_py
     hz = oracle_py.TemplateHarness()
     n = 200
@@ -255,8 +299,15 @@ def test_tnls_device_matches_host_template(harness, kw, mode):
     rng = np.random.default_rng(6)
     b, x0 = rng.normal(size=n), rng.normal(size=n)
     d = harness.tnls_affine(A, b, x0, mode=mode, **kw)
-    h = hz.tnls_affine(A.toarray(), b, x0, **kw)
+    fx = [c for c in golden("lsqr_tnls.json")["tnls"] if c["kw"] == kw][0]
+    assert abs(float(A.sum()) - fx["A_checksum"]) < 1e-9
     assert d["rc"] == 0, d["err"]
+    assert d["status"] == fx["status"]
+    if kw.get("root_tolerance", 1.0) > 0:
+        assert (d["outer"], d["inner_total"]) == (fx["outer"], fx["inner_total"])
+    assert np.abs(d["x"] - np.array(fx["x"])).max() <= 1e-9 * max(1.0, np.abs(fx["x"]).max())
+    assert abs(d["f"] - fx["f"]) <= 1e-9 * max(1.0, abs(fx["f"]))
+    h = hz.tnls_affine(A.toarray(), b, x0, **kw)
     assert d["status"] == h["status"]
     if kw.get("root_tolerance", 1.0) > 0:
         assert (d["outer"], d["inner_total"]) == (h["outer"], h["inner_total"])
