@@ -23,7 +23,7 @@ ARCH = "gfx950"
 CFLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-    "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", "/opt/rocm/include",
+    "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", os.path.join(HERE, "include"), "-I", "/opt/rocm/include",
 ]
 CFLAGS += os.environ.get("MI355OPT_EXTRA_CFLAGS", "").split()  # experiments (e.g. -DMI_SPMM_CHUNK=8)
 LDFLAGS = ["-shared", "-L/opt/rocm/lib", "-lrccl", "-ldl", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
@@ -38,7 +38,8 @@ def _newer(src, dst, deps):
 
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
-    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        glob.glob(os.path.join(HERE, "include", "Optimization", "LinearAlgebra", "DenseSymmetricEigen.h"))
     if not force and not _newer(src, obj, deps):
         return obj, False, ""
     cmd = [HIPCC] + CFLAGS + ["-c", src, "-o", obj]

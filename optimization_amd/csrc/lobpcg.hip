@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "mi_internal.h"
+#include "Optimization/LinearAlgebra/DenseSymmetricEigen.h"
 
 using namespace mi;
 
@@ -522,206 +523,7 @@ __global__ __launch_bounds__(256) void k_rowscale(size_t m, size_t k, const doub
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) Y[i] = d[i % m] * X[i];
 }
 
-// ---- host: generalized symmetric-definite eigenproblem (LOBPCG.h:53-62) ---------------------
-// Left-looking in COLUMN (axpy) form: every inner loop runs down a column of the column-major array, unit stride,
-// so the compiler vectorises it (the row-oriented dot form cost 4x more at n = 72).
-int cholesky_lower(int n, std::vector<double> &A) {
-  for (int j = 0; j < n; ++j) {
-    double *aj = &A[(size_t)j * n];
-    for (int k = 0; k < j; ++k) {  // column j -= L[j,k] * column k   (rows j..n-1)
-      const double *ak = &A[(size_t)k * n];
-      const double ljk = ak[j];
-      for (int i = j; i < n; ++i) aj[i] -= ljk * ak[i];
-    }
-    const double d = aj[j];
-    if (!(d > 0)) return -1;
-    const double r = std::sqrt(d);
-    aj[j] = r;
-    for (int i = j + 1; i < n; ++i) aj[i] /= r;
-    for (int i = 0; i < j; ++i) aj[i] = 0;
-  }
-  return 0;
-}
-
-// X <- L^-1 X for the n x n column-major X (forward substitution, axpy form: unit stride down L's columns)
-void lower_solve_inplace(int n, const std::vector<double> &L, std::vector<double> &X) {
-  for (int j = 0; j < n; ++j) {
-    double *x = &X[(size_t)j * n];
-    for (int k = 0; k < n; ++k) {
-      const double *lk = &L[(size_t)k * n];
-      const double xk = x[k] / lk[k];
-      x[k] = xk;
-      for (int i = k + 1; i < n; ++i) x[i] -= lk[i] * xk;
-    }
-  }
-}
-
-// Symmetric eigen-decomposition of the ns x ns projected pencil (ns <= 96): Householder reduction to
-// tridiagonal form followed by implicit-shift QL with accumulated transformations (the classic
-// EISPACK tred2/tql2 pair).  O(n^3) with a small constant: 72 x 72 takes well under a millisecond
-// on one host core, so the device never waits long for the Ritz coefficients (a cyclic Jacobi here
-// cost 60 ms per LOBPCG iteration, 10x the whole device side of the iteration).
-// M is destroyed; on return V(:, j) is the eigenvector of w[j], ascending.
-// sqrt(a^2 + b^2): std::hypot's overflow/underflow care costs ~40 ns a call and tql2 makes ~10^4 of them per
-// 72 x 72 problem (a third of its time); the plain form is exact enough whenever neither square can overflow or
-// vanish, which holds for the equilibrated pencils this is fed -- the guarded branch keeps the general case
-static inline double fast_hypot(double a, double b) {
-  const double aa = std::fabs(a), ab = std::fabs(b), big = aa > ab ? aa : ab;
-  if (big < 1e150 && big > 1e-150) return std::sqrt(a * a + b * b);
-  return std::hypot(a, b);
-}
-
-// dot product on four independent accumulators (a single one is a chain of dependent fmas, ~4 cycles each)
-static inline double dot4(const double *a, const double *b, int n) {
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int k = 0;
-  for (; k + 4 <= n; k += 4) {
-    s0 += a[k] * b[k];
-    s1 += a[k + 1] * b[k + 1];
-    s2 += a[k + 2] * b[k + 2];
-    s3 += a[k + 3] * b[k + 3];
-  }
-  for (; k < n; ++k) s0 += a[k] * b[k];
-  return (s0 + s1) + (s2 + s3);
-}
-
-void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, double *w) {
-  V = M;
-  std::vector<double> ev((size_t)n, 0.0);
-  double *d = w, *e = ev.data();
-#define VV(i, j) V[(size_t)(i) + (size_t)(j) * n]
-  // --- Householder tridiagonalisation, last row first
-  for (int j = 0; j < n; ++j) d[j] = VV(n - 1, j);
-  for (int i = n - 1; i > 0; --i) {
-    double scale = 0, h = 0;
-    for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
-    if (scale == 0) {
-      e[i] = d[i - 1];
-      for (int j = 0; j < i; ++j) {
-        d[j] = VV(i - 1, j);
-        VV(i, j) = 0;
-        VV(j, i) = 0;
-      }
-    } else {
-      for (int k = 0; k < i; ++k) {
-        d[k] /= scale;
-        h += d[k] * d[k];
-      }
-      double f = d[i - 1];
-      double g = f > 0 ? -std::sqrt(h) : std::sqrt(h);
-      e[i] = scale * g;
-      h -= f * g;
-      d[i - 1] = f - g;
-      for (int j = 0; j < i; ++j) e[j] = 0;
-      for (int j = 0; j < i; ++j) {  // e = (A u) / h, using the lower triangle only
-        f = d[j];
-        VV(j, i) = f;
-        g = e[j] + VV(j, j) * f;
-        for (int k = j + 1; k < i; ++k) {
-          g += VV(k, j) * d[k];
-          e[k] += VV(k, j) * f;
-        }
-        e[j] = g;
-      }
-      f = 0;
-      for (int j = 0; j < i; ++j) {
-        e[j] /= h;
-        f += e[j] * d[j];
-      }
-      const double hh = f / (h + h);
-      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
-      for (int j = 0; j < i; ++j) {  // rank-2 update of the leading block
-        f = d[j];
-        g = e[j];
-        for (int k = j; k < i; ++k) VV(k, j) -= f * e[k] + g * d[k];
-        d[j] = VV(i - 1, j);
-        VV(i, j) = 0;
-      }
-    }
-    d[i] = h;
-  }
-  // --- accumulate the reflectors
-  for (int i = 0; i + 1 < n; ++i) {
-    VV(n - 1, i) = VV(i, i);
-    VV(i, i) = 1;
-    const double h = d[i + 1];
-    if (h != 0) {
-      for (int k = 0; k <= i; ++k) d[k] = VV(k, i + 1) / h;
-      for (int j = 0; j <= i; ++j) {
-        const double g = dot4(&VV(0, i + 1), &VV(0, j), i + 1);
-        for (int k = 0; k <= i; ++k) VV(k, j) -= g * d[k];
-      }
-    }
-    for (int k = 0; k <= i; ++k) VV(k, i + 1) = 0;
-  }
-  for (int j = 0; j < n; ++j) {
-    d[j] = VV(n - 1, j);
-    VV(n - 1, j) = 0;
-  }
-  VV(n - 1, n - 1) = 1;
-  // --- implicit QL on (d, e)
-  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
-  e[n - 1] = 0;
-  double shift = 0, tst = 0;
-  const double eps = 2.220446049250313e-16;
-  for (int l = 0; l < n; ++l) {
-    tst = std::max(tst, std::fabs(d[l]) + std::fabs(e[l]));
-    int mm = l;
-    while (mm < n - 1 && std::fabs(e[mm]) > eps * tst) ++mm;
-    if (mm > l) {
-      int guard = 0;
-      do {
-        double g = d[l];
-        double p = (d[l + 1] - g) / (2 * e[l]);
-        double r = fast_hypot(p, 1.0);
-        if (p < 0) r = -r;
-        d[l] = e[l] / (p + r);
-        d[l + 1] = e[l] * (p + r);
-        const double dl1 = d[l + 1];
-        double h = g - d[l];
-        for (int i = l + 2; i < n; ++i) d[i] -= h;
-        shift += h;
-        p = d[mm];
-        double c = 1, c2 = 1, c3 = 1, s = 0, s2 = 0;
-        const double el1 = e[l + 1];
-        for (int i = mm - 1; i >= l; --i) {
-          c3 = c2;
-          c2 = c;
-          s2 = s;
-          g = c * e[i];
-          h = c * p;
-          r = fast_hypot(p, e[i]);
-          e[i + 1] = s * r;
-          s = e[i] / r;
-          c = p / r;
-          p = c * d[i] - s * g;
-          d[i + 1] = h + s * (c * g + s * d[i]);
-          for (int k = 0; k < n; ++k) {
-            h = VV(k, i + 1);
-            VV(k, i + 1) = s * VV(k, i) + c * h;
-            VV(k, i) = c * VV(k, i) - s * h;
-          }
-        }
-        p = -s * s2 * c3 * el1 * e[l] / dl1;
-        e[l] = s * p;
-        d[l] = c * p;
-      } while (std::fabs(e[l]) > eps * tst && ++guard < 200);
-    }
-    d[l] += shift;
-    e[l] = 0;
-  }
-#undef VV
-  for (int i = 0; i + 1 < n; ++i) {  // ascending
-    int mn = i;
-    for (int j = i + 1; j < n; ++j)
-      if (w[j] < w[mn]) mn = j;
-    if (mn != i) {
-      std::swap(w[i], w[mn]);
-      for (int k = 0; k < n; ++k) std::swap(V[k + (size_t)i * n], V[k + (size_t)mn * n]);
-    }
-  }
-}
-
+// (the host Rayleigh-Ritz solver lives in Optimization/LinearAlgebra/DenseSymmetricEigen.h)
 int check_panel(mi_ctx *ctx, size_t m, int k, const mi_vec *P, const char *what) {
   MI_REQUIRE(P, "%s is null", what);
   MI_REQUIRE(P->ctx == ctx, "%s belongs to another context", what);
@@ -933,52 +735,15 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
 
 int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C) {
   MI_REQUIRE(n >= 1 && A && B && Theta && C, "bad argument");
-  std::vector<double> D(n), L((size_t)n * n), M((size_t)n * n), T((size_t)n * n), Y;
-  for (int i = 0; i < n; ++i) {
-    MI_REQUIRE(B[i + (size_t)i * n] > 0, "B has a non-positive diagonal entry (%d)", i);
-    D[i] = 1.0 / std::sqrt(B[i + (size_t)i * n]);  // LOBPCG.h:56
-  }
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) {
-      L[i + (size_t)j * n] = D[i] * B[i + (size_t)j * n] * D[j];  // D B D  :59
-      M[i + (size_t)j * n] = D[i] * A[i + (size_t)j * n] * D[j];  // D A D  :59
-    }
-  if (cholesky_lower(n, L)) {
-    set_error("Rayleigh-Ritz: equilibrated B is not positive definite");
+  // header-only host solver shared with the generic path of the LOBPCG template (same bits on both paths)
+  const int rc = Optimization::LinearAlgebra::dense::generalized_symmetric_eig(n, A, B, Theta, C);
+  if (rc == 1) {
+    set_error("Rayleigh-Ritz: B has a non-positive diagonal entry");
     return MI_ERR_INVALID_ARGUMENT;
   }
-  // M <- L^-1 M L^-T as two forward substitutions with a transposition in between:
-  // T = L^-1 M, then (T L^-T)' = L^-1 T'
-  lower_solve_inplace(n, L, M);
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) T[i + (size_t)j * n] = M[j + (size_t)i * n];
-  lower_solve_inplace(n, L, T);
-  for (int j = 0; j < n; ++j)
-    for (int i = 0; i < n; ++i) M[i + (size_t)j * n] = T[j + (size_t)i * n];
-  for (int j = 0; j < n; ++j)
-    for (int i = j + 1; i < n; ++i) {
-      const double a = .5 * (M[i + (size_t)j * n] + M[j + (size_t)i * n]);
-      M[i + (size_t)j * n] = a;
-      M[j + (size_t)i * n] = a;
-    }
-  static const bool prof = getenv("MI355OPT_RR_PROFILE") != nullptr;
-  const auto t_a = std::chrono::steady_clock::now();
-  sym_eigh(n, M, Y, Theta);
-  const auto t_b = std::chrono::steady_clock::now();
-  if (prof) fprintf(stderr, "rr: sym_eigh %.1f us\n", std::chrono::duration<double, std::micro>(t_b - t_a).count());
-  // x = L^-T y ; C = D x  (:61): backward substitution in axpy form on U = L' (unit stride down U's columns; the
-  // dot form is a chain of dependent fmas, 4x slower)
-  for (int k = 0; k < n; ++k)
-    for (int i = 0; i < n; ++i) T[i + (size_t)k * n] = L[k + (size_t)i * n];  // T = U = L'
-  for (int j = 0; j < n; ++j) {
-    double *x = &Y[(size_t)j * n];
-    for (int k = n; k-- > 0;) {
-      const double *uk = &T[(size_t)k * n];
-      const double xk = x[k] / uk[k];
-      x[k] = xk;
-      for (int i = 0; i < k; ++i) x[i] -= uk[i] * xk;
-    }
-    for (int i = 0; i < n; ++i) C[i + (size_t)j * n] = D[i] * x[i];
+  if (rc == 2) {
+    set_error("Rayleigh-Ritz: equilibrated B is not positive definite");
+    return MI_ERR_INVALID_ARGUMENT;
   }
   return MI_OK;
 }

@@ -7,38 +7,81 @@
 //              LOBPCG (random X0) :376-390
 //
 // MI355X build, written from scratch against that interface (same template parameters, argument
-// order, defaults, exceptions, iteration structure -- see the :line tags).  The reference is written
-// against Eigen's dense API; here the panel algebra goes through a handful of free functions found
-// by argument-dependent lookup on the Matrix type (Optimization/MI355/Matrix.h provides them for
-// MI355::DeviceMatrix: column-major panels in HBM, Gram products on fp64 MFMA):
-//     gram(S, T) -> small host matrix S'T          times_small(S, C, row0, kc) -> S C[row0:, :kc]
-//     residual_and_norms(AX, BX, X, theta, r, xn)   gaussian_probe(like, m, nx)   rayleigh_ritz(A, B)
-//     ritz_update(S, C, nx, X, P) -> X = S C[:, :nx] and P = S[:, nx:] C[nx:, :nx] in one pass over S
-//   plus the members rows(), cols(), leftCols(k), middleCols(j,k), rightCols(k), set_cols(...),
-//   truncate_cols(k), norm().
-// As in the reference, the operators are invoked WITHOUT the Args pack (reference :213-219,247,267-282).
+// order, defaults, exceptions, iteration structure -- see the :line tags).  Two bodies behind the one template:
+//
+//   * Matrix = MI355::DeviceMatrix (column-major panels in HBM, Optimization/MI355/Matrix.h, included when the
+//     C ABI header is on the include path): the panel algebra goes through a handful of free functions found by
+//     argument-dependent lookup -- gram (fp64 MFMA), times_small, ritz_update_into, residual_and_norms, ... -- and
+//     the search basis lives in two panels that are written in place (detail::lobpcg_device).
+//   * any other dense Matrix / Vector pair (the reference's use with Eigen::MatrixXd / VectorXd; anything with
+//     Matrix(rows, cols), rows(), cols(), operator()(i, j) and Vector(n), operator()(i), size()): a host
+//     implementation written with element access only (detail::lobpcg_dense), statement by statement the
+//     reference's iteration.  It needs neither Eigen nor the device library.
+//
+// Both use the same host Rayleigh-Ritz (DenseSymmetricEigen.h), so a host run and a device run of one problem
+// can be compared iteration by iteration.  As in the reference, the operators are invoked WITHOUT the Args pack
+// (reference :213-219,247,267-282).
 #pragma once
 
 #include <cmath>
 #include <cstddef>
 #include <functional>
 #include <optional>
+#include <random>
 #include <stdexcept>
 #include <tuple>
+#include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "Optimization/LinearAlgebra/Concepts.h"
+#include "Optimization/LinearAlgebra/DenseSymmetricEigen.h"
+#if __has_include("mi355opt.h") && __has_include("Optimization/MI355/Matrix.h")
 #include "Optimization/MI355/Matrix.h"
+#define OPTIMIZATION_LOBPCG_HAS_DEVICE_PANELS 1
+#endif
 
 namespace Optimization {
 namespace LinearAlgebra {
+
+namespace detail {
+template <typename M>
+struct is_device_panel : std::false_type {};
+template <typename M>
+struct is_mi355_small : std::false_type {};
+#ifdef OPTIMIZATION_LOBPCG_HAS_DEVICE_PANELS
+template <>
+struct is_device_panel<MI355::DeviceMatrix> : std::true_type {};
+template <>
+struct is_mi355_small<MI355::HostMatrix> : std::true_type {};
+#endif
+}  // namespace detail
 
 // Basic Rayleigh-Ritz step: for symmetric A and SPD B returns (Theta, C) with Theta ascending,
 // C'AC = diag(Theta), C'BC = I; B is diagonally equilibrated first.           (reference :53-62)
 template <typename Vector, typename Matrix>
 std::pair<Vector, Matrix> RayleighRitz(const Matrix &A, const Matrix &B) {
-  auto tc = rayleigh_ritz(A, B);  // ADL on the small-matrix type
-  return std::pair<Vector, Matrix>(std::move(tc.first), std::move(tc.second));
+  if constexpr (detail::is_mi355_small<Matrix>::value) {
+    auto tc = rayleigh_ritz(A, B);  // ADL on the small-matrix type
+    return std::pair<Vector, Matrix>(std::move(tc.first), std::move(tc.second));
+  } else {
+    const size_t n = A.rows();
+    std::vector<double> a(n * n), b(n * n), th(n), c(n * n);
+    for (size_t j = 0; j < n; ++j)
+      for (size_t i = 0; i < n; ++i) {
+        a[i + j * n] = A(i, j);
+        b[i + j * n] = B(i, j);
+      }
+    if (dense::generalized_symmetric_eig((int)n, a.data(), b.data(), th.data(), c.data()))
+      throw std::invalid_argument("RayleighRitz: B must be symmetric positive definite");
+    Vector Theta(n);
+    Matrix C(n, n);
+    for (size_t j = 0; j < n; ++j) {
+      Theta(j) = th[j];
+      for (size_t i = 0; i < n; ++i) C(i, j) = c[i + j * n];
+    }
+    return std::make_pair(std::move(Theta), std::move(C));
+  }
 }
 
 // Observer called once per iteration after the Ritz pairs and residuals are updated; true stops.
@@ -50,26 +93,19 @@ using LOBPCGUserFunction = std::function<bool(
     const std::optional<SymmetricLinearOperator<Matrix, Args...>> &T, size_t nev, const Vector &Theta,
     const Matrix &X, const Vector &residuals, size_t nc, Args &...args)>;
 
-// nev smallest eigenpairs from the block X0 (m x nx, nev <= nx <= m).  Eigenpair i counts as
-// converged when |A x_i - theta_i B x_i| <= tau (|A|_2 + |theta_i| |B|_2) |x_i| with the 2-norms
-// estimated from a Gaussian probe (Sec. 4.3 of "A Robust and Efficient Implementation of LOBPCG");
-// only the leading run of converged pairs is soft-locked.                       (reference :131-337)
-template <typename Vector, typename Matrix, typename Scalar = double, typename... Args>
+namespace detail {
+
+#ifdef OPTIMIZATION_LOBPCG_HAS_DEVICE_PANELS
+// ---- device panels (MI355::DeviceMatrix) -----------------------------------------------------------------------
+template <typename Vector, typename Matrix, typename Scalar, typename... Args>
 std::pair<Vector, Matrix>
-LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
-       const std::optional<SymmetricLinearOperator<Matrix, Args...>> &B,
-       const std::optional<SymmetricLinearOperator<Matrix, Args...>> &T, const Matrix &X0, size_t nev,
-       size_t max_iters, size_t &num_iters, size_t &nc, Args &...args, Scalar tau = 1e-6,
-       const std::optional<LOBPCGUserFunction<Vector, Matrix, Scalar, Args...>> &user_function =
-           std::nullopt) {
+lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
+              const std::optional<SymmetricLinearOperator<Matrix, Args...>> &B,
+              const std::optional<SymmetricLinearOperator<Matrix, Args...>> &T, const Matrix &X0, size_t nev,
+              size_t max_iters, size_t &num_iters, size_t &nc, Args &...args, Scalar tau,
+              const std::optional<LOBPCGUserFunction<Vector, Matrix, Scalar, Args...>> &user_function) {
   const size_t m = X0.rows();
   const size_t nx = X0.cols();
-  if (nev > nx)
-    throw std::invalid_argument("Block size nx must be greater than or equal to the number nev of "
-                                "desired eigenpairs");  // :150
-  if (nx > m)
-    throw std::invalid_argument("Block size nx must be less than or equal to the dimension m of the "
-                                "problem");  // :155
 
   Matrix X = X0;  // :162
   Matrix AX, BX, R, W, P;
@@ -168,6 +204,167 @@ LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
   X.truncate_cols(nev);
   Matrix Xout = X;  // own storage: X may be a view that keeps a whole 3 nx panel alive
   return std::make_pair(Theta, std::move(Xout));
+}
+#endif  // OPTIMIZATION_LOBPCG_HAS_DEVICE_PANELS
+
+// ---- any dense Matrix / Vector pair, host, element access only -----------------------------------------------
+template <typename Vector, typename Matrix, typename Scalar, typename... Args>
+std::pair<Vector, Matrix>
+lobpcg_dense(const SymmetricLinearOperator<Matrix, Args...> &A,
+             const std::optional<SymmetricLinearOperator<Matrix, Args...>> &B,
+             const std::optional<SymmetricLinearOperator<Matrix, Args...>> &T, const Matrix &X0, size_t nev,
+             size_t max_iters, size_t &num_iters, size_t &nc, Args &...args, Scalar tau,
+             const std::optional<LOBPCGUserFunction<Vector, Matrix, Scalar, Args...>> &user_function) {
+  const size_t m = X0.rows();
+  const size_t nx = X0.cols();
+  // the handful of dense operations the iteration needs
+  auto cols = [m](const Matrix &M, size_t j0, size_t k) {  // M.middleCols(j0, k)
+    Matrix out(m, k);
+    for (size_t j = 0; j < k; ++j)
+      for (size_t i = 0; i < m; ++i) out(i, j) = M(i, j0 + j);
+    return out;
+  };
+  auto set_cols = [m](Matrix &D, size_t j0, const Matrix &S, size_t i0, size_t k) {  // D.middleCols(j0,k) = S.middleCols(i0,k)
+    for (size_t j = 0; j < k; ++j)
+      for (size_t i = 0; i < m; ++i) D(i, j0 + j) = S(i, i0 + j);
+  };
+  auto gram = [m](const Matrix &S, const Matrix &Tm) {  // S' T
+    Matrix G(S.cols(), Tm.cols());
+    for (size_t b = 0; b < (size_t)Tm.cols(); ++b)
+      for (size_t a = 0; a < (size_t)S.cols(); ++a) {
+        Scalar s = 0;
+        for (size_t i = 0; i < m; ++i) s += S(i, a) * Tm(i, b);
+        G(a, b) = s;
+      }
+    return G;
+  };
+  auto times = [m](const Matrix &S, size_t s0, size_t ks, const Matrix &C, size_t r0, size_t kc) {
+    Matrix Y(m, kc);  // S[:, s0 : s0 + ks) * C[r0 : r0 + ks, 0 : kc)
+    for (size_t j = 0; j < kc; ++j) {
+      for (size_t i = 0; i < m; ++i) Y(i, j) = 0;
+      for (size_t r = 0; r < ks; ++r) {
+        const Scalar c = C(r0 + r, j);
+        for (size_t i = 0; i < m; ++i) Y(i, j) += S(i, s0 + r) * c;
+      }
+    }
+    return Y;
+  };
+  auto fro = [](const Matrix &M) {
+    Scalar s = 0;
+    for (size_t j = 0; j < (size_t)M.cols(); ++j)
+      for (size_t i = 0; i < (size_t)M.rows(); ++i) s += M(i, j) * M(i, j);
+    return std::sqrt(s);
+  };
+  auto col_norm = [m](const Matrix &M, size_t j) {
+    Scalar s = 0;
+    for (size_t i = 0; i < m; ++i) s += M(i, j) * M(i, j);
+    return std::sqrt(s);
+  };
+  auto residuals = [m, nx](const Matrix &AX, const Matrix &BX, const Vector &Theta) {  // AX - BX diag(Theta(:nx))
+    Matrix R(m, nx);
+    for (size_t j = 0; j < nx; ++j)
+      for (size_t i = 0; i < m; ++i) R(i, j) = AX(i, j) - BX(i, j) * Theta(j);
+    return R;
+  };
+
+  Matrix X = X0;                    // :162
+  Matrix AX, BX, R, W, P;
+  Matrix S(m, 3 * nx);              // :185
+  Vector Theta, r(nx);
+  size_t ns = 0;
+
+  Scalar A2normest, B2normest;      // :205-214
+  {
+    std::default_random_engine gen;
+    std::normal_distribution<double> normal(0, 1.0);
+    Matrix Omega(m, nx);
+    for (size_t i = 0; i < m; ++i)
+      for (size_t j = 0; j < nx; ++j) Omega(i, j) = normal(gen);
+    const Scalar om = fro(Omega);
+    A2normest = fro(A(Omega)) / om;
+    B2normest = B ? fro((*B)(Omega)) / om : 1.0;
+  }
+
+  AX = A(X);                        // :218
+  BX = B ? (*B)(X) : X;             // :219
+  {
+    auto tc = RayleighRitz<Vector, Matrix>(gram(X, AX), gram(X, BX));  // :222-223
+    Theta = std::move(tc.first);
+    AX = times(AX, 0, nx, tc.second, 0, nx);  // :226 (X itself is NOT rotated)
+    BX = times(BX, 0, nx, tc.second, 0, nx);  // :227
+  }
+  R = residuals(AX, BX, Theta);     // :230
+  nc = 0;                           // :233
+
+  for (num_iters = 1; num_iters < max_iters; ++num_iters) {  // :237
+    W = T ? (*T)(R) : R;                                     // :247
+    set_cols(S, 0, X, 0, nx);                                // :254
+    set_cols(S, nx, W, nc, nx - nc);                         // :255 (soft locking drops the FIRST nc columns)
+    if (num_iters > 1) {
+      set_cols(S, 2 * nx - nc, P, nc, nx - nc);              // :259
+      ns = 3 * nx - 2 * nc;
+    } else {
+      ns = 2 * nx - nc;                                      // :263
+    }
+    const Matrix Sns = cols(S, 0, ns);
+    const Matrix AS = A(Sns);                                // :267
+    const Matrix BS = B ? (*B)(Sns) : Sns;                   // :268
+    auto tc = RayleighRitz<Vector, Matrix>(gram(Sns, AS), gram(Sns, BS));  // :271-275
+    Theta = std::move(tc.first);
+    const Matrix &C = tc.second;
+    X = times(Sns, 0, ns, C, 0, nx);                         // :278
+    AX = A(X);                                               // :281
+    BX = B ? (*B)(X) : X;                                    // :282
+    R = residuals(AX, BX, Theta);                            // :285
+    P = times(Sns, nx, ns - nx, C, nx, nx);                  // :288
+    for (size_t j = 0; j < nx; ++j) r(j) = col_norm(R, j);   // :293
+    for (nc = 0; nc < nev; ++nc) {                           // :298-318 leading run of converged pairs
+      const Scalar tol = tau * (A2normest + B2normest * std::fabs(Theta(nc))) * col_norm(X, nc);
+      if (!(r(nc) <= tol)) break;
+    }
+    if (user_function) {                                     // :322-324
+      Vector th(nx);
+      for (size_t j = 0; j < nx; ++j) th(j) = Theta(j);
+      if ((*user_function)(num_iters, A, B, T, nev, th, X, r, nc, args...)) break;
+    }
+    if (nc == nev) break;                                    // :327
+  }
+
+  Vector Tout(nev);                                          // :333-334
+  for (size_t j = 0; j < nev; ++j) Tout(j) = Theta(j);
+  return std::make_pair(std::move(Tout), cols(X, 0, nev));
+}
+
+}  // namespace detail
+
+// nev smallest eigenpairs from the block X0 (m x nx, nev <= nx <= m).  Eigenpair i counts as
+// converged when |A x_i - theta_i B x_i| <= tau (|A|_2 + |theta_i| |B|_2) |x_i| with the 2-norms
+// estimated from a Gaussian probe (Sec. 4.3 of "A Robust and Efficient Implementation of LOBPCG");
+// only the leading run of converged pairs is soft-locked.                       (reference :131-337)
+template <typename Vector, typename Matrix, typename Scalar = double, typename... Args>
+std::pair<Vector, Matrix>
+LOBPCG(const SymmetricLinearOperator<Matrix, Args...> &A,
+       const std::optional<SymmetricLinearOperator<Matrix, Args...>> &B,
+       const std::optional<SymmetricLinearOperator<Matrix, Args...>> &T, const Matrix &X0, size_t nev,
+       size_t max_iters, size_t &num_iters, size_t &nc, Args &...args, Scalar tau = 1e-6,
+       const std::optional<LOBPCGUserFunction<Vector, Matrix, Scalar, Args...>> &user_function =
+           std::nullopt) {
+  const size_t m = X0.rows();
+  const size_t nx = X0.cols();
+  if (nev > nx)
+    throw std::invalid_argument("Block size nx must be greater than or equal to the number nev of "
+                                "desired eigenpairs");  // :150
+  if (nx > m)
+    throw std::invalid_argument("Block size nx must be less than or equal to the dimension m of the "
+                                "problem");  // :155
+#ifdef OPTIMIZATION_LOBPCG_HAS_DEVICE_PANELS
+  if constexpr (detail::is_device_panel<Matrix>::value)
+    return detail::lobpcg_device<Vector, Matrix, Scalar, Args...>(A, B, T, X0, nev, max_iters, num_iters, nc, args...,
+                                                                   tau, user_function);
+  else
+#endif
+    return detail::lobpcg_dense<Vector, Matrix, Scalar, Args...>(A, B, T, X0, nev, max_iters, num_iters, nc, args...,
+                                                                  tau, user_function);
 }
 
 // Same, starting from a random m x nx block                                       (reference :376-390)

@@ -541,6 +541,40 @@ class Reference(_Lib):
         super().__init__(_REF, "ref", False)
 
 
+def lobpcg_dense_template(lib, m, nx, nev, Adiag=None, csr=None, Bdiag=None, Tdiag=None, X0=None, max_iters=1000,
+                          tau=1e-6, trace_cap=0):
+    """hz_lobpcg_dense: the template layer's GENERIC LOBPCG path on a plain dense host matrix
+    (tests/cpp/harness_host.cpp); trace_cap > 0 also returns the per-iteration Ritz values / residual norms."""
+    ip32 = C.POINTER(C.c_int32)
+    fn = lib.hz_lobpcg_dense
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, c_double_p, ip32, ip32, c_double_p, c_double_p, c_double_p,
+                   c_double_p, C.c_size_t, C.c_double, c_double_p, c_double_p, c_size_p, c_size_p, c_double_p,
+                   c_double_p, C.c_size_t]
+
+    def arr(a):
+        return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+    Ad, Bd, Td = arr(Adiag), arr(Bdiag), arr(Tdiag)
+    X0f = np.asfortranarray(X0, dtype=np.float64)
+    rp = cl = vl = None
+    if csr is not None:
+        rp = np.ascontiguousarray(csr[0], dtype=np.int32)
+        cl = np.ascontiguousarray(csr[1], dtype=np.int32)
+        vl = np.ascontiguousarray(csr[2], dtype=np.float64)
+    th = np.zeros(nev)
+    X = np.zeros((m, nev), order="F")
+    it, nc = C.c_size_t(0), C.c_size_t(0)
+    tt = np.zeros((max(trace_cap, 1), nx))
+    rt = np.zeros((max(trace_cap, 1), nx))
+    rc = fn(m, nx, nev, _dp(Ad) if Ad is not None else None, rp.ctypes.data_as(ip32) if rp is not None else None,
+            cl.ctypes.data_as(ip32) if cl is not None else None, _dp(vl) if vl is not None else None,
+            _dp(Bd) if Bd is not None else None, _dp(Td) if Td is not None else None, _dp(X0f), max_iters, tau,
+            _dp(th), _dp(X), C.byref(it), C.byref(nc), _dp(tt) if trace_cap else None,
+            _dp(rt) if trace_cap else None, trace_cap)
+    k = min(it.value, trace_cap)
+    return dict(rc=rc, Theta=th, X=X, num_iters=it.value, nc=nc.value, theta_trace=tt[:k], r_trace=rt[:k])
+
+
 def have_reference():
     return os.path.exists(_REF)
 

@@ -491,6 +491,14 @@ extern "C" int hd_gaussian_probe(size_t m, size_t nx, double *out) {
 }
 
 static std::vector<std::chrono::steady_clock::time_point> g_lobpcg_stamps;
+// per-iteration Ritz values / residual norms of the last hd_lobpcg call (nx per iteration, as the user function saw them)
+static std::vector<double> g_lobpcg_theta_trace, g_lobpcg_r_trace;
+extern "C" size_t hd_lobpcg_trace(double *theta, double *r, size_t cap) {
+  const size_t n = g_lobpcg_theta_trace.size() < cap ? g_lobpcg_theta_trace.size() : cap;
+  if (theta) std::memcpy(theta, g_lobpcg_theta_trace.data(), n * sizeof(double));
+  if (r) std::memcpy(r, g_lobpcg_r_trace.data(), n * sizeof(double));
+  return g_lobpcg_theta_trace.size();
+}
 
 extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, const int32_t *rowptr,
                          const int32_t *col, const double *val, const double *Bdiag, const double *Tdiag,
@@ -529,10 +537,14 @@ extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, c
   if (Tdiag) T = diag_op(Tdiag);
   size_t iters = 0, nc = 0;
   std::vector<double> resid;
+  g_lobpcg_theta_trace.clear();
+  g_lobpcg_r_trace.clear();
   std::optional<LA::LOBPCGUserFunction<HostVectorD, DeviceMatrix>> uf =
-      [&](size_t, const Op &, const std::optional<Op> &, const std::optional<Op> &, size_t, const HostVectorD &,
+      [&](size_t, const Op &, const std::optional<Op> &, const std::optional<Op> &, size_t, const HostVectorD &th,
           const DeviceMatrix &, const HostVectorD &r, size_t) {
         resid.assign(r.data(), r.data() + r.size());
+        g_lobpcg_theta_trace.insert(g_lobpcg_theta_trace.end(), th.data(), th.data() + th.size());
+        g_lobpcg_r_trace.insert(g_lobpcg_r_trace.end(), r.data(), r.data() + r.size());
         g_lobpcg_stamps.push_back(std::chrono::steady_clock::now());
         return false;
       };

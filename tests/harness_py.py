@@ -158,8 +158,17 @@ class DeviceHarness:
                               _dp(vl) if vl is not None else None, _dp(Bd) if Bd is not None else None,
                               _dp(Td) if Td is not None else None, _dp(X0f) if X0f is not None else None,
                               max_iters, tau, _dp(th), _dp(X), C.byref(it), C.byref(nc), _dp(res))
-        return dict(rc=rc, err=self.err() if rc else "", Theta=th, X=X, num_iters=it.value, nc=nc.value,
-                    residuals=res)
+        out = dict(rc=rc, err=self.err() if rc else "", Theta=th, X=X, num_iters=it.value, nc=nc.value,
+                   residuals=res)
+        # per-iteration Ritz values / residual norms as the user function saw them (hd_lobpcg_trace)
+        self.L.hd_lobpcg_trace.restype = C.c_size_t
+        self.L.hd_lobpcg_trace.argtypes = [dp, dp, C.c_size_t]
+        n = self.L.hd_lobpcg_trace(None, None, 0)
+        tt, rt = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+        self.L.hd_lobpcg_trace(_dp(tt), _dp(rt), n)
+        out["theta_trace"] = tt[:n].reshape(-1, nx)
+        out["r_trace"] = rt[:n].reshape(-1, nx)
+        return out
 
     def tnt_sphere(self, with_precon, x0, params):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
