@@ -104,6 +104,10 @@ MI_API int mi_vec_download(const mi_vec *v, double *host, size_t n);       /* sy
 MI_API int mi_vec_copy(mi_vec *dst, const mi_vec *src);   /* `r_k = g;` IterativeSolvers.h:214,231,383 */
 MI_API int mi_vec_fill(mi_vec *v, double a);
 MI_API int mi_vec_scale(mi_vec *v, double a);             /* `p_k *= -1;` :324 ; `u /= beta` :653 */
+MI_API int mi_vec_div(mi_vec *v, double a);               /* `u /= beta` :653,712, `v /= alpha` :658,723: a true
+                                                             division, rounded like the reference's */
+MI_API int mi_vec_scale_to(mi_vec *z, double a, const mi_vec *x); /* z = a * x: `0 * g` :211 (0 * Inf = NaN, -0.0
+                                                             kept), `sigma_k * p_k`, unary minus :256 */
 MI_API int mi_vec_axpy(mi_vec *y, double a, const mi_vec *x); /* `s_k += sigma_k * p_k;` :336,360,377 */
 /* z = a*x + b*y (z may alias x or y): `s_k = s_k + alpha_k*p_k` :374, `p_k = -v_k + beta_k*p_k` :420,
  * `0 * g` :211, unary minus :256, `X + V` Riemannian/Concepts.h:189 */

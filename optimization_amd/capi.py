@@ -109,6 +109,8 @@ def load():
         "mi_vec_copy": [vp, vp],
         "mi_vec_fill": [vp, C.c_double],
         "mi_vec_scale": [vp, C.c_double],
+        "mi_vec_div": [vp, C.c_double],
+        "mi_vec_scale_to": [vp, C.c_double, vp],
         "mi_vec_axpy": [vp, C.c_double, vp],
         "mi_vec_axpby": [vp, C.c_double, vp, C.c_double, vp],
         "mi_vec_dot": [vp, vp, c_double_p],
@@ -580,6 +582,15 @@ class Vec:
     def scale(self, a):
         check(self.L.mi_vec_scale(self.h, a))
         return self
+
+    def div(self, a):
+        check(self.L.mi_vec_div(self.h, a))
+        return self
+
+    def scaled(self, a):
+        z = Vec(self.ctx, self.n)
+        check(self.L.mi_vec_scale_to(z.h, a, self.h))
+        return z
 
     def axpy(self, a, x):
         check(self.L.mi_vec_axpy(self.h, a, x.h))

@@ -7,7 +7,7 @@ using namespace mi;
 
 namespace {
 
-// MODE 0: z = a*x + b*y ; MODE 1: z = a*x ; MODE 2: z = a
+// MODE 0: z = a*x + b*y ; MODE 1: z = a*x ; MODE 2: z = a ; MODE 3: z = x / a (a true division, like the host code)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_axpby(size_t n, double a, const double *__restrict__ x,
                                                   double b, const double *__restrict__ y,
@@ -22,6 +22,8 @@ __global__ __launch_bounds__(kBlock) void k_axpby(size_t n, double a, const doub
       const double2 xv = reinterpret_cast<const double2 *>(x)[i];
       if (MODE == 1) {
         r.x = a * xv.x; r.y = a * xv.y;
+      } else if (MODE == 3) {
+        r.x = xv.x / a; r.y = xv.y / a;
       } else {
         const double2 yv = reinterpret_cast<const double2 *>(y)[i];
         r.x = a * xv.x + b * yv.x;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void k_axpby(size_t n, double a, const doub
   }
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const size_t i = n - 1;
-    z[i] = (MODE == 2) ? a : (MODE == 1) ? a * x[i] : a * x[i] + b * y[i];
+    z[i] = (MODE == 2) ? a : (MODE == 1) ? a * x[i] : (MODE == 3) ? x[i] / a : a * x[i] + b * y[i];
   }
 }
 
@@ -214,6 +216,26 @@ int mi_vec_scale(mi_vec *v, double a) {
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+                     (const double *)v->d, 0.0, (const double *)nullptr, v->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_vec_scale_to(mi_vec *z, double a, const mi_vec *x) {
+  MI_TRY(check_same(z, x));
+  if (z->n == 0) return MI_OK;
+  KScope ks(z->ctx, MI_K_BLAS1);
+  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
+                     (const double *)x->d, 0.0, (const double *)nullptr, z->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+int mi_vec_div(mi_vec *v, double a) {
+  MI_REQUIRE(v, "null vector");
+  if (v->n == 0) return MI_OK;
+  KScope ks(v->ctx, MI_K_BLAS1);
+  hipLaunchKernelGGL(k_axpby<3>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)v->d, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;

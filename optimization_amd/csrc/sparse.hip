@@ -555,7 +555,9 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   MI_REQUIRE(ctx && rowptr && col_global && val && row_starts && out, "null argument");
   MI_REQUIRE(row_begin <= row_end && row_end <= n_global, "bad local row range");
   const size_t n = row_end - row_begin;
-  MI_REQUIRE((size_t)rowptr[n] == nnz_local, "rowptr inconsistent with nnz_local");
+  MI_REQUIRE(n < (size_t)INT32_MAX, "local row count too large for int32 indices");
+  MI_REQUIRE(rowptr[0] == 0 && (size_t)rowptr[n] == nnz_local, "rowptr inconsistent with nnz_local");
+  for (size_t i = 0; i < n; ++i) MI_REQUIRE(rowptr[i + 1] >= rowptr[i], "rowptr not monotone at row %zu", i);
   const int ws = ctx->world_size, rk = ctx->rank;
   MI_REQUIRE(row_starts[rk] == row_begin && row_starts[rk + 1] == row_end,
              "row_starts does not match this rank's range");
@@ -569,12 +571,21 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   A->halo_hi = need_hi;
   // what we must SEND equals what the neighbours need; exchanged once through the communicator
   size_t max_halo_rows = 0;
-  MI_TRY(comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi, &A->peer_lo_rows,
-                                   &max_halo_rows));
-  // same size on every rank, so that the arena offsets of the peer-memory layer agree
-  A->halo_stride = std::max<size_t>(1, max_halo_rows * 4);  // doubles per buffer (p <= 4); two buffers
-  MI_TRY(comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo, &A->halo_in_arena, &A->halo_off));
-  MI_REQUIRE(A->send_lo <= n && A->send_hi <= n, "neighbour halo request exceeds local rows");
+  int st = comm_exchange_halo_counts(ctx, need_lo, need_hi, &A->send_lo, &A->send_hi, &A->peer_lo_rows,
+                                     &max_halo_rows);
+  if (st == MI_OK) {
+    // same size on every rank, so that the arena offsets of the peer-memory layer agree
+    A->halo_stride = std::max<size_t>(1, max_halo_rows * 4);  // doubles per buffer (p <= 4); two buffers
+    st = comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo, &A->halo_in_arena, &A->halo_off);
+  }
+  if (st == MI_OK && !(A->send_lo <= n && A->send_hi <= n)) {
+    set_error("neighbour halo request exceeds local rows");
+    st = MI_ERR_INVALID_ARGUMENT;
+  }
+  if (st != MI_OK) {  // (the matrix and its device buffers must not leak on these paths)
+    mi_csr_destroy(A);
+    return st;
+  }
   *out = A;
   return MI_OK;
 }

@@ -147,8 +147,8 @@ class DeviceVector {
     check(mi_vec_scale(v_, a));
     return *this;
   }
-  DeviceVector &operator/=(double a) {  // `u /= beta` IterativeSolvers.h:653: true division
-    check(mi_vec_axpby(v_, 1.0 / a, v_, 0.0, v_));
+  DeviceVector &operator/=(double a) {  // `u /= beta` IterativeSolvers.h:653: a true division (mi_vec_div)
+    check(mi_vec_div(v_, a));
     return *this;
   }
   // z = a x + b y without temporaries
@@ -177,8 +177,10 @@ class DeviceVector {
   bool borrowed_ = false;
 };
 
-inline DeviceVector operator*(double a, const DeviceVector &v) {  // `0 * g`, `alpha * p`
-  return DeviceVector::axpby(a, v, 0.0, v);
+inline DeviceVector operator*(double a, const DeviceVector &v) {  // `0 * g`, `alpha * p`: one product per element
+  DeviceVector z = DeviceVector::like(v);                        // (a*v + 0*v would turn Inf into NaN and -0.0 into +0.0)
+  check(mi_vec_scale_to(z.handle(), a, v.handle()));
+  return z;
 }
 inline DeviceVector operator*(const DeviceVector &v, double a) { return a * v; }
 inline DeviceVector operator/(const DeviceVector &v, double a) {

@@ -151,23 +151,26 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
   linearise();
 
   // operators of the LSQR sub-problem, following x / dF as they change           :432-462
-  LA::LinearOperator<TangentX, VectorY, Args...> A;
-  LA::LinearOperator<VectorY, TangentX, Args...> At;
+  LA::LinearOperator<TangentX, VectorY, Args...> A_generic;
+  LA::LinearOperator<VectorY, TangentX, Args...> At_generic;
   if (precon) {
-    A = [&x, &dF, &precon](const TangentX &v, Args &...a) -> VectorY {
+    A_generic = [&x, &dF, &precon](const TangentX &v, Args &...a) -> VectorY {
       return dF(x, precon->first(x, v, a...), a...);
     };
-    At = [&x, &dFt, &precon](const VectorY &w, Args &...a) -> TangentX {
+    At_generic = [&x, &dFt, &precon](const VectorY &w, Args &...a) -> TangentX {
       return precon->second(x, dFt(x, w, a...), a...);
     };
   } else {
-    A = [&x, &dF](const TangentX &v, Args &...a) -> VectorY { return dF(x, v, a...); };
-    At = [&x, &dFt](const VectorY &w, Args &...a) -> TangentX { return dFt(x, w, a...); };
+    A_generic = [&x, &dF](const TangentX &v, Args &...a) -> VectorY { return dF(x, v, a...); };
+    At_generic = [&x, &dFt](const VectorY &w, Args &...a) -> TangentX { return dFt(x, w, a...); };
   }
-  LA::InnerProduct<TangentX, Scalar, Args...> inner_product_X =
+  const LA::InnerProduct<TangentX, Scalar, Args...> inner_product_X_generic =
       [&x, &metric_X](const TangentX &a, const TangentX &b, Args &...aa) -> Scalar {
     return metric_X(x, a, b, aa...);
   };
+  LA::LinearOperator<TangentX, VectorY, Args...> A = A_generic;
+  LA::LinearOperator<VectorY, TangentX, Args...> At = At_generic;
+  LA::InnerProduct<TangentX, Scalar, Args...> inner_product_X = inner_product_X_generic;
 
 #if OPTIMIZATION_HAVE_MI355
   // Device fast path: when the Jacobian pair handed back by J consists of tagged device operators (an
@@ -178,6 +181,11 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
                                 MI355::is_device_vector<VectorY>::value && sizeof...(Args) == 0;
   auto retag_for_device = [&]() {
     if constexpr (device_types) {
+      // back to the generic views first (J may hand back tagged device operators at one iterate and plain callables
+      // at the next: a stale tagged view would point at an operator bound to an old base point)
+      A = A_generic;
+      At = At_generic;
+      inner_product_X = inner_product_X_generic;
       if (precon) return;
       const auto *a = dF.template target<MI355::DeviceHessian>();
       const auto *at = dFt.template target<MI355::DeviceHessian>();

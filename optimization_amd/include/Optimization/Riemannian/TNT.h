@@ -161,18 +161,20 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
   measure_gradient();
 
   // x-free views of the model for the inner solver; they follow x / Hess as those change  :400-426
-  LA::SymmetricLinearOperator<Tangent, Args...> H = [&x, &Hess](const Tangent &v, Args &...a) -> Tangent {
+  const LA::SymmetricLinearOperator<Tangent, Args...> H_generic = [&x, &Hess](const Tangent &v,
+                                                                               Args &...a) -> Tangent {
     return Hess(x, v, a...);
   };
-  LA::InnerProduct<Tangent, Scalar, Args...> inner_product = [&x, &metric](const Tangent &a, const Tangent &b,
-                                                                           Args &...aa) -> Scalar {
-    return metric(x, a, b, aa...);
-  };
-  std::optional<LA::STPCGPreconditioner<Tangent, Multiplier, Args...>> Pop;
+  const LA::InnerProduct<Tangent, Scalar, Args...> inner_product_generic =
+      [&x, &metric](const Tangent &a, const Tangent &b, Args &...aa) -> Scalar { return metric(x, a, b, aa...); };
+  std::optional<LA::STPCGPreconditioner<Tangent, Multiplier, Args...>> Pop_generic;
   if (precon)
-    Pop = [&x, &precon](const Tangent &v, Args &...a) -> std::pair<Tangent, Multiplier> {
+    Pop_generic = [&x, &precon](const Tangent &v, Args &...a) -> std::pair<Tangent, Multiplier> {
       return std::pair<Tangent, Multiplier>((*precon)(x, v, a...), Multiplier());
     };
+  LA::SymmetricLinearOperator<Tangent, Args...> H = H_generic;
+  LA::InnerProduct<Tangent, Scalar, Args...> inner_product = inner_product_generic;
+  std::optional<LA::STPCGPreconditioner<Tangent, Multiplier, Args...>> Pop = Pop_generic;
 
 #if OPTIMIZATION_HAVE_MI355
   // Device fast path: swap the generic lambdas for the tagged function objects that STPCG recognises.
@@ -181,6 +183,11 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
   constexpr bool device_types = MI355::is_device_vector<Tangent>::value && sizeof...(Args) == 0;
   auto retag_for_device = [&]() {
     if constexpr (device_types) {
+      // back to the generic views first: a QuadraticModel may hand back a tagged device operator at one iterate and
+      // a plain callable at the next, and a stale tagged view would point at an operator bound to an old base point
+      H = H_generic;
+      inner_product = inner_product_generic;
+      Pop = Pop_generic;
       if (metric.template target<MI355::FrobeniusMetric>()) inner_product = MI355::FrobeniusInnerProduct{};
       if (const auto *dh = Hess.template target<MI355::DeviceHessian>()) H = MI355::DeviceOperator{dh->op};
       if (precon)
