@@ -61,6 +61,10 @@ MI_API int mi_device_count(int *count);
 MI_API int mi_ctx_create(int device, mi_ctx **out);
 MI_API int mi_ctx_destroy(mi_ctx *ctx);
 MI_API int mi_ctx_sync(mi_ctx *ctx);                   /* sync: hipStreamSynchronize */
+/* number of times the library waited for the device on this context (scalar read-backs, solver exits, explicit
+ * syncs; uploads/downloads of whole vectors not counted): how often the host sits on the critical path of e.g. one
+ * TNT outer iteration (tools/bench_tnt.py) */
+MI_API int mi_ctx_sync_count(mi_ctx *ctx, size_t *count);
 MI_API int mi_ctx_stream(mi_ctx *ctx, void **stream);  /* the hipStream_t all work is enqueued on */
 MI_API int mi_ctx_device_name(mi_ctx *ctx, char *buf, size_t buflen);
 MI_API int mi_ctx_pool_bytes(mi_ctx *ctx, size_t *bytes_reserved);
@@ -249,6 +253,14 @@ MI_API int mi_stiefel_rq_objective(mi_stiefel_rq *prob, const mi_vec *X, double 
 /* QuadraticModel: grad = AX - X sym(X'AX); caches S = sym(X'AX) on the device and binds the
  * Hessian operator  Hess[V] = P_X(A V - V S)  to X (X must outlive the operator's use). */
 MI_API int mi_stiefel_rq_model(mi_stiefel_rq *prob, const mi_vec *X, mi_vec *grad, mi_op **hess);
+/* One trial step at the point X the model is bound to -- the statements between the inner solve and the
+ * accept/reject decision of Riemannian/TNT.h:493-512 (|h|, x_trial = retract(x, h), f(x_trial), <g,h>, <h, Hess h>)
+ * plus, speculatively, the model at the trial point (:573-585: gradient and its norm) -- as one launch chain with ONE
+ * read-back (sync).  out[5] = {f(X+), <h,h>, <g,h>, <h,Hess h>, |grad f(X+)|^2}.  A following
+ * mi_stiefel_rq_model(prob, X_trial, ...) reuses A X+, S+ and the gradient instead of recomputing them.  Every number
+ * has the bits the separate calls would produce. */
+MI_API int mi_stiefel_rq_trial(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *h, const mi_vec *g,
+                               mi_vec *X_trial, double out[5]);
 /* row-scaling (Jacobi) preconditioner projected to the tangent space: v = P_X(dinv_rows .* r) */
 MI_API int mi_stiefel_rq_precon(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *dinv_rows,
                                 mi_precon **out);

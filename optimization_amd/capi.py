@@ -90,6 +90,7 @@ def load():
         "mi_ctx_create": [C.c_int, C.POINTER(vp)],
         "mi_ctx_destroy": [vp],
         "mi_ctx_sync": [vp],
+        "mi_ctx_sync_count": [vp, c_size_p],
         "mi_ctx_stream": [vp, C.POINTER(vp)],
         "mi_ctx_device_name": [vp, C.c_char_p, C.c_size_t],
         "mi_ctx_pool_bytes": [vp, c_size_p],
@@ -141,6 +142,7 @@ def load():
         "mi_stiefel_rq_destroy": [vp],
         "mi_stiefel_rq_objective": [vp, vp, c_double_p],
         "mi_stiefel_rq_model": [vp, vp, vp, C.POINTER(vp)],
+        "mi_stiefel_rq_trial": [vp, vp, vp, vp, vp, c_double_p],
         "mi_stiefel_rq_precon": [vp, vp, vp, C.POINTER(vp)],
         "mi_so3n_create": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, c_double_p,
                            C.POINTER(vp)],
@@ -233,6 +235,11 @@ class Context:
 
     def sync(self):
         check(self.L.mi_ctx_sync(self.h))
+
+    def sync_count(self):
+        n = C.c_size_t(0)
+        check(self.L.mi_ctx_sync_count(self.h, C.byref(n)))
+        return n.value
 
     def device_name(self):
         buf = C.create_string_buffer(256)
@@ -747,6 +754,13 @@ class StiefelRQ:
         hop = vp()
         check(self.L.mi_stiefel_rq_model(self.h, X.h, g.h, C.byref(hop)))
         return g, Op(self.ctx, hop, keep=[self, X], borrowed=True)
+
+    def trial(self, X, h, g):
+        """mi_stiefel_rq_trial: (X_trial Vec, dict(f, hh, gh, hHh, grad_sqnorm))"""
+        Xt = Vec(self.ctx, self.n * self.p)
+        out = np.zeros(5)
+        check(self.L.mi_stiefel_rq_trial(self.h, X.h, h.h, g.h, Xt.h, _dp(out)))
+        return Xt, dict(f=out[0], hh=out[1], gh=out[2], hHh=out[3], grad_sqnorm=out[4])
 
     def precon(self, X, dinv_rows):
         h = vp()

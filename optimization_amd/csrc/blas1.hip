@@ -134,6 +134,7 @@ int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out) {
   MI_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + slot0, sizeof(double) * k,
                         hipMemcpyDeviceToHost, ctx->stream));
   MI_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->host_syncs++;
   for (int i = 0; i < k; ++i) out[i] = ctx->host_scalars[i];
   return MI_OK;
 }

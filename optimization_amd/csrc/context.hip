@@ -221,6 +221,13 @@ int mi_ctx_destroy(mi_ctx *ctx) {
 int mi_ctx_sync(mi_ctx *ctx) {
   MI_REQUIRE(ctx, "ctx is null");
   MI_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->host_syncs++;
+  return MI_OK;
+}
+
+int mi_ctx_sync_count(mi_ctx *ctx, size_t *count) {
+  MI_REQUIRE(ctx && count, "null argument");
+  *count = ctx->host_syncs;
   return MI_OK;
 }
 

@@ -484,6 +484,7 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
     LsqrState h;
     hipError_t e = hipMemcpyAsync(&h, sa, sizeof(LsqrState), hipMemcpyDeviceToHost, stq);
     if (e == hipSuccess) e = hipStreamSynchronize(stq);
+    ctx->host_syncs++;
     if (e != hipSuccess) LQ_CHECK(hip_fail(e, "lsqr read-back", __FILE__, __LINE__));
     result->xnorm = h.xnorm;
     result->num_iterations = (size_t)h.k;

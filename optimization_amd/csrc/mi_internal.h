@@ -123,6 +123,7 @@ struct mi_ctx {
   double *trace_dev = nullptr;           // 4 x trace_cap doubles
   size_t trace_cap = 0;
   unsigned int epoch = 0;
+  size_t host_syncs = 0;  // stream synchronisations the library made on this context (mi_ctx_sync_count)
   // timing
   mi::KTimer ktime[MI_K_COUNT];
   std::vector<hipEvent_t> event_pool;

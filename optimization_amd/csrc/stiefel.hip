@@ -606,6 +606,12 @@ struct mi_stiefel_rq {
   mi_dirgram dg;
   mi_op hess;     // borrowed operator object bound to X
   const mi_vec *X;
+  // mi_stiefel_rq_trial: what it already worked out at the trial point (A X+, sym(X+'A X+), the gradient), handed
+  // to the next mi_stiefel_rq_model call if that call is for the same vector
+  double *S_next = nullptr;
+  mi_vec *Y_next = nullptr, *grad_next = nullptr, *Hh = nullptr;
+  const mi_vec *trial_X = nullptr;
+  const double *trial_d = nullptr;
 };
 
 namespace {
@@ -794,8 +800,12 @@ int mi_stiefel_rq_destroy(mi_stiefel_rq *q) {
   if (!q) return MI_OK;
   (void)hipStreamSynchronize(q->ctx->stream);
   (void)hipFree(q->S_dev);
+  (void)hipFree(q->S_next);
   mi_vec_destroy(q->Z);
   mi_vec_destroy(q->Y);
+  mi_vec_destroy(q->Y_next);
+  mi_vec_destroy(q->grad_next);
+  mi_vec_destroy(q->Hh);
   delete q;
   return MI_OK;
 }
@@ -804,6 +814,7 @@ int mi_stiefel_rq_objective(mi_stiefel_rq *q, const mi_vec *X, double *f) {
   MI_REQUIRE(q && X && f, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;
+  q->trial_X = nullptr;  // (Z is scratch of both)
   int count = 0;
   MI_TRY(launch_spmm_gram(ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Z->d, &count));
   double *slots = ctx->scalars + SLOT_GRAM;
@@ -824,11 +835,19 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   MI_REQUIRE(q && X && grad, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, grad, nullptr));
   int count = 0;
-  // Y = A X (kept: the direction-Gram identity needs it) ; S = sym(X'AX) (kept on the device for the
-  // Hessian) ; grad = Y - X S
-  MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Y->d, &count));
-  MI_TRY(launch_finish(q->ctx, q->n, q->p, nullptr, X->d, q->Y->d, nullptr, count, q->S_dev, grad->d, false,
-                       nullptr));
+  if (q->trial_X == X && q->trial_d == X->d) {
+    // X is the point mi_stiefel_rq_trial just evaluated: A X, S and the gradient exist already
+    std::swap(q->Y, q->Y_next);
+    std::swap(q->S_dev, q->S_next);
+    MI_TRY(mi_vec_copy(grad, q->grad_next));
+  } else {
+    // Y = A X (kept: the direction-Gram identity needs it) ; S = sym(X'AX) (kept on the device for the
+    // Hessian) ; grad = Y - X S
+    MI_TRY(launch_spmm_gram(q->ctx, q->A, q->p, nullptr, X->d, X->d, nullptr, q->Y->d, &count));
+    MI_TRY(launch_finish(q->ctx, q->n, q->p, nullptr, X->d, q->Y->d, nullptr, count, q->S_dev, grad->d, false,
+                         nullptr));
+  }
+  q->trial_X = nullptr;
   q->X = X;
   q->dg.p = q->p;
   q->dg.n = q->n;
@@ -838,6 +857,67 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator
   q->hess.dirgram = sell_stream_ok(q->A, q->p) ? &q->dg : nullptr;
   if (hess) *hess = &q->hess;
+  return MI_OK;
+}
+
+// One trial step of a trust-region / line-search method at the point X the model is bound to (reference
+// Riemannian/TNT.h:493-512,573-585): step norm, retraction, objective at the trial point, predicted-decrease terms and
+// -- speculatively -- the model at the trial point, as ONE launch chain and ONE read-back.  Every number is produced
+// by the same kernels, in the same order of summation, as the separate calls (mi_vec_dot_batch, mi_stiefel_retract,
+// mi_stiefel_rq_objective, mi_stiefel_rq_model) would: only one sparse product (A X+ serves the objective AND the
+// next gradient) and the intermediate synchronisations disappear.
+//   out[0] = f(X+), out[1] = <h,h>, out[2] = <g,h>, out[3] = <h, Hess h>, out[4] = |grad f(X+)|^2
+int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, const mi_vec *g, mi_vec *X_trial,
+                        double out[5]) {
+  MI_REQUIRE(q && X && h && g && X_trial && out, "null argument");
+  MI_REQUIRE(q->X == X, "mi_stiefel_rq_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
+  MI_TRY(check_np(q->ctx, q->n, q->p, X, h, g));
+  MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
+  mi_ctx *ctx = q->ctx;
+  const size_t N = q->n * (size_t)q->p;
+  if (!q->Y_next) {
+    MI_TRY(mi_vec_create(ctx, N, &q->Y_next));
+    MI_TRY(mi_vec_create(ctx, N, &q->grad_next));
+    MI_TRY(mi_vec_create(ctx, N, &q->Hh));
+    MI_HIP(hipMalloc((void **)&q->S_next, 16 * sizeof(double)));
+  }
+  q->trial_X = nullptr;
+  // (a) Hess h, then |h|^2, <g,h>, <h, Hess h> in one pass (as MI355::dot_batch does)
+  MI_TRY(rq_apply(&q->hess, h, q->Hh));
+  {
+    const double *xs[3] = {h->d, g->d, h->d}, *ys[3] = {h->d, h->d, q->Hh->d};
+    MI_TRY(dot_batch_to_slots(ctx, 3, xs, ys, N, SLOT_MISC));
+  }
+  // (b) X+ = polar(X + h)
+  MI_TRY(mi_stiefel_retract(ctx, q->n, q->p, X, h, X_trial));
+  // (c) A X+ with the Gram rows of sym(X+' A X+): the objective (reduced exactly as mi_stiefel_rq_objective does)
+  //     and, through the same rows, S+ and the gradient at X+ (exactly as mi_stiefel_rq_model does)
+  int count = 0;
+  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, nullptr, X_trial->d, X_trial->d, nullptr, q->Y_next->d, &count));
+  const int ns = nsym(q->p);
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, count, ns, ctx->scalars + SLOT_GRAM));
+  MI_TRY(launch_finish(ctx, q->n, q->p, nullptr, X_trial->d, q->Y_next->d, nullptr, count, q->S_next,
+                       q->grad_next->d, false, nullptr));
+  {
+    const double *xs[1] = {q->grad_next->d}, *ys[1] = {q->grad_next->d};
+    MI_TRY(dot_batch_to_slots(ctx, 1, xs, ys, N, SLOT_MISC + 3));
+  }
+  // (d) one read-back: slots [SLOT_GRAM, SLOT_MISC + 4)
+  static_assert(SLOT_GRAM < SLOT_MISC && SLOT_MISC + 4 <= kScalarSlots, "slot map");
+  double buf[SLOT_MISC + 4 - SLOT_GRAM];
+  MI_TRY(read_slots_sync(ctx, SLOT_GRAM, SLOT_MISC + 4 - SLOT_GRAM, buf));
+  double tr = 0;
+  for (int a = 0, idx = 0; a < q->p; ++a) {  // diagonal entries of the packed symmetric Gram
+    tr += buf[idx];
+    idx += q->p - a;
+  }
+  out[0] = .5 * tr;
+  out[1] = buf[SLOT_MISC - SLOT_GRAM + 0];
+  out[2] = buf[SLOT_MISC - SLOT_GRAM + 1];
+  out[3] = buf[SLOT_MISC - SLOT_GRAM + 2];
+  out[4] = buf[SLOT_MISC - SLOT_GRAM + 3];
+  q->trial_X = X_trial;
+  q->trial_d = X_trial->d;
   return MI_OK;
 }
 

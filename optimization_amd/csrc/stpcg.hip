@@ -902,6 +902,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   {
     hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    ctx->host_syncs++;
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
     {
       int ipc_err = 0;

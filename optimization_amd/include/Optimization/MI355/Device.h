@@ -263,6 +263,22 @@ struct DeviceOperator {
     return out;
   }
 };
+// Riemannian::Retraction whose owner can evaluate a WHOLE TRIAL STEP of a trust-region method in one launch chain
+// with one read-back (reference Riemannian/TNT.h:493-512,573-585): the step norm, x_trial = retract(x, h), f(x_trial),
+// <g,h>, <h, Hess h> and, speculatively, the gradient norm at x_trial.  TNT recognises it (std::function::target) and
+// calls trial() instead of retract / f / metric one by one; used as a plain Retraction it retracts.
+struct DeviceTrialRetraction {
+  struct Trial {
+    DeviceVector x_trial;
+    double f_trial, hh, gh, hHh, grad_trial_sqnorm;
+  };
+  std::function<DeviceVector(const DeviceVector &, const DeviceVector &)> retract;
+  std::function<Trial(const DeviceVector &x, const DeviceVector &h, const DeviceVector &grad)> trial;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &X, const DeviceVector &V, A &...) const {
+    return retract(X, V);
+  }
+};
 // Riemannian::LinearOperator<DeviceVector, DeviceVector, ...> (the Hessian set by a QuadraticModel)
 // backed by an mi_op that is already bound to the base point X
 struct DeviceHessian {

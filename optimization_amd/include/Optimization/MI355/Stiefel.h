@@ -60,8 +60,31 @@ class StiefelRayleighQuotient {
     };
   }
   Riemannian::RiemannianMetric<Vector, Vector, double> metric() { return FrobeniusMetric{}; }
-  // polar retraction (X + V) ((X+V)'(X+V))^-1/2
+  // polar retraction (X + V) ((X+V)'(X+V))^-1/2 -- tagged: TNT evaluates a whole trial step (retraction, f at the
+  // trial point, the predicted-decrease terms, the next gradient) through mi_stiefel_rq_trial, one read-back
   Riemannian::Retraction<Vector, Vector> retraction() {
+    DeviceTrialRetraction r;
+    r.retract = [this](const Vector &X, const Vector &V) {
+      Vector Y = Vector::like(X);
+      check(mi_stiefel_retract(ctx_.get(), n_, p_, X.handle(), V.handle(), Y.handle()));
+      return Y;
+    };
+    r.trial = [this](const Vector &X, const Vector &h, const Vector &g) {
+      DeviceTrialRetraction::Trial t;
+      t.x_trial = Vector::like(X);
+      double out[5];
+      check(mi_stiefel_rq_trial(prob_, X.handle(), h.handle(), g.handle(), t.x_trial.handle(), out));
+      t.f_trial = out[0];
+      t.hh = out[1];
+      t.gh = out[2];
+      t.hHh = out[3];
+      t.grad_trial_sqnorm = out[4];
+      return t;
+    };
+    return r;
+  }
+  // the same without the tag (one call per statement of the reference's loop)
+  Riemannian::Retraction<Vector, Vector> plain_retraction() {
     return [this](const Vector &X, const Vector &V) {
       Vector Y = Vector::like(X);
       check(mi_stiefel_retract(ctx_.get(), n_, p_, X.handle(), V.handle(), Y.handle()));

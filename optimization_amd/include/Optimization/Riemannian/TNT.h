@@ -250,11 +250,29 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
     // Device path (Frobenius metric, tagged Hessian): the three step scalars |h|^2, <g,h>, <h,Hess h> of
     // :496,:511-512 come from ONE pass and ONE synchronisation instead of three (the Hessian application is a
     // pure device operation, so evaluating it before the retraction is unobservable).
-    bool step_scalars_batched = false;
-    Scalar gh = 0, hHh = 0;
+    bool step_scalars_batched = false, trial_done = false;
+    Scalar gh = 0, hHh = 0, trial_grad_sqnorm = 0;
 #if OPTIMIZATION_HAVE_MI355
     if constexpr (device_types) {
-      if (metric.template target<MI355::FrobeniusMetric>() && Hess.template target<MI355::DeviceHessian>()) {
+      // A retraction whose owner evaluates the whole trial step (|h|, x_trial, f(x_trial), <g,h>, <h,Hess h> and the
+      // gradient norm at x_trial) in one launch chain with one read-back: :493-512 and :573-585 in one call.
+      if (!precon && metric.template target<MI355::FrobeniusMetric>() &&
+          Hess.template target<MI355::DeviceHessian>()) {
+        if (const auto *tr = retract.template target<MI355::DeviceTrialRetraction>()) {
+          if (tr->trial) {
+            auto t = tr->trial(x, h, grad);
+            x_trial = std::move(t.x_trial);
+            fx_trial = t.f_trial;
+            h_norm = sqrt(t.hh);
+            gh = t.gh;
+            hHh = t.hHh;
+            trial_grad_sqnorm = t.grad_trial_sqnorm;
+            step_scalars_batched = trial_done = true;
+          }
+        }
+      }
+      if (!trial_done && metric.template target<MI355::FrobeniusMetric>() &&
+          Hess.template target<MI355::DeviceHessian>()) {
         const Tangent Hh = Hess(x, h, args...);
         const std::vector<double> d = MI355::dot_batch({{&h, &h}, {&grad, &h}, {&h, &Hh}});
         h_norm = sqrt(d[0]);
@@ -272,8 +290,10 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
       std::cout << inner_iterations << ", |h|: " << h_norm << ", |h|_M: " << h_M_norm;
     }
 
-    x_trial = retract(x, h, args...);   // :505
-    fx_trial = f(x_trial, args...);     // :508
+    if (!trial_done) {
+      x_trial = retract(x, h, args...);   // :505
+      fx_trial = f(x_trial, args...);     // :508
+    }
 
     // predicted vs. actual decrease                                                 :511-521
     const Scalar dm = step_scalars_batched
@@ -318,7 +338,11 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
       }
       QM(x, grad, Hess, args...);
       retag_for_device();
-      measure_gradient();
+      if (trial_done) {  // (|grad f(x_trial)|^2 came with the trial step; no preconditioner on this path)
+        grad_norm = precon_grad_norm = sqrt(trial_grad_sqnorm);
+      } else {
+        measure_gradient();
+      }
     }
 
     // radius update: both branches scale |h|_M, not Delta                          :590-603

@@ -63,6 +63,9 @@ static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
 }
 
 static double g_last_tnt_seconds = 0.0;
+static size_t g_last_tnt_syncs = 0;
+// host<->device synchronisations the library made during the last hd_tnt_stiefel run (mi_ctx_sync_count)
+extern "C" size_t hd_last_tnt_syncs() { return g_last_tnt_syncs; }
 static double g_last_solve_seconds = 0.0;
 // wall time of the last LSQR call through this harness (device drained before and after)
 extern "C" double hd_last_solve_seconds() { return g_last_solve_seconds; }
@@ -256,6 +259,7 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
   RM::QuadraticModel<DeviceVector, DeviceVector> QM = prob.quadratic_model();
   RM::RiemannianMetric<DeviceVector, DeviceVector> metric = prob.metric();
   RM::Retraction<DeviceVector, DeviceVector> retract = prob.retraction();
+  if (mode == 2) retract = prob.plain_retraction();  // tagged model and metric, but no fused trial step
   if (mode == 1) {  // hide the tags
     auto QMt = prob.quadratic_model();
     QM = [QMt](const DeviceVector &X, DeviceVector &g, RM::LinearOperator<DeviceVector, DeviceVector> &Hs) {
@@ -265,9 +269,13 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
     };
     metric = [](const DeviceVector &, const DeviceVector &a, const DeviceVector &b) { return a.dot(b); };
   }
+  size_t s0 = 0, s1 = 0;
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s0));
   RM::TNTResult<DeviceVector, double> r =
       RM::TNT<DeviceVector, DeviceVector>(f, QM, metric, retract, x0,
                                           std::optional<RM::LinearOperator<DeviceVector, DeviceVector>>(), tp, uf);
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s1));
+  g_last_tnt_syncs = s1 - s0;
   export_result(r, accepted, res);
   HD_GUARD_END
 }

@@ -420,3 +420,36 @@ def test_spmm_packed_matrix_ragged_vs_plain_and_oracle(oracle, monkeypatch, n, p
     assert np.array_equal(out["packed"], out["plain"])
     assert np.array_equal(out["packed"], out["straight"])
     assert np.array_equal(out["packed"], Wo)  # same per-row order, products and sums rounded separately
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_fused_trial_step_has_the_bits_of_the_separate_calls(ctx, p):
+    """mi_stiefel_rq_trial (reference Riemannian/TNT.h:493-512,573-585 as one launch chain, one read-back) against
+    the separate calls it replaces -- dot products, retraction, objective, model at the trial point: bit for bit."""
+    nx, ny, nz = 20, 17, 13
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    X = ctx.upload(wl.random_stiefel(n, p, seed=3))
+    g, H = prob.model(X)
+    h = ctx.stiefel_project(n, p, X, ctx.upload(np.random.default_rng(4).normal(size=(n, p)) * 1e-2))
+    # separate calls
+    Hh = H.apply(h)
+    hh, gh, hHh = ctx.dot_batch([h, g, h], [h, h, Hh])
+    Xt_ref = ctx.stiefel_retract(n, p, X, h)
+    f_ref = prob.objective(Xt_ref)
+    # fused
+    Xt, t = prob.trial(X, h, g)
+    assert np.array_equal(Xt.numpy(), Xt_ref.numpy())
+    assert (t["f"], t["hh"], t["gh"], t["hHh"]) == (f_ref, hh, gh, hHh)
+    g2, H2 = prob.model(Xt)          # takes A X+, S+ and the gradient from the trial call
+    prob2 = ctx.stiefel_rq(A, n, p)
+    g2_ref, H2_ref = prob2.model(Xt_ref)
+    assert np.array_equal(g2.numpy(), g2_ref.numpy())
+    assert t["grad_sqnorm"] == g2_ref.dot(g2_ref)
+    v = ctx.upload(np.random.default_rng(5).normal(size=(n, p)))
+    assert np.array_equal(H2.apply(v).numpy(), H2_ref.apply(v).numpy())
+    r1 = ctx.stpcg(g2, H2, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
+    r2 = ctx.stpcg(g2_ref, H2_ref, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
+    assert np.array_equal(r1["s"].numpy(), r2["s"].numpy())

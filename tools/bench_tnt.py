@@ -16,15 +16,18 @@ X0, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=float(sys.argv[1]) if len(sy
 hz = harness_py.DeviceHarness()
 O = op.Oracle()   # only for the default parameter struct (TNTParams defaults, TNT.h:76-128)
 hz.L.hd_last_tnt_seconds.restype = ctypes.c_double
+hz.L.hd_last_tnt_syncs.restype = ctypes.c_size_t
 out = {}
-for tag, kw in (("warmup", dict(max_iterations=2)), ("run", dict(max_iterations=12))):
+for tag, kw, mode in (("warmup", dict(max_iterations=2), 0), ("run", dict(max_iterations=12), 0),
+                      ("run_without_fused_trial_step", dict(max_iterations=12), 2)):
     prm = O.default_params(max_TPCG_iterations=50, gradient_tolerance=1e-12, relative_decrease_tolerance=0.0,
                            stepsize_tolerance=0.0, preconditioned_gradient_tolerance=0.0, **kw)
-    r = hz.tnt_stiefel(n, p, rowptr, col, val, X0, prm)
+    r = hz.tnt_stiefel(n, p, rowptr, col, val, X0, prm, mode)
     secs = hz.L.hd_last_tnt_seconds()
     inner = int(np.sum(r["inner_iterations"]))
     out[tag] = {"seconds": secs, "outer": int(r["outer_iterations"]), "inner_total": inner,
                 "ms_per_outer": 1e3 * secs / max(1, int(r["outer_iterations"])),
                 "us_per_inner_if_all_time_were_inner": 1e6 * secs / max(1, inner), "f": float(r["f"]),
-                "status": int(r["status"])}
+                "status": int(r["status"]), "host_syncs": int(hz.L.hd_last_tnt_syncs()),
+                "host_syncs_per_outer": hz.L.hd_last_tnt_syncs() / max(1, int(r["outer_iterations"]))}
 print(json.dumps(out))
