@@ -261,6 +261,12 @@ MI_API int mi_stiefel_rq_model(mi_stiefel_rq *prob, const mi_vec *X, mi_vec *gra
  * has the bits the separate calls would produce. */
 MI_API int mi_stiefel_rq_trial(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *h, const mi_vec *g,
                                mi_vec *X_trial, double out[5]);
+/* One Armijo trial of a backtracking line search along -g (Riemannian/GradientDescent.h:266-286: h = -t g, x_trial =
+ * retract(x, h), f(x_trial)) plus, speculatively, the gradient at the trial point and its squared norm (:325-327):
+ * one launch chain, ONE read-back (sync).  out[2] = {f(X+), |grad f(X+)|^2}; h_out receives -t g.  A following
+ * mi_stiefel_rq_model(prob, X_trial, ...) reuses what was computed. */
+MI_API int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *g, double t, mi_vec *h_out,
+                                      mi_vec *X_trial, double out[2]);
 /* row-scaling (Jacobi) preconditioner projected to the tangent space: v = P_X(dinv_rows .* r) */
 MI_API int mi_stiefel_rq_precon(mi_stiefel_rq *prob, const mi_vec *X, const mi_vec *dinv_rows,
                                 mi_precon **out);

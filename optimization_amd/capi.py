@@ -143,6 +143,7 @@ def load():
         "mi_stiefel_rq_objective": [vp, vp, c_double_p],
         "mi_stiefel_rq_model": [vp, vp, vp, C.POINTER(vp)],
         "mi_stiefel_rq_trial": [vp, vp, vp, vp, vp, c_double_p],
+        "mi_stiefel_rq_armijo_trial": [vp, vp, vp, C.c_double, vp, vp, c_double_p],
         "mi_stiefel_rq_precon": [vp, vp, vp, C.POINTER(vp)],
         "mi_so3n_create": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, c_double_p,
                            C.POINTER(vp)],

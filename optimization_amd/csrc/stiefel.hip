@@ -921,6 +921,50 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
   return MI_OK;
 }
 
+// One Armijo trial of a backtracking line search along -g (reference Riemannian/GradientDescent.h:266-286:
+// h = -t g; x_trial = retract(x, h); f(x_trial)) plus, speculatively, the gradient at the trial point and its squared
+// norm (:325-327, used if the trial is accepted): one launch chain, one read-back.  Same kernels and summation
+// orders as the separate calls.  out[0] = f(X+), out[1] = |grad f(X+)|^2.
+int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *g, double t, mi_vec *h_out,
+                               mi_vec *X_trial, double out[2]) {
+  MI_REQUIRE(q && X && g && h_out && X_trial && out, "null argument");
+  MI_TRY(check_np(q->ctx, q->n, q->p, X, g, h_out));
+  MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
+  mi_ctx *ctx = q->ctx;
+  const size_t N = q->n * (size_t)q->p;
+  if (!q->Y_next) {
+    MI_TRY(mi_vec_create(ctx, N, &q->Y_next));
+    MI_TRY(mi_vec_create(ctx, N, &q->grad_next));
+    MI_TRY(mi_vec_create(ctx, N, &q->Hh));
+    MI_HIP(hipMalloc((void **)&q->S_next, 16 * sizeof(double)));
+  }
+  q->trial_X = nullptr;
+  MI_TRY(mi_vec_scale_to(h_out, -t, g));  // h = -t * g (:276)
+  MI_TRY(mi_stiefel_retract(ctx, q->n, q->p, X, h_out, X_trial));
+  int count = 0;
+  MI_TRY(launch_spmm_gram(ctx, q->A, q->p, nullptr, X_trial->d, X_trial->d, nullptr, q->Y_next->d, &count));
+  const int ns = nsym(q->p);
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, count, ns, ctx->scalars + SLOT_GRAM));
+  MI_TRY(launch_finish(ctx, q->n, q->p, nullptr, X_trial->d, q->Y_next->d, nullptr, count, q->S_next,
+                       q->grad_next->d, false, nullptr));
+  {
+    const double *xs[1] = {q->grad_next->d}, *ys[1] = {q->grad_next->d};
+    MI_TRY(dot_batch_to_slots(ctx, 1, xs, ys, N, SLOT_MISC));
+  }
+  double buf[SLOT_MISC + 1 - SLOT_GRAM];
+  MI_TRY(read_slots_sync(ctx, SLOT_GRAM, SLOT_MISC + 1 - SLOT_GRAM, buf));
+  double tr = 0;
+  for (int a = 0, idx = 0; a < q->p; ++a) {
+    tr += buf[idx];
+    idx += q->p - a;
+  }
+  out[0] = .5 * tr;
+  out[1] = buf[SLOT_MISC - SLOT_GRAM];
+  q->trial_X = X_trial;
+  q->trial_d = X_trial->d;
+  return MI_OK;
+}
+
 int mi_stiefel_rq_precon(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *dinv_rows, mi_precon **out) {
   MI_REQUIRE(q && X && dinv_rows && out, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, nullptr, nullptr));

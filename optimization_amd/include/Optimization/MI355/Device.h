@@ -272,8 +272,15 @@ struct DeviceTrialRetraction {
     DeviceVector x_trial;
     double f_trial, hh, gh, hHh, grad_trial_sqnorm;
   };
+  // the same for a backtracking line search along -g (Riemannian/GradientDescent.h:266-286): h = -t g, x_trial,
+  // f(x_trial) and the squared gradient norm at x_trial, one read-back per trial
+  struct ArmijoTrial {
+    DeviceVector h, x_trial;
+    double f_trial, grad_trial_sqnorm;
+  };
   std::function<DeviceVector(const DeviceVector &, const DeviceVector &)> retract;
   std::function<Trial(const DeviceVector &x, const DeviceVector &h, const DeviceVector &grad)> trial;
+  std::function<ArmijoTrial(const DeviceVector &x, const DeviceVector &grad, double t)> armijo;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &X, const DeviceVector &V, A &...) const {
     return retract(X, V);

@@ -81,7 +81,25 @@ class StiefelRayleighQuotient {
       t.grad_trial_sqnorm = out[4];
       return t;
     };
+    r.armijo = [this](const Vector &X, const Vector &g, double t) {
+      DeviceTrialRetraction::ArmijoTrial a;
+      a.h = Vector::like(X);
+      a.x_trial = Vector::like(X);
+      double out[2];
+      check(mi_stiefel_rq_armijo_trial(prob_, X.handle(), g.handle(), t, a.h.handle(), a.x_trial.handle(), out));
+      a.f_trial = out[0];
+      a.grad_trial_sqnorm = out[1];
+      return a;
+    };
     return r;
+  }
+  // grad f(X) as a VectorField (GradientDescent's interface); after a fused trial at X it is already there
+  Riemannian::VectorField<Vector, Vector> gradient() {
+    return [this](const Vector &X) {
+      Vector grad(ctx_, n_ * (size_t)p_);
+      check(mi_stiefel_rq_model(prob_, X.handle(), grad.handle(), nullptr));
+      return grad;
+    };
   }
   // the same without the tag (one call per statement of the reference's loop)
   Riemannian::Retraction<Vector, Vector> plain_retraction() {

@@ -23,6 +23,13 @@
 #include "Optimization/Riemannian/Concepts.h"
 #include "Optimization/Util/Stopwatch.h"
 
+#if __has_include("mi355opt.h")
+#include "Optimization/MI355/Device.h"
+#define OPTIMIZATION_GD_HAVE_MI355 1
+#else
+#define OPTIMIZATION_GD_HAVE_MI355 0
+#endif
+
 namespace Optimization {
 namespace Riemannian {
 
@@ -126,12 +133,42 @@ GradientDescentResult<Variable, Scalar> GradientDescent(
     Scalar t = params.alpha / params.beta;
     ls_iters = 0;
     bool sufficient = false;
+    // Device path: a tagged retraction (MI355::DeviceTrialRetraction, Frobenius metric) evaluates a whole Armijo
+    // trial -- h = -t g, the retraction, f at the trial point and, speculatively, the gradient norm there -- as one
+    // launch chain with one read-back.
+    bool fused_trial = false;
+    Scalar trial_grad_sqnorm = 0;
+#if OPTIMIZATION_GD_HAVE_MI355
+    const MI355::DeviceTrialRetraction *armijo = nullptr;
+    if constexpr (MI355::is_device_vector<Tangent>::value && MI355::is_device_vector<Variable>::value &&
+                  sizeof...(Args) == 0) {
+      if (metric.template target<MI355::FrobeniusMetric>()) {
+        armijo = retract.template target<MI355::DeviceTrialRetraction>();
+        if (armijo && !armijo->armijo) armijo = nullptr;
+      }
+    }
+#endif
     do {
       ls_iters++;
       t *= params.beta;
-      h = -t * g;
-      x_trial = retract(x, h, args...);
-      fx_trial = f(x_trial, args...);
+#if OPTIMIZATION_GD_HAVE_MI355
+      if constexpr (MI355::is_device_vector<Tangent>::value && MI355::is_device_vector<Variable>::value &&
+                    sizeof...(Args) == 0) {
+        if (armijo) {
+          auto a = armijo->armijo(x, g, t);
+          h = std::move(a.h);
+          x_trial = std::move(a.x_trial);
+          fx_trial = a.f_trial;
+          trial_grad_sqnorm = a.grad_trial_sqnorm;
+          fused_trial = true;
+        }
+      }
+#endif
+      if (!fused_trial) {
+        h = -t * g;
+        x_trial = retract(x, h, args...);
+        fx_trial = f(x_trial, args...);
+      }
       df = fx - fx_trial;
       sufficient = (df > params.sigma * t * g_norm * g_norm);
     } while ((!sufficient) && (ls_iters < params.max_ls_iterations));
@@ -157,10 +194,17 @@ GradientDescentResult<Variable, Scalar> GradientDescent(
       std::cout << ", |h|: " << h_norm << ", df: " << df << std::endl;
     }
 
-    x = x_trial;  // :323-327
-    fx = fx_trial;
-    g = grad_f(x, args...);
-    g_norm = sqrt(metric(x, g, g, args...));
+    if (fused_trial) {  // :323-327 (x_trial keeps its device handle: the gradient callable recognises the point)
+      x = std::move(x_trial);
+      fx = fx_trial;
+      g = grad_f(x, args...);
+      g_norm = sqrt(trial_grad_sqnorm);
+    } else {
+      x = x_trial;
+      fx = fx_trial;
+      g = grad_f(x, args...);
+      g_norm = sqrt(metric(x, g, g, args...));
+    }
 
     if (relative_decrease < params.relative_decrease_tolerance) {  // :330
       result.status = GradientDescentStatus::RelativeDecrease;

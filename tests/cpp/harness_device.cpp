@@ -585,7 +585,8 @@ extern "C" double hd_lobpcg_seconds_per_iteration() {
 
 // RiemannianGradientDescentSphere (tests/GradientDescent_unit_test.cpp:76-130) on the device
 extern "C" int hd_gd_sphere(const double *x0, double *x_out, double *f_out, double *gradnorm_out,
-                            int *status_out, size_t *iterations_out) {
+                            int *status_out, size_t *iterations_out, size_t cap, double *objective_values,
+                            size_t *linesearch_iterations) {
   HD_GUARD_BEGIN
   Context ctx(0);
   SphereProblem sp(ctx);
@@ -604,6 +605,54 @@ extern "C" int hd_gd_sphere(const double *x0, double *x_out, double *f_out, doub
   *gradnorm_out = r.gradfx_norm;
   *status_out = static_cast<int>(r.status);
   *iterations_out = r.linesearch_iterations.size();
+  for (size_t i = 0; i < r.objective_values.size() && i < cap; ++i) objective_values[i] = r.objective_values[i];
+  for (size_t i = 0; i < r.linesearch_iterations.size() && i < cap; ++i)
+    linesearch_iterations[i] = r.linesearch_iterations[i];
+  HD_GUARD_END
+}
+
+// GradientDescent<DeviceVector, DeviceVector> on f(X) = 1/2 tr(X'AX) over St(n,p).
+//   mode 0: tagged retraction + Frobenius metric -> each Armijo trial is one fused launch chain with one
+//           read-back (mi_stiefel_rq_armijo_trial);  mode 1: plain retraction -> the reference's statement sequence
+// Per-iteration objective values and line-search counts (capacity cap), and the host<->device synchronisations.
+extern "C" int hd_gd_stiefel(size_t n, int p, const int32_t *rowptr, const int32_t *col, const double *val,
+                             const double *X0, size_t max_iterations, double gradient_tolerance, double alpha,
+                             double beta, double sigma, size_t max_ls_iterations, int mode, double *x_out,
+                             double *f_out, double *gradnorm_out, int *status_out, size_t *iterations_out, size_t cap,
+                             double *objective_values, size_t *linesearch_iterations, size_t *syncs_out) {
+  HD_GUARD_BEGIN
+  Context ctx(0);
+  MI355::StiefelRayleighQuotient prob(ctx, n, p, rowptr, col, val);
+  DeviceVector x0(ctx, X0, n * (size_t)p);
+  RM::GradientDescentParams<double> gp;
+  gp.max_iterations = max_iterations;
+  gp.gradient_tolerance = gradient_tolerance;
+  gp.relative_decrease_tolerance = 0;
+  gp.stepsize_tolerance = 0;
+  gp.alpha = alpha;
+  gp.beta = beta;
+  gp.sigma = sigma;
+  gp.max_ls_iterations = max_ls_iterations;
+  Objective<DeviceVector> f = prob.objective();
+  RM::VectorField<DeviceVector, DeviceVector> grad = prob.gradient();
+  RM::RiemannianMetric<DeviceVector, DeviceVector> metric = prob.metric();
+  RM::Retraction<DeviceVector, DeviceVector> retract = prob.retraction();
+  if (mode == 1) retract = prob.plain_retraction();
+  size_t s0 = 0, s1 = 0;
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s0));
+  RM::GradientDescentResult<DeviceVector, double> r =
+      RM::GradientDescent<DeviceVector, DeviceVector, double>(f, grad, metric, retract, x0, gp);
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s1));
+  *syncs_out = s1 - s0;
+  const std::vector<double> x = r.x.to_host();
+  std::memcpy(x_out, x.data(), x.size() * sizeof(double));
+  *f_out = r.f;
+  *gradnorm_out = r.gradfx_norm;
+  *status_out = static_cast<int>(r.status);
+  *iterations_out = r.linesearch_iterations.size();
+  for (size_t i = 0; i < r.objective_values.size() && i < cap; ++i) objective_values[i] = r.objective_values[i];
+  for (size_t i = 0; i < r.linesearch_iterations.size() && i < cap; ++i)
+    linesearch_iterations[i] = r.linesearch_iterations[i];
   HD_GUARD_END
 }
 

@@ -182,6 +182,34 @@ def main():
         out["block_jacobi" if pk else "plain"] = rec
         O.free(pr)
     json.dump(out, open(os.path.join(OUT, "tnt_so3n_40.json"), "w"), indent=1)
+    # --- GradientDescent (Riemannian/GradientDescent.h:196-380): iteration and line-search counts ----------
+    def gd_record(r):
+        return dict(status=int(r["status"]), iterations=int(r["iterations"]),
+                    linesearch_iterations=[int(v) for v in r["linesearch_iterations"]],
+                    objective_values=lst(r["objective_values"]), f=float(r["f"]), gradfx_norm=float(r["gradfx_norm"]),
+                    x=lst(r["x"]))
+
+    out = {}
+    # the reference's own sphere case: tests/GradientDescent_unit_test.cpp:76-130
+    pr = O.sphere((0.0, 0.0, 1.0))
+    kw = dict(max_iterations=1000000, gradient_tolerance=1e-6, relative_decrease_tolerance=0.0,
+              stepsize_tolerance=0.0)
+    r = R.gd(pr, [-0.5, -0.5, -0.707107], **kw)
+    out["sphere"] = dict(gd_record(r), x0=[-0.5, -0.5, -0.707107], params=kw)
+    O.free(pr)
+    # Stiefel Rayleigh quotient, 6x5x4 grid, p = 2 and 3
+    for pcols in (2, 3):
+        nx, ny, nz = 6, 5, 4
+        n = nx * ny * nz
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+        X0 = wl.random_stiefel(n, pcols, seed=31 + pcols)
+        pr = O.stiefel_rq(n, pcols, rowptr, col, val)
+        kw = dict(max_iterations=60, gradient_tolerance=1e-9, relative_decrease_tolerance=0.0,
+                  stepsize_tolerance=0.0, alpha=2.0, beta=.5, sigma=.5, max_ls_iterations=100)
+        r = R.gd(pr, X0.ravel(), **kw)
+        out["stiefel_p%d" % pcols] = dict(gd_record(r), grid=[nx, ny, nz], p=pcols, seed=31 + pcols, params=kw)
+        O.free(pr)
+    json.dump(out, open(os.path.join(OUT, "gd_counts.json"), "w"), indent=1)
     print("golden fixtures written to", OUT)
 
 

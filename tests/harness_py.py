@@ -34,7 +34,11 @@ class DeviceHarness:
         L.hd_tnt_sphere.restype = C.c_int
         L.hd_tnt_sphere.argtypes = [C.c_int, dp, C.POINTER(op.TntParams), C.POINTER(op.TntResult)]
         L.hd_gd_sphere.restype = C.c_int
-        L.hd_gd_sphere.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_int), sp]
+        L.hd_gd_sphere.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_int), sp, C.c_size_t, dp, sp]
+        L.hd_gd_stiefel.restype = C.c_int
+        L.hd_gd_stiefel.argtypes = [C.c_size_t, C.c_int, ip32, ip32, dp, dp, C.c_size_t, C.c_double, C.c_double,
+                                    C.c_double, C.c_double, C.c_size_t, C.c_int, dp, dp, dp, C.POINTER(C.c_int), sp,
+                                    C.c_size_t, dp, sp, sp]
 
     def err(self):
         return self.L.hd_last_error().decode()
@@ -227,10 +231,38 @@ class DeviceHarness:
         return dict(rc=rc, err=self.err() if rc else "", x=x, f=f.value, gradfx_norm=gn.value, status=st.value,
                     outer=outer.value, inner_total=inner.value)
 
-    def gd_sphere(self, x0):
+    def gd_sphere(self, x0, cap=4096):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         x = np.zeros(3)
         f, gn = C.c_double(0), C.c_double(0)
         st, it = C.c_int(-1), C.c_size_t(0)
-        rc = self.L.hd_gd_sphere(_dp(x0), _dp(x), C.byref(f), C.byref(gn), C.byref(st), C.byref(it))
-        return dict(rc=rc, x=x, f=f.value, gradfx_norm=gn.value, status=st.value, iterations=it.value)
+        fv = np.zeros(cap)
+        ls = np.zeros(cap, dtype=np.uint64)
+        rc = self.L.hd_gd_sphere(_dp(x0), _dp(x), C.byref(f), C.byref(gn), C.byref(st), C.byref(it), cap, _dp(fv),
+                                 ls.ctypes.data_as(sp))
+        k = min(it.value, cap)
+        return dict(rc=rc, err=self.err() if rc else "", x=x, f=f.value, gradfx_norm=gn.value, status=st.value,
+                    iterations=it.value, objective_values=fv[:k].copy(),
+                    linesearch_iterations=ls[:k].astype(np.int64))
+
+    def gd_stiefel(self, n, p, rowptr, col, val, X0, max_iterations, gradient_tolerance, alpha=1.0, beta=.5,
+                   sigma=.5, max_ls_iterations=100, mode=0, cap=4096):
+        """hd_gd_stiefel: GradientDescent<DeviceVector> on the Stiefel Rayleigh quotient (mode 0 fused Armijo
+        trials, mode 1 the reference's statement sequence)"""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        X0 = np.ascontiguousarray(X0, dtype=np.float64).ravel()
+        x = np.zeros(n * p)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, it, sy = C.c_int(-1), C.c_size_t(0), C.c_size_t(0)
+        fv = np.zeros(cap)
+        ls = np.zeros(cap, dtype=np.uint64)
+        rc = self.L.hd_gd_stiefel(n, p, rowptr.ctypes.data_as(ip32), col.ctypes.data_as(ip32), _dp(val), _dp(X0),
+                                  max_iterations, gradient_tolerance, alpha, beta, sigma, max_ls_iterations, mode,
+                                  _dp(x), C.byref(f), C.byref(gn), C.byref(st), C.byref(it), cap, _dp(fv),
+                                  ls.ctypes.data_as(sp), C.byref(sy))
+        k = min(it.value, cap)
+        return dict(rc=rc, err=self.err() if rc else "", x=x.reshape(n, p), f=f.value, gradfx_norm=gn.value,
+                    status=st.value, iterations=it.value, objective_values=fv[:k].copy(),
+                    linesearch_iterations=ls[:k].astype(np.int64), syncs=sy.value)

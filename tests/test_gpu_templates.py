@@ -141,13 +141,53 @@ def test_tnt_rosenbrock100_device_golden(harness, oracle, golden, key, pk, mode)
           int(np.sum(r["inner_iterations"])), "ref", int(np.sum(g["inner_iterations"])))
 
 
-def test_gd_sphere_device(harness):
-    """tests/GradientDescent_unit_test.cpp:76-130 on the device."""
-    r = harness.gd_sphere([-0.5, -0.5, -0.707107])
-    assert r["rc"] == 0
+def test_gd_sphere_device(harness, golden):
+    """tests/GradientDescent_unit_test.cpp:76-130 on the device: the same iteration and line-search counts as the
+    real reference (tests/golden/gd_counts.json)."""
+    g = golden("gd_counts.json")["sphere"]
+    r = harness.gd_sphere(g["x0"])
+    assert r["rc"] == 0, r["err"]
     assert r["status"] == 0
     assert abs(r["f"]) < 1e-4 and r["gradfx_norm"] < 1e-4
     assert np.linalg.norm(r["x"] - np.array([0, 0, 1.0])) < 1e-4
+    assert r["iterations"] == g["iterations"]
+    assert list(r["linesearch_iterations"]) == g["linesearch_iterations"]
+    # f -> 0 at the optimum: absolute comparison
+    assert np.allclose(r["objective_values"], g["objective_values"], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("key", ["stiefel_p2", "stiefel_p3"])
+def test_gd_stiefel_device_counts_vs_reference_fixture(harness, golden, key):
+    """GradientDescent<DeviceVector> on the Stiefel Rayleigh quotient: iteration count, every line-search count and
+    the objective trace of the REAL reference (tests/golden/gd_counts.json); the fused Armijo trial
+    (mi_stiefel_rq_armijo_trial, one read-back per trial) gives the same bits as the statement-by-statement loop."""
+    g = golden("gd_counts.json")[key]
+    nx, ny, nz = g["grid"]
+    p, n = g["p"], nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = wl.random_stiefel(n, p, seed=g["seed"])
+    prm = g["params"]
+    runs = {}
+    for mode in (0, 1):
+        r = harness.gd_stiefel(n, p, rowptr, col, val, X0, prm["max_iterations"], prm["gradient_tolerance"],
+                               prm["alpha"], prm["beta"], prm["sigma"], prm["max_ls_iterations"], mode)
+        assert r["rc"] == 0, r["err"]
+        assert r["status"] == g["status"]
+        assert r["iterations"] == g["iterations"]
+        assert list(r["linesearch_iterations"]) == g["linesearch_iterations"], mode
+        assert np.allclose(r["objective_values"], g["objective_values"], rtol=1e-12)
+        assert abs(r["f"] - g["f"]) <= 1e-12 * abs(g["f"])
+        assert abs(r["gradfx_norm"] - g["gradfx_norm"]) <= 1e-6 * g["gradfx_norm"]
+        runs[mode] = r
+    assert np.array_equal(runs[0]["x"], runs[1]["x"])
+    assert np.array_equal(runs[0]["objective_values"], runs[1]["objective_values"])
+    assert runs[0]["gradfx_norm"] == runs[1]["gradfx_norm"]
+    trials = int(np.sum(runs[0]["linesearch_iterations"]))
+    print(key, "trials", trials, "syncs fused", runs[0]["syncs"], "plain", runs[1]["syncs"])
+    # one read-back per Armijo trial and nothing else; the statement-by-statement loop adds the gradient norm of
+    # every iteration (and recomputes A X for the gradient, which the fused trial keeps from the objective)
+    assert runs[0]["syncs"] <= trials + 4
+    assert runs[1]["syncs"] >= runs[0]["syncs"] + g["iterations"] - 4
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused", "generic"])
