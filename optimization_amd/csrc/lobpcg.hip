@@ -523,6 +523,21 @@ __global__ __launch_bounds__(256) void k_rowscale(size_t m, size_t k, const doub
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) Y[i] = d[i % m] * X[i];
 }
 
+// Row-sharded matrices: kc <= 4 columns of a column-major panel <-> a row-major m x kc field, the layout whose halo
+// exchange and SpMM kernels exist (sparse.hip, comm.hip)
+__global__ __launch_bounds__(256) void k_cols_to_rows(size_t m, int kc, const double *__restrict__ X,
+                                                      double *__restrict__ V) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+    for (int j = 0; j < kc; ++j) V[i * kc + j] = X[i + (size_t)j * m];
+}
+__global__ __launch_bounds__(256) void k_rows_to_cols(size_t m, int kc, const double *__restrict__ V,
+                                                      double *__restrict__ Y) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+    for (int j = 0; j < kc; ++j) Y[i + (size_t)j * m] = V[i * kc + j];
+}
+
 // (the host Rayleigh-Ritz solver lives in Optimization/LinearAlgebra/DenseSymmetricEigen.h)
 int check_panel(mi_ctx *ctx, size_t m, int k, const mi_vec *P, const char *what) {
   MI_REQUIRE(P, "%s is null", what);
@@ -763,11 +778,33 @@ int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_ve
 int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   MI_REQUIRE(A && X && Y, "null argument");
   MI_REQUIRE(k >= 1 && k <= kGramMaxK, "panel width must be in [1,%d]", kGramMaxK);
-  MI_REQUIRE(A->halo_lo + A->halo_hi == 0, "column-major SpMM does not support sharded matrices yet");
   MI_TRY(check_panel(A->ctx, A->n, k, X, "X"));
   MI_TRY(check_panel(A->ctx, A->n, k, Y, "Y"));
   MI_REQUIRE(X->d != Y->d, "SpMM input and output must not alias");
   mi_ctx *ctx = A->ctx;
+  if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi > 0) {
+    // Row-sharded matrix (8(e): "LOBPCG: row-shard S"): four columns at a time through the row-major sharded
+    // product -- its halo exchange is sized for p <= 4 -- at the price of two extra passes over those columns.
+    // COLLECTIVE: every rank of the communicator makes the same call.
+    void *vin = nullptr, *vout = nullptr;
+    MI_TRY(pool_alloc(ctx, A->n * 4 * sizeof(double), &vin));
+    int st = pool_alloc(ctx, A->n * 4 * sizeof(double), &vout);
+    const int tgrid = (int)std::max<size_t>(1, std::min<size_t>((A->n + 255) / 256, 2048));
+    for (int c0 = 0; c0 < k && st == MI_OK; c0 += 4) {
+      const int kc = std::min(4, k - c0);
+      hipLaunchKernelGGL(k_cols_to_rows, dim3(tgrid), dim3(256), 0, ctx->stream, A->n, kc,
+                         (const double *)X->d + (size_t)c0 * A->n, (double *)vin);
+      st = comm_halo_exchange(ctx, A, kc, (const double *)vin);
+      if (st == MI_OK) st = csr_spmm_launch(A, kc, (const double *)vin, (double *)vout);
+      hipLaunchKernelGGL(k_rows_to_cols, dim3(tgrid), dim3(256), 0, ctx->stream, A->n, kc, (const double *)vout,
+                         Y->d + (size_t)c0 * A->n);
+    }
+    pool_free(ctx, vin);
+    if (vout) pool_free(ctx, vout);
+    MI_TRY(st);
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
   if (A->pk) {

@@ -47,10 +47,18 @@ class Context {
     check(mi_ctx_create(device, &c));
     h_ = std::shared_ptr<mi_ctx>(c, [](mi_ctx *p) { mi_ctx_destroy(p); });
   }
+  // a context made elsewhere (e.g. one that already carries a communicator, mi_comm_init): not destroyed here
+  static Context adopt(mi_ctx *c) {
+    Context r{Adopt{}};
+    r.h_ = std::shared_ptr<mi_ctx>(c, [](mi_ctx *) {});
+    return r;
+  }
   mi_ctx *get() const { return h_.get(); }
   void synchronize() const { check(mi_ctx_sync(h_.get())); }
 
  private:
+  struct Adopt {};
+  explicit Context(Adopt) {}
   std::shared_ptr<mi_ctx> h_;
 };
 

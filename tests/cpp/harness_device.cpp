@@ -575,6 +575,46 @@ extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, c
   HD_GUARD_END
 }
 
+// LOBPCG on a context and a CSR matrix made by the caller -- e.g. a rank of a communicator with its row shard of A
+// (8(e): panels row-sharded, Gram and residual norms all-reduced, Rayleigh-Ritz replicated).  m = local rows.
+// COLLECTIVE when the context carries a communicator.
+extern "C" int hd_lobpcg_on(void *ctx_handle, void *csr_handle, size_t m, size_t nx, size_t nev, const double *X0,
+                            size_t max_iters, double tau, double *Theta_out, double *X_out, size_t *num_iters,
+                            size_t *nc_out, double *resid_out) {
+  HD_GUARD_BEGIN
+  using MI355::DeviceMatrix;
+  using MI355::HostVectorD;
+  using Op = LA::SymmetricLinearOperator<DeviceMatrix>;
+  Context ctx = Context::adopt(static_cast<mi_ctx *>(ctx_handle));
+  MI355::make_current(ctx);
+  mi_ctx *c = ctx.get();
+  const mi_csr *csr = static_cast<const mi_csr *>(csr_handle);
+  Op A = [csr, c, m](const DeviceMatrix &X) {
+    DeviceMatrix Y(c, m, X.cols());
+    MI355::check(mi_csr_spmm_colmajor(csr, (int)X.cols(), X.handle(), Y.handle()));
+    return Y;
+  };
+  size_t iters = 0, nc = 0;
+  std::vector<double> resid;
+  std::optional<LA::LOBPCGUserFunction<HostVectorD, DeviceMatrix>> uf =
+      [&](size_t, const Op &, const std::optional<Op> &, const std::optional<Op> &, size_t, const HostVectorD &,
+          const DeviceMatrix &, const HostVectorD &r, size_t) {
+        resid.assign(r.data(), r.data() + r.size());
+        return false;
+      };
+  DeviceMatrix X0d(ctx, m, nx, X0);
+  std::pair<HostVectorD, DeviceMatrix> out = LA::LOBPCG<HostVectorD, DeviceMatrix>(
+      A, std::optional<Op>(), std::optional<Op>(), X0d, nev, max_iters, iters, nc, tau, uf);
+  for (size_t i = 0; i < nev; ++i) Theta_out[i] = out.first(i);
+  const std::vector<double> xh = out.second.to_host();
+  std::memcpy(X_out, xh.data(), xh.size() * sizeof(double));
+  *num_iters = iters;
+  *nc_out = nc;
+  if (resid_out)
+    for (size_t i = 0; i < resid.size() && i < nx; ++i) resid_out[i] = resid[i];
+  HD_GUARD_END
+}
+
 // mean wall time of one LOBPCG iteration of the last hd_lobpcg call, seconds (user-function to user-function,
 // first interval dropped); 0 if fewer than 3 iterations ran
 extern "C" double hd_lobpcg_seconds_per_iteration() {

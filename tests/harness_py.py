@@ -231,6 +231,22 @@ class DeviceHarness:
         return dict(rc=rc, err=self.err() if rc else "", x=x, f=f.value, gradfx_norm=gn.value, status=st.value,
                     outer=outer.value, inner_total=inner.value)
 
+    def lobpcg_on(self, ctx, csr, m, nx, nev, X0, max_iters=500, tau=1e-8):
+        """hd_lobpcg_on: LOBPCG on the caller's capi.Context / capi.Csr (a rank's shard when the context carries a
+        communicator); X0 is the local m x nx block, column-major"""
+        self.L.hd_lobpcg_on.restype = C.c_int
+        self.L.hd_lobpcg_on.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, dp, C.c_size_t,
+                                        C.c_double, dp, dp, sp, sp, dp]
+        X0 = np.asfortranarray(X0, dtype=np.float64)
+        th = np.zeros(nev)
+        X = np.zeros((m, nev), order="F")
+        it, nc = C.c_size_t(0), C.c_size_t(0)
+        res = np.zeros(nx)
+        rc = self.L.hd_lobpcg_on(ctx.h, csr.h, m, nx, nev, _dp(X0.ravel(order="F")), max_iters, tau, _dp(th),
+                                 X.ctypes.data_as(dp), C.byref(it), C.byref(nc), _dp(res))
+        return dict(rc=rc, err=self.err() if rc else "", theta=th, X=X, iterations=it.value, nconv=nc.value,
+                    residuals=res)
+
     def gd_sphere(self, x0, cap=4096):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         x = np.zeros(3)

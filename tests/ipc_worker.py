@@ -78,6 +78,35 @@ def main():
     Ynew = c.stiefel_retract(r1 - r0, p, X, rb["s"]).numpy().reshape(r1 - r0, p)
     s_loc = r["s"].numpy().reshape(r1 - r0, p)
     g_loc = g.numpy().reshape(r1 - r0, p)
+
+    # D. row-sharded LOBPCG: Gram and residual norms are local products + an all-reduce, the operator
+    #    is the sharded column-major SpMM, Rayleigh-Ritz is replicated
+    k = 6
+    m = r1 - r0
+    Sg = rng.normal(size=(n, k))
+    Tg = rng.normal(size=(n, k))
+    Sd = c.upload(np.asfortranarray(Sg[r0:r1]).ravel(order="F"))
+    Td = c.upload(np.asfortranarray(Tg[r0:r1]).ravel(order="F"))
+    G = c.lobpcg_gram(m, Sd, k, Td, k)
+    Gref = Sg.T @ Tg
+    out["gram_err"] = float(np.abs(G - Gref).max() / np.abs(Gref).max())
+    out["gram_bits"] = G.tobytes().hex()
+    th = np.linspace(.5, 2.0, k)
+    _, rn, xn = c.lobpcg_residual(m, k, Sd, Td, Sd, th)
+    rn_ref = np.linalg.norm(Sg - Tg * th[None, :], axis=0)
+    out["resid_err"] = float(np.abs(rn - rn_ref).max() / rn_ref.max())
+    out["xnorm_err"] = float(np.abs(xn - np.linalg.norm(Sg, axis=0)).max())
+    out["resid_bits"] = rn.tobytes().hex()
+    Yc = A.spmm_colmajor(k, Sd).numpy().reshape(k, m).T
+    out["spmm_colmajor_err"] = float(np.abs(Yc - (Ag @ Sg)[r0:r1]).max())
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import harness_py
+    hd = harness_py.DeviceHarness()
+    X0g = np.linalg.qr(rng.normal(size=(n, k)))[0]
+    lob = hd.lobpcg_on(c, A, m, k, 4, X0g[r0:r1], max_iters=400, tau=1e-7)
+    out.update(lobpcg_rc=lob["rc"], lobpcg_err=lob["err"], lobpcg_iters=lob["iterations"], lobpcg_nconv=lob["nconv"],
+               lobpcg_theta=[float(v) for v in lob["theta"]])
     out["ipc_error"] = c.comm_ipc_error()
 
     # reference: the same problem on one plain context (every rank computes it: the GPU is shared anyway)
@@ -97,6 +126,11 @@ def main():
                g_err=float(np.abs(g_loc - gref[r0:r1]).max() / np.abs(gref).max()),
                s_err=float(np.abs(s_loc - sref[r0:r1]).max() / np.abs(sref).max()),
                retract_err=float(np.abs(Ynew - Y1[r0:r1]).max()))
+    lob1 = hd.lobpcg_on(c1, A1, n, k, 4, X0g, max_iters=400, tau=1e-7)
+    w = np.linalg.eigvalsh(Ag.toarray())[:4]
+    out.update(lobpcg_iters_ref=lob1["iterations"], lobpcg_nconv_ref=lob1["nconv"],
+               lobpcg_theta_ref=[float(v) for v in lob1["theta"]], lobpcg_exact=[float(v) for v in w],
+               lobpcg_x_err=float(np.abs(np.abs(lob["X"]) - np.abs(lob1["X"][r0:r1])).max()))
     c1.close()
     dist.barrier()
     c.comm_finalize()

@@ -216,8 +216,17 @@ def test_peer_memory_layer_with_real_peers_on_one_gpu(world):
         assert (o["iters"], o["exit"]) == (o["iters_ref"], o["exit_ref"])
         assert (o["b_iters"], o["b_exit"]) == (o["b_iters_ref"], o["b_exit_ref"])
         assert abs(o["M"] - o["M_ref"]) <= 1e-10 * abs(o["M_ref"]) and o["same_s"]
+        # row-sharded LOBPCG pieces and the whole loop
+        assert o["gram_err"] < 1e-13 and o["resid_err"] < 1e-13 and o["xnorm_err"] < 1e-12, o
+        assert o["spmm_colmajor_err"] < 1e-13, o
+        assert o["lobpcg_rc"] == 0, o["lobpcg_err"]
+        assert o["lobpcg_nconv"] >= 4 and o["lobpcg_nconv_ref"] >= 4
+        assert abs(o["lobpcg_iters"] - o["lobpcg_iters_ref"]) <= 2, o
+        assert np.allclose(o["lobpcg_theta"], o["lobpcg_theta_ref"], rtol=0, atol=1e-9), o
+        assert np.allclose(o["lobpcg_theta"], o["lobpcg_exact"], rtol=0, atol=1e-6), o
+        assert o["lobpcg_x_err"] < 1e-4, o
     # replicated scalars are bit-identical on all ranks, and so is the number of enqueued iterations
-    for k in ("dot", "f", "M", "b_M", "iters", "hvp1", "hvp5"):
+    for k in ("dot", "f", "M", "b_M", "iters", "hvp1", "hvp5", "gram_bits", "resid_bits", "lobpcg_iters"):
         assert len({o[k] for o in outs}) == 1, (k, [o[k] for o in outs])
 
 
