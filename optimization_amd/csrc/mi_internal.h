@@ -356,6 +356,11 @@ struct mi_csr {
   uint32_t win_zero = 0;   // word of a non-entry: zero row, index of 0.0 in vtab
   uint32_t *wk = nullptr;  // device, padded + kWinHead * 64
   int32_t *wfar = nullptr; // device, (nslices + 1) * 2 * 64
+  size_t win_far_stride = 0;       // |column - row| shared by >= 80 % of the far entries, or 0
+  // workgroup -> first tile table of the window kernels (stiefel.hip window_bounds), built on first use for one
+  // workgroup budget: win_bounds_n + 1 device ints
+  mutable int *win_bounds = nullptr;
+  mutable int win_bounds_n = 0, win_bounds_for = 0;
   // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
   // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.

@@ -247,6 +247,8 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   const size_t stored = pk.size();
   std::vector<uint32_t> wk(stored + (size_t)kWinHead * 64, zw);
   std::vector<int32_t> wfar((nslices + 1) * kFarCap * 64, 0);
+  std::unordered_map<unsigned long long, size_t> far_strides;  // |column - row| of the far entries
+  size_t far_total = 0;
   for (size_t sl = 0; sl < nslices; ++sl) {
     for (int lane = 0; lane < 64; ++lane) {
       const size_t r = sl * 64 + lane;
@@ -270,6 +272,10 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
                    (uint32_t)lane;
           wfar[(sl * kFarCap + nfar) * 64 + lane] = (int32_t)c;
           ++nfar;
+          if ((size_t)c < n) {
+            ++far_strides[(unsigned long long)(d < 0 ? -d : d)];
+            ++far_total;
+          }
         }
         wk[e] = (rowidx << 8) | vi;
       }
@@ -281,6 +287,11 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   A->win_chunks = wc;
   A->win_head = head;
   A->win_zero = zw;
+  // one stride carrying most of the far entries (the plane stride of a 3-D stencil): the workgroup ranges are then
+  // cut so that this stride is a whole number of ranges (stiefel.hip window_bounds)
+  A->win_far_stride = 0;
+  for (const auto &kv : far_strides)
+    if (kv.second * 10 >= far_total * 8) A->win_far_stride = (size_t)kv.first;
   return MI_OK;
 }
 
@@ -496,6 +507,7 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->vtab);
   (void)hipFree(A->wk);
   (void)hipFree(A->wfar);
+  if (A->win_bounds) (void)hipFree(A->win_bounds);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;
   return MI_OK;

@@ -27,6 +27,8 @@ typedef __attribute__((address_space(4))) const long long ConstLL;
 __device__ __forceinline__ long long slice_bound(const long long *sp, size_t i) {
   return ((ConstLL *)sp)[i];
 }
+typedef __attribute__((address_space(4))) const int ConstInt;
+__device__ __forceinline__ int scalar_int(const int *p, size_t i) { return ((ConstInt *)p)[i]; }
 
 #ifndef MI_SPMM_CHUNK
 #define MI_SPMM_CHUNK 4  // measured on cfg2: 4 -> 33.4 us, 8 -> 34.1 us, entry-at-a-time -> 35 us
@@ -297,6 +299,7 @@ struct WinView {
   const int32_t *__restrict__ wfar;
   int wc, nc;     // window half-width in chunks; ring chunks (2 kWinWaves + 2 wc)
   uint32_t zw;    // word of a non-entry: zero row, index of 0.0
+  const int *__restrict__ bounds;  // first tile of every workgroup (+ end), or null: equal runs
 };
 
 // Tiles [t0, t1) of kWinWaves slices for this workgroup; `lds_rows` = kWinLdsRows x P doubles (ring, zero row, far slots).

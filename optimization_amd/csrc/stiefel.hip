@@ -18,7 +18,9 @@
 #include "stiefel_core.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 using namespace mi;
 
@@ -364,7 +366,11 @@ __global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, WinView Wv
   if constexpr (WIN) {
     // a contiguous run of whole TILES (16 slices) per workgroup, the same number for every workgroup but the last
     const int ntiles = (int)((A.nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + (int)nb - 1) / (int)nb;
-    const int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    if (Wv.bounds) {  // runs cut to the stride of the far entries (window_bounds)
+      t0 = scalar_int(Wv.bounds, lb);
+      t1 = scalar_int(Wv.bounds, lb + 1);
+    }
     sell_window<P, HW, HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
   } else {
     sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
@@ -632,6 +638,89 @@ int rq_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
 }
 
 // one-pass Hessian for STPCG: the direction kernel left `gram_count` partial rows of sym(Y'in - (X'in) S)
+
+// Workgroup runs of the window kernels: how many workgroups, and which tiles each takes.
+//
+// Cost of a plan with nb workgroups whose longest run has L tiles, on a chip of C CUs: the busiest CU works through
+// ceil(nb / C) runs -- a CU's tile rate is the same with 8 or 16 resident waves -- and every run costs about half a
+// tile on top (ring fill, the 2 wc chunks of V re-read around the run):  ceil(nb / C) * (L + 1/2).  Measured on
+// cfg2 (3907 tiles): 977 runs of 4 -> 28.7 us (model 18), 500 of 8 -> 27.6 us (17), 600 of 7 -> 30.9 us (22.5),
+// 400 of 10 -> 31.5 us (21).  Plans within 2 % of the best: the one with the most workgroups (St(8e6,3), memory
+// latency beyond the Infinity Cache: 1000 runs 253 us, 500 runs 261 us).
+//
+// When most far entries of the matrix share one stride D (rows; the plane stride of a 3-D stencil) the runs are
+// D / m rows long (m integer), rounded to whole tiles: a far row is some other workgroup's own row, and with runs
+// that divide D both touch it at the same moment of their runs, i.e. of the kernel -- one fetch into the XCD's L2
+// instead of two (138 -> 133 MB read per launch on cfg2, exact request-size counters).
+struct WinPlan {
+  int nb = 0;
+  double run = 0;  // tiles per run when cut by the far stride, else 0: equal runs of `per`
+  int per = 0;
+};
+WinPlan window_plan(int ntiles, int max_wgs, int num_cu, size_t far_stride) {
+  const double tile_rows = 64.0 * kWinWaves;
+  const int min_wgs = std::min(max_wgs, num_cu + num_cu / 2);  // at least 6 waves on most CUs
+  struct Cand { WinPlan p; double cost; };
+  std::vector<Cand> cands;
+  auto add = [&](WinPlan p, int longest) {
+    if (p.nb < 1 || p.nb > max_wgs) return;
+    if (p.nb < min_wgs && p.nb < ntiles) return;
+    cands.push_back({p, std::ceil(p.nb / (double)num_cu) * (longest + .5)});
+  };
+  if (far_stride)
+    for (int m = 1; far_stride / (double)m >= tile_rows; ++m) {
+      WinPlan p;
+      p.run = far_stride / (double)m / tile_rows;
+      p.nb = (int)std::ceil(ntiles / p.run - 1e-9);
+      add(p, (int)std::ceil(p.run - 1e-9));
+    }
+  if (cands.empty())
+    for (int per = 1; per <= ntiles; ++per) {
+      WinPlan p;
+      p.per = per;
+      p.nb = (ntiles + per - 1) / per;
+      add(p, per);
+    }
+  WinPlan best;
+  double best_cost = 0;
+  for (const Cand &c : cands)
+    if (!best.nb || c.cost < best_cost) { best = c.p; best_cost = c.cost; }
+  for (const Cand &c : cands)
+    if (c.cost <= 1.02 * best_cost && c.p.nb > best.nb) best = c.p;
+  return best;
+}
+
+// the plan of a matrix for a workgroup budget, cached on the matrix: grid and (if cut by the far stride) the
+// workgroup -> first tile table on the device
+int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, const int **bounds_out) {
+  *bounds_out = nullptr;
+  static const bool off = [] { const char *e = getenv("MI355OPT_NO_WIN_BOUNDS"); return e && e[0] == '1'; }();
+  if (A->win_bounds_for != wgs) {
+    A->win_bounds_for = wgs;
+    const WinPlan plan = window_plan(ntiles, wgs, ctx->num_cu, off ? 0 : A->win_far_stride);
+    if (A->win_bounds) (void)hipFree(A->win_bounds);
+    A->win_bounds = nullptr;
+    A->win_bounds_n = plan.nb;
+    std::vector<int> b;
+    for (int k = 0;; ++k) {
+      const int t = std::min(ntiles, plan.run > 0 ? (int)std::llround(k * plan.run) : k * plan.per);
+      b.push_back(t);
+      if (t >= ntiles) break;
+    }
+    if ((int)b.size() - 1 > wgs || plan.nb < 1) {  // (rounding produced one run too many: equal runs instead)
+      const int per = (ntiles + wgs - 1) / wgs;
+      b.clear();
+      for (int t = 0; t < ntiles; t += per) b.push_back(t);
+      b.push_back(ntiles);
+    }
+    A->win_bounds_n = (int)b.size() - 1;
+    MI_HIP(hipMalloc((void **)&A->win_bounds, b.size() * sizeof(int)));
+    MI_HIP(hipMemcpy(A->win_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  *grid = A->win_bounds_n;
+  *bounds_out = A->win_bounds;
+  return MI_OK;
+}
 int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
   mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
   mi_ctx *ctx = q->ctx;
@@ -649,15 +738,19 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   // the window form when the matrix qualifies (decided at creation, sparse.hip build_window); p = 4 does not fit
   static const bool no_win = [] { const char *e = getenv("MI355OPT_NO_WINDOW"); return e && e[0] == '1'; }();
   const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
-  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero};
+  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr};
 #ifdef MI_WIN_DEBUG
   if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
   const bool win = recur && wc > 0;
   if (win && !g_uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
-    const int wgs = cap * (kWaves / kWinWaves) <= kMaxRows ? cap * (kWaves / kWinWaves) : kMaxRows;
-    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + wgs - 1) / wgs;
-    grid = (ntiles + per - 1) / per;
+    static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
+    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
+    int wgs = cap * (kWaves / kWinWaves) <= kMaxRows ? cap * (kWaves / kWinWaves) : kMaxRows;
+    if (win_wgs > 0) wgs = std::min(win_wgs, kMaxRows);
+    const int *bounds = nullptr;
+    MI_TRY(window_bounds(ctx, A, wgs, ntiles, &grid, &bounds));
+    wv.bounds = bounds;
   }
   const int block = win ? kWinBlock : kBlock;
   MI_TRY(comm_halo_exchange(ctx, A, p, in->d));

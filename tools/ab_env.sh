@@ -10,7 +10,7 @@ for rep in 1 2; do
   for v in "$@"; do
     i=$((i+1))
     e="$v"; [ "$v" = "-" ] && e=""
-    env $e python bench.py --no-cpu-baseline --steps 300 --warmup 50 > $OUT/${TAG}_v${i}_r${rep}.json 2> $OUT/${TAG}_v${i}_r${rep}.err
+    env $e python bench.py --no-cpu-baseline --no-legs --steps 300 --warmup 50 > $OUT/${TAG}_v${i}_r${rep}.json 2> $OUT/${TAG}_v${i}_r${rep}.err
     python - "$OUT/${TAG}_v${i}_r${rep}.json" "$v" <<'PY'
 import json, sys
 try:
