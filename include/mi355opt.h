@@ -292,6 +292,11 @@ MI_API int mi_so3n_retract(mi_so3n *prob, const mi_vec *R, const mi_vec *xi, mi_
 /* G (ka x kb, column-major, host, sync) = S' * AS  -- LOBPCG.h:223,271-272 ; fp64 MFMA */
 MI_API int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *AS,
                           double *G_host);
+/* The same for T = [T1 (m x k1) | T2 (m x (k - k1))] held in two panels, G = S' T (k x k): the reference's S' A(S)
+ * (LOBPCG.h:267,271) with A(S) = [A(X) | A([W P])] where A(X) is the panel of the previous iteration (:281) -- the same
+ * columns, hence the same bits, one operator application fewer.  sync */
+MI_API int mi_lobpcg_gram_split(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1, const mi_vec *T1,
+                                const mi_vec *T2, double *G_host);
 /* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
 MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
                             const double *C_host, int ldc, mi_vec *Y);

@@ -158,6 +158,7 @@ def load():
                                c_double_p],
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
         "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
+        "mi_lobpcg_gram_split": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
         "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
         "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
@@ -424,6 +425,12 @@ class Context:
     def lobpcg_gram(self, m, S, ka, T, kb):
         G = np.zeros((ka, kb), order="F")
         check(self.L.mi_lobpcg_gram(self.h, m, ka, kb, S.h, T.h, _dp(G)))
+        return G
+
+    def lobpcg_gram_split(self, m, S, k, T1, k1, T2):
+        """S' [T1 | T2] with T in two panels (mi_lobpcg_gram_split)"""
+        G = np.zeros((k, k), order="F")
+        check(self.L.mi_lobpcg_gram_split(self.h, m, k, S.h, k1, T1.h, T2.h, _dp(G)))
         return G
 
     def lobpcg_update(self, m, S, ks, Cmat):

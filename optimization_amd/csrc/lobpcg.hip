@@ -227,9 +227,12 @@ constexpr bool gd_need_col(int T, bool same, int lo, int hi, int b) {  // operan
   return false;
 }
 
+// The T panel may come in two pieces (columns [0, k1) at Tm, [k1, k) at T2; T2 == null: one piece): LOBPCG's
+// AS = [AX | A(R) A(P)] without assembling it.  Same row partition, same order of contraction: same bits.
 template <int T, bool SAME, int LO, int HI>
 __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, const double *__restrict__ S,
-                                                 const double *__restrict__ Tm, size_t rowwave, size_t nrow,
+                                                 const double *__restrict__ Tm, const double *__restrict__ T2,
+                                                 int k1, size_t rowwave, size_t nrow,
                                                  double *__restrict__ out) {
   const int lane = threadIdx.x & 63;
   // columns past k are clamped to column k-1: their products land in rows/columns that are never stored
@@ -237,7 +240,14 @@ __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, 
   const double *ps[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) ps[t] = S + (size_t)std::min(16 * t + (lane & 15), k - 1) * m + lane_off;
-  const size_t dT = (size_t)(Tm - S);  // uniform: the T panel's operand addresses are ps[t] + dT
+  const double *pt[SAME ? 1 : T];  // the T panel's operand columns
+  if (!SAME) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int c = std::min(16 * t + (lane & 15), k - 1);
+      pt[t] = (T2 && c >= k1 ? T2 + (size_t)(c - k1) * m : Tm + (size_t)c * m) + lane_off;
+    }
+  }
   double4v acc[T][T];
 #pragma unroll
   for (int a = 0; a < T; ++a)
@@ -258,7 +268,7 @@ __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, 
         if (gd_need_row(T, SAME, LO, HI, t) || (SAME && gd_need_col(T, SAME, LO, HI, t)))
           va[h][t] = *reinterpret_cast<const double4l *>(ps[t] + r + 16 * h);
         if (!SAME && gd_need_col(T, SAME, LO, HI, t))
-          vb[h][t] = *reinterpret_cast<const double4l *>(ps[t] + dT + r + 16 * h);
+          vb[h][t] = *reinterpret_cast<const double4l *>(pt[SAME ? 0 : t] + r + 16 * h);
       }
   };
   auto mma = [&](const double4l(&va)[kGdH][T], const double4l(&vb)[kGdH][T]) {
@@ -311,21 +321,24 @@ __device__ __forceinline__ void gram_direct_body(size_t mfull, size_t m, int k, 
 template <int T, bool SAME>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_gram_direct(
     size_t mfull, size_t m, int k, const double *__restrict__ S, const double *__restrict__ Tm,
-    double *__restrict__ partial) {
+    const double *__restrict__ T2, int k1, double *__restrict__ partial) {
   constexpr int NT = SAME ? T * (T + 1) / 2 : T * T;
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, wave, (size_t)gridDim.x * 4, partial + wave * (size_t)k * k);
+  gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, T2, k1, wave, (size_t)gridDim.x * 4,
+                                   partial + wave * (size_t)k * k);
 }
 
 // rows [r_begin, m) (fewer than 16) of S'T as one more partial Gram: one thread per output element
 __global__ __launch_bounds__(256) void k_gram_tail(size_t m, size_t r_begin, int ka, int kb,
                                                    const double *__restrict__ S, const double *__restrict__ Tm,
+                                                   const double *__restrict__ T2, int k1,
                                                    double *__restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ka * kb) return;
   const int row = e % ka, col = e / ka;
+  const double *tc = (T2 && col >= k1) ? T2 + (size_t)(col - k1) * m : Tm + (size_t)col * m;
   double s = 0;
-  for (size_t r = r_begin; r < m; ++r) s += S[(size_t)row * m + r] * Tm[(size_t)col * m + r];
+  for (size_t r = r_begin; r < m; ++r) s += S[(size_t)row * m + r] * tc[r];
   out[e] = s;
 }
 
@@ -550,18 +563,18 @@ int check_panel(mi_ctx *ctx, size_t m, int k, const mi_vec *P, const char *what)
 
 extern "C" {
 
-int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, double *G_host) {
-  MI_REQUIRE(ctx && G_host, "null argument");
-  MI_REQUIRE(ka >= 1 && ka <= kGramMaxK && kb >= 1 && kb <= kGramMaxK, "panel widths must be in [1,%d]", kGramMaxK);
-  MI_TRY(check_panel(ctx, m, ka, S, "S"));
-  MI_TRY(check_panel(ctx, m, kb, T, "T"));
-  const bool same = (S->d == T->d) && ka == kb;
+// T = [T (k1 columns) | T2 (kb - k1 columns)] when T2 != null (square direct shapes only), else T alone
+static int gram_impl(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, const mi_vec *T2v,
+                     int k1, double *G_host) {
+  const double *T2 = T2v ? T2v->d : nullptr;
+  const bool same = !T2 && (S->d == T->d) && ka == kb;
   const bool aligned = (m % 2 == 0) && ((uintptr_t)S->d % 16 == 0) && ((uintptr_t)T->d % 16 == 0);
   const int nelem = ka * kb;
   const int kapad = (ka + 15) / 16 * 16, kbpad = (kb + 15) / 16 * 16;
   // square panels of up to 80 columns on 32-byte-aligned columns: the LDS-free one-wave-per-row-range kernel
   const bool direct = ka == kb && ka <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T->d % 32 == 0 &&
-                      m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+                      (!T2 || (uintptr_t)T2 % 32 == 0) && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+  MI_REQUIRE(!T2 || direct, "split panels need the direct Gram kernel");
   size_t nb, nwaves = 0;
   const size_t mfull = m - m % (16 * kGdH);  // rows k_gram_direct covers in whole pipeline steps
   if (direct) {  // one partial per wave + one for the leftover rows
@@ -581,10 +594,11 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
     if (mfull < m)
       hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, ka, kb,
-                         (const double *)S->d, (const double *)T->d, (double *)partial + (nb - 1) * (size_t)nelem);
+                         (const double *)S->d, (const double *)T->d, T2, k1,
+                         (double *)partial + (nb - 1) * (size_t)nelem);
 #define GD(TT, SAME, NS)                                                                                  \
   hipLaunchKernelGGL((k_gram_direct<TT, SAME>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, \
-                     mfull, m, ka, (const double *)S->d, (const double *)T->d, (double *)partial)
+                     mfull, m, ka, (const double *)S->d, (const double *)T->d, T2, k1, (double *)partial)
 #define GD_T(SAME)                   \
   switch (kapad / 16) {              \
     case 1: GD(1, SAME, 1); break;   \
@@ -644,6 +658,38 @@ int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const
   pool_free(ctx, Gdev);
   if (e != hipSuccess) return hip_fail(e, "gram read-back", __FILE__, __LINE__);
   return MI_OK;
+}
+
+int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, double *G_host) {
+  MI_REQUIRE(ctx && G_host, "null argument");
+  MI_REQUIRE(ka >= 1 && ka <= kGramMaxK && kb >= 1 && kb <= kGramMaxK, "panel widths must be in [1,%d]", kGramMaxK);
+  MI_TRY(check_panel(ctx, m, ka, S, "S"));
+  MI_TRY(check_panel(ctx, m, kb, T, "T"));
+  return gram_impl(ctx, m, ka, kb, S, T, nullptr, kb, G_host);
+}
+
+int mi_lobpcg_gram_split(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1, const mi_vec *T1, const mi_vec *T2,
+                         double *G_host) {
+  MI_REQUIRE(ctx && G_host, "null argument");
+  MI_REQUIRE(k >= 1 && k <= kGramMaxK && k1 >= 1 && k1 < k, "need 1 <= k1 < k <= %d", kGramMaxK);
+  MI_TRY(check_panel(ctx, m, k, S, "S"));
+  MI_TRY(check_panel(ctx, m, k1, T1, "T1"));
+  MI_TRY(check_panel(ctx, m, k - k1, T2, "T2"));
+  // the kernel that takes the two pieces as they lie (square panels of <= 80 columns, 32-byte aligned) ...
+  const bool direct = k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T1->d % 32 == 0 &&
+                      (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+  if (direct) return gram_impl(ctx, m, k, k, S, T1, T2, k1, G_host);
+  // ... else T = [T1 | T2] assembled once
+  mi_vec *T = nullptr;
+  MI_TRY(mi_vec_create(ctx, m * (size_t)k, &T));
+  hipError_t e = hipMemcpyAsync(T->d, T1->d, m * (size_t)k1 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(T->d + m * (size_t)k1, T2->d, m * (size_t)(k - k1) * sizeof(double), hipMemcpyDeviceToDevice,
+                       ctx->stream);
+  int st = e == hipSuccess ? gram_impl(ctx, m, k, k, S, T, nullptr, k, G_host)
+                           : hip_fail(e, "panel assembly", __FILE__, __LINE__);
+  mi_vec_destroy(T);
+  return st;
 }
 
 int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const double *C_host, int ldc,

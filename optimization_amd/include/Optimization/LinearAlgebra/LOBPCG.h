@@ -171,9 +171,16 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
     }
     const Matrix Sns = S.leftCols(ns);  // view
 
-    const Matrix AS = A(Sns);                       // :267
-    const Matrix BS = B ? (*B)(Sns) : Matrix();     // :268 (B absent: S'BS = S'S, no copy)
-    auto tc = rayleigh_ritz(gram(Sns, AS), B ? gram(Sns, BS) : gram(Sns, Sns));  // :271-275
+    // A(S) (:267) column by column is [A(X) | A([W P])], and A(X) is the AX of the previous iteration (:281; the
+    // start block's AX was rotated, :226, so the first iteration applies A to all of S): the same columns through
+    // the same operator, hence the same bits, without applying it to X twice.  The Gram kernel takes the two pieces
+    // as they lie.  (BS likewise: BX is kept, :282.)
+    const bool reuse_x = num_iters > 1 && ns > nx;
+    const Matrix Srest = reuse_x ? S.middleCols(nx, ns - nx) : Matrix();
+    const Matrix AS = reuse_x ? A(Srest) : A(Sns);  // :267
+    const Matrix BS = !B ? Matrix() : (reuse_x ? (*B)(Srest) : (*B)(Sns));  // :268 (B absent: S'BS = S'S, no copy)
+    auto tc = reuse_x ? rayleigh_ritz(gram_split(Sns, AX, AS), B ? gram_split(Sns, BX, BS) : gram(Sns, Sns))
+                      : rayleigh_ritz(gram(Sns, AS), B ? gram(Sns, BS) : gram(Sns, Sns));  // :271-275
     Theta = Vector(std::move(tc.first));
     const auto &C = tc.second;
 

@@ -188,6 +188,13 @@ inline HostMatrix gram(const DeviceMatrix &S, const DeviceMatrix &T) {
   check(mi_lobpcg_gram(S.context(), S.rows(), (int)S.cols(), (int)T.cols(), S.handle(), T.handle(), G.data()));
   return G;
 }
+// G = S' [T1 | T2] for a panel held in two pieces (S.cols() == T1.cols() + T2.cols()): same bits as gram(S, T)
+inline HostMatrix gram_split(const DeviceMatrix &S, const DeviceMatrix &T1, const DeviceMatrix &T2) {
+  HostMatrix G(S.cols(), S.cols());
+  check(mi_lobpcg_gram_split(S.context(), S.rows(), (int)S.cols(), S.handle(), (int)T1.cols(), T1.handle(),
+                             T2.handle(), G.data()));
+  return G;
+}
 // Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
 inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size_t row0, size_t kc) {
   DeviceMatrix Y(S.context(), S.rows(), kc);

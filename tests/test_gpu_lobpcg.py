@@ -38,6 +38,23 @@ def test_gram_mfma_vs_numpy(ctx, m, ka, kb):
     assert np.array_equal(ctx.lobpcg_gram(m, Sd, ka, Td, kb), G)  # deterministic
 
 
+@pytest.mark.parametrize("m,k,k1", [(1000, 24, 8), (4100, 33, 16), (100_004, 48, 24), (200_012, 72, 24),
+                                    (65_538, 72, 24), (65_536, 80, 31), (40_000, 96, 24), (1001, 10, 3)])
+def test_gram_of_a_panel_held_in_two_pieces_has_the_bits_of_the_assembled_panel(ctx, m, k, k1):
+    """mi_lobpcg_gram_split: S' [T1 | T2] (LOBPCG's A(S) = [AX | A([W P])] without assembling it) == S' T bit for
+    bit, on shapes of the direct kernel (with and without leftover rows) and of the assembling fallback."""
+    rng = np.random.default_rng(m + k)
+    S = rng.normal(size=(m, k))
+    T = rng.normal(size=(m, k)) + np.arange(k)[None, :]
+    Sd, Td = ctx.upload(S.ravel(order="F")), ctx.upload(T.ravel(order="F"))
+    T1, T2 = ctx.upload(T[:, :k1].ravel(order="F")), ctx.upload(T[:, k1:].ravel(order="F"))
+    G = ctx.lobpcg_gram(m, Sd, k, Td, k)
+    Gs = ctx.lobpcg_gram_split(m, Sd, k, T1, k1, T2)
+    assert np.array_equal(G, Gs)
+    ref = S.T @ T
+    assert np.abs(Gs - ref).max() <= 1e-12 * np.abs(ref).max() * max(1, np.sqrt(m) / 10)
+
+
 def test_gram_identity_operand(ctx):
     """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
     m, k = 64, 16

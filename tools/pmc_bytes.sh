@@ -1,7 +1,7 @@
 #!/bin/bash
 # Exact L2<->fabric bytes per launch of the bench kernels: read requests resolved by size (128/64/32 B, calibrated in
 # tools/fetch_calib.sh: sum equals the known bytes of every stream pattern) and WRITE_SIZE.  On the GPU box:
-#   bash tools/pmc_bytes.sh [outdir] [extra bench args]
+#   bash tools/pmc_bytes.sh [outdir] [extra bench args]      (PMC_CMD="python tools/x.py ..." profiles that instead)
 set -u
 REPO=$(pwd)
 OUT=$REPO/${1:-gpurun_out/pmc_bytes}
@@ -9,6 +9,7 @@ shift || true
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline --no-legs --steps 60 --warmup 10 $*"
+[ -n "${PMC_CMD:-}" ] && BENCH="$PMC_CMD"
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum --kernel-trace --output-format csv -d "$OUT/rd_a" -- $BENCH > "$OUT/rd_a.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d "$OUT/rd_b" -- $BENCH > "$OUT/rd_b.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/wr" -- $BENCH > "$OUT/wr.log" 2>&1
@@ -26,7 +27,7 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
 res = {}
 for k, d in sorted(agg.items()):
     c = {n: sum(v) / len(v) for n, v in d.items()}
-    if "TCC_EA0_RDREQ_sum" not in c or c["TCC_EA0_RDREQ_sum"] < 1000:
+    if "TCC_EA0_RDREQ_sum" not in c or c["TCC_EA0_RDREQ_sum"] + c.get("WRITE_SIZE", 0) < 1000:
         continue
     n128, n64, n32 = c.get("TCC_EA0_RDREQ_128B_sum", 0), c.get("TCC_EA0_RDREQ_64B_sum", 0), c.get("TCC_EA0_RDREQ_32B_sum", 0)
     rd = 128 * n128 + 64 * n64 + 32 * n32
