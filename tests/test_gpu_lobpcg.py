@@ -117,6 +117,23 @@ def test_lobpcg_small_eigenvalue_problem(harness):
     assert r["nc"] == 2 and np.allclose(r["Theta"], [1, 2], atol=1e-3)
 
 
+@pytest.mark.parametrize("start", ["random", "given"])
+def test_lobpcg_reference_example_known_answer(harness, start):
+    """examples/LOBPCG_example.cpp:35-60 on the device: m = 500, A = diag(LinSpaced(-250, 250)), nx = 10, nev = 5,
+    max_iters = 3 m, tau = 1e-6 -> the five smallest eigenvalues of the requested spectrum, with the template's own
+    random start (as the example runs it) and with a given one."""
+    m, nx, nev = 500, 10, 5
+    lam = np.linspace(-.5 * m, .5 * m, m)
+    X0 = None if start == "random" else np.random.default_rng(11).uniform(-1, 1, size=(m, nx))
+    r = harness.lobpcg(m, nx, nev, Adiag=lam, X0=X0, max_iters=3 * m, tau=1e-6)
+    assert r["rc"] == 0, r["err"]
+    assert r["nc"] == nev and r["num_iters"] < 3 * m
+    assert np.allclose(r["Theta"], lam[:nev], atol=1e-4)
+    X = r["X"]
+    assert np.abs(X.T @ X - np.eye(nev)).max() < 1e-6
+    assert np.abs(lam[:, None] * X - X * r["Theta"][None, :]).max() < 1e-2
+
+
 @pytest.mark.parametrize("useB,useT", [(False, False), (False, True), (True, True), (True, False)])
 def test_lobpcg_reference_diagonal_problems(harness, oracle, useB, useT):
     n, nx, nev = 1000, 10, 5

@@ -55,27 +55,22 @@ def main(tag):
         for row in csv.DictReader(f):
             stats[short(row["Name"])] = dict(calls=int(row["Calls"]), avg_us=float(row["AverageNs"]) / 1e3,
                                              pct=float(row["Percentage"]))
-    pmc = collections.defaultdict(dict)
-    for cnt, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-        acc = collections.defaultdict(list)
-        with open(find(sub, "counter_collection.csv")) as f:
-            for row in csv.DictReader(f):
-                if row["Counter_Name"] == cnt:
-                    acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
-        for k, v in acc.items():
-            pmc[k][cnt] = sum(v) / len(v)
-            pmc[k][cnt + "_launches"] = len(v)
-    kb = kernel_bytes(1_000_000, 6_940_000, 3)
+    # exact bytes between L2 and the fabric per launch: tools/pmc_bytes.sh (read requests resolved by size, WRITE_SIZE),
+    # calibrated on kernels of known byte counts (tools/fetch_calib.sh -> <tag>_fetch_calibration.json)
+    kb = kernel_bytes(1_000_000, 6_940_000, 3, True)
     traffic = {}
-    for k, v in pmc.items():
-        if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
-            continue
-        fetch_raw = v["FETCH_SIZE"] * 1024.0   # counter is in kilobytes
-        write = v["WRITE_SIZE"] * 1024.0
-        traffic[k] = {"fetch_bytes_raw": fetch_raw, "fetch_bytes_x2_gfx950": 2 * fetch_raw, "write_bytes": write,
-                      "hbm_bytes_per_launch": 2 * fetch_raw + write, "algorithmic_bytes": kb.get(k),
-                      "launches_sampled": v["FETCH_SIZE_launches"]}
+    pj = os.path.join(g, f"{tag}_pmc", "bytes.json")
+    if os.path.exists(pj):
+        for name, v in json.load(open(pj)).items():
+            k = short(name + "(")
+            traffic[k] = {"read_bytes": v["read_bytes"], "write_bytes": v["write_bytes"],
+                          "hbm_bytes_per_launch": v["total"], "l2_hit_rate": v["l2_hit"],
+                          "algorithmic_bytes": kb.get(k), "launches_sampled": v["launches"],
+                          "method": "128*TCC_EA0_RDREQ_128B + 64*TCC_EA0_RDREQ_64B + 32*TCC_EA0_RDREQ_32B + 1024*WRITE_SIZE"}
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    cj = os.path.join(g, f"{tag}_fetch_calibration.json")
+    if os.path.exists(cj):
+        shutil.copy(cj, os.path.join(out, f"{tag}_fetch_calibration.json"))
     bench = None
     bj = os.path.join(g, f"{tag}_bench.json")
     if os.path.exists(bj):
@@ -87,8 +82,8 @@ def main(tag):
     with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
         f.write(f"# {tag}: rocprofv3 summary of `python bench.py` (cfg2, Stiefel(1e6,3), 1x MI355X)\n\n")
         f.write("Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 500 "
-                "--warmup 50 --no-cpu-baseline --no-roofline`; PMC: two further runs with `--pmc FETCH_SIZE` and "
-                "`--pmc WRITE_SIZE` (100 steps).  bench.py's own per-kernel figures (HIP event pairs on the launch "
+                "--warmup 50 --no-cpu-baseline --no-roofline --no-legs`; PMC: separate runs per counter group "
+                "(`tools/pmc_bytes.sh`: read requests by size, WRITE_SIZE, L2 hit/miss).  bench.py's own per-kernel figures (HIP event pairs on the launch "
                 "stream) run 1-2 us above the profiler's kernel durations: an event pair also times the gap to "
                 "the event records.\n\n")
         if bench:
@@ -97,22 +92,24 @@ def main(tag):
                     f"on `{bench['roofline']['kernel']}`, cpu_baseline = {bench['cpu_baseline']['value']:.2f} GB/s "
                     f"({bench['cpu_baseline']['kind']}, {bench['cpu_baseline']['cores']} core, "
                     f"{bench['cpu_baseline']['cpu']}).\n\n")
-        f.write("| kernel | calls | avg us | % time | algorithmic MB/launch | algorithmic GB/s | PMC fetch MB (x2) | "
-                "PMC write MB | PMC total MB |\n|---|---|---|---|---|---|---|---|---|\n")
+        f.write("| kernel | calls | avg us | % time | algorithmic MB/launch | algorithmic GB/s | PMC read MB | "
+                "PMC write MB | PMC total MB | fabric GB/s |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["pct"]):
             ab = kb.get(k)
             t = traffic.get(k, {})
             f.write(f"| {k} | {s['calls']} | {s['avg_us']:.2f} | {s['pct']:.2f} | "
                     f"{(ab / 1e6 if ab else float('nan')):.1f} | "
                     f"{(ab / s['avg_us'] / 1e3 if ab else float('nan')):.0f} | "
-                    f"{t.get('fetch_bytes_x2_gfx950', float('nan')) / 1e6:.1f} | "
+                    f"{t.get('read_bytes', float('nan')) / 1e6:.1f} | "
                     f"{t.get('write_bytes', float('nan')) / 1e6:.1f} | "
-                    f"{t.get('hbm_bytes_per_launch', float('nan')) / 1e6:.1f} |\n")
-        f.write("\nFETCH_SIZE is doubled as the guide prescribes for gfx950 wide (16 B/lane) reads.  The one-pass "
-                "Hessian mixes 4 B/lane (packed matrix words), 8 B/lane and 24-byte row gathers, which is outside "
-                "the calibrated access width: its true fetch lies between the raw counter and the doubled figure "
-                "(algorithmic reads 103.8 MB: 31.8 MB matrix + 3 fields).  The working set (6 fields x 24 MB + "
-                "32 MB matrix) is smaller than the 256 MiB Infinity Cache.\n")
+                    f"{t.get('hbm_bytes_per_launch', float('nan')) / 1e6:.1f} | "
+                    f"{t.get('hbm_bytes_per_launch', float('nan')) / s['avg_us'] / 1e3:.0f} |\n")
+        f.write("\nPMC bytes are what crossed between the L2s and the fabric (Infinity Cache / HBM): every read request "
+                "on gfx950 is a 128-byte line (`TCC_EA0_RDREQ_128B`; the 64- and 32-byte classes stay empty), "
+                "`FETCH_SIZE` tallies it at 64 bytes; the sum over request sizes reproduces the known byte count of "
+                "16/8/4-byte-per-lane streams and 24-byte row reads to 0.1 % (`<tag>_fetch_calibration.json`), and "
+                "`WRITE_SIZE` is exact.  The cfg2 working set (6 fields x 24 MB + the matrix) is smaller than the "
+                "256 MiB Infinity Cache, so these bytes are mostly served from it, not from HBM.\n")
     for name in ("extra", "lsqr", "tnt"):
         src = os.path.join(g, f"{tag}_{name}.json")
         if os.path.exists(src) and os.path.getsize(src) > 0:
