@@ -117,7 +117,7 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
     a.x[i] = x[i < k ? i : 0];
     a.y[i] = y[i < k ? i : 0];
   }
-  const int grid = grid_for(n, 4);
+  const int grid = grid_for(ctx, n, 4);
   {
     KScope ks(ctx, MI_K_BLAS1);
     switch (k) {
@@ -206,7 +206,7 @@ int mi_vec_fill(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+  hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)nullptr, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -216,7 +216,7 @@ int mi_vec_scale(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)v->d, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -226,7 +226,7 @@ int mi_vec_scale_to(mi_vec *z, double a, const mi_vec *x) {
   MI_TRY(check_same(z, x));
   if (z->n == 0) return MI_OK;
   KScope ks(z->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
+  hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(z->ctx, z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
                      (const double *)x->d, 0.0, (const double *)nullptr, z->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -236,7 +236,7 @@ int mi_vec_div(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<3>, dim3(grid_for(v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
+  hipLaunchKernelGGL(k_axpby<3>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
                      (const double *)v->d, 0.0, (const double *)nullptr, v->d);
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -247,7 +247,7 @@ int mi_vec_axpby(mi_vec *z, double a, const mi_vec *x, double b, const mi_vec *y
   MI_TRY(check_same(z, y));
   if (z->n == 0) return MI_OK;
   KScope ks(z->ctx, MI_K_BLAS1);
-  hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
+  hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->ctx, z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
                      (const double *)x->d, b, (const double *)y->d, z->d);
   MI_HIP(hipGetLastError());
   return MI_OK;

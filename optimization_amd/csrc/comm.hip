@@ -153,14 +153,18 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
   if (!last) return;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (rank > 0 && lo_doubles)  // I am rank-1's upper neighbour: flag[1] there
+    // Both ranks of a pair that exchanges anything raise each other's flag and wait for it, also in the direction
+    // in which no rows travel (expect_* = "this pair is active", the same on both of its ranks): a rank that only
+    // sends could otherwise run exchanges ahead of the neighbour that still reads the halo buffer it would
+    // overwrite (two buffers, so two exchanges ahead) whenever no collective separates two exchanges.
+    if (rank > 0 && expect_lo)  // I am rank-1's upper neighbour: flag[1] there
       __hip_atomic_store(&reinterpret_cast<IpcMailbox *>(peers[rank - 1])->halo_flag[1], seq, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    if (rank + 1 < P && hi_doubles)
+    if (rank + 1 < P && expect_hi)
       __hip_atomic_store(&reinterpret_cast<IpcMailbox *>(peers[rank + 1])->halo_flag[0], seq, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    if (expect_lo) ipc_wait(&mine->halo_flag[0], seq, err, timeout);
-    if (expect_hi) ipc_wait(&mine->halo_flag[1], seq, err, timeout);
+    if (rank > 0 && expect_lo) ipc_wait(&mine->halo_flag[0], seq, err, timeout);
+    if (rank + 1 < P && expect_hi) ipc_wait(&mine->halo_flag[1], seq, err, timeout);
   }
 }
 
@@ -246,7 +250,8 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
                        (char *const *)c->peer_dev, ws, rk,
                        buf_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
                        buf_off,                                          // rank+1's lower halo
-                       (int)(rk > 0 && A->halo_lo > 0), (int)(rk + 1 < ws && A->halo_hi > 0), ++c->halo_seq,
+                       (int)(rk > 0 && A->halo_lo + A->send_lo > 0), (int)(rk + 1 < ws && A->halo_hi + A->send_hi > 0),
+                       ++c->halo_seq,
                        c->err_dev, c->timeout);
     MI_HIP(hipGetLastError());
     return MI_OK;
@@ -354,7 +359,7 @@ int mi_comm_init(mi_ctx *ctx, int world_size, int rank, const unsigned char uid[
   ctx->comm = c;
   ctx->world_size = world_size;
   ctx->rank = rank;
-  g_uniform_grid = world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr;
+  ctx->uniform_grid = world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr;
   // warm the communicator (first collective builds the rings) with one tiny all-reduce
   MI_HIP(hipMemsetAsync(ctx->scalars + SLOT_MISC, 0, sizeof(double), ctx->stream));
   MI_TRY(comm_allreduce(ctx, ctx->scalars + SLOT_MISC, 1));
@@ -460,7 +465,7 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
   c->ipc_enabled = on != 0;
   if (!c->ipc_enabled && c->err_host) *c->err_host = 0;  // a failed layer must not poison the RCCL path
   // slot path (peer-memory): rows never cross ranks; RCCL rows mode needs the same row count everywhere
-  g_uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr);
+  ctx->uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr);
   return MI_OK;
 }
 
@@ -488,7 +493,7 @@ int mi_comm_finalize(mi_ctx *ctx) {
   ctx->comm = nullptr;
   ctx->world_size = 1;
   ctx->rank = 0;
-  g_uniform_grid = false;
+  ctx->uniform_grid = false;
   return MI_OK;
 }
 

@@ -139,11 +139,8 @@ int mi_device_count(int *count) {
   return MI_OK;
 }
 
-int mi_ctx_create(int device, mi_ctx **out) {
-  MI_REQUIRE(out, "out is null");
-  MI_TRY(ensure_device());
-  MI_HIP(hipSetDevice(device));
-  mi_ctx *ctx = new mi_ctx();
+// everything of mi_ctx_create that can fail; the caller destroys the half-built context on error
+static int ctx_init(mi_ctx *ctx, int device) {
   ctx->device = device;
   hipDeviceProp_t prop;
   MI_HIP(hipGetDeviceProperties(&prop, device));
@@ -188,16 +185,30 @@ int mi_ctx_create(int device, mi_ctx **out) {
   { const char *e = getenv("MI355OPT_DIRGRAM_DIRECT"); ctx->dirgram_direct = e && e[0] == '1'; }
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
-  *out = ctx;
   return MI_OK;
 }
 
 int mi_comm_finalize(mi_ctx *ctx);
+int mi_ctx_destroy(mi_ctx *ctx);
+
+int mi_ctx_create(int device, mi_ctx **out) {
+  MI_REQUIRE(out, "out is null");
+  MI_TRY(ensure_device());
+  MI_HIP(hipSetDevice(device));
+  mi_ctx *ctx = new mi_ctx();
+  const int st = ctx_init(ctx, device);
+  if (st != MI_OK) {
+    (void)mi_ctx_destroy(ctx);  // tolerates the members that were never created
+    return st;
+  }
+  *out = ctx;
+  return MI_OK;
+}
 
 int mi_ctx_destroy(mi_ctx *ctx) {
   if (!ctx) return MI_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)mi_comm_finalize(ctx);
   for (auto &kv : ctx->pool_all) (void)hipFree(kv.first);
   for (int i = 0; i < MI_K_COUNT; ++i)
@@ -211,9 +222,10 @@ int mi_ctx_destroy(mi_ctx *ctx) {
   (void)hipHostFree(ctx->host_scalars);
   (void)hipHostFree(ctx->cg_host);
   (void)hipHostFree((void *)ctx->status);
-  (void)hipEventDestroy(ctx->t_start);
-  (void)hipEventDestroy(ctx->t_stop);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->t_start) (void)hipEventDestroy(ctx->t_start);
+  if (ctx->t_stop) (void)hipEventDestroy(ctx->t_stop);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  (void)hipGetLastError();
   delete ctx;
   return MI_OK;
 }

@@ -767,7 +767,7 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
   MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
   MI_HIP(hipMemcpyAsync(thdev, theta_host, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MI_HIP(hipStreamSynchronize(ctx->stream));
-  const int grid = grid_for(m, 2);
+  const int grid = grid_for(ctx, m, 2);
   // 8 columns per launch (16 reduction components); every chunk's sums land in their own 16 doubles of
   // one device buffer, read back with ONE copy + sync after the last chunk
   const int nchunks = (nx + 7) / 8;

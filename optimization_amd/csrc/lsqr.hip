@@ -416,7 +416,7 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
   const LsqrConst c{prm->lambda, std::sqrt(prm->lambda), prm->btol, prm->Atol, prm->Acond_limit, prm->Delta,
                     (unsigned long long)prm->max_iterations};
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
-  const int gx = grid_for(nx, 4), gy = grid_for(ny, 4), gmax = gx > gy ? gx : gy;
+  const int gx = grid_for(ctx, nx, 4), gy = grid_for(ctx, ny, 4), gmax = gx > gy ? gx : gy;
   double *pa = ctx->partials, *pb = ctx->partials_b, *p3 = ctx->partials2;
   size_t applies = 0;
   ctx->epoch++;

@@ -102,6 +102,7 @@ struct mi_ctx {
   hipStream_t stream = nullptr;
   char device_name[128] = {0};
   int num_cu = 256;
+  bool uniform_grid = false;  // see uniform_grid() below
   // memory pool: free lists keyed by byte size
   std::multimap<size_t, void *> pool_free;
   std::map<void *, size_t> pool_all;
@@ -152,20 +153,19 @@ int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements
 // per grid-stride step
-// Set by mi_comm_init when world_size > 1 (one process per GPU, one context per process): every
-// reduction-producing kernel then runs with exactly kMaxGrid workgroups on EVERY rank, so that all
+// mi_ctx::uniform_grid is set by mi_comm_init when world_size > 1 (one process per GPU): every
+// reduction-producing kernel of that context then runs with exactly kMaxGrid workgroups on EVERY rank, so that all
 // ranks leave the same number of partial rows and the component-major partial buffers can be
 // all-reduced row by row (comm_allreduce_rows) -- idle workgroups store zero partials.
-inline bool g_uniform_grid = false;
-inline int uniform_grid(size_t blocks) {
-  if (g_uniform_grid) return kMaxGrid;
+inline int uniform_grid(const mi_ctx *ctx, size_t blocks) {
+  if (ctx->uniform_grid) return kMaxGrid;
   if (blocks < 1) blocks = 1;
   if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
   return (int)blocks;
 }
 
-inline int grid_for(size_t n, int per_thread) {
-  if (g_uniform_grid) return kMaxGrid;
+inline int grid_for(const mi_ctx *ctx, size_t n, int per_thread) {
+  if (ctx->uniform_grid) return kMaxGrid;
   size_t blocks = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
   if (blocks < 1) blocks = 1;
   if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;

@@ -52,7 +52,7 @@ struct DiagImpl {
 };
 int op_diag_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
   mi_ctx *ctx = self->ctx;
-  const int grid = grid_for(self->n, 4);
+  const int grid = grid_for(ctx, self->n, 4);
   hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid), dim3(kBlock), 0, ctx->stream, self->n,
                      ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d, ctx->partials);
   *nparts = grid;
@@ -60,7 +60,7 @@ int op_diag_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) 
 }
 int op_diag_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
   mi_ctx *ctx = self->ctx;
-  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 4)), dim3(kBlock), 0, ctx->stream,
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(ctx, self->n, 4)), dim3(kBlock), 0, ctx->stream,
                      self->n, ((DiagImpl *)self->impl)->d, (const double *)in->d, out->d,
                      (double *)nullptr);
   return MI_OK;
@@ -112,13 +112,13 @@ __global__ __launch_bounds__(kBlock) void k_block3_apply(size_t nb, const double
 }
 
 int precon_diag_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
-  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->n, 4)), dim3(kBlock), 0, self->ctx->stream,
+  hipLaunchKernelGGL(k_diag_apply_dots, dim3(grid_for(self->ctx, self->n, 4)), dim3(kBlock), 0, self->ctx->stream,
                      self->n, self->data, (const double *)r->d, v->d, (double *)nullptr);
   return MI_OK;
 }
 int precon_block3_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
   const size_t nb = self->n / 3;
-  hipLaunchKernelGGL(k_block3_apply, dim3(grid_for(nb, 2)), dim3(kBlock), 0, self->ctx->stream, nb,
+  hipLaunchKernelGGL(k_block3_apply, dim3(grid_for(self->ctx, nb, 2)), dim3(kBlock), 0, self->ctx->stream, nb,
                      self->data, (const double *)r->d, v->d);
   return MI_OK;
 }

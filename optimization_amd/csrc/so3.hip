@@ -285,7 +285,7 @@ int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int 
   mi_so3n *q = (mi_so3n *)self->impl;
   mi_ctx *ctx = q->ctx;
   const size_t ngroups = (q->nslices + kWaves - 1) / kWaves;
-  const int grid = uniform_grid(ngroups);
+  const int grid = uniform_grid(ctx, ngroups);
   KScope ks(ctx, MI_K_BSR3_SPMV_DOTS);
   if (dots)
     hipLaunchKernelGGL(k_bsr3_spmv<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), ctx->cg_live,
@@ -424,7 +424,7 @@ int mi_so3n_objective(mi_so3n *q, const mi_vec *R, double *f) {
   MI_REQUIRE(q && R && f, "null argument");
   MI_REQUIRE(R->ctx == q->ctx && R->n == 9 * q->N, "R must hold N row-major 3x3 blocks");
   mi_ctx *ctx = q->ctx;
-  const int grid = grid_for(q->E, 1);
+  const int grid = grid_for(ctx, q->E, 1);
   hipLaunchKernelGGL(k_so3_objective, dim3(grid), dim3(kBlock), 0, ctx->stream, q->E, (const int *)q->ei,
                      (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R->d,
                      ctx->partials2);
@@ -454,7 +454,7 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
 int mi_so3n_retract(mi_so3n *q, const mi_vec *R, const mi_vec *xi, mi_vec *Y) {
   MI_REQUIRE(q && R && xi && Y, "null argument");
   MI_REQUIRE(R->n == 9 * q->N && Y->n == 9 * q->N && xi->n == 3 * q->N, "dimension mismatch");
-  hipLaunchKernelGGL(k_so3_retract, dim3(grid_for(q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
+  hipLaunchKernelGGL(k_so3_retract, dim3(grid_for(q->ctx, q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
                      (const double *)R->d, (const double *)xi->d, Y->d);
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -436,8 +436,8 @@ int csr_spmm_dots(const mi_csr *A, int p, const mi_vec *V, mi_vec *W, int *npart
   *unsupported = !(p >= 1 && p <= 4 && sell_stream_ok(A, p)) || A->n == 0;
   if (*unsupported) return MI_OK;
   MI_TRY(comm_halo_exchange(ctx, A, p, V->d));
-  int grid = uniform_grid(sell_groups(A));
-  if (!g_uniform_grid && grid > 256) grid = 256;
+  int grid = uniform_grid(ctx, sell_groups(A));
+  if (!ctx->uniform_grid && grid > 256) grid = 256;
   SellView view = sell_view(A);
   KScope ks(ctx, MI_K_SPMM);
 #define SD(PV, HL, PKV)                                                                                       \
@@ -463,11 +463,11 @@ int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, c
                         mi_vec *W, double *partials, int *nparts) {
   mi_ctx *ctx = A->ctx;
   MI_TRY(comm_halo_exchange(ctx, A, 1, V->d));
-  int grid = uniform_grid(sell_groups(A));
+  int grid = uniform_grid(ctx, sell_groups(A));
   KScope ks(ctx, MI_K_SPMM);
   static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
   if (!no_stream && sell_stream_ok(A, 1)) {
-    if (!g_uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
+    if (!ctx->uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
 #define SV(HL, PKV)                                                                                          \
   hipLaunchKernelGGL((k_spmv_sub_scaled_stream<HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, sell_view(A), \
                      (const double *)V->d, scale, mode, gate, W->d, partials)

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_st_polar(size_t n, double *__restric
     default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT; \
   }
 
-inline int row_grid(size_t n) { return grid_for(n, 2); }
+inline int row_grid(const mi_ctx *ctx, size_t n) { return grid_for(ctx, n, 2); }
 inline int nsym(int p) { return p * (p + 1) / 2; }
 
 // sharded only: partial rows -> slots -> all-reduce
@@ -540,13 +540,13 @@ int sharded_reduce(mi_ctx *ctx, int count, int k, double *slots) {
 int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, const double *V,
                      const double *X, const double *S, double *Z, int *count) {
   const size_t ngroups = sell_groups(A);
-  int grid = uniform_grid(ngroups);
+  int grid = uniform_grid(ctx, ngroups);
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
   static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
   if (!no_stream && sell_stream_ok(A, p)) {
-    if (!g_uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
+    if (!ctx->uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
 #define SG(HL, PKV)                                                                                            \
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_spmm_gram_stream<P, HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
                                    view, st, V, X, S, Z, ctx->partials2))
@@ -564,7 +564,7 @@ int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, con
 // out = Z - X sym(Gram) where the symmetrised Gram partial rows are in ctx->partials2
 int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double *X, const double *Z,
                   const double *Vin, int count, double *M_out, double *out, bool dots, int *nparts) {
-  const int grid = row_grid(n);
+  const int grid = row_grid(ctx, n);
   double *slots = ctx->scalars + SLOT_GRAM;
   // several ranks: all-reduce the Gram partial rows themselves and keep the prologue re-reduction
   // (no one-workgroup reduce kernel); the slot variant stays reachable through MI355OPT_FORCE_SLOT_PATH
@@ -729,8 +729,8 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   // one workgroup per CU and one round (the kernel needs > 64 VGPRs: a second round would only repeat the
   // prologue); the rows mode of several ranks needs the uniform 512-row partial layout instead
   static const int cap = [] { const char *e = getenv("MI355OPT_HESS_GRID"); return e ? atoi(e) : 256; }();
-  int grid = uniform_grid(sell_groups(A));
-  if (!g_uniform_grid && grid > cap) grid = cap;
+  int grid = uniform_grid(ctx, sell_groups(A));
+  if (!ctx->uniform_grid && grid > cap) grid = cap;
   double *slots = ctx->scalars + SLOT_GRAM;
   const bool recur = gram_count < 0;
   const bool sharded = slot_mode(ctx) && !recur;
@@ -743,7 +743,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
   const bool win = recur && wc > 0;
-  if (win && !g_uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
+  if (win && !ctx->uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
     static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
     int wgs = cap * (kWaves / kWinWaves) <= kMaxRows ? cap * (kWaves / kWinWaves) : kMaxRows;
@@ -799,7 +799,7 @@ int rq_precon_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
   RqPreconImpl *im = (RqPreconImpl *)self->impl;
   mi_stiefel_rq *q = im->q;
   mi_ctx *ctx = q->ctx;
-  const int grid = row_grid(q->n);
+  const int grid = row_grid(q->ctx, q->n);
   const int p = q->p;
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q->n,
                                    (const double *)im->X->d, (const double *)r->d,
@@ -824,7 +824,7 @@ __attribute__((visibility("default"))) int mi_debug_stamp_buffer(void *dev_ptr) 
 int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, double *G_host) {
   MI_TRY(check_np(ctx, n, p, X, Z, nullptr));
   MI_REQUIRE(X && Z && G_host, "null argument");
-  const int grid = row_grid(n);
+  const int grid = row_grid(ctx, n);
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
@@ -836,7 +836,7 @@ int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec 
 int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, mi_vec *out) {
   MI_TRY(check_np(ctx, n, p, X, Z, out));
   MI_REQUIRE(X && Z && out, "null argument");
-  const int grid = row_grid(n);
+  const int grid = row_grid(ctx, n);
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
@@ -846,7 +846,7 @@ int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
 int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *V, mi_vec *Y) {
   MI_TRY(check_np(ctx, n, p, X, V, Y));
   MI_REQUIRE(X && V && Y, "null argument");
-  const int grid = row_grid(n);
+  const int grid = row_grid(ctx, n);
   KScope ks(ctx, MI_K_STIEFEL_RETRACT);
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)V->d, (const double *)nullptr,

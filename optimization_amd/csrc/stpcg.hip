@@ -645,7 +645,7 @@ inline void cpu_relax() { __builtin_ia32_pause(); }
 
 namespace mi {
 int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts) {
-  const int grid = grid_for(n, 4);
+  const int grid = grid_for(ctx, n, 4);
   KScope ks(ctx, MI_K_CG_DOT3);
   hipLaunchKernelGGL(k_cg_dot3, dim3(grid), dim3(kBlock), 0, ctx->stream, n, ctx->cg_live, x, y,
                      ctx->partials);
@@ -726,7 +726,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
               (unsigned long long)prm->max_iterations};
   const CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations};
   hipStream_t st = ctx->stream;
-  const int grid = (pre == PRE_BLOCK3) ? grid_for(n / 3, 2) : grid_for(n, 4);
+  const int grid = (pre == PRE_BLOCK3) ? grid_for(ctx, n / 3, 2) : grid_for(ctx, n, 4);
   // recurrence form of the direction Gram: needs v == r (no preconditioner)
   const bool recur = dgp && pre == PRE_NONE && !ctx->dirgram_direct;
   const int gns = dgp ? dgp->p * (dgp->p + 1) / 2 : 0;
