@@ -409,6 +409,10 @@ def main():
                     "survey_8d_bytes_per_launch": a8d,
                     "achieved_survey_8d": a8d / (per[dom]["avg_us"] * 1e-6) / 1e9,
                     "avg_launch_us": per[dom]["avg_us"],
+                    # an event pair also times the gap to the event records (the launches of the timed region run
+                    # back to back): the same averages scaled so that they add up to the un-instrumented step
+                    "avg_launch_us_in_pipeline": per[dom]["avg_us"] * min(
+                        1.0, dt / args.steps * 1e6 / max(sum(per[k]["avg_us"] for k in ran), 1e-9)),
                     "kernels": per}
         barrier()
         if rank != 0:
