@@ -30,12 +30,8 @@ st = buf.numpy().view(np.uint64).reshape(NW, NS).astype(np.int64)
 st = st[st[:, 56] > 0]  # waves that ran
 t0 = st[:, 0:1]
 rel = np.where(st > 0, st - t0, -1)
-span = (st[:, NS - 1] - st[:, 0])
-gstart = st[:, 0].min()
-print(f"kernel {us:.2f} us/launch (stamped build); wave spans: median {np.median(span)} max {span.max()} cycles; "
-      f"first entry -> last exit {st[:, NS-1].max() - gstart} cycles")
-clk = (st[:, NS - 1].max() - gstart) / us1 if us1 > 0 else 0
-names = {0: "entry", 1: "ring filled + barrier", NS - 1: "exit"}
+print(f"kernel {us:.2f} us/launch (stamped build)")
+names = {0: "entry", 1: "ring filled + barrier"}
 for t in range(6):
     b = 2 + 8 * t
     names.update({b: f"tile {t} start", b + 1: f"tile {t} chunk0 matrix words in", b + 2: f"tile {t} chunk0 consumed",
@@ -47,17 +43,6 @@ print("kernel entry/exit (100 MHz): launch %.2f us; first entry -> last exit %.2
       % (us, (e1.max() - e0.min()) / 100, np.median(e1 - e0) / 100, (e1 - e0).max() / 100, np.median(e0 - e0.min()) / 100,
          np.percentile(e0 - e0.min(), 90) / 100, (e0 - e0.min()).max() / 100, (e1.max() - np.median(e1)) / 100,
          np.median(e1 - eb) / 100))
-if st[:, 0].max() == 0:
-    sys.exit(0)
-real0, real1 = st[:, NS - 3], st[:, NS - 2]
-rs = (real1 - real0)
-print("100 MHz clock: wave spans median %.2f us max %.2f us; first entry -> last exit %.2f us; entry skew median %.2f us max %.2f us"
-      % (np.median(rs) / 100, rs.max() / 100, (real1.max() - real0.min()) / 100, np.median(real0 - real0.min()) / 100,
-         (real0 - real0.min()).max() / 100))
-print("shader clock / 100 MHz clock over a wave span: median %.1f  => %.2f GHz" % (np.median(span / np.maximum(rs, 1)),
-      np.median(span / np.maximum(rs, 1)) / 10))
-print("entry skew (cycles after the first wave's entry): median %d  p90 %d  max %d" %
-      (np.median(st[:, 0] - gstart), np.percentile(st[:, 0] - gstart, 90), (st[:, 0] - gstart).max()))
 for sl in range(NS):
     v = rel[:, sl][rel[:, sl] >= 0]
     if sl == 0 or v.size == 0 or sl in (NS - 3, NS - 2, 56, 57, 58):
