@@ -350,13 +350,19 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     unsigned c[HW];
     unsigned f[kFarCap];
   };
-  auto load_head = [&](Head &h, int kk, int sl) {
+  auto load_words = [&](Head &h, int kk) {
     const char *pb = reinterpret_cast<const char *>(W.wk) + (unsigned)kk * 256u + lane4;
 #pragma unroll
     for (int j = 0; j < HW; ++j) h.c[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
+  };
+  auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
     const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
 #pragma unroll
-    for (int j = 0; j < kFarCap; ++j) h.f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+    for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+  };
+  auto load_head = [&](Head &h, int kk, int sl) {
+    load_words(h, kk);
+    load_far(h.f, sl);
   };
   auto far_row = [&](unsigned c, double (&out)[P]) {
     const char *base = reinterpret_cast<const char *>(V);
@@ -380,23 +386,48 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     b1 = (int)slice_bound(A.slice_ptr, slice + 1);
   }
   Head h;
+#ifndef MI_WIN_NO_FARAHEAD
+  // Far rows are gathered ONE TILE AHEAD: during a tile the registers gf hold this slice's far rows (gathered while
+  // the previous tile ran), h.c its words and h.f the far columns of the NEXT slice.  The entry loop then waits for
+  // no memory at all; the tile's only waits are for the staged chunk and for the X/Y rows at its end.
+  unsigned f0[kFarCap];
+  load_far(f0, have ? slice : 0);
+  load_words(h, k);
+#else
   load_head(h, k, have ? slice : 0);
+#endif
   // ring: the first tile's window, the zero row
   int slot_own;  // ring slot of the wave's own chunk (= slice % nc), advanced by 16 per tile
   {
     const int lo = t0 * NW - wc;
     int hi = t0 * NW + NW + wc;
     if (hi > nchunks) hi = nchunks;
-    for (int q = lo + w; q < hi; q += NW) {
-      if (q < 0) continue;
-      double b[P];
-      chunk_load(q, b);
-      chunk_store(q % nc, b);
+    // all of this wave's chunks requested before the first is stored: one memory round trip, not one per chunk
+    constexpr int kFill = (NW + 2 * kMaxWinChunks + NW - 1) / NW;
+    double b[kFill][P];
+#pragma unroll
+    for (int i = 0; i < kFill; ++i) {
+      const int q = lo + w + i * NW;
+      chunk_load(q >= 0 && q < hi ? q : 0, b[i]);  // (unconditional: chunk 0 when there is none)
+    }
+#pragma unroll
+    for (int i = 0; i < kFill; ++i) {
+      const int q = lo + w + i * NW;
+      if (q >= 0 && q < hi) chunk_store(q % nc, b[i]);
     }
     if (threadIdx.x < P) L[zrow * P + threadIdx.x] = 0.0;
     slot_own = (t0 * NW + w) % nc;
   }
   int slot_job = (t0 * NW + NW + wc + w) % nc;  // slot of the chunk this wave stages during the first tile
+#ifndef MI_WIN_NO_FARAHEAD
+  double gf[kFarCap][P];
+  {
+    const bool more0 = have && t0 + 1 < t1 && slice + NW < nchunks;
+    load_far(h.f, more0 ? slice + NW : (have ? slice : 0));
+#pragma unroll
+    for (int s = 0; s < kFarCap; ++s) far_row(f0[s], gf[s]);
+  }
+#endif
   lds_barrier();
   MI_STAMP(1, 0.0);
 
@@ -412,6 +443,21 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       int q0 = k, q1 = b1;  // nothing follows: the prefetch re-reads this slice
       if (more) { q0 = (int)slice_bound(A.slice_ptr, nslice); q1 = (int)slice_bound(A.slice_ptr, nslice + 1); }
       // ---- this slice's operands become LDS contents and addresses; the registers take the next slice's -------
+#ifndef MI_WIN_NO_FARAHEAD
+      unsigned wd[HW];
+#pragma unroll
+      for (int j = 0; j < HW; ++j) wd[j] = (k + j < b1) ? h.c[j] : W.zw;  // (wave-uniform condition)
+      MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
+      double gn[kFarCap][P];  // the NEXT slice's far rows (h.f: its far columns, loaded a tile ago)
+#pragma unroll
+      for (int s = 0; s < kFarCap; ++s) far_row(h.f[s], gn[s]);
+      load_words(h, q0);
+      {
+        const int nslice2 = nslice + NW;
+        const bool more2 = more && t + 2 < t1 && nslice2 < nchunks;
+        load_far(h.f, more2 ? nslice2 : (more ? nslice : slice));
+      }
+#else
       double gf[kFarCap][P];
 #pragma unroll
       for (int s = 0; s < kFarCap; ++s) far_row((dbg & 1) ? (unsigned)(slice * 64 + lane) : h.f[s], gf[s]);
@@ -420,6 +466,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       for (int j = 0; j < HW; ++j) wd[j] = (k + j < b1) ? h.c[j] : W.zw;  // (wave-uniform condition)
       MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
       if (!(dbg & 8)) load_head(h, q0, more ? nslice : slice);
+#endif
       if (!(dbg & 2)) epi.request(slice);  // the epilogue rows of THIS slice: the entries' work lies between here and their use
       // the gathers (and only they: 2 P + HW + 2 + 2 P pinned loads were issued behind them) -> far slots
 #pragma unroll
@@ -453,6 +500,12 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
         if (!(dbg & 4)) epi.end(slice, acc, vrow);
         MI_STAMP(2 + 8 * (t - t0) + 5, acc[0]);  // epilogue done, stores issued
       }
+#ifndef MI_WIN_NO_FARAHEAD
+#pragma unroll
+      for (int s = 0; s < kFarCap; ++s)
+#pragma unroll
+        for (int c = 0; c < P; ++c) gf[s][c] = gn[s][c];
+#endif
       have = more;
       slice = nslice;
       k = q0;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // ring and every entry's row is read from LDS at an address the host worked out (spmm_core.h sell_window); HW = the
 // entries per slice.  Same arithmetic, bit-identical results.
 template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW>
-__global__ __launch_bounds__(kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
+__global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
                                                           const double *__restrict__ Y,
@@ -721,6 +721,29 @@ int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, 
   *bounds_out = A->win_bounds;
   return MI_OK;
 }
+// resident workgroups per CU of the window instantiation that will run (registers + LDS), asked of the runtime once
+// per instantiation: the launch plan must fit one round
+int window_occupancy(int p, bool halo, int hw) {
+  static int cache[4][2][2] = {};
+  int &slot = cache[p][halo ? 1 : 0][hw == 7 ? 0 : 1];
+  if (slot == 0) {
+    int nb = 0;
+    hipError_t e = hipErrorUnknown;
+#define OCC(PV, HL, HWV)                                                                                  \
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_st_hess_fused<PV, false, HL, true, true, HWV>,  \
+                                                   kWinBlock, 0)
+#define OCC_P(PV)                                                \
+  if (halo) { if (hw == 7) OCC(PV, true, 7); else OCC(PV, true, 8); } \
+  else { if (hw == 7) OCC(PV, false, 7); else OCC(PV, false, 8); }
+    if (p == 1) { OCC_P(1) } else if (p == 2) { OCC_P(2) } else { OCC_P(3) }
+#undef OCC_P
+#undef OCC
+    slot = (e == hipSuccess && nb > 0) ? nb : 1;
+    (void)hipGetLastError();
+  }
+  return slot;
+}
+
 int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
   mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
   mi_ctx *ctx = q->ctx;
@@ -746,7 +769,9 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   if (win && !ctx->uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
     static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
-    int wgs = cap * (kWaves / kWinWaves) <= kMaxRows ? cap * (kWaves / kWinWaves) : kMaxRows;
+    // the workgroup budget: what is resident at once (one round), at most kMaxRows partial rows
+    const int occ = std::min(window_occupancy(p, halo, A->win_head <= 7 ? 7 : 8), kWaves / kWinWaves);
+    int wgs = std::min(cap * occ, kMaxRows);
     if (win_wgs > 0) wgs = std::min(win_wgs, kMaxRows);
     const int *bounds = nullptr;
     MI_TRY(window_bounds(ctx, A, wgs, ntiles, &grid, &bounds));
