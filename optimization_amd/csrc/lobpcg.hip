@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "mi_internal.h"
+#include "spmm_core.h"
 #include "Optimization/LinearAlgebra/DenseSymmetricEigen.h"
 
 using namespace mi;
@@ -529,6 +530,192 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslic
   }
 }
 
+// The packed product in WINDOW form (the matrix's wk / wfar arrays, sparse.hip build_window; spmm_core.h): a workgroup
+// of 4 waves takes a contiguous run of tiles; the rows of X near its own live in an LDS ring, column-major like the
+// panel (KC columns x ring rows; staging a chunk is KC coalesced 512-byte loads and conflict-free ds_write_b64), so
+// only the rows' own chunk and the two far rows of every row are loaded from global memory: 3.25 loads per output
+// element instead of 7 through the L1-miss path, which is what bounds k_spmm_colmajor_pk (317 us per 24 columns at
+// cfg5; 180 us when all seven hit L1).  Far rows are gathered one tile ahead (they are then in flight while their
+// owner stages them: one fetch into the XCD's L2) and enter the entry loop from registers, selected per lane, in
+// storage order: the same fused multiply-adds in the same order as the kernels above.
+template <int KC, int HW, int WC>
+__global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c0,
+                                                                 const double *__restrict__ X,
+                                                                 double *__restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) double ring_dyn[];  // KC x (ring rows + zero row)
+  __shared__ double vt[256];
+  constexpr int NW = kWinWaves;
+  static_assert(kWinBlock == 256 && kFarCap == 2, "table fill and far-slot decoding");
+  vt[threadIdx.x] = A.vtab[threadIdx.x];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const int nchunks = (int)A.nslices, ntiles = (nchunks + NW - 1) / NW, per = (ntiles + (int)nb - 1) / (int)nb;
+  int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  if (W.bounds) {
+    t0 = scalar_int(W.bounds, lb);
+    t1 = scalar_int(W.bounds, lb + 1);
+  }
+  if (t0 >= t1) return;
+  // (the half-width is a template parameter: the column offsets c * RR of the ring are then immediates of the LDS
+  // instructions instead of eight address additions per entry)
+  constexpr int wc = WC, nc = 2 * NW + 2 * WC, zrow = nc * 64;
+  constexpr unsigned RR = (unsigned)zrow + 1u;  // ring rows per column (+ the zero row)
+  LdsDouble *const L = (LdsDouble *)ring_dyn;
+  const size_t m = A.n;
+  const unsigned mbytes = (unsigned)(m * 8);
+  const unsigned lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
+  const double *xc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) xc[c] = X + (size_t)std::min(c0 + c, k - 1) * m;
+  auto chunk_load = [&](int q, double (&buf)[KC]) {
+    const unsigned off = (unsigned)q * 512u + lane8, offs = off < mbytes ? off : 0u;  // past the last row: any valid address
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+      buf[c] = pinned_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(xc[c]) + offs));
+  };
+  auto chunk_store = [&](int slot, const double (&buf)[KC]) {
+    LdsDouble *dst = L + (unsigned)slot * 64u + (unsigned)lane;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) dst[(unsigned)c * RR] = buf[c];
+  };
+  auto load_words = [&](unsigned (&cw)[HW], int kk) {
+    const char *pb = reinterpret_cast<const char *>(W.wk) + (unsigned)kk * 256u + lane4;
+#pragma unroll
+    for (int j = 0; j < HW; ++j) cw[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
+  };
+  auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
+    const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
+#pragma unroll
+    for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+  };
+  auto far_rows = [&](const unsigned (&f)[kFarCap], double (&g)[kFarCap][KC]) {
+#pragma unroll
+    for (int s_ = 0; s_ < kFarCap; ++s_)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) g[s_][c] = pinned_load(xc[c] + f[s_]);
+  };
+
+  int slice = t0 * NW + w;
+  bool have = slice < nchunks;
+  int kq = 0, b1 = 0;
+  if (have) {
+    kq = (int)slice_bound(A.slice_ptr, slice);
+    b1 = (int)slice_bound(A.slice_ptr, slice + 1);
+  }
+  unsigned f0[kFarCap], cw[HW], fn[kFarCap];
+  load_far(f0, have ? slice : 0);
+  load_words(cw, kq);
+  int slot_own;
+  {
+    const int lo = t0 * NW - wc;
+    int hi = t0 * NW + NW + wc;
+    if (hi > nchunks) hi = nchunks;
+    constexpr int kFill = (NW + 2 * kMaxWinChunks + NW - 1) / NW;
+    double b[kFill][KC];
+#pragma unroll
+    for (int i = 0; i < kFill; ++i) {
+      const int q = lo + w + i * NW;
+      chunk_load(q >= 0 && q < hi ? q : 0, b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kFill; ++i) {
+      const int q = lo + w + i * NW;
+      if (q >= 0 && q < hi) chunk_store(q % nc, b[i]);
+    }
+    if (threadIdx.x < KC) L[(unsigned)threadIdx.x * RR + (unsigned)zrow] = 0.0;
+    slot_own = (t0 * NW + w) % nc;
+  }
+  int slot_job = (t0 * NW + NW + wc + w) % nc;
+  double gf[kFarCap][KC];
+  {
+    const bool more0 = have && t0 + 1 < t1 && slice + NW < nchunks;
+    load_far(fn, more0 ? slice + NW : (have ? slice : 0));
+    far_rows(f0, gf);
+  }
+  lds_barrier();
+
+  for (int t = t0; t < t1; ++t) {
+    const int qj = (t + 1) * NW + wc + w;
+    const bool job = t + 1 < t1 && qj < nchunks;
+    double pre[KC];
+    chunk_load(job ? qj : 0, pre);
+    if (have) {
+      const int nslice = slice + NW;
+      const bool more = t + 1 < t1 && nslice < nchunks;
+      int q0 = kq, q1 = b1;
+      if (more) { q0 = (int)slice_bound(A.slice_ptr, nslice); q1 = (int)slice_bound(A.slice_ptr, nslice + 1); }
+      unsigned wd[HW];
+#pragma unroll
+      for (int j = 0; j < HW; ++j) wd[j] = (kq + j < b1) ? cw[j] : W.zw;
+      double gn[kFarCap][KC];
+      far_rows(fn, gn);
+      load_words(cw, q0);
+      {
+        const int nslice2 = nslice + NW;
+        const bool more2 = more && t + 2 < t1 && nslice2 < nchunks;
+        load_far(fn, more2 ? nslice2 : (more ? nslice : slice));
+      }
+      double acc[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] = 0;
+      // Entry j of a slice is nearly always of one kind for all 64 rows (a stencil's j-th neighbour): one scalar
+      // branch per entry on the ballots picks ring / first far row / second far row for the whole wave; only mixed
+      // slices (grid boundaries) pay per-lane selects.  (With selects everywhere the loop was ~950 instructions per
+      // slice and the kernel VALU-bound.)
+      const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+      for (int j = 0; j < HW; ++j) {
+        const double a = vt[wd[j] & 255u];
+        const int ri0 = (int)(wd[j] >> 8), fr = ri0 - (zrow + 1);
+        const bool isfar = fr >= 0, second = ((fr >> 6) & 1) != 0;
+        const unsigned long long mfar = __builtin_amdgcn_ballot_w64(isfar);
+        const unsigned long long msec = __builtin_amdgcn_ballot_w64(isfar && second);
+        if (mfar == 0) {
+          const LdsDouble *l = L + (unsigned)ri0;
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, l[(unsigned)c * RR], acc[c]);
+        } else if (mfar == all && msec == 0) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, gf[0][c], acc[c]);
+        } else if (mfar == all && msec == all) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, gf[1][c], acc[c]);
+        } else {
+          const LdsDouble *l = L + (isfar ? (unsigned)zrow : (unsigned)ri0);
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {
+            double v = l[(unsigned)c * RR];
+            v = isfar ? (second ? gf[1][c] : gf[0][c]) : v;
+            acc[c] = __builtin_fma(a, v, acc[c]);
+          }
+        }
+      }
+      if (job) chunk_store(slot_job, pre);
+      const size_t row = (size_t)slice * 64 + lane;
+      if (row < m) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+          if (c0 + c < k) __builtin_nontemporal_store(acc[c], Y + (size_t)(c0 + c) * m + row);
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < kFarCap; ++s_)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) gf[s_][c] = gn[s_][c];
+      have = more;
+      slice = nslice;
+      kq = q0;
+      b1 = q1;
+    } else if (job) {
+      chunk_store(slot_job, pre);
+    }
+    slot_own += NW;
+    slot_own = slot_own >= nc ? slot_own - nc : slot_own;
+    slot_job += NW;
+    slot_job = slot_job >= nc ? slot_job - nc : slot_job;
+    if (t + 1 < t1) lds_barrier();
+  }
+}
+
 // Y[r, c] = d[r] X[r, c]  (diagonal operators of the reference's LOBPCG tests, tests/LOBPCG_unit_test.cpp:56-74)
 __global__ __launch_bounds__(256) void k_rowscale(size_t m, size_t k, const double *__restrict__ d,
                                                   const double *__restrict__ X, double *__restrict__ Y) {
@@ -853,6 +1040,43 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   }
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
+  const char *no_win_env = getenv("MI355OPT_NO_SPMM_WIN");  // (read per call: the tests compare both forms in one process)
+  const bool no_win = no_win_env && no_win_env[0] == '1';
+  if (A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !no_win && !ctx->uniform_grid &&
+      A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n * 8 < ((size_t)1 << 32)) {
+    // the window form (matrices that qualify, sparse.hip build_window), 8 columns per pass: 49 KB of ring at a
+    // half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 per pass: 313 us per 24 columns, 8: 251)
+    constexpr int kSpmmWinCols = 8;
+    const int nc = 2 * kWinWaves + 2 * A->win_chunks;
+    const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
+    const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1;
+    const void *fn = nullptr;
+    if (wc1) fn = hw7 ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, 7, 1> : (const void *)k_spmm_colmajor_win<kSpmmWinCols, 8, 1>;
+    else fn = hw7 ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, 7, 2> : (const void *)k_spmm_colmajor_win<kSpmmWinCols, 8, 2>;
+    static int occ_cache[2][2] = {};
+    int &occ = occ_cache[hw7 ? 0 : 1][wc1 ? 0 : 1];
+    if (occ == 0) {
+      int nbk = 0;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fn, kWinBlock, lds);
+      occ = (e == hipSuccess && nbk > 0) ? nbk : 1;
+      (void)hipGetLastError();
+    }
+    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
+    int wgrid = 0;
+    const int *bounds = nullptr;
+    static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
+    MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
+    SellView view = sell_view(A);
+    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds};
+    const double *Xd = X->d;
+    double *Yd = Y->d;
+    for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
+      void *args[] = {&view, &wv, &k, &c0, &Xd, &Yd};
+      MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
+    }
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
   if (A->pk) {
     static const int chunk = [] { const char *e = getenv("MI355OPT_SPMM_PK_CHUNK"); return e ? atoi(e) : 24; }();
     for (int c0 = 0; c0 < k;) {

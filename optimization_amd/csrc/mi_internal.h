@@ -398,6 +398,9 @@ int comm_halo_alloc(mi_ctx *ctx, size_t bytes, double **ptr, bool *in_arena, siz
 void comm_halo_free(mi_ctx *ctx, double *ptr, bool in_arena);
 // W = A V without the halo exchange (callers that fuse do it themselves)
 int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W);
+// launch plan of the LDS-window kernels for a workgroup budget (sparse.hip): grid and, when the runs are cut by the
+// far stride, the workgroup -> first tile table on the device (cached on the matrix)
+int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, const int **bounds_out);
 }  // namespace mi
 
 // operator / preconditioner objects --------------------------------------------------------

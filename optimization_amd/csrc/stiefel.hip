@@ -639,88 +639,6 @@ int rq_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
 
 // one-pass Hessian for STPCG: the direction kernel left `gram_count` partial rows of sym(Y'in - (X'in) S)
 
-// Workgroup runs of the window kernels: how many workgroups, and which tiles each takes.
-//
-// Cost of a plan with nb workgroups whose longest run has L tiles, on a chip of C CUs: the busiest CU works through
-// ceil(nb / C) runs -- a CU's tile rate is the same with 8 or 16 resident waves -- and every run costs about half a
-// tile on top (ring fill, the 2 wc chunks of V re-read around the run):  ceil(nb / C) * (L + 1/2).  Measured on
-// cfg2 (3907 tiles): 977 runs of 4 -> 28.7 us (model 18), 500 of 8 -> 27.6 us (17), 600 of 7 -> 30.9 us (22.5),
-// 400 of 10 -> 31.5 us (21).  Plans within 2 % of the best: the one with the most workgroups (St(8e6,3), memory
-// latency beyond the Infinity Cache: 1000 runs 253 us, 500 runs 261 us).
-//
-// When most far entries of the matrix share one stride D (rows; the plane stride of a 3-D stencil) the runs are
-// D / m rows long (m integer), rounded to whole tiles: a far row is some other workgroup's own row, and with runs
-// that divide D both touch it at the same moment of their runs, i.e. of the kernel -- one fetch into the XCD's L2
-// instead of two (138 -> 133 MB read per launch on cfg2, exact request-size counters).
-struct WinPlan {
-  int nb = 0;
-  double run = 0;  // tiles per run when cut by the far stride, else 0: equal runs of `per`
-  int per = 0;
-};
-WinPlan window_plan(int ntiles, int max_wgs, int num_cu, size_t far_stride) {
-  const double tile_rows = 64.0 * kWinWaves;
-  const int min_wgs = std::min(max_wgs, num_cu + num_cu / 2);  // at least 6 waves on most CUs
-  struct Cand { WinPlan p; double cost; };
-  std::vector<Cand> cands;
-  auto add = [&](WinPlan p, int longest) {
-    if (p.nb < 1 || p.nb > max_wgs) return;
-    if (p.nb < min_wgs && p.nb < ntiles) return;
-    cands.push_back({p, std::ceil(p.nb / (double)num_cu) * (longest + .5)});
-  };
-  if (far_stride)
-    for (int m = 1; far_stride / (double)m >= tile_rows; ++m) {
-      WinPlan p;
-      p.run = far_stride / (double)m / tile_rows;
-      p.nb = (int)std::ceil(ntiles / p.run - 1e-9);
-      add(p, (int)std::ceil(p.run - 1e-9));
-    }
-  if (cands.empty())
-    for (int per = 1; per <= ntiles; ++per) {
-      WinPlan p;
-      p.per = per;
-      p.nb = (ntiles + per - 1) / per;
-      add(p, per);
-    }
-  WinPlan best;
-  double best_cost = 0;
-  for (const Cand &c : cands)
-    if (!best.nb || c.cost < best_cost) { best = c.p; best_cost = c.cost; }
-  for (const Cand &c : cands)
-    if (c.cost <= 1.02 * best_cost && c.p.nb > best.nb) best = c.p;
-  return best;
-}
-
-// the plan of a matrix for a workgroup budget, cached on the matrix: grid and (if cut by the far stride) the
-// workgroup -> first tile table on the device
-int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, const int **bounds_out) {
-  *bounds_out = nullptr;
-  static const bool off = [] { const char *e = getenv("MI355OPT_NO_WIN_BOUNDS"); return e && e[0] == '1'; }();
-  if (A->win_bounds_for != wgs) {
-    A->win_bounds_for = wgs;
-    const WinPlan plan = window_plan(ntiles, wgs, ctx->num_cu, off ? 0 : A->win_far_stride);
-    if (A->win_bounds) (void)hipFree(A->win_bounds);
-    A->win_bounds = nullptr;
-    A->win_bounds_n = plan.nb;
-    std::vector<int> b;
-    for (int k = 0;; ++k) {
-      const int t = std::min(ntiles, plan.run > 0 ? (int)std::llround(k * plan.run) : k * plan.per);
-      b.push_back(t);
-      if (t >= ntiles) break;
-    }
-    if ((int)b.size() - 1 > wgs || plan.nb < 1) {  // (rounding produced one run too many: equal runs instead)
-      const int per = (ntiles + wgs - 1) / wgs;
-      b.clear();
-      for (int t = 0; t < ntiles; t += per) b.push_back(t);
-      b.push_back(ntiles);
-    }
-    A->win_bounds_n = (int)b.size() - 1;
-    MI_HIP(hipMalloc((void **)&A->win_bounds, b.size() * sizeof(int)));
-    MI_HIP(hipMemcpy(A->win_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
-  }
-  *grid = A->win_bounds_n;
-  *bounds_out = A->win_bounds;
-  return MI_OK;
-}
 // resident workgroups per CU of the window instantiation that will run (registers + LDS), asked of the runtime once
 // per instantiation: the launch plan must fit one round
 int window_occupancy(int p, bool halo, int hw) {

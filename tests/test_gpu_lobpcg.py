@@ -55,6 +55,29 @@ def test_gram_of_a_panel_held_in_two_pieces_has_the_bits_of_the_assembled_panel(
     assert np.abs(Gs - ref).max() <= 1e-12 * np.abs(ref).max() * max(1, np.sqrt(m) / 10)
 
 
+@pytest.mark.parametrize("grid,k", [((20, 20, 20), 3), ((37, 29, 23), 5), ((50, 50, 50), 24), ((64, 64, 16), 9),
+                                    ((126, 30, 30), 24)])
+def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, monkeypatch):
+    """mi_csr_spmm_colmajor on matrices that qualify for the LDS-window form (k_spmm_colmajor_win: ring in LDS, far
+    rows from registers, per-entry wave-uniform dispatch) against the same call with MI355OPT_NO_SPMM_WIN=1
+    (k_spmm_colmajor_pk): the same fused multiply-adds in the same order, bit for bit, including the slices at the
+    grid boundaries where the entries of a slice are of mixed kinds; and against scipy."""
+    import scipy.sparse as sps
+    nx, ny, nz = grid
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    X = np.random.default_rng(n + k).normal(size=(n, k))
+    Xd = ctx.upload(np.asfortranarray(X).ravel(order="F"))
+    monkeypatch.delenv("MI355OPT_NO_SPMM_WIN", raising=False)
+    Yw = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    monkeypatch.setenv("MI355OPT_NO_SPMM_WIN", "1")
+    Yg = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    assert np.array_equal(Yw, Yg)
+    ref = sps.csr_matrix((val, col, rowptr), shape=(n, n)) @ X
+    assert np.abs(Yw - ref).max() <= 1e-14 * np.abs(ref).max()
+
+
 def test_gram_identity_operand(ctx):
     """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
     m, k = 64, 16
