@@ -382,10 +382,11 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
 template <int KC>
 __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const double *__restrict__ S,
                                                       const double *__restrict__ Ct, int c0, int kc,
-                                                      double *__restrict__ Y, int k1, double *__restrict__ Y2) {
+                                                      double *__restrict__ Y, int k1, double *__restrict__ Y2,
+                                                      size_t r_begin) {
   const double *__restrict__ smem = Ct;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
+  for (size_t r = r_begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
     double acc[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) acc[c] = 0;
@@ -423,6 +424,87 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
         else Y2[(size_t)(col - k1) * m + r] = acc[c];
       }
   }
+}
+
+// The 48-column update (X and P of one LOBPCG iteration) on the matrix pipe, operand-stationary: the transposed
+// product Y' = C' S' in 16 x 16 tiles, A operand = C' (16 output columns x 4 basis columns per step) held in
+// REGISTERS for the whole kernel (KS4 steps x 3 tiles: <= 54 doubles per lane), B operand = 16 rows x 4 basis
+// columns of S straight from global memory (four 128-byte row segments per wave load, every byte used once), the next
+// 16-row block's operands in flight during the current block's MFMAs.  Lane (i = l & 15, q = l >> 4) of the result
+// holds Y[row0 + i][16 t + q + 4 j], so a store instruction writes four 128-byte segments.  The VALU form above
+// streams the 27 KB coefficient block through the scalar cache once per 64 rows and sits at 40 % of the fp64 rate.
+// Rows are taken in whole 16-row blocks; the m % 16 leftover rows go through the VALU kernel.
+template <int KS4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_panel_update_mfma(
+    size_t nblocks, size_t m, int /*ks == 4 KS4*/, const double *__restrict__ S, const double *__restrict__ Ct, int kc,
+    double *__restrict__ Y, int k1, double *__restrict__ Y2) {
+  constexpr int NT = 3;  // 48 output columns
+  const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+  // coefficients: A operand of step kk, tile t: C[4 kk + q][16 t + i] (zero past ks; Ct is ks x 48 row-major by s)
+  double ca[KS4][NT];
+#pragma unroll
+  for (int kk = 0; kk < KS4; ++kk)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      ca[kk][t] = Ct[(size_t)(4 * kk + q) * 48 + 16 * t + i];
+    }
+  // B operand of step kk: S[row0 + i][4 kk + q] = one per-lane base + kk * (4 m doubles), a wave-uniform offset
+  // (ks == 4 KS4 exactly: other widths take the VALU kernel)
+  const double *sbase = S + (size_t)q * m + i;
+  const size_t step = 4 * m;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+  // no explicit double buffering: with it the 18-step instance needs 292 registers (one wave per SIMD); at <= 256 two
+  // waves share a SIMD and one's operand loads overlap the other's MFMA block
+  double cur[KS4];
+  for (size_t b = wave; b < nblocks; b += nwaves) {
+#pragma unroll
+    for (int kk = 0; kk < KS4; ++kk) cur[kk] = sbase[(size_t)kk * step + b * 16];
+    double4v acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KS4; ++kk)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[kk][t], cur[kk], acc[t], 0, 0, 0);
+    const size_t row = b * 16 + i;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 16 * t + q + 4 * j;
+        if (col < kc) {
+          if (col < k1) Y[(size_t)col * m + row] = acc[t][j];
+          else Y2[(size_t)(col - k1) * m + row] = acc[t][j];
+        }
+      }
+  }
+}
+
+// rows [r_begin, m) (fewer than 16) of the same product, one thread per output element (the VALU kernel above would
+// put all of them on one wave that streams the whole coefficient block: 70 us for 8 rows)
+__global__ __launch_bounds__(256) void k_panel_update_tail(size_t m, size_t r_begin, int ks, int width,
+                                                           const double *__restrict__ S, const double *__restrict__ Ct,
+                                                           int kc, double *__restrict__ Y, int k1,
+                                                           double *__restrict__ Y2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nrows = m - r_begin;
+  if (e >= nrows * (size_t)kc) return;
+  const size_t r = r_begin + e % nrows;
+  const int col = (int)(e / nrows);
+  double acc = 0;
+  int s_ = 0;
+  for (; s_ + 8 <= ks; s_ += 8) {  // eight independent loads in flight, then the products in order
+    double sv[8], cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sv[i] = S[(size_t)(s_ + i) * m + r];
+      cv[i] = Ct[(size_t)(s_ + i) * width + col];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = __builtin_fma(sv[i], cv[i], acc);
+  }
+  for (; s_ < ks; ++s_) acc = __builtin_fma(S[(size_t)s_ * m + r], Ct[(size_t)s_ * width + col], acc);
+  if (col < k1) Y[(size_t)col * m + r] = acc;
+  else Y2[(size_t)(col - k1) * m + r] = acc;
 }
 
 // columns [c0, c0 + 8): R = AX - BX theta; partial rows of |R_j|^2 (comps 0..7) and |X_j|^2 (comps 8..15)
@@ -928,7 +1010,29 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
   for (const Chunk &ch : chunks) {
 #define UPD(KC)                                                                                       \
   hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), 0, ctx->stream, m, ks, (const double *)S->d, \
-                     (const double *)Cdev + ch.off, ch.c0, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr)
+                     (const double *)Cdev + ch.off, ch.c0, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr, r_begin)
+    size_t r_begin = 0;
+    // the whole-iteration update (48 columns from <= 72) on the matrix pipe, leftover rows through the VALU kernel
+    const char *no_mfma_env = getenv("MI355OPT_NO_UPDATE_MFMA");
+    if (ch.width == 48 && ch.c0 == 0 && (ks == 48 || ks == 72) && m >= 16 &&
+        !(no_mfma_env && no_mfma_env[0] == '1')) {
+      const size_t nblocks = m / 16;
+      const int mgrid = (int)std::min<size_t>((nblocks + 3) / 4, (size_t)2 * ctx->num_cu);
+      if (ks == 48)
+        hipLaunchKernelGGL(k_panel_update_mfma<12>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, ks,
+                           (const double *)S->d, (const double *)Cdev + ch.off, kc, Y->d, k1,
+                           Y2 ? Y2->d : (double *)nullptr);
+      else
+        hipLaunchKernelGGL(k_panel_update_mfma<18>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, ks,
+                           (const double *)S->d, (const double *)Cdev + ch.off, kc, Y->d, k1,
+                           Y2 ? Y2->d : (double *)nullptr);
+      r_begin = nblocks * 16;
+      if (r_begin < m)
+        hipLaunchKernelGGL(k_panel_update_tail, dim3((unsigned)(((m - r_begin) * 48 + 255) / 256)), dim3(256), 0,
+                           ctx->stream, m, r_begin, ks, 48, (const double *)S->d, (const double *)Cdev + ch.off, kc,
+                           Y->d, k1, Y2 ? Y2->d : (double *)nullptr);
+      continue;
+    }
     switch (ch.width) {
       case 48: UPD(48); break;
       case 24: UPD(24); break;

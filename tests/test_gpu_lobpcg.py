@@ -78,6 +78,30 @@ def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, mo
     assert np.abs(Yw - ref).max() <= 1e-14 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("m,ks", [(100_008, 72), (65_536, 48), (4099, 72), (1000, 72), (40, 48), (7, 72)])
+def test_panel_update_on_the_matrix_pipe_has_the_bits_of_the_vector_kernel(ctx, m, ks, monkeypatch):
+    """The 48-column update of a LOBPCG iteration (mi_lobpcg_update, ks = 48 or 72): k_panel_update_mfma (coefficients
+    stationary in registers, fp64 MFMA) + k_panel_update_tail for the m % 16 leftover rows against the VALU kernel
+    (MI355OPT_NO_UPDATE_MFMA=1): the matrix pipe contracts its four basis columns per step in order with fused
+    multiply-adds, so the results are bit-identical; and against numpy."""
+    rng = np.random.default_rng(m + ks)
+    S = rng.normal(size=(m, ks))
+    Cm = rng.normal(size=(ks, 48))
+    Sd = ctx.upload(np.asfortranarray(S).ravel(order="F"))
+    monkeypatch.delenv("MI355OPT_NO_UPDATE_MFMA", raising=False)
+    Y1 = ctx.lobpcg_update(m, Sd, ks, Cm).numpy().reshape(48, m).T
+    monkeypatch.setenv("MI355OPT_NO_UPDATE_MFMA", "1")
+    Y0 = ctx.lobpcg_update(m, Sd, ks, Cm).numpy().reshape(48, m).T
+    assert np.array_equal(Y0, Y1)
+    ref = S @ Cm
+    assert np.abs(Y1 - ref).max() <= 1e-13 * np.abs(ref).max()
+    # two destinations (X and P of an iteration) through the same kernels
+    monkeypatch.delenv("MI355OPT_NO_UPDATE_MFMA", raising=False)
+    Ya, Yb = ctx.lobpcg_update2(m, Sd, ks, Cm, 24)
+    assert np.array_equal(Ya.numpy().reshape(24, m).T, Y1[:, :24])
+    assert np.array_equal(Yb.numpy()[:m * 24].reshape(24, m).T, Y1[:, 24:])
+
+
 def test_gram_identity_operand(ctx):
     """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
     m, k = 64, 16
