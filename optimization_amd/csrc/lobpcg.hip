@@ -361,7 +361,16 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
       const int row = e % ka, col = e / ka;
       if (row / 16 > col / 16) src = row * ka + col;
     }
-    for (int b = g; b < nblocks; b += kRedGroups) s += partial[(size_t)b * nelem + src];
+    // eight independent loads in flight, added in the same ascending order as one at a time
+    int b = g;
+    for (; b + 7 * kRedGroups < nblocks; b += 8 * kRedGroups) {
+      double t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = partial[(size_t)(b + i * kRedGroups) * nelem + src];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += t[i];
+    }
+    for (; b < nblocks; b += kRedGroups) s += partial[(size_t)b * nelem + src];
   }
   part[g][ex] = s;
   __syncthreads();

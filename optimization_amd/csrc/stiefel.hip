@@ -279,20 +279,6 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
     // end(slice, acc, vrow) consumes them
     double xn[WIN ? P : 1], yn[WIN ? P : 1];
     __device__ __forceinline__ void request(size_t slice) {
-#ifdef MI_EXP_XY_COALESCED  // timing experiment (wrong results): the same bytes as three 512-byte coalesced loads
-      {
-        const unsigned offc = (unsigned)lane * 8u;
-        const double *xc = row_of(X, slice, offc);
-#pragma unroll
-        for (int c = 0; c < P; ++c) xn[WIN ? c : 0] = pinned_load(xc + c * 64);
-        if (RECUR) {
-          const double *yc = row_of(Y, slice, offc);
-#pragma unroll
-          for (int c = 0; c < P; ++c) yn[WIN ? c : 0] = pinned_load(yc + c * 64);
-        }
-        return;
-      }
-#endif
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off);
 #pragma unroll
@@ -324,21 +310,13 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
         acc[b] -= t;  // Z = A V - V S
       }
       double o[P];
-#ifdef MI_EXP_ST_COALESCED  // timing experiment (wrong results): the output as three 512-byte coalesced stores
-      os = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (unsigned)slice * (unsigned)(64 * P * 8) +
-                                      (unsigned)lane * 8u);
-#endif
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
         o[b] = acc[b] - t;  // Z - X M
-#ifdef MI_EXP_ST_COALESCED
-        os[b * 64] = o[b];
-#else
         os[b] = o[b];
-#endif
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
       }
       if (RECUR) {  // packed sym(y o' - x (o S)'): the Gram of this output row
