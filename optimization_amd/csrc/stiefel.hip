@@ -655,7 +655,8 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
   // the window form when the matrix qualifies (decided at creation, sparse.hip build_window); p = 4 does not fit
-  static const bool no_win = [] { const char *e = getenv("MI355OPT_NO_WINDOW"); return e && e[0] == '1'; }();
+  const char *no_win_env = getenv("MI355OPT_NO_WINDOW");  // (per call: the tests compare both forms in one process)
+  const bool no_win = no_win_env && no_win_env[0] == '1';
   const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
   WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr};
 #ifdef MI_WIN_DEBUG

@@ -297,6 +297,46 @@ def _graph_laplacian(n, seed, weights):
     return L
 
 
+@pytest.mark.parametrize("grid,p", [((24, 20, 16), 3), ((40, 40, 40), 3), ((64, 48, 5), 3), ((30, 30, 30), 2),
+                                    ((33, 27, 21), 1), ((100, 10, 9), 3), ((16, 16, 130), 3)])
+def test_window_form_of_the_hessian_has_the_bits_of_the_streaming_form(monkeypatch, grid, p):
+    """The fused STPCG with the one-pass Hessian in its LDS-window form (sell_window: ring, far rows a tile ahead,
+    planned runs cut to the far stride) against the same solve with MI355OPT_NO_WINDOW=1 (sell_stream) and with
+    equal runs (MI355OPT_NO_WIN_BOUNDS=1): every output row is formed by the same products and sums in the same
+    order; only the partition of the rows into per-workgroup partial sums differs, so the replicated scalars and
+    with them the iterates agree to rounding (1e-11), the iteration counts and exit reasons exactly -- on cubes,
+    slabs thinner than a run, grids whose plane is smaller than a tile, and p = 1, 2, 3."""
+    from optimization_amd import capi
+    nx, ny, nz = grid
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=3 + p)
+    res = {}
+    for mode, env in (("window", {}), ("stream", {"MI355OPT_NO_WINDOW": "1"}),
+                      ("window-equal-runs", {"MI355OPT_NO_WIN_BOUNDS": "1"})):
+        for k in ("MI355OPT_NO_WINDOW", "MI355OPT_NO_WIN_BOUNDS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            prob = c.stiefel_rq(A, n, p)
+            g, H = prob.model(c.upload(Xb))
+            r = c.stpcg(g, H, Delta=1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0)
+            res[mode] = (r["s"].numpy().copy(), r["iterations"], r["exit_reason"], r["M_norm"])
+        finally:
+            c.close()
+    w, st, eq = res["window"], res["stream"], res["window-equal-runs"]
+    assert w[1:3] == st[1:3] == eq[1:3] and w[1] > 3
+    # the partial rows are summed per workgroup: the forms partition the rows differently, so the replicated scalars
+    # (and with them the iterates) agree to rounding, not to the bit, unless the partitions coincide
+    scale = np.abs(st[0]).max()
+    assert np.abs(w[0] - st[0]).max() <= 1e-11 * scale
+    assert np.abs(eq[0] - st[0]).max() <= 1e-11 * scale
+    assert abs(w[3] - st[3]) <= 1e-11 * abs(st[3])
+
+
 @pytest.mark.parametrize("kind", ["few-values", "signed-zero", "many-values"])
 def test_one_pass_hessian_random_graph_all_matrix_formats(oracle, monkeypatch, kind):
     """The one-pass Hessian on an unstructured matrix (ragged rows): value-indexed packed entries (few distinct
