@@ -297,6 +297,12 @@ MI_API int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S
  * columns, hence the same bits, one operator application fewer.  sync */
 MI_API int mi_lobpcg_gram_split(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1, const mi_vec *T1,
                                 const mi_vec *T2, double *G_host);
+/* Both Grams of a Rayleigh-Ritz step (LOBPCG.h:271-272: S'AS and S'BS) with ONE synchronisation: enqueued back to
+ * back, read back together.  Each right-hand panel is one panel of k columns (T?2 == NULL, k1? ignored) or two
+ * pieces [T?1 (k1? columns) | T?2].  Same kernels, same bits as the separate calls.  sync */
+MI_API int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
+                               const mi_vec *Ta2, int k1b, const mi_vec *Tb1, const mi_vec *Tb2, double *Ga_host,
+                               double *Gb_host);
 /* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
 MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
                             const double *C_host, int ldc, mi_vec *Y);

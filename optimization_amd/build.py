@@ -49,6 +49,24 @@ def _compile(src, force):
     return obj, True, r.stderr
 
 
+# Host-only sources (csrc/*.cpp): g++ with AVX2, fused multiply-adds OFF (bit-identical to a scalar build; see
+# csrc/rr_host.cpp); hipcc's host pass when there is no g++
+HOST_CXX = os.environ.get("CXX", "g++")
+HOST_CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-mavx2", "-ffp-contract=off", "-Wall",
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", os.path.join(HERE, "include")]
+
+
+def _compile_host(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    deps = glob.glob(os.path.join(HERE, "include", "Optimization", "LinearAlgebra", "*.h"))
+    if not force and not _newer(src, obj, deps):
+        return obj, False, ""
+    r = subprocess.run([HOST_CXX] + HOST_CFLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{HOST_CXX} failed on {src}:\n{r.stderr[-6000:]}")
+    return obj, True, r.stderr
+
+
 # Sources compiled as ONE translation unit = one code object: the four kernels of an STPCG iteration
 # (k_st_spmm_gram, k_st_finish, k_cg_update, k_cg_pupdate) then sit next to each other in device memory
 # instead of in separately loaded code objects at unrelated addresses.
@@ -78,6 +96,10 @@ def build(force=False, jobs=None, verbose=False):
             rebuilt |= did
             if verbose and err.strip():
                 print(err, file=sys.stderr)
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.cpp"))):
+        obj, did, err = _compile_host(src, force)
+        objs.append(obj)
+        rebuilt |= did
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, f"--offload-arch={ARCH}"] + objs + LDFLAGS + ["-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -159,6 +159,7 @@ def load():
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
         "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
         "mi_lobpcg_gram_split": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p],
+        "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
         "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
         "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
@@ -432,6 +433,13 @@ class Context:
         G = np.zeros((k, k), order="F")
         check(self.L.mi_lobpcg_gram_split(self.h, m, k, S.h, k1, T1.h, T2.h, _dp(G)))
         return G
+
+    def lobpcg_gram_pair(self, m, S, k, Ta1, k1a, Ta2, Tb1, k1b, Tb2):
+        """(S'[Ta1|Ta2], S'[Tb1|Tb2]) with one synchronisation; T?2 may be None (one panel of k columns)"""
+        Ga, Gb = np.zeros((k, k), order="F"), np.zeros((k, k), order="F")
+        check(self.L.mi_lobpcg_gram_pair(self.h, m, k, S.h, k1a, Ta1.h, Ta2.h if Ta2 is not None else None, k1b,
+                                         Tb1.h, Tb2.h if Tb2 is not None else None, _dp(Ga), _dp(Gb)))
+        return Ga, Gb
 
     def lobpcg_update(self, m, S, ks, Cmat):
         Cmat = np.asfortranarray(Cmat, dtype=np.float64)

@@ -1,5 +1,6 @@
 // context.hip -- context, stream, pooled allocator, event timing, error reporting.
 #include "mi_internal.h"
+#include <cstring>
 
 #include <dlfcn.h>
 
@@ -69,6 +70,22 @@ void pool_free(mi_ctx *ctx, void *p) {
   auto it = ctx->pool_all.find(p);
   if (it == ctx->pool_all.end()) return;
   ctx->pool_free.insert({it->second, p});
+}
+
+int stage_upload(mi_ctx *ctx, const void *src, size_t bytes, void *dst_dev) {
+  MI_REQUIRE(bytes <= mi_ctx::kStageBytes, "staged upload of %zu bytes exceeds the slot size", bytes);
+  const int slot = ctx->stage_next;
+  ctx->stage_next = (slot + 1) % mi_ctx::kStageSlots;
+  if (!ctx->stage_host[slot]) {
+    MI_HIP(hipHostMalloc(&ctx->stage_host[slot], mi_ctx::kStageBytes, hipHostMallocDefault));
+    MI_HIP(hipEventCreateWithFlags(&ctx->stage_ev[slot], hipEventDisableTiming));
+  } else {
+    MI_HIP(hipEventSynchronize(ctx->stage_ev[slot]));  // the copy that last read this slot (long done in practice)
+  }
+  memcpy(ctx->stage_host[slot], src, bytes);
+  MI_HIP(hipMemcpyAsync(dst_dev, ctx->stage_host[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
+  MI_HIP(hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+  return MI_OK;
 }
 
 hipEvent_t event_get(mi_ctx *ctx) {
@@ -217,6 +234,10 @@ int mi_ctx_destroy(mi_ctx *ctx) {
       (void)hipEventDestroy(pr.second);
     }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < mi_ctx::kStageSlots; ++i) {
+    if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
+    if (ctx->stage_host[i]) (void)hipHostFree(ctx->stage_host[i]);
+  }
   (void)hipFree(ctx->control_slab);
   (void)hipFree(ctx->trace_dev);
   (void)hipHostFree(ctx->host_scalars);

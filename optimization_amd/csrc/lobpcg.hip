@@ -25,7 +25,10 @@
 
 #include "mi_internal.h"
 #include "spmm_core.h"
-#include "Optimization/LinearAlgebra/DenseSymmetricEigen.h"
+
+namespace mi {
+int rr_host(int n, const double *A, const double *B, double *Theta, double *C);  // rr_host.cpp (g++, AVX2, no FMA)
+}
 
 using namespace mi;
 
@@ -841,9 +844,30 @@ int check_panel(mi_ctx *ctx, size_t m, int k, const mi_vec *P, const char *what)
 
 extern "C" {
 
-// T = [T (k1 columns) | T2 (kb - k1 columns)] when T2 != null (square direct shapes only), else T alone
+// a Gram whose kernels are enqueued but whose result has not been read back yet (gram_impl with job != null)
+struct GramJob {
+  void *partial = nullptr, *Gdev = nullptr;
+  int nelem = 0;
+};
+static int gram_finish(mi_ctx *ctx, GramJob *jobs, int njobs, double *const *G_host) {
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < njobs && e == hipSuccess; ++i)
+    e = hipMemcpyAsync(G_host[i], jobs[i].Gdev, (size_t)jobs[i].nelem * sizeof(double), hipMemcpyDeviceToHost,
+                       ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ctx->host_syncs++;
+  for (int i = 0; i < njobs; ++i) {
+    pool_free(ctx, jobs[i].partial);
+    pool_free(ctx, jobs[i].Gdev);
+  }
+  if (e != hipSuccess) return hip_fail(e, "gram read-back", __FILE__, __LINE__);
+  return MI_OK;
+}
+
+// T = [T (k1 columns) | T2 (kb - k1 columns)] when T2 != null (square direct shapes only), else T alone.
+// job != null: only enqueue; the caller reads back with gram_finish.
 static int gram_impl(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, const mi_vec *T2v,
-                     int k1, double *G_host) {
+                     int k1, double *G_host, GramJob *job = nullptr) {
   const double *T2 = T2v ? T2v->d : nullptr;
   const bool same = !T2 && (S->d == T->d) && ka == kb;
   const bool aligned = (m % 2 == 0) && ((uintptr_t)S->d % 16 == 0) && ((uintptr_t)T->d % 16 == 0);
@@ -930,12 +954,70 @@ static int gram_impl(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, con
     for (int off = 0; off < nelem; off += 4096)  // all-reduce in chunks the comm layer accepts
       MI_TRY(comm_allreduce(ctx, (double *)Gdev + off, std::min(4096, nelem - off)));
   }
-  hipError_t e = hipMemcpyAsync(G_host, Gdev, (size_t)nelem * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  pool_free(ctx, partial);
-  pool_free(ctx, Gdev);
-  if (e != hipSuccess) return hip_fail(e, "gram read-back", __FILE__, __LINE__);
+  GramJob mine{partial, Gdev, nelem};
+  if (job) {
+    *job = mine;
+    return MI_OK;
+  }
+  double *dst[1] = {G_host};
+  return gram_finish(ctx, &mine, 1, dst);
+}
+
+// assembles T = [T1 | T2] in a fresh panel (for shapes the split kernel does not take)
+static int assemble_panel(mi_ctx *ctx, size_t m, int k, int k1, const mi_vec *T1, const mi_vec *T2, mi_vec **out) {
+  MI_TRY(mi_vec_create(ctx, m * (size_t)k, out));
+  hipError_t e = hipMemcpyAsync((*out)->d, T1->d, m * (size_t)k1 * sizeof(double), hipMemcpyDeviceToDevice,
+                                ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync((*out)->d + m * (size_t)k1, T2->d, m * (size_t)(k - k1) * sizeof(double),
+                       hipMemcpyDeviceToDevice, ctx->stream);
+  if (e != hipSuccess) {
+    mi_vec_destroy(*out);
+    *out = nullptr;
+    return hip_fail(e, "panel assembly", __FILE__, __LINE__);
+  }
   return MI_OK;
+}
+static bool split_direct_ok(size_t m, int k, const mi_vec *S, const mi_vec *T1, const mi_vec *T2) {
+  return k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T1->d % 32 == 0 &&
+         (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+}
+
+// The two Grams of a Rayleigh-Ritz step with ONE synchronisation: both are enqueued back to back (the device goes
+// from the first straight into the second), then both results are read back.  Each right-hand panel is either one
+// panel of k columns (T?2 == null) or two pieces [T?1 (k1? columns) | T?2].
+int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1, const mi_vec *Ta2,
+                        int k1b, const mi_vec *Tb1, const mi_vec *Tb2, double *Ga_host, double *Gb_host) {
+  MI_REQUIRE(ctx && S && Ta1 && Tb1 && Ga_host && Gb_host, "null argument");
+  MI_REQUIRE(k >= 1 && k <= kGramMaxK, "panel width must be in [1,%d]", kGramMaxK);
+  MI_TRY(check_panel(ctx, m, k, S, "S"));
+  const mi_vec *T1[2] = {Ta1, Tb1}, *T2[2] = {Ta2, Tb2};
+  const int k1[2] = {k1a, k1b};
+  GramJob jobs[2];
+  mi_vec *tmp[2] = {nullptr, nullptr};
+  int st = MI_OK, started = 0;
+  for (int i = 0; i < 2 && st == MI_OK; ++i) {
+    if (T2[i]) {
+      if (!(k1[i] >= 1 && k1[i] < k)) { set_error("need 1 <= k1 < k"); st = MI_ERR_INVALID_ARGUMENT; break; }
+      st = check_panel(ctx, m, k1[i], T1[i], "T1");
+      if (st == MI_OK) st = check_panel(ctx, m, k - k1[i], T2[i], "T2");
+      if (st != MI_OK) break;
+      if (split_direct_ok(m, k, S, T1[i], T2[i])) {
+        st = gram_impl(ctx, m, k, k, S, T1[i], T2[i], k1[i], nullptr, &jobs[i]);
+      } else {
+        st = assemble_panel(ctx, m, k, k1[i], T1[i], T2[i], &tmp[i]);
+        if (st == MI_OK) st = gram_impl(ctx, m, k, k, S, tmp[i], nullptr, k, nullptr, &jobs[i]);
+      }
+    } else {
+      st = check_panel(ctx, m, k, T1[i], "T");
+      if (st == MI_OK) st = gram_impl(ctx, m, k, k, S, T1[i], nullptr, k, nullptr, &jobs[i]);
+    }
+    if (st == MI_OK) ++started;
+  }
+  double *dst[2] = {Ga_host, Gb_host};
+  const int fin = gram_finish(ctx, jobs, started, dst);  // (also releases what was enqueued when a later step failed)
+  for (int i = 0; i < 2; ++i) mi_vec_destroy(tmp[i]);
+  return st != MI_OK ? st : fin;
 }
 
 int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, double *G_host) {
@@ -1012,8 +1094,12 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
         Ct[ch.off + (size_t)s * ch.width + c] = C_host[(size_t)(ch.c0 + c) * ldc + s];
   void *Cdev = nullptr;
   MI_TRY(pool_alloc(ctx, total * sizeof(double), &Cdev));
-  MI_HIP(hipMemcpyAsync(Cdev, Ct.data(), total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  MI_HIP(hipStreamSynchronize(ctx->stream));  // Ct dies with this call
+  if (total * sizeof(double) <= mi_ctx::kStageBytes) {
+    MI_TRY(stage_upload(ctx, Ct.data(), total * sizeof(double), Cdev));  // Ct may die: the bytes are in a pinned slot
+  } else {
+    MI_HIP(hipMemcpyAsync(Cdev, Ct.data(), total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));  // Ct dies with this call
+  }
   const int grid = (int)std::min<size_t>((m + 255) / 256, 2048);
   KScope ksc(ctx, MI_K_LOBPCG_UPDATE);
   for (const Chunk &ch : chunks) {
@@ -1065,8 +1151,7 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
   MI_TRY(check_panel(ctx, m, nx, R, "R"));
   void *thdev = nullptr;
   MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
-  MI_HIP(hipMemcpyAsync(thdev, theta_host, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  MI_HIP(hipStreamSynchronize(ctx->stream));
+  MI_TRY(stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev));  // (no host wait)
   const int grid = grid_for(ctx, m, 2);
   // 8 columns per launch (16 reduction components); every chunk's sums land in their own 16 doubles of
   // one device buffer, read back with ONE copy + sync after the last chunk
@@ -1096,8 +1181,8 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
 
 int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C) {
   MI_REQUIRE(n >= 1 && A && B && Theta && C, "bad argument");
-  // header-only host solver shared with the generic path of the LOBPCG template (same bits on both paths)
-  const int rc = Optimization::LinearAlgebra::dense::generalized_symmetric_eig(n, A, B, Theta, C);
+  // the header-only host solver of the template's generic path, compiled in its own host-only unit
+  const int rc = mi::rr_host(n, A, B, Theta, C);
   if (rc == 1) {
     set_error("Rayleigh-Ritz: B has a non-positive diagonal entry");
     return MI_ERR_INVALID_ARGUMENT;

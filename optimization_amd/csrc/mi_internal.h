@@ -125,6 +125,12 @@ struct mi_ctx {
   size_t trace_cap = 0;
   unsigned int epoch = 0;
   size_t host_syncs = 0;  // stream synchronisations the library made on this context (mi_ctx_sync_count)
+  // pinned staging ring for small host -> device uploads that must not stall the host (stage_upload, context.hip)
+  static constexpr int kStageSlots = 4;
+  static constexpr size_t kStageBytes = 96 * 96 * sizeof(double);
+  void *stage_host[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_next = 0;
   // timing
   mi::KTimer ktime[MI_K_COUNT];
   std::vector<hipEvent_t> event_pool;
@@ -149,6 +155,10 @@ namespace mi {
 
 int pool_alloc(mi_ctx *ctx, size_t bytes, void **out);
 void pool_free(mi_ctx *ctx, void *p);
+// Asynchronous upload of <= mi_ctx::kStageBytes from pageable host memory: copied into a pinned slot of a small ring
+// and from there in-stream; the caller's buffer may die at once, the host does not wait for the device (a slot is
+// reused only after the copy that read it has completed).
+int stage_upload(mi_ctx *ctx, const void *src, size_t bytes, void *dst_dev);
 int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements

@@ -179,8 +179,11 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
     const Matrix Srest = reuse_x ? S.middleCols(nx, ns - nx) : Matrix();
     const Matrix AS = reuse_x ? A(Srest) : A(Sns);  // :267
     const Matrix BS = !B ? Matrix() : (reuse_x ? (*B)(Srest) : (*B)(Sns));  // :268 (B absent: S'BS = S'S, no copy)
-    auto tc = reuse_x ? rayleigh_ritz(gram_split(Sns, AX, AS), B ? gram_split(Sns, BX, BS) : gram(Sns, Sns))
-                      : rayleigh_ritz(gram(Sns, AS), B ? gram(Sns, BS) : gram(Sns, Sns));  // :271-275
+    // both Grams enqueued back to back, one read-back (:271-275)
+    const Matrix none;
+    auto gg = reuse_x ? (B ? gram_pair(Sns, AX, AS, BX, BS) : gram_pair(Sns, AX, AS, Sns, none))
+                      : (B ? gram_pair(Sns, AS, none, BS, none) : gram_pair(Sns, AS, none, Sns, none));
+    auto tc = rayleigh_ritz(gg.first, gg.second);
     Theta = Vector(std::move(tc.first));
     const auto &C = tc.second;
 

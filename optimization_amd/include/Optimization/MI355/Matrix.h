@@ -195,6 +195,17 @@ inline HostMatrix gram_split(const DeviceMatrix &S, const DeviceMatrix &T1, cons
                              T2.handle(), G.data()));
   return G;
 }
+// (S' [A1 | A2], S' [B1 | B2]) with one synchronisation; A2 / B2 may be empty (then A1 / B1 has S.cols() columns)
+inline std::pair<HostMatrix, HostMatrix> gram_pair(const DeviceMatrix &S, const DeviceMatrix &A1,
+                                                   const DeviceMatrix &A2, const DeviceMatrix &B1,
+                                                   const DeviceMatrix &B2) {
+  HostMatrix GA(S.cols(), S.cols()), GB(S.cols(), S.cols());
+  const bool sa = A2.cols() > 0, sb = B2.cols() > 0;
+  check(mi_lobpcg_gram_pair(S.context(), S.rows(), (int)S.cols(), S.handle(), (int)A1.cols(), A1.handle(),
+                            sa ? A2.handle() : nullptr, (int)B1.cols(), B1.handle(), sb ? B2.handle() : nullptr,
+                            GA.data(), GB.data()));
+  return {std::move(GA), std::move(GB)};
+}
 // Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
 inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size_t row0, size_t kc) {
   DeviceMatrix Y(S.context(), S.rows(), kc);

@@ -102,6 +102,27 @@ def test_panel_update_on_the_matrix_pipe_has_the_bits_of_the_vector_kernel(ctx, 
     assert np.array_equal(Yb.numpy()[:m * 24].reshape(24, m).T, Y1[:, 24:])
 
 
+@pytest.mark.parametrize("m,k,k1", [(100_004, 48, 24), (200_012, 72, 24), (65_538, 72, 24), (1001, 10, 3)])
+def test_gram_pair_with_one_synchronisation_has_the_bits_of_the_separate_grams(ctx, m, k, k1):
+    """mi_lobpcg_gram_pair: S'[T1|T2] and S'S (and S'U for a one-piece panel) enqueued back to back and read back
+    together == the separate calls, bit for bit, on direct-kernel shapes and on the assembling fallback."""
+    rng = np.random.default_rng(m + k)
+    S = rng.normal(size=(m, k))
+    T = rng.normal(size=(m, k))
+    U = rng.normal(size=(m, k))
+    Sd, Ud = ctx.upload(S.ravel(order="F")), ctx.upload(U.ravel(order="F"))
+    T1, T2 = ctx.upload(T[:, :k1].ravel(order="F")), ctx.upload(T[:, k1:].ravel(order="F"))
+    s0 = ctx.sync_count()
+    Ga, Gb = ctx.lobpcg_gram_pair(m, Sd, k, T1, k1, T2, Sd, k, None)
+    assert ctx.sync_count() - s0 == 1
+    assert np.array_equal(Ga, ctx.lobpcg_gram_split(m, Sd, k, T1, k1, T2))
+    assert np.array_equal(Gb, ctx.lobpcg_gram(m, Sd, k, Sd, k))
+    Ga2, Gb2 = ctx.lobpcg_gram_pair(m, Sd, k, Ud, k, None, T1, k1, T2)
+    assert np.array_equal(Ga2, ctx.lobpcg_gram(m, Sd, k, Ud, k)) and np.array_equal(Gb2, Ga)
+    ref = S.T @ T
+    assert np.abs(Ga - ref).max() <= 1e-12 * np.abs(ref).max() * max(1, np.sqrt(m) / 10)
+
+
 def test_gram_identity_operand(ctx):
     """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
     m, k = 64, 16
