@@ -351,6 +351,10 @@ MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounde
  * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
  * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in
  * surface; with a communicator the halo is filled by the in-stream ncclSend/ncclRecv exchange. */
+/* host-only: the run plan of the LDS-window kernels (first tile of every run + the end) for `ntiles` tiles of 256 rows,
+ * a workgroup budget, a CU count and the matrix's far stride in rows (0: none); needs no GPU */
+MI_API int mi_debug_window_runs(int ntiles, int max_wgs, int num_cu, size_t far_stride, int *bounds_out, int cap,
+                                int *nb_out);
 MI_API int mi_debug_set_rank(mi_ctx *ctx, int world_size, int rank);
 MI_API int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host); /* (need_lo+need_hi) x p */
 /* Measurement hook: average microseconds of `reps` back-to-back applications of the operator in the fused form

@@ -159,6 +159,7 @@ def load():
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
         "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
         "mi_lobpcg_gram_split": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p],
+        "mi_debug_window_runs": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)],
         "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
         "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
@@ -191,6 +192,16 @@ def load():
 def check(status):
     if status != MI_OK:
         raise MiError(status, load().mi_last_error().decode())
+
+
+def window_runs(ntiles, max_wgs, num_cu=256, far_stride=0):
+    """run plan of the LDS-window kernels (host-only, mi_debug_window_runs): array of run starts + the end"""
+    L = load()
+    cap = max(ntiles, max_wgs, 1) + 2
+    buf = (C.c_int * cap)()
+    nb = C.c_int(0)
+    check(L.mi_debug_window_runs(ntiles, max_wgs, num_cu, far_stride, buf, cap, C.byref(nb)))
+    return np.array(buf[:nb.value + 1], dtype=np.int64)
 
 
 def csr_shard_plan(n_global, world_size, rank, row_starts, col_global):

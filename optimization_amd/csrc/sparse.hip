@@ -440,32 +440,51 @@ WinPlan window_plan(int ntiles, int max_wgs, int num_cu, size_t far_stride) {
     if (!best.nb || c.cost < best_cost) { best = c.p; best_cost = c.cost; }
   for (const Cand &c : cands)
     if (c.cost <= 1.02 * best_cost && c.p.nb > best.nb) best = c.p;
+  if (!best.nb) {  // nothing between the occupancy wish and the budget (e.g. budget < ntiles < 2 min_wgs): equal runs
+    best.run = 0;
+    best.per = std::max(1, (ntiles + std::max(1, max_wgs) - 1) / std::max(1, max_wgs));
+    best.nb = (ntiles + best.per - 1) / best.per;
+  }
   return best;
+}
+
+// first tile of every run (+ the end): strictly increasing from 0 to ntiles, at most max_wgs runs
+std::vector<int> window_runs(int ntiles, int max_wgs, int num_cu, size_t far_stride) {
+  std::vector<int> b;
+  if (ntiles <= 0 || max_wgs <= 0 || num_cu <= 0) {
+    b.push_back(0);
+    b.push_back(std::max(0, ntiles));
+    return b;
+  }
+  const WinPlan plan = window_plan(ntiles, max_wgs, num_cu, far_stride);
+  if (plan.run >= 1.0) {
+    for (int k = 0;; ++k) {
+      const int t = std::min(ntiles, (int)std::llround(k * plan.run));
+      b.push_back(t);
+      if (t >= ntiles) break;
+    }
+  }
+  if (b.empty() || (int)b.size() - 1 > max_wgs) {  // equal runs (also when rounding produced one run too many)
+    const int per = plan.run >= 1.0 || plan.per < 1 ? std::max(1, (ntiles + max_wgs - 1) / max_wgs) : plan.per;
+    b.clear();
+    for (int t = 0; t < ntiles; t += per) b.push_back(t);
+    b.push_back(ntiles);
+  }
+  return b;
 }
 
 // the plan of a matrix for a workgroup budget, cached on the matrix: grid and (if cut by the far stride) the
 // workgroup -> first tile table on the device
 int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, const int **bounds_out) {
   *bounds_out = nullptr;
-  static const bool off = [] { const char *e = getenv("MI355OPT_NO_WIN_BOUNDS"); return e && e[0] == '1'; }();
-  if (A->win_bounds_for != wgs) {
-    A->win_bounds_for = wgs;
-    const WinPlan plan = window_plan(ntiles, wgs, ctx->num_cu, off ? 0 : A->win_far_stride);
+  const char *off_env = getenv("MI355OPT_NO_WIN_BOUNDS");  // (per call: tests compare the plans in one process)
+  const bool off = off_env && off_env[0] == '1';
+  const int key = off ? -wgs : wgs;
+  if (A->win_bounds_for != key) {
+    A->win_bounds_for = key;
+    const std::vector<int> b = window_runs(ntiles, wgs, ctx->num_cu, off ? 0 : A->win_far_stride);
     if (A->win_bounds) (void)hipFree(A->win_bounds);
     A->win_bounds = nullptr;
-    A->win_bounds_n = plan.nb;
-    std::vector<int> b;
-    for (int k = 0;; ++k) {
-      const int t = std::min(ntiles, plan.run > 0 ? (int)std::llround(k * plan.run) : k * plan.per);
-      b.push_back(t);
-      if (t >= ntiles) break;
-    }
-    if ((int)b.size() - 1 > wgs || plan.nb < 1) {  // (rounding produced one run too many: equal runs instead)
-      const int per = (ntiles + wgs - 1) / wgs;
-      b.clear();
-      for (int t = 0; t < ntiles; t += per) b.push_back(t);
-      b.push_back(ntiles);
-    }
     A->win_bounds_n = (int)b.size() - 1;
     MI_HIP(hipMalloc((void **)&A->win_bounds, b.size() * sizeof(int)));
     MI_HIP(hipMemcpy(A->win_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -682,6 +701,19 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
     return st;
   }
   *out = A;
+  return MI_OK;
+}
+
+// Host-only: the run plan of the LDS-window kernels (window_runs) for ntiles tiles, a workgroup budget, a CU count
+// and the matrix's far stride in rows (0: none).  bounds_out (capacity cap) receives the first tile of every run and
+// the end; *nb_out the number of runs.  No GPU needed (tests/test_cpu_oracle_templates.py).
+int mi_debug_window_runs(int ntiles, int max_wgs, int num_cu, size_t far_stride, int *bounds_out, int cap,
+                         int *nb_out) {
+  MI_REQUIRE(bounds_out && nb_out && cap >= 2, "null argument");
+  const std::vector<int> b = mi::window_runs(ntiles, max_wgs, num_cu, far_stride);
+  MI_REQUIRE((int)b.size() <= cap, "plan of %d runs exceeds the output capacity %d", (int)b.size() - 1, cap - 1);
+  for (size_t i = 0; i < b.size(); ++i) bounds_out[i] = b[i];
+  *nb_out = (int)b.size() - 1;
   return MI_OK;
 }
 
