@@ -99,3 +99,10 @@ extern "C" int hz_lobpcg_dense(size_t m, size_t nx, size_t nev, const double *Ad
   }
   return 0;
 }
+
+// The header-only Rayleigh-Ritz solver as THIS translation unit compiles it (g++ -O2 -march=x86-64-v3
+// -ffp-contract=off): pytest compares it bit for bit with the library's own unit (csrc/rr_host.cpp: g++ -O3 -mavx2
+// -ffp-contract=off) -- vector width and optimisation level must not change a bit as long as nothing is fused.
+extern "C" int hz_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C) {
+  return Optimization::LinearAlgebra::dense::generalized_symmetric_eig(n, A, B, Theta, C);
+}

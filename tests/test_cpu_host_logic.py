@@ -1,8 +1,12 @@
 """Host-side logic of the product that needs no GPU: the run plan of the LDS-window kernels (sparse.hip window_plan /
 window_runs through mi_debug_window_runs)."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
+from conftest import ROOT
 from optimization_amd import capi
 
 TILE = 256  # rows per tile (4 slices of 64)
@@ -43,3 +47,36 @@ def test_window_run_plan_prefers_more_workgroups_among_equal_costs():
     few = len(capi.window_runs(31_250, 512, 256, 40_000)) - 1
     many = len(capi.window_runs(31_250, 1024, 256, 40_000)) - 1
     assert few <= 512 < many <= 1024
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 24, 48, 72, 96])
+def test_library_rayleigh_ritz_unit_has_the_bits_of_the_header_compiled_elsewhere(n):
+    """mi_rayleigh_ritz (csrc/rr_host.cpp: the header-only solver of LinearAlgebra/DenseSymmetricEigen.h compiled by
+    g++ -O3 -mavx2 -ffp-contract=off) against the same header inside tests/cpp/libharness_host.so (g++ -O2
+    -march=x86-64-v3 -ffp-contract=off): identical Ritz values and vectors, bit for bit; and the identities of
+    LOBPCG.h:53-62 (C'AC = Theta, C'BC = I)."""
+    path = os.path.join(ROOT, "tests", "cpp", "libharness_host.so")
+    if not os.path.exists(path):
+        pytest.skip("harness not built")
+    hz = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    hz.hz_rayleigh_ritz.restype = C.c_int
+    hz.hz_rayleigh_ritz.argtypes = [C.c_int, dp, dp, dp, dp]
+    rng = np.random.default_rng(100 + n)
+    M = rng.normal(size=(3 * n + 5, n))
+    A = np.asfortranarray(M.T @ M * rng.uniform(.5, 2.0))
+    K = rng.normal(size=(n, n))
+    B = np.asfortranarray(np.diag(rng.uniform(.5, 50.0, n)) + .05 * (K @ K.T))
+    L = capi.load()
+    L.mi_rayleigh_ritz.argtypes = [C.c_int, dp, dp, dp, dp]
+    th1, C1 = np.zeros(n), np.zeros((n, n), order="F")
+    th2, C2 = np.zeros(n), np.zeros((n, n), order="F")
+    assert L.mi_rayleigh_ritz(n, A.ctypes.data_as(dp), B.ctypes.data_as(dp), th1.ctypes.data_as(dp),
+                              C1.ctypes.data_as(dp)) == 0
+    assert hz.hz_rayleigh_ritz(n, A.ctypes.data_as(dp), B.ctypes.data_as(dp), th2.ctypes.data_as(dp),
+                               C2.ctypes.data_as(dp)) == 0
+    assert np.array_equal(th1, th2) and np.array_equal(C1, C2)
+    assert np.all(np.diff(th1) >= 0)
+    scale = np.abs(th1).max()
+    assert np.abs(C1.T @ A @ C1 - np.diag(th1)).max() <= 1e-10 * scale
+    assert np.abs(C1.T @ B @ C1 - np.eye(n)).max() <= 1e-10
