@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslic
 // cfg5; 180 us when all seven hit L1).  Far rows are gathered one tile ahead (they are then in flight while their
 // owner stages them: one fetch into the XCD's L2) and enter the entry loop from registers, selected per lane, in
 // storage order: the same fused multiply-adds in the same order as the kernels above.
-template <int KC, int HW, int WC>
+template <int KC, int HW, int WC, bool FARD>
 __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c0,
                                                                  const double *__restrict__ X,
                                                                  double *__restrict__ Y) {
@@ -678,9 +678,15 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
     for (int j = 0; j < HW; ++j) cw[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
   };
   auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
-    const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
+    if constexpr (FARD) {  // pure far structure (mi_csr::win_far_pure): row + D, row - D, computed
+      const unsigned nrows = (unsigned)m, r = (unsigned)sl * 64u + (unsigned)lane, rr = r < nrows ? r : nrows - 1u;
+      f[0] = rr + W.far_d < nrows ? rr + W.far_d : rr;
+      f[1] = rr >= W.far_d ? rr - W.far_d : rr;
+    } else {
+      const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
 #pragma unroll
-    for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+      for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+    }
   };
   auto far_rows = [&](const unsigned (&f)[kFarCap], double (&g)[kFarCap][KC]) {
 #pragma unroll
@@ -1249,10 +1255,17 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
     const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
     const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1;
     const void *fn = nullptr;
-    if (wc1) fn = hw7 ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, 7, 1> : (const void *)k_spmm_colmajor_win<kSpmmWinCols, 8, 1>;
-    else fn = hw7 ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, 7, 2> : (const void *)k_spmm_colmajor_win<kSpmmWinCols, 8, 2>;
-    static int occ_cache[2][2] = {};
-    int &occ = occ_cache[hw7 ? 0 : 1][wc1 ? 0 : 1];
+    const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
+    const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
+                      !(no_fard_env && no_fard_env[0] == '1');
+#define PICK(HWV, WCV) \
+  fn = fard ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, true> \
+            : (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, false>
+    if (wc1) { if (hw7) { PICK(7, 1); } else { PICK(8, 1); } }
+    else { if (hw7) { PICK(7, 2); } else { PICK(8, 2); } }
+#undef PICK
+    static int occ_cache[2][2][2] = {};
+    int &occ = occ_cache[hw7 ? 0 : 1][wc1 ? 0 : 1][fard ? 1 : 0];
     if (occ == 0) {
       int nbk = 0;
       hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fn, kWinBlock, lds);
@@ -1265,7 +1278,7 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
     static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
     MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
     SellView view = sell_view(A);
-    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds};
+    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u};
     const double *Xd = X->d;
     double *Yd = Y->d;
     for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {

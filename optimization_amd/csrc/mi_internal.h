@@ -367,6 +367,7 @@ struct mi_csr {
   uint32_t *wk = nullptr;  // device, padded + kWinHead * 64
   int32_t *wfar = nullptr; // device, (nslices + 1) * 2 * 64
   size_t win_far_stride = 0;       // |column - row| shared by >= 80 % of the far entries, or 0
+  size_t win_far_pure = 0;         // D when EVERY far entry is at row +- D (slot 0: +D, slot 1: -D), else 0
   // workgroup -> first tile table of the window kernels (stiefel.hip window_bounds), built on first use for one
   // workgroup budget: win_bounds_n + 1 device ints
   mutable int *win_bounds = nullptr;

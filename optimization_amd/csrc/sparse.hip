@@ -250,6 +250,22 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   std::vector<int32_t> wfar((nslices + 1) * kFarCap * 64, 0);
   std::unordered_map<unsigned long long, size_t> far_strides;  // |column - row| of the far entries
   size_t far_total = 0;
+  // "Pure" far structure: EVERY entry outside the window lies exactly D rows above or below its row (the two plane
+  // neighbours of a 3-D stencil) and none is a halo column.  The far slots are then assigned by direction -- slot 0
+  // = row + D, slot 1 = row - D -- and the kernels compute the far columns instead of loading them (mi_csr::
+  // win_far_pure; 8 bytes per row less to read).
+  size_t pure_D = 0;
+  bool pure = true;
+  for (size_t r = 0; r < n && pure; ++r)
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const long long c = col[k], d = c - (long long)r;
+      const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+      if ((size_t)c < n && ad <= 64ull * wc) continue;  // in the window
+      if ((size_t)c >= n) { pure = false; break; }
+      if (pure_D == 0) pure_D = (size_t)ad;
+      if ((size_t)ad != pure_D) { pure = false; break; }
+    }
+  if (pure_D == 0) pure = false;
   for (size_t sl = 0; sl < nslices; ++sl) {
     for (int lane = 0; lane < 64; ++lane) {
       const size_t r = sl * 64 + lane;
@@ -269,9 +285,10 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
           rowidx = (uint32_t)(((size_t)c >> 6) % (size_t)nc) * 64u + (uint32_t)(c & 63);
         } else {
           if (nfar == kFarCap) return MI_OK;  // a row with a third far entry: not eligible
-          rowidx = zrow + 1u + (uint32_t)(sl % kWinWaves) * (uint32_t)(kFarCap * 64) + (uint32_t)nfar * 64u +
+          const int slot = pure ? (d > 0 ? 0 : 1) : nfar;
+          rowidx = zrow + 1u + (uint32_t)(sl % kWinWaves) * (uint32_t)(kFarCap * 64) + (uint32_t)slot * 64u +
                    (uint32_t)lane;
-          wfar[(sl * kFarCap + nfar) * 64 + lane] = (int32_t)c;
+          wfar[(sl * kFarCap + slot) * 64 + lane] = (int32_t)c;
           ++nfar;
           if ((size_t)c < n) {
             ++far_strides[(unsigned long long)(d < 0 ? -d : d)];
@@ -288,6 +305,7 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   A->win_chunks = wc;
   A->win_head = head;
   A->win_zero = zw;
+  A->win_far_pure = pure ? pure_D : 0;
   // one stride carrying most of the far entries (the plane stride of a 3-D stencil): the workgroup ranges are then
   // cut so that this stride is a whole number of ranges (stiefel.hip window_bounds)
   A->win_far_stride = 0;

@@ -300,10 +300,13 @@ struct WinView {
   int wc, nc;     // window half-width in chunks; ring chunks (2 kWinWaves + 2 wc)
   uint32_t zw;    // word of a non-entry: zero row, index of 0.0
   const int *__restrict__ bounds;  // first tile of every workgroup (+ end), or null: equal runs
+  unsigned far_d;                  // FARD kernels: the far stride D (far columns = row + D, row - D; wfar unused)
 };
 
 // Tiles [t0, t1) of kWinWaves slices for this workgroup; `lds_rows` = kWinLdsRows x P doubles (ring, zero row, far slots).
-template <int P, int HW, bool HALO, class Epi>
+// FARD: the matrix's far structure is pure (mi_csr::win_far_pure): the far columns of a row are row + D and row - D
+// (slot 0, slot 1) and are computed, not loaded (never with HALO: a far column could then be a halo column)
+template <int P, int HW, bool HALO, bool FARD, class Epi>
 __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
                                             const double *__restrict__ V, const double *vt, double *lds_rows,
                                             Epi &epi) {
@@ -356,9 +359,16 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     for (int j = 0; j < HW; ++j) h.c[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
   };
   auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
-    const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
+    if constexpr (FARD) {
+      static_assert(!FARD || (!HALO && kFarCap == 2), "computed far columns: local rows only, two slots");
+      const unsigned r = (unsigned)sl * 64u + (unsigned)lane, rr = r < nloc ? r : nloc - 1u;
+      f[0] = rr + W.far_d < nloc ? rr + W.far_d : rr;  // (a row without that neighbour has no word for the slot)
+      f[1] = rr >= W.far_d ? rr - W.far_d : rr;
+    } else {
+      const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
 #pragma unroll
-    for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+      for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
+    }
   };
   auto load_head = [&](Head &h, int kk, int sl) {
     load_words(h, kk);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // HW > 0 (mi_csr::win_chunks > 0): the window form -- the rows of V near the workgroup's own are staged in an LDS
 // ring and every entry's row is read from LDS at an address the host worked out (spmm_core.h sell_window); HW = the
 // entries per slice.  Same arithmetic, bit-identical results.
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW>
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW, bool FARD = false>
 __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
       t0 = scalar_int(Wv.bounds, lb);
       t1 = scalar_int(Wv.bounds, lb + 1);
     }
-    sell_window<P, HW, HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
+    sell_window<P, HW, HALO, FARD && !HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
   } else {
     sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   }
@@ -658,7 +658,11 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const char *no_win_env = getenv("MI355OPT_NO_WINDOW");  // (per call: the tests compare both forms in one process)
   const bool no_win = no_win_env && no_win_env[0] == '1';
   const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
-  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr};
+  // (computed far columns: matrices whose far entries are all at row +- D, not sharded, D in 32 bits)
+  const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
+  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !A->halo &&
+                    !(no_fard_env && no_fard_env[0] == '1');
+  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr, fard ? (unsigned)A->win_far_pure : 0u};
 #ifdef MI_WIN_DEBUG
   if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
@@ -692,7 +696,16 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
 #define HF(F, HL, RC)                                                          \
   if (A->pk) { HF3(F, HL, RC, true, 0); }                                      \
   else { HF3(F, HL, RC, false, 0); }
-  if (win) {  // the window form (recurrence form only: the unpreconditioned solve)
+#define HF3D(HWV)                                                                                             \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, false, true, true, HWV, true>), dim3(grid),      \
+                                   dim3(block), 0, ctx->stream, view, wv, (const CgState *)ctx->cg_live,      \
+                                   (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
+                                   (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
+                                   (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
+                                   out->d, ctx->partials))
+  if (win && fard) {  // the window form with computed far columns
+    if (A->win_head <= 7) { HF3D(7); } else { HF3D(8); }
+  } else if (win) {  // the window form (recurrence form only: the unpreconditioned solve)
     if (A->win_head <= 7) {
       if (halo) { HF3(false, true, true, true, 7); } else { HF3(false, false, true, true, 7); }
     } else {
@@ -705,6 +718,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   } else {
     if (sharded) { HF(true, false, false); } else { HF(false, false, false); }
   }
+#undef HF3D
 #undef HF3
 #undef HF
   *nparts = grid;

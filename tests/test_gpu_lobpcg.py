@@ -71,9 +71,12 @@ def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, mo
     Xd = ctx.upload(np.asfortranarray(X).ravel(order="F"))
     monkeypatch.delenv("MI355OPT_NO_SPMM_WIN", raising=False)
     Yw = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    monkeypatch.setenv("MI355OPT_NO_FAR_COMPUTED", "1")  # far columns loaded from wfar instead of computed
+    Yl = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    monkeypatch.delenv("MI355OPT_NO_FAR_COMPUTED")
     monkeypatch.setenv("MI355OPT_NO_SPMM_WIN", "1")
     Yg = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
-    assert np.array_equal(Yw, Yg)
+    assert np.array_equal(Yw, Yg) and np.array_equal(Yw, Yl)
     ref = sps.csr_matrix((val, col, rowptr), shape=(n, n)) @ X
     assert np.abs(Yw - ref).max() <= 1e-14 * np.abs(ref).max()
 

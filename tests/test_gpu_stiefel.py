@@ -313,8 +313,9 @@ def test_window_form_of_the_hessian_has_the_bits_of_the_streaming_form(monkeypat
     Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=3 + p)
     res = {}
     for mode, env in (("window", {}), ("stream", {"MI355OPT_NO_WINDOW": "1"}),
-                      ("window-equal-runs", {"MI355OPT_NO_WIN_BOUNDS": "1"})):
-        for k in ("MI355OPT_NO_WINDOW", "MI355OPT_NO_WIN_BOUNDS"):
+                      ("window-equal-runs", {"MI355OPT_NO_WIN_BOUNDS": "1"}),
+                      ("window-loaded-far", {"MI355OPT_NO_FAR_COMPUTED": "1"})):
+        for k in ("MI355OPT_NO_WINDOW", "MI355OPT_NO_WIN_BOUNDS", "MI355OPT_NO_FAR_COMPUTED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -328,6 +329,10 @@ def test_window_form_of_the_hessian_has_the_bits_of_the_streaming_form(monkeypat
         finally:
             c.close()
     w, st, eq = res["window"], res["stream"], res["window-equal-runs"]
+    # far columns computed (row +- D, the default for a pure stencil) or loaded from wfar: the same kernel otherwise,
+    # the same partition of the rows: bit-identical
+    lf = res["window-loaded-far"]
+    assert np.array_equal(w[0], lf[0]) and w[1:] == lf[1:]
     assert w[1:3] == st[1:3] == eq[1:3] and w[1] > 3
     # the partial rows are summed per workgroup: the forms partition the rows differently, so the replicated scalars
     # (and with them the iterates) agree to rounding, not to the bit, unless the partitions coincide
