@@ -60,6 +60,9 @@ def kernel_bytes(n, nnz, p, packed=True):
     # the one-pass Hessian streams the value-indexed packed copy of A (4 B per entry: the bench matrix has 2
     # distinct values) unless that format is switched off
     a_fused = (4 if packed else 12) * nnz + 4 * (n + 1)
+    if packed and os.environ.get("MI355OPT_WORDS16", "0") == "1":
+        # opt-in 16-bit window words: eight 2-byte entries per row (padded to whole 64-row slices), no row pointers
+        a_fused = 16 * ((n + 63) // 64 * 64)
     kb = {
         # A; V gathered, X read; Hp written (the projection matrix is known before the pass); recurrence
         # form: + Y read for the Gram of the output

@@ -1278,7 +1278,8 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
     static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
     MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
     SellView view = sell_view(A);
-    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u};
+    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
+               nullptr};
     const double *Xd = X->d;
     double *Yd = Y->d;
     for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {

@@ -366,6 +366,10 @@ struct mi_csr {
   uint32_t win_zero = 0;   // word of a non-entry: zero row, index of 0.0 in vtab
   uint32_t *wk = nullptr;  // device, padded + kWinHead * 64
   int32_t *wfar = nullptr; // device, (nslices + 1) * 2 * 64
+  // 16-bit form of the words (matrices with <= 32 table values incl. 0.0 and LDS rows < 2048): entry = (LDS row << 5)
+  // | value index, EIGHT entries per row in four dwords, (slice * 4 + q) * 64 + lane -- fixed 16 bytes per row,
+  // non-entries are the zero word, no slice bounds needed.  Null when the matrix does not qualify.
+  uint32_t *wk16 = nullptr;
   size_t win_far_stride = 0;       // |column - row| shared by >= 80 % of the far entries, or 0
   size_t win_far_pure = 0;         // D when EVERY far entry is at row +- D (slot 0: +D, slot 1: -D), else 0
   // workgroup -> first tile table of the window kernels (stiefel.hip window_bounds), built on first use for one

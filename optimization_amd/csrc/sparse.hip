@@ -302,6 +302,29 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   }
   MI_TRY(upload((void **)&A->wk, wk.data(), wk.size() * sizeof(uint32_t)));
   MI_TRY(upload((void **)&A->wfar, wfar.data(), wfar.size() * sizeof(int32_t)));
+  {  // the 16-bit form, when every value index (0.0 included) fits 5 bits and every LDS row 11 bits
+    const uint32_t max_row = zrow + 1u + (uint32_t)(kWinWaves * kFarCap * 64);
+    const int nvals = std::max(ntable, zidx + 1);
+    if (nvals <= 32 && max_row < 2048u && head <= 8) {
+      std::vector<uint32_t> w16((nslices + 1) * 4 * 64, 0u);
+      const uint32_t z16 = (zrow << 5) | (uint32_t)zidx;
+      for (size_t sl = 0; sl <= nslices; ++sl) {
+        const int width = sl < nslices ? (int)(sp[sl + 1] - sp[sl]) : 0;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) {
+            uint32_t e[2];
+            for (int h = 0; h < 2; ++h) {
+              const int j = 2 * q + h;
+              const uint32_t w32 = j < width ? wk[(size_t)(sp[sl] + j) * 64 + lane] : zw;
+              e[h] = ((w32 >> 8) << 5) | (w32 & 255u);
+              (void)z16;
+            }
+            w16[(sl * 4 + q) * 64 + lane] = e[0] | (e[1] << 16);
+          }
+      }
+      MI_TRY(upload((void **)&A->wk16, w16.data(), w16.size() * sizeof(uint32_t)));
+    }
+  }
   A->win_chunks = wc;
   A->win_head = head;
   A->win_zero = zw;
@@ -627,6 +650,7 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->vtab);
   (void)hipFree(A->wk);
   (void)hipFree(A->wfar);
+  (void)hipFree(A->wk16);
   if (A->win_bounds) (void)hipFree(A->win_bounds);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;

@@ -301,12 +301,15 @@ struct WinView {
   uint32_t zw;    // word of a non-entry: zero row, index of 0.0
   const int *__restrict__ bounds;  // first tile of every workgroup (+ end), or null: equal runs
   unsigned far_d;                  // FARD kernels: the far stride D (far columns = row + D, row - D; wfar unused)
+  const uint32_t *__restrict__ wk16;  // W16 kernels: the 16-bit form of the words (mi_csr::wk16)
 };
 
 // Tiles [t0, t1) of kWinWaves slices for this workgroup; `lds_rows` = kWinLdsRows x P doubles (ring, zero row, far slots).
 // FARD: the matrix's far structure is pure (mi_csr::win_far_pure): the far columns of a row are row + D and row - D
 // (slot 0, slot 1) and are computed, not loaded (never with HALO: a far column could then be a halo column)
-template <int P, int HW, bool HALO, bool FARD, class Epi>
+// W16: the words come in the 16-bit form (mi_csr::wk16: eight entries per row in four dwords, indexed by slice; a
+// non-entry is the zero word, so no slice bounds are consulted)
+template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi>
 __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
                                             const double *__restrict__ V, const double *vt, double *lds_rows,
                                             Epi &epi) {
@@ -349,14 +352,25 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   // raw operands of a slice: its words (ONE scalar base + immediate offsets j * 256: the words behind a narrower
   // slice belong to the next slice or to the padding mi_csr keeps behind the array, and are replaced by zw when
   // consumed) and its two far columns
+  constexpr int NWORD = W16 ? 4 : HW;
   struct Head {
-    unsigned c[HW];
+    unsigned c[NWORD];
     unsigned f[kFarCap];
   };
-  auto load_words = [&](Head &h, int kk) {
-    const char *pb = reinterpret_cast<const char *>(W.wk) + (unsigned)kk * 256u + lane4;
+  auto load_words = [&](Head &h, int kk, int sl) {
+    const char *pb = W16 ? reinterpret_cast<const char *>(W.wk16) + (unsigned)sl * 1024u + lane4
+                         : reinterpret_cast<const char *>(W.wk) + (unsigned)kk * 256u + lane4;
 #pragma unroll
-    for (int j = 0; j < HW; ++j) h.c[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
+    for (int j = 0; j < NWORD; ++j) h.c[j] = pinned_load(reinterpret_cast<const unsigned *>(pb + j * 256));
+  };
+  // entry j of the slice as (LDS row << 8 | value index)
+  auto entry_word = [&](const Head &h, int j, int kcur, int bcur) -> unsigned {
+    if constexpr (W16) {
+      const unsigned e = (h.c[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      return ((e >> 5) << 8) | (e & 31u);
+    } else {
+      return (kcur + j < bcur) ? h.c[j] : W.zw;  // (wave-uniform condition)
+    }
   };
   auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
     if constexpr (FARD) {
@@ -371,7 +385,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     }
   };
   auto load_head = [&](Head &h, int kk, int sl) {
-    load_words(h, kk);
+    load_words(h, kk, sl);
     load_far(h.f, sl);
   };
   auto far_row = [&](unsigned c, double (&out)[P]) {
@@ -402,7 +416,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   // no memory at all; the tile's only waits are for the staged chunk and for the X/Y rows at its end.
   unsigned f0[kFarCap];
   load_far(f0, have ? slice : 0);
-  load_words(h, k);
+  load_words(h, k, have ? slice : 0);
 #else
   load_head(h, k, have ? slice : 0);
 #endif
@@ -456,12 +470,12 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
 #ifndef MI_WIN_NO_FARAHEAD
       unsigned wd[HW];
 #pragma unroll
-      for (int j = 0; j < HW; ++j) wd[j] = (k + j < b1) ? h.c[j] : W.zw;  // (wave-uniform condition)
+      for (int j = 0; j < HW; ++j) wd[j] = entry_word(h, j, k, b1);
       MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
       double gn[kFarCap][P];  // the NEXT slice's far rows (h.f: its far columns, loaded a tile ago)
 #pragma unroll
       for (int s = 0; s < kFarCap; ++s) far_row(h.f[s], gn[s]);
-      load_words(h, q0);
+      load_words(h, q0, more ? nslice : slice);
       {
         const int nslice2 = nslice + NW;
         const bool more2 = more && t + 2 < t1 && nslice2 < nchunks;
@@ -473,7 +487,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       for (int s = 0; s < kFarCap; ++s) far_row((dbg & 1) ? (unsigned)(slice * 64 + lane) : h.f[s], gf[s]);
       unsigned wd[HW];
 #pragma unroll
-      for (int j = 0; j < HW; ++j) wd[j] = (k + j < b1) ? h.c[j] : W.zw;  // (wave-uniform condition)
+      for (int j = 0; j < HW; ++j) wd[j] = entry_word(h, j, k, b1);
       MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
       if (!(dbg & 8)) load_head(h, q0, more ? nslice : slice);
 #endif

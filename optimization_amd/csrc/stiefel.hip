@@ -194,7 +194,8 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // HW > 0 (mi_csr::win_chunks > 0): the window form -- the rows of V near the workgroup's own are staged in an LDS
 // ring and every entry's row is read from LDS at an address the host worked out (spmm_core.h sell_window); HW = the
 // entries per slice.  Same arithmetic, bit-identical results.
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW, bool FARD = false>
+// FAR (window form, unsharded): 0 far columns loaded; 1 computed (pure far structure); 2 computed + 16-bit words
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW, int FAR = 0>
 __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
       t0 = scalar_int(Wv.bounds, lb);
       t1 = scalar_int(Wv.bounds, lb + 1);
     }
-    sell_window<P, HW, HALO, FARD && !HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
+    sell_window<P, HW, HALO, (FAR >= 1) && !HALO, (FAR == 2) && !HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
   } else {
     sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   }
@@ -662,7 +663,12 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
   const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !A->halo &&
                     !(no_fard_env && no_fard_env[0] == '1');
-  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr, fard ? (unsigned)A->win_far_pure : 0u};
+  // 16-bit words: opt-in (MI355OPT_WORDS16=1).  On cfg2 they shorten the pass by ~1 us (25.9 -> 24.9 us) by halving
+  // the matrix stream (28 -> 16 MB of 132 MB); the pass then runs at the same ~5.5 TB/s of a smaller total.
+  const char *w16_env = getenv("MI355OPT_WORDS16");
+  const bool w16 = fard && A->wk16 && w16_env && w16_env[0] == '1';
+  WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr, fard ? (unsigned)A->win_far_pure : 0u,
+             A->wk16};
 #ifdef MI_WIN_DEBUG
   if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
@@ -696,15 +702,17 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
 #define HF(F, HL, RC)                                                          \
   if (A->pk) { HF3(F, HL, RC, true, 0); }                                      \
   else { HF3(F, HL, RC, false, 0); }
-#define HF3D(HWV)                                                                                             \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, false, true, true, HWV, true>), dim3(grid),      \
+#define HF3D(HWV, FARV)                                                                                       \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, false, true, true, HWV, FARV>), dim3(grid),      \
                                    dim3(block), 0, ctx->stream, view, wv, (const CgState *)ctx->cg_live,      \
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
                                    out->d, ctx->partials))
-  if (win && fard) {  // the window form with computed far columns
-    if (A->win_head <= 7) { HF3D(7); } else { HF3D(8); }
+  if (win && w16) {  // the window form with computed far columns and 16-bit words
+    if (A->win_head <= 7) { HF3D(7, 2); } else { HF3D(8, 2); }
+  } else if (win && fard) {  // ... with computed far columns
+    if (A->win_head <= 7) { HF3D(7, 1); } else { HF3D(8, 1); }
   } else if (win) {  // the window form (recurrence form only: the unpreconditioned solve)
     if (A->win_head <= 7) {
       if (halo) { HF3(false, true, true, true, 7); } else { HF3(false, false, true, true, 7); }

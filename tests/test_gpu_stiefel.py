@@ -314,8 +314,9 @@ def test_window_form_of_the_hessian_has_the_bits_of_the_streaming_form(monkeypat
     res = {}
     for mode, env in (("window", {}), ("stream", {"MI355OPT_NO_WINDOW": "1"}),
                       ("window-equal-runs", {"MI355OPT_NO_WIN_BOUNDS": "1"}),
-                      ("window-loaded-far", {"MI355OPT_NO_FAR_COMPUTED": "1"})):
-        for k in ("MI355OPT_NO_WINDOW", "MI355OPT_NO_WIN_BOUNDS", "MI355OPT_NO_FAR_COMPUTED"):
+                      ("window-loaded-far", {"MI355OPT_NO_FAR_COMPUTED": "1"}),
+                      ("window-words16", {"MI355OPT_WORDS16": "1"})):
+        for k in ("MI355OPT_NO_WINDOW", "MI355OPT_NO_WIN_BOUNDS", "MI355OPT_NO_FAR_COMPUTED", "MI355OPT_WORDS16"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -333,6 +334,9 @@ def test_window_form_of_the_hessian_has_the_bits_of_the_streaming_form(monkeypat
     # the same partition of the rows: bit-identical
     lf = res["window-loaded-far"]
     assert np.array_equal(w[0], lf[0]) and w[1:] == lf[1:]
+    # 16-bit words (opt-in; value table of <= 32 entries) or 32-bit words: the same entries
+    w16 = res["window-words16"]
+    assert np.array_equal(w[0], w16[0]) and w[1:] == w16[1:]
     assert w[1:3] == st[1:3] == eq[1:3] and w[1] > 3
     # the partial rows are summed per workgroup: the forms partition the rows differently, so the replicated scalars
     # (and with them the iterates) agree to rounding, not to the bit, unless the partitions coincide
