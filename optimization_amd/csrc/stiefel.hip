@@ -343,7 +343,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
   const int wu = __builtin_amdgcn_readfirstlane(w);
   if constexpr (WIN) {
-    // a contiguous run of whole TILES (16 slices) per workgroup, the same number for every workgroup but the last
+    // a contiguous run of whole TILES (kWinWaves slices) per workgroup: the launch plan's table, or equal runs
     const int ntiles = (int)((A.nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + (int)nb - 1) / (int)nb;
     int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
     if (Wv.bounds) {  // runs cut to the stride of the far entries (window_bounds)
@@ -673,7 +673,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
 #endif
   const bool win = recur && wc > 0;
-  if (win && !ctx->uniform_grid) {  // whole tiles per workgroup, as evenly as the CUs allow (16 waves per CU)
+  if (win && !ctx->uniform_grid) {  // planned runs of whole tiles (sparse.hip window_bounds)
     static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
     // the workgroup budget: what is resident at once (one round), at most kMaxRows partial rows
