@@ -358,12 +358,12 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
   const int ex = threadIdx.x % kRedElems, g = threadIdx.x / kRedElems;
   const int e = blockIdx.x * kRedElems + ex;
   double s = 0;
-  if (e < nelem) {
-    int src = e;
-    if (sym) {
-      const int row = e % ka, col = e / ka;
-      if (row / 16 > col / 16) src = row * ka + col;
-    }
+  // sym: elements below the block diagonal are not summed here (their mirror's thread stores them too): reading them
+  // from the mirrored positions was a 576-byte-strided gather, 3x the bytes of the whole reduction
+  const int erow = e % ka, ecol = e / ka;
+  const bool lower = sym && e < nelem && erow / 16 > ecol / 16;
+  if (e < nelem && !lower) {
+    const int src = e;
     // eight independent loads in flight, added in the same ascending order as one at a time
     int b = g;
     for (; b + 7 * kRedGroups < nblocks; b += 8 * kRedGroups) {
@@ -377,11 +377,12 @@ __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nbloc
   }
   part[g][ex] = s;
   __syncthreads();
-  if (g == 0 && e < nelem) {
+  if (g == 0 && e < nelem && !lower) {
     double tot = part[0][ex];
 #pragma unroll
     for (int q = 1; q < kRedGroups; ++q) tot += part[q][ex];
     G[e] = tot;
+    if (sym && erow / 16 < ecol / 16) G[(size_t)erow * ka + ecol] = tot;  // the mirrored element (col, row)
   }
 }
 
