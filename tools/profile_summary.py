@@ -83,9 +83,9 @@ def main(tag):
         f.write(f"# {tag}: rocprofv3 summary of `python bench.py` (cfg2, Stiefel(1e6,3), 1x MI355X)\n\n")
         f.write("Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 500 "
                 "--warmup 50 --no-cpu-baseline --no-roofline --no-legs`; PMC: separate runs per counter group "
-                "(`tools/pmc_bytes.sh`: read requests by size, WRITE_SIZE, L2 hit/miss).  bench.py's own per-kernel figures (HIP event pairs on the launch "
-                "stream) run 1-2 us above the profiler's kernel durations: an event pair also times the gap to "
-                "the event records.\n\n")
+                "(`tools/pmc_bytes.sh`: read requests by size, WRITE_SIZE, L2 hit/miss).  bench.py's raw per-kernel figures (HIP event pairs on the launch "
+                "stream, `roofline.kernels`) run 1.6-1.9 us above the profiler's kernel durations: an event pair also "
+                "times its own two records; `roofline.avg_launch_us` / `frac` subtract that cost, measured live.\n\n")
         if bench:
             f.write(f"Un-profiled bench line of the same build: value = {bench['value']:.1f} GB/s "
                     f"({bench['ms_per_step'] * 1e3:.2f} us/step), roofline.frac = {bench['roofline']['frac']:.3f} "
