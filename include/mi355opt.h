@@ -172,6 +172,10 @@ typedef struct mi_stpcg_params {
   double theta;          /* :172 (.5) */
   double epsilon;        /* :179 (1e-8) */
   int run_ahead;         /* iterations the host may enqueue beyond the last one known complete (0 -> default 3) */
+  int defer_result;      /* nonzero: do NOT wait for the device at the exit.  s_out is valid in stream order (anything
+                            enqueued afterwards sees it); `result` only receives hvp_calls, the other fields arrive
+                            through mi_stpcg_collect.  Lets a caller put its next launch chain (e.g. the trust-region
+                            trial step, Riemannian/TNT.h:493-512) behind the solve and read both back with ONE wait. */
 } mi_stpcg_params;
 
 enum {
@@ -200,6 +204,10 @@ MI_API void mi_stpcg_default_params(mi_stpcg_params *p);
 MI_API int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P /*nullable*/,
                     const mi_stpcg_params *params, mi_vec *s_out, mi_stpcg_result *result,
                     mi_stpcg_trace *trace /*nullable*/);
+/* Result of the last mi_stpcg call made with defer_result on this context (update_step_M_norm :334,359,424,
+ * num_iterations :285, exit reason, last <r,v>).  Waits only if the state copy enqueued at the solve's exit has not
+ * completed yet -- after any later read-back on the same context it has.  (trace is not available in deferred mode.) */
+MI_API int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result);
 
 /* ---------------------------------------------------------------------------------------------
  * (5b) fused LSQR  <->  LinearAlgebra::LSQR  IterativeSolvers.h:552-855 (Paige & Saunders, damped,
@@ -284,6 +292,14 @@ MI_API int mi_so3n_objective(mi_so3n *prob, const mi_vec *R, double *f); /* sync
 MI_API int mi_so3n_model(mi_so3n *prob, const mi_vec *R, mi_vec *grad, mi_op **hess,
                          mi_precon **block_jacobi /*nullable*/);
 MI_API int mi_so3n_retract(mi_so3n *prob, const mi_vec *R, const mi_vec *xi, mi_vec *Y);
+/* One trial step at the point R the model is bound to (Riemannian/TNT.h:493-512: |h|, R_trial = retract(R, h),
+ * f(R_trial), <g,h>, <h, Hess h>) plus, speculatively, the model at the trial point (:573-585: gradient, Hessian blocks,
+ * block-Jacobi blocks, |grad|^2 and -- with_precon -- |M^-1 grad|^2 with the preconditioner rebuilt there): one launch
+ * chain, ONE read-back (sync).  out[6] = {f(R+), <h,h>, <g,h>, <h,Hess h>, |grad f(R+)|^2, |M+^-1 grad f(R+)|^2 or -1}.
+ * A following mi_so3n_model(prob, R_trial, ...) swaps the speculative model in instead of rebuilding it.  Every number
+ * has the bits the separate calls would produce. */
+MI_API int mi_so3n_trial(mi_so3n *prob, const mi_vec *R, const mi_vec *h, const mi_vec *g, int with_precon,
+                         mi_vec *R_trial, double out[6]);
 
 /* ---------------------------------------------------------------------------------------------
  * (8) LOBPCG building blocks (LinearAlgebra/LOBPCG.h:131-337).  Panels are column-major m x k

@@ -39,7 +39,8 @@ class MiError(RuntimeError):
 
 class StpcgParams(C.Structure):
     _fields_ = [("Delta", C.c_double), ("max_iterations", C.c_size_t), ("kappa_fgr", C.c_double),
-                ("theta", C.c_double), ("epsilon", C.c_double), ("run_ahead", C.c_int)]
+                ("theta", C.c_double), ("epsilon", C.c_double), ("run_ahead", C.c_int),
+                ("defer_result", C.c_int)]
 
 
 class StpcgResult(C.Structure):
@@ -151,6 +152,8 @@ def load():
         "mi_so3n_objective": [vp, vp, c_double_p],
         "mi_so3n_model": [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)],
         "mi_so3n_retract": [vp, vp, vp, vp],
+        "mi_so3n_trial": [vp, vp, vp, vp, C.c_int, vp, c_double_p],
+        "mi_stpcg_collect": [vp, C.POINTER(StpcgResult)],
         "mi_lobpcg_gram": [vp, C.c_size_t, C.c_int, C.c_int, vp, vp, c_double_p],
         "mi_lobpcg_update": [vp, C.c_size_t, C.c_int, C.c_int, vp, c_double_p, C.c_int, vp],
         "mi_lobpcg_update2": [vp, C.c_size_t, C.c_int, C.c_int, vp, c_double_p, C.c_int, vp, C.c_int, vp],
@@ -377,8 +380,10 @@ class Context:
 
     # fused STPCG ------------------------------------------------------------------------------
     def stpcg(self, g, H, P=None, Delta=1.0, max_iterations=1000, kappa_fgr=.1, theta=.5,
-              epsilon=1e-8, run_ahead=0, trace_cap=0, s_out=None):
-        prm = StpcgParams(Delta, max_iterations, kappa_fgr, theta, epsilon, run_ahead)
+              epsilon=1e-8, run_ahead=0, trace_cap=0, s_out=None, defer=False):
+        """defer=True: mi_stpcg returns without waiting for the device (s is valid in stream order); the scalar
+        results come from stpcg_collect()."""
+        prm = StpcgParams(Delta, max_iterations, kappa_fgr, theta, epsilon, run_ahead, int(defer))
         res = StpcgResult()
         s = s_out if s_out is not None else Vec(self, g.n)
         tr = None
@@ -394,6 +399,12 @@ class Context:
         if tr:
             out["trace"] = {k: v[:tr.len].copy() for k, v in arrs.items()}
         return out
+
+    def stpcg_collect(self):
+        res = StpcgResult()
+        check(self.L.mi_stpcg_collect(self.h, C.byref(res)))
+        return dict(M_norm=res.update_step_M_norm, iterations=res.num_iterations, exit_reason=res.exit_reason,
+                    hvp_calls=res.hvp_calls, rv_final=res.rv_final)
 
     # fused LSQR ---------------------------------------------------------------------------------
     def lsqr(self, A, At, b, x_out=None, **kw):
@@ -755,6 +766,13 @@ class So3N:
         Y = Vec(self.ctx, 9 * self.N)
         check(self.L.mi_so3n_retract(self.h, R.h, xi.h, Y.h))
         return Y
+
+    def trial(self, R, h, g, with_precon=True):
+        """mi_so3n_trial: (R_trial Vec, dict(f, hh, gh, hHh, grad_sqnorm, precon_grad_sqnorm))"""
+        Rt = Vec(self.ctx, 9 * self.N)
+        out = np.zeros(6)
+        check(self.L.mi_so3n_trial(self.h, R.h, h.h, g.h, int(with_precon), Rt.h, _dp(out)))
+        return Rt, dict(f=out[0], hh=out[1], gh=out[2], hHh=out[3], grad_sqnorm=out[4], precon_grad_sqnorm=out[5])
 
     def __del__(self):
         try:

@@ -146,7 +146,7 @@ int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out) {
   MI_REQUIRE(ctx && out, "null argument");
   void *p = nullptr;
   MI_TRY(pool_alloc(ctx, n * sizeof(double), &p));
-  mi_vec *v = new mi_vec{ctx, n, (double *)p, true};
+  mi_vec *v = new mi_vec{ctx, n, (double *)p, true, ++ctx->vec_serial, 0};
   *out = v;
   return MI_OK;
 }
@@ -162,7 +162,7 @@ int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out) {
   MI_REQUIRE(base && out, "null argument");
   MI_REQUIRE(offset + n <= base->n, "view [%zu, %zu) exceeds the base vector (%zu)", offset, offset + n, base->n);
   // an odd offset only costs alignment: gfx950 global 16-byte accesses need 4-byte alignment
-  *out = new mi_vec{base->ctx, n, base->d + offset, false};
+  *out = new mi_vec{base->ctx, n, base->d + offset, false, ++base->ctx->vec_serial, 0};
   return MI_OK;
 }
 
@@ -181,6 +181,7 @@ int mi_vec_data(const mi_vec *v, void **p) {
 int mi_vec_upload(mi_vec *v, const double *host, size_t n) {
   MI_REQUIRE(v && (host || n == 0), "null argument");
   MI_REQUIRE(n == v->n, "upload length %zu != vector length %zu", n, v->n);
+  touch(v);
   MI_HIP(hipMemcpyAsync(v->d, host, n * sizeof(double), hipMemcpyHostToDevice, v->ctx->stream));
   MI_HIP(hipStreamSynchronize(v->ctx->stream));
   return MI_OK;
@@ -197,6 +198,7 @@ int mi_vec_download(const mi_vec *v, double *host, size_t n) {
 int mi_vec_copy(mi_vec *dst, const mi_vec *src) {
   MI_TRY(check_same(dst, src));
   if (dst->d == src->d) return MI_OK;
+  touch(dst);
   MI_HIP(hipMemcpyAsync(dst->d, src->d, src->n * sizeof(double), hipMemcpyDeviceToDevice,
                         dst->ctx->stream));
   return MI_OK;
@@ -204,6 +206,7 @@ int mi_vec_copy(mi_vec *dst, const mi_vec *src) {
 
 int mi_vec_fill(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
+  touch(v);
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<2>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
@@ -214,6 +217,7 @@ int mi_vec_fill(mi_vec *v, double a) {
 
 int mi_vec_scale(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
+  touch(v);
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
@@ -224,6 +228,7 @@ int mi_vec_scale(mi_vec *v, double a) {
 
 int mi_vec_scale_to(mi_vec *z, double a, const mi_vec *x) {
   MI_TRY(check_same(z, x));
+  touch(z);
   if (z->n == 0) return MI_OK;
   KScope ks(z->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<1>, dim3(grid_for(z->ctx, z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,
@@ -234,6 +239,7 @@ int mi_vec_scale_to(mi_vec *z, double a, const mi_vec *x) {
 
 int mi_vec_div(mi_vec *v, double a) {
   MI_REQUIRE(v, "null vector");
+  touch(v);
   if (v->n == 0) return MI_OK;
   KScope ks(v->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<3>, dim3(grid_for(v->ctx, v->n, 4)), dim3(kBlock), 0, v->ctx->stream, v->n, a,
@@ -245,6 +251,7 @@ int mi_vec_div(mi_vec *v, double a) {
 int mi_vec_axpby(mi_vec *z, double a, const mi_vec *x, double b, const mi_vec *y) {
   MI_TRY(check_same(z, x));
   MI_TRY(check_same(z, y));
+  touch(z);
   if (z->n == 0) return MI_OK;
   KScope ks(z->ctx, MI_K_BLAS1);
   hipLaunchKernelGGL(k_axpby<0>, dim3(grid_for(z->ctx, z->n, 4)), dim3(kBlock), 0, z->ctx->stream, z->n, a,

@@ -241,6 +241,7 @@ int mi_ctx_destroy(mi_ctx *ctx) {
   (void)hipFree(ctx->control_slab);
   (void)hipFree(ctx->trace_dev);
   (void)hipHostFree(ctx->host_scalars);
+  if (ctx->cg_deferred_ev) (void)hipEventDestroy(ctx->cg_deferred_ev);
   (void)hipHostFree(ctx->cg_host);
   (void)hipHostFree((void *)ctx->status);
   if (ctx->t_start) (void)hipEventDestroy(ctx->t_start);

@@ -1071,6 +1071,8 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
   MI_REQUIRE(k1 >= 1 && k1 <= kc && (k1 == kc || Y2), "bad split of the output columns");
   MI_TRY(check_panel(ctx, m, ks, S, "S"));
   MI_TRY(check_panel(ctx, m, k1, Y, "Y"));
+  touch(Y);
+  touch(Y2);
   if (k1 < kc) MI_TRY(check_panel(ctx, m, kc - k1, Y2, "Y2"));
   {  // neither destination may overlap the basis: the update reads S while other rows' results are written
     const double *s0 = S->d, *s1 = S->d + (size_t)ks * m;
@@ -1155,6 +1157,7 @@ int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi
   MI_TRY(check_panel(ctx, m, nx, AX, "AX"));
   MI_TRY(check_panel(ctx, m, nx, BX, "BX"));
   MI_TRY(check_panel(ctx, m, nx, X, "X"));
+  touch(R);
   MI_TRY(check_panel(ctx, m, nx, R, "R"));
   void *thdev = nullptr;
   MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
@@ -1206,6 +1209,7 @@ int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_ve
   MI_REQUIRE(d->n == m, "scaling vector must have m entries");
   MI_TRY(check_panel(ctx, m, k, X, "X"));
   MI_TRY(check_panel(ctx, m, k, Y, "Y"));
+  touch(Y);
   const int grid = (int)std::min<size_t>((m * (size_t)k + 255) / 256, 4096);
   hipLaunchKernelGGL(k_rowscale, dim3(grid), dim3(256), 0, ctx->stream, m, (size_t)k, (const double *)d->d,
                      (const double *)X->d, Y->d);
@@ -1219,6 +1223,7 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   MI_TRY(check_panel(A->ctx, A->n, k, X, "X"));
   MI_TRY(check_panel(A->ctx, A->n, k, Y, "Y"));
   MI_REQUIRE(X->d != Y->d, "SpMM input and output must not alias");
+  touch(Y);
   mi_ctx *ctx = A->ctx;
   if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi > 0) {
     // Row-sharded matrix (8(e): "LOBPCG: row-shard S"): four columns at a time through the row-major sharded

@@ -387,6 +387,7 @@ void mi_lsqr_default_params(mi_lsqr_params *p) {
 int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_params *prm, mi_vec *x_out,
             mi_lsqr_result *result) {
   MI_REQUIRE(ctx && A && At && b && prm && x_out && result, "null argument");
+  touch(x_out);
   RangeScope range("mi_lsqr");
   // the reference's own argument checks (:573-590), same messages
   MI_REQUIRE(!(prm->lambda < 0), "Tikhonov regularization parameter (lambda) must be a nonnegative real value");

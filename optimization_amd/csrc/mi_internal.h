@@ -119,11 +119,16 @@ struct mi_ctx {
   mi::CgState *cg1 = nullptr;       // device, copy 1
   mi::CgState *cg_host = nullptr;   // pinned copy for read-back
   const mi::CgState *cg_live = nullptr;  // state copy operators may consult to skip work after exit
+  // mi_stpcg with defer_result: the state copy into cg_host is in flight behind this event (mi_stpcg_collect)
+  hipEvent_t cg_deferred_ev = nullptr;
+  bool cg_deferred = false;
+  size_t cg_deferred_hvp = 0;
   mi::HostStatus *status = nullptr;      // pinned, device-visible
   mi::HostStatus *status_dev = nullptr;  // device pointer of the same memory
   double *trace_dev = nullptr;           // 4 x trace_cap doubles
   size_t trace_cap = 0;
   unsigned int epoch = 0;
+  uint64_t vec_serial = 0;  // mi_vec::serial source
   size_t host_syncs = 0;  // stream synchronisations the library made on this context (mi_ctx_sync_count)
   // pinned staging ring for small host -> device uploads that must not stall the host (stage_upload, context.hip)
   static constexpr int kStageSlots = 4;
@@ -149,7 +154,17 @@ struct mi_vec {
   size_t n;
   double *d;
   bool owned;  // storage belongs to the pool
+  // Identity of the CONTENTS, for caches keyed on "this vector as it was when I looked" (the speculative trial point
+  // of mi_stiefel_rq_trial): `serial` is unique per mi_vec_create/mi_vec_view on a context (handles and pooled
+  // device pointers are both recycled), `gen` is bumped by every entry point that writes the vector (mi::touch).
+  uint64_t serial = 0;
+  uint64_t gen = 0;
 };
+namespace mi {
+inline void touch(mi_vec *v) {
+  if (v) ++v->gen;
+}
+}  // namespace mi
 
 namespace mi {
 

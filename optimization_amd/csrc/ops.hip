@@ -179,6 +179,7 @@ int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out) {
   MI_REQUIRE(op && in && out, "null argument");
   MI_REQUIRE(in->n == op->n && out->n == (op->n_out ? op->n_out : op->n), "operator dimension mismatch");
   MI_REQUIRE(in->d != out->d, "operator input and output must not alias");
+  touch(out);
   return op->apply(op, in, out);
 }
 
@@ -268,6 +269,7 @@ int mi_precon_create_block3(mi_ctx *ctx, const mi_vec *inv_blocks, mi_precon **o
 int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v) {
   MI_REQUIRE(P && r && v, "null argument");
   MI_REQUIRE(r->n == P->n && v->n == P->n, "preconditioner dimension mismatch");
+  touch(v);
   return P->apply(P, r, v);
 }
 

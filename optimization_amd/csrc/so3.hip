@@ -273,6 +273,18 @@ struct mi_so3n {
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
   mi_op hess;
   mi_precon bj;
+  const mi_vec *R = nullptr;                // the point the model is bound to (mi_so3n_model)
+  // mi_so3n_trial: the model assembled speculatively at the trial point (a second set of the arrays above plus the
+  // gradient), swapped in by the next mi_so3n_model call if that call is for the same vector -- keyed on the
+  // handle AND the identity of its contents (mi_vec::serial / gen), as in stiefel.hip
+  mi_vec *Dblk_next = nullptr, *Dinv_next = nullptr, *grad_next = nullptr, *Hh = nullptr, *Pg = nullptr;
+  double *Bblk_next = nullptr, *Dsl_next = nullptr;
+  const mi_vec *trial_R = nullptr;
+  const double *trial_d = nullptr;
+  uint64_t trial_serial = 0, trial_gen = 0;
+  bool is_trial(const mi_vec *X) const {
+    return trial_R == X && trial_d == X->d && trial_serial == X->serial && trial_gen == X->gen;
+  }
 };
 
 namespace {
@@ -414,8 +426,14 @@ int mi_so3n_destroy(mi_so3n *q) {
   (void)hipFree(q->ei); (void)hipFree(q->ej); (void)hipFree(q->Rt); (void)hipFree(q->w);
   (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr); (void)hipFree(q->edge); (void)hipFree(q->dir);
   (void)hipFree(q->Bblk); (void)hipFree(q->perm); (void)hipFree(q->Dsl);
+  (void)hipFree(q->Bblk_next); (void)hipFree(q->Dsl_next);
   mi_vec_destroy(q->Dblk);
   mi_vec_destroy(q->Dinv);
+  mi_vec_destroy(q->Dblk_next);
+  mi_vec_destroy(q->Dinv_next);
+  mi_vec_destroy(q->grad_next);
+  mi_vec_destroy(q->Hh);
+  mi_vec_destroy(q->Pg);
   delete q;
   return MI_OK;
 }
@@ -440,12 +458,25 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
   MI_REQUIRE(q && R && grad, "null argument");
   MI_REQUIRE(R->ctx == q->ctx && R->n == 9 * q->N, "R must hold N row-major 3x3 blocks");
   MI_REQUIRE(grad->n == 3 * q->N, "gradient must hold 3N doubles");
+  touch(grad);
   mi_ctx *ctx = q->ctx;
-  const int grid = (int)((q->nslices + 3) / 4);
-  hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
-                     (const double *)q->Rt, (const double *)q->w, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk,
-                     q->Dsl);
-  MI_HIP(hipGetLastError());
+  if (q->is_trial(R)) {
+    // R is the point mi_so3n_trial just evaluated: its model exists already
+    std::swap(q->Dblk, q->Dblk_next);
+    std::swap(q->Dinv, q->Dinv_next);
+    std::swap(q->Bblk, q->Bblk_next);
+    std::swap(q->Dsl, q->Dsl_next);
+    q->bj.data = q->Dinv->d;
+    MI_TRY(mi_vec_copy(grad, q->grad_next));
+  } else {
+    const int grid = (int)((q->nslices + 3) / 4);
+    hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
+                       (const double *)q->Rt, (const double *)q->w, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk,
+                       q->Dsl);
+    MI_HIP(hipGetLastError());
+  }
+  q->trial_R = nullptr;
+  q->R = R;
   if (hess) *hess = &q->hess;
   if (block_jacobi) *block_jacobi = &q->bj;
   return MI_OK;
@@ -454,9 +485,88 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
 int mi_so3n_retract(mi_so3n *q, const mi_vec *R, const mi_vec *xi, mi_vec *Y) {
   MI_REQUIRE(q && R && xi && Y, "null argument");
   MI_REQUIRE(R->n == 9 * q->N && Y->n == 9 * q->N && xi->n == 3 * q->N, "dimension mismatch");
+  touch(Y);
   hipLaunchKernelGGL(k_so3_retract, dim3(grid_for(q->ctx, q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
                      (const double *)R->d, (const double *)xi->d, Y->d);
   MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// One trial step of a trust-region method at the point R the model is bound to (reference Riemannian/TNT.h:493-512,
+// 573-585): Hess h with |h|^2, <g,h>, <h,Hess h>; R+ = retract(R, h); f(R+); and -- speculatively -- the model at R+
+// (gradient, Hessian blocks, block-Jacobi inverse blocks) with |grad f(R+)|^2 and, if asked, |M+^-1 grad f(R+)|^2: ONE
+// launch chain, ONE read-back.  Every number comes from the kernels, grids and summation orders the separate calls
+// (mi_op_apply + mi_vec_dot_batch, mi_so3n_retract, mi_so3n_objective, mi_so3n_model, mi_vec_dot, mi_precon_apply)
+// use.  out[6] = {f(R+), <h,h>, <g,h>, <h,Hess h>, |grad f(R+)|^2, |M+^-1 grad f(R+)|^2 (-1 unless with_precon)}.
+int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g, int with_precon, mi_vec *R_trial,
+                  double out[6]) {
+  MI_REQUIRE(q && R && h && g && R_trial && out, "null argument");
+  MI_REQUIRE(q->R == R, "mi_so3n_trial: the model is not bound to this R (call mi_so3n_model first)");
+  MI_REQUIRE(R->n == 9 * q->N && R_trial->n == 9 * q->N && h->n == 3 * q->N && g->n == 3 * q->N, "dimension mismatch");
+  MI_REQUIRE(R_trial->d != R->d, "the trial point must not alias the current one");
+  mi_ctx *ctx = q->ctx;
+  const size_t N3 = 3 * q->N;
+  if (!q->grad_next) {
+    MI_TRY(mi_vec_create(ctx, 9 * q->N, &q->Dblk_next));
+    MI_TRY(mi_vec_create(ctx, 9 * q->N, &q->Dinv_next));
+    MI_TRY(mi_vec_create(ctx, N3, &q->grad_next));
+    MI_TRY(mi_vec_create(ctx, N3, &q->Hh));
+    MI_TRY(mi_vec_create(ctx, N3, &q->Pg));
+    MI_HIP(hipMalloc((void **)&q->Bblk_next, std::max<size_t>(1, q->padded * 9) * sizeof(double)));
+    MI_HIP(hipMalloc((void **)&q->Dsl_next, q->nslices * 9 * 64 * sizeof(double)));
+  }
+  q->trial_R = nullptr;
+  // (a) Hess h, then |h|^2, <g,h>, <h, Hess h> in one pass (as MI355::dot_batch does)
+  MI_TRY(so3_apply(&q->hess, h, q->Hh));
+  {
+    const double *xs[3] = {h->d, g->d, h->d}, *ys[3] = {h->d, h->d, q->Hh->d};
+    MI_TRY(dot_batch_to_slots(ctx, 3, xs, ys, N3, SLOT_MISC));
+  }
+  // (b) R+ = R exp(hat h)
+  MI_TRY(mi_so3n_retract(q, R, h, R_trial));
+  // (c) f(R+), reduced exactly as mi_so3n_objective does
+  {
+    const int grid = grid_for(ctx, q->E, 1);
+    hipLaunchKernelGGL(k_so3_objective, dim3(grid), dim3(kBlock), 0, ctx->stream, q->E, (const int *)q->ei,
+                       (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R_trial->d,
+                       ctx->partials2);
+    MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, 1, ctx->scalars + SLOT_MISC + 3));
+  }
+  // (d) the model at R+ into the second set of arrays
+  {
+    const int grid = (int)((q->nslices + 3) / 4);
+    hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
+                       (const double *)q->Rt, (const double *)q->w, q->grad_next->d, q->Dblk_next->d,
+                       q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
+    MI_HIP(hipGetLastError());
+  }
+  {
+    const double *xs[1] = {q->grad_next->d}, *ys[1] = {q->grad_next->d};
+    MI_TRY(dot_batch_to_slots(ctx, 1, xs, ys, N3, SLOT_MISC + 4));
+  }
+  if (with_precon) {
+    mi_precon *tmp = nullptr;
+    MI_TRY(mi_precon_create_block3(ctx, q->Dinv_next, &tmp));
+    const int s = mi_precon_apply(tmp, q->grad_next, q->Pg);
+    mi_precon_destroy(tmp);
+    MI_TRY(s);
+    const double *xs[1] = {q->Pg->d}, *ys[1] = {q->Pg->d};
+    MI_TRY(dot_batch_to_slots(ctx, 1, xs, ys, N3, SLOT_MISC + 5));
+  }
+  // (e) one read-back
+  static_assert(SLOT_MISC + 6 <= SLOT_GDIR, "slot map");
+  double buf[6];
+  MI_TRY(read_slots_sync(ctx, SLOT_MISC, with_precon ? 6 : 5, buf));
+  out[0] = .5 * buf[3];
+  out[1] = buf[0];
+  out[2] = buf[1];
+  out[3] = buf[2];
+  out[4] = buf[4];
+  out[5] = with_precon ? buf[5] : -1.0;
+  q->trial_R = R_trial;
+  q->trial_d = R_trial->d;
+  q->trial_serial = R_trial->serial;
+  q->trial_gen = R_trial->gen;
   return MI_OK;
 }
 

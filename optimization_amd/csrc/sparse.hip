@@ -663,6 +663,7 @@ int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W) {
   MI_REQUIRE(V->n == A->n * (size_t)p && W->n == A->n * (size_t)p,
              "SpMM dimension mismatch: A has %zu rows, p=%d, V %zu, W %zu", A->n, p, V->n, W->n);
   MI_REQUIRE(V->d != W->d, "SpMM input and output must not alias");
+  touch(W);
   MI_TRY(comm_halo_exchange(A->ctx, A, p, V->d));
   return csr_spmm_launch(A, p, V->d, W->d);
 }

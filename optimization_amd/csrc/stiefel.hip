@@ -595,8 +595,20 @@ struct mi_stiefel_rq {
   // to the next mi_stiefel_rq_model call if that call is for the same vector
   double *S_next = nullptr;
   mi_vec *Y_next = nullptr, *grad_next = nullptr, *Hh = nullptr;
+  // The cache key is the trial vector's handle AND its contents' identity (mi_vec::serial / gen): handles and pooled
+  // device pointers are both recycled, and an in-place write must invalidate the speculation too.
   const mi_vec *trial_X = nullptr;
   const double *trial_d = nullptr;
+  uint64_t trial_serial = 0, trial_gen = 0;
+  void remember_trial(const mi_vec *Xt) {
+    trial_X = Xt;
+    trial_d = Xt->d;
+    trial_serial = Xt->serial;
+    trial_gen = Xt->gen;
+  }
+  bool is_trial(const mi_vec *X) const {
+    return trial_X == X && trial_d == X->d && trial_serial == X->serial && trial_gen == X->gen;
+  }
 };
 
 namespace {
@@ -780,6 +792,7 @@ int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec 
 int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, mi_vec *out) {
   MI_TRY(check_np(ctx, n, p, X, Z, out));
   MI_REQUIRE(X && Z && out, "null argument");
+  touch(out);
   const int grid = row_grid(ctx, n);
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
@@ -790,6 +803,7 @@ int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
 int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *V, mi_vec *Y) {
   MI_TRY(check_np(ctx, n, p, X, V, Y));
   MI_REQUIRE(X && V && Y, "null argument");
+  touch(Y);
   const int grid = row_grid(ctx, n);
   KScope ks(ctx, MI_K_STIEFEL_RETRACT);
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
@@ -872,7 +886,8 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   MI_REQUIRE(q && X && grad, "null argument");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, grad, nullptr));
   int count = 0;
-  if (q->trial_X == X && q->trial_d == X->d) {
+  touch(grad);
+  if (q->is_trial(X)) {
     // X is the point mi_stiefel_rq_trial just evaluated: A X, S and the gradient exist already
     std::swap(q->Y, q->Y_next);
     std::swap(q->S_dev, q->S_next);
@@ -953,8 +968,7 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
   out[2] = buf[SLOT_MISC - SLOT_GRAM + 1];
   out[3] = buf[SLOT_MISC - SLOT_GRAM + 2];
   out[4] = buf[SLOT_MISC - SLOT_GRAM + 3];
-  q->trial_X = X_trial;
-  q->trial_d = X_trial->d;
+  q->remember_trial(X_trial);
   return MI_OK;
 }
 
@@ -965,6 +979,7 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
 int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *g, double t, mi_vec *h_out,
                                mi_vec *X_trial, double out[2]) {
   MI_REQUIRE(q && X && g && h_out && X_trial && out, "null argument");
+  MI_REQUIRE(q->X == X, "mi_stiefel_rq_armijo_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, g, h_out));
   MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;
@@ -976,6 +991,7 @@ int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *
     MI_HIP(hipMalloc((void **)&q->S_next, 16 * sizeof(double)));
   }
   q->trial_X = nullptr;
+  touch(X_trial);
   MI_TRY(mi_vec_scale_to(h_out, -t, g));  // h = -t * g (:276)
   MI_TRY(mi_stiefel_retract(ctx, q->n, q->p, X, h_out, X_trial));
   int count = 0;
@@ -997,8 +1013,7 @@ int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *
   }
   out[0] = .5 * tr;
   out[1] = buf[SLOT_MISC - SLOT_GRAM];
-  q->trial_X = X_trial;
-  q->trial_d = X_trial->d;
+  q->remember_trial(X_trial);
   return MI_OK;
 }
 

@@ -664,6 +664,32 @@ void mi_stpcg_default_params(mi_stpcg_params *p) {
   p->theta = .5;
   p->epsilon = 1e-8;  // :179
   p->run_ahead = 3;
+  p->defer_result = 0;
+}
+
+int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result) {
+  MI_REQUIRE(ctx && result, "null argument");
+  MI_REQUIRE(ctx->cg_deferred, "mi_stpcg_collect: no deferred solve is pending on this context");
+  ctx->cg_deferred = false;
+  hipError_t e = hipEventQuery(ctx->cg_deferred_ev);
+  if (e == hipErrorNotReady) {
+    e = hipEventSynchronize(ctx->cg_deferred_ev);
+    ctx->host_syncs++;
+  }
+  if (e != hipSuccess) return hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__);
+  int ipc_err = 0;
+  (void)mi_comm_ipc_error(ctx, &ipc_err);
+  if (ipc_err) {
+    set_error("a wait in the peer-memory exchange layer timed out: the result of this solve is invalid");
+    return MI_ERR_COMM;
+  }
+  const CgState &f = *ctx->cg_host;
+  result->update_step_M_norm = f.M_norm;
+  result->num_iterations = (size_t)f.k;
+  result->exit_reason = f.exit_reason;
+  result->rv_final = f.rv;
+  result->hvp_calls = ctx->cg_deferred_hvp;
+  return MI_OK;
 }
 
 int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpcg_params *prm,
@@ -673,6 +699,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   MI_REQUIRE(g->n == s_out->n && g->n == H->n, "dimension mismatch: g %zu, s %zu, H %zu", g->n,
              s_out->n, H->n);
   MI_REQUIRE(g->d != s_out->d, "g and s_out must not alias");
+  touch(s_out);
   MI_REQUIRE(!P || (P->ctx == ctx && P->n == g->n), "preconditioner dimension/context mismatch");
   // reference argument checks, IterativeSolvers.h:183-205
   MI_REQUIRE(prm->Delta > 0, "Trust-region radius (Delta) must be a positive real value");
@@ -718,6 +745,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     tcap = ctx->trace_cap;  // layout stride
   }
 
+  ctx->cg_deferred = false;  // (a result nobody collected is superseded)
   ctx->epoch++;
   ctx->status->word = 0;
   ctx->status->epoch = ctx->epoch;
@@ -899,7 +927,20 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
 
   // --- read back the final state ----------------------------------------------------------------
-  {
+  if (prm->defer_result && !(trace && trace->cap)) {
+    // the copy travels behind the solve; whoever waits for the stream next (or mi_stpcg_collect) completes it
+    hipError_t e = hipSuccess;
+    if (!ctx->cg_deferred_ev) e = hipEventCreateWithFlags(&ctx->cg_deferred_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipEventRecord(ctx->cg_deferred_ev, st);
+    if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__));
+    ctx->cg_deferred = true;
+    ctx->cg_deferred_hvp = result->hvp_calls;
+    result->update_step_M_norm = 0;
+    result->num_iterations = 0;
+    result->exit_reason = -1;
+    result->rv_final = 0;
+  } else {
     hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     ctx->host_syncs++;

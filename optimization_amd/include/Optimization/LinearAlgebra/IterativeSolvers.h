@@ -89,10 +89,14 @@ bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args
     prm.kappa_fgr = kappa_fgr;
     prm.theta = theta;
     prm.epsilon = epsilon;
+    // a caller that reads the result together with its own next chain (TNT's fused trial step): no wait here
+    DeferScope *defer = DeferScope::active();
+    prm.defer_result = defer ? 1 : 0;
     mi_stpcg_result res;
     s_out = DeviceVector::like(g);
     check(mi_stpcg(g.context(), g.handle(), dop->op, prec, &prm, s_out.handle(), &res, nullptr));
-    update_step_M_norm = res.update_step_M_norm;
+    if (defer) defer->taken_on(g.context());
+    update_step_M_norm = res.update_step_M_norm;  // (placeholders in deferred mode: DeferScope::collect)
     num_iterations = res.num_iterations;
     return true;
   }

@@ -236,6 +236,35 @@ inline std::vector<double> dot_batch(std::initializer_list<std::pair<const Devic
   return out;
 }
 
+// A caller that is about to enqueue more device work right behind an inner solve and will read everything back with
+// one wait (TNT's fused trial step) opens a DeferScope around its STPCG call: the fused solver (mi_stpcg) then returns
+// without waiting for the device -- the step is valid in stream order -- and the scope's collect() delivers
+// |s|_M and the iteration count afterwards (mi_stpcg_collect; no wait if something else has synchronised since).
+// Thread-local, so concurrent optimizers on different contexts/threads do not see each other's requests.
+struct DeferScope {
+  explicit DeferScope(bool want) : prev_(slot()) { slot() = want ? this : nullptr; }
+  ~DeferScope() { slot() = prev_; }
+  DeferScope(const DeferScope &) = delete;
+  DeferScope &operator=(const DeferScope &) = delete;
+  static DeferScope *active() { return slot(); }
+  void taken_on(mi_ctx *ctx) { ctx_ = ctx; }
+  bool taken() const { return ctx_ != nullptr; }
+  mi_stpcg_result collect() {
+    mi_stpcg_result r{};
+    check(mi_stpcg_collect(ctx_, &r));
+    ctx_ = nullptr;
+    return r;
+  }
+
+ private:
+  static DeferScope *&slot() {
+    static thread_local DeferScope *s = nullptr;
+    return s;
+  }
+  DeferScope *prev_;
+  mi_ctx *ctx_ = nullptr;
+};
+
 template <typename T>
 struct is_device_vector : std::false_type {};
 template <>
@@ -271,6 +300,28 @@ struct DeviceOperator {
     return out;
   }
 };
+// Callables handed out by a problem object (MI355/Stiefel.h, MI355/SO3.h) carry the address of that object as
+// `owner`.  TNT / GradientDescent replace their statement-by-statement trial step by the owner's fused chain only
+// when the objective, the model (through the Hessian it sets), the gradient field and the retraction ALL name the
+// same owner -- a wrapped, penalised or logging objective, or callables of two different problem objects, keep the
+// reference's statement sequence (which always calls the supplied f and metric).
+struct DeviceObjective {
+  const void *owner = nullptr;
+  std::function<double(const DeviceVector &)> f;
+  template <typename... A>
+  double operator()(const DeviceVector &X, A &...) const {
+    return f(X);
+  }
+};
+struct DeviceGradientField {
+  const void *owner = nullptr;
+  std::function<DeviceVector(const DeviceVector &)> grad;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &X, A &...) const {
+    return grad(X);
+  }
+};
+
 // Riemannian::Retraction whose owner can evaluate a WHOLE TRIAL STEP of a trust-region method in one launch chain
 // with one read-back (reference Riemannian/TNT.h:493-512,573-585): the step norm, x_trial = retract(x, h), f(x_trial),
 // <g,h>, <h, Hess h> and, speculatively, the gradient norm at x_trial.  TNT recognises it (std::function::target) and
@@ -279,6 +330,9 @@ struct DeviceTrialRetraction {
   struct Trial {
     DeviceVector x_trial;
     double f_trial, hh, gh, hHh, grad_trial_sqnorm;
+    // |M^-1 grad f(x_trial)|^2 with the OWNER's preconditioner rebuilt at x_trial (TNT.h:578-580), or < 0 when the
+    // owner has none / it was not requested
+    double precon_grad_trial_sqnorm = -1;
   };
   // the same for a backtracking line search along -g (Riemannian/GradientDescent.h:266-286): h = -t g, x_trial,
   // f(x_trial) and the squared gradient norm at x_trial, one read-back per trial
@@ -286,8 +340,10 @@ struct DeviceTrialRetraction {
     DeviceVector h, x_trial;
     double f_trial, grad_trial_sqnorm;
   };
+  const void *owner = nullptr;
   std::function<DeviceVector(const DeviceVector &, const DeviceVector &)> retract;
-  std::function<Trial(const DeviceVector &x, const DeviceVector &h, const DeviceVector &grad)> trial;
+  // with_precon: the caller runs TNT with the owner's preconditioner and wants |M^-1 grad|^2 at x_trial as well
+  std::function<Trial(const DeviceVector &x, const DeviceVector &h, const DeviceVector &grad, bool with_precon)> trial;
   std::function<ArmijoTrial(const DeviceVector &x, const DeviceVector &grad, double t)> armijo;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &X, const DeviceVector &V, A &...) const {
@@ -298,6 +354,7 @@ struct DeviceTrialRetraction {
 // backed by an mi_op that is already bound to the base point X
 struct DeviceHessian {
   mi_op *op = nullptr;
+  const void *owner = nullptr;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &, const DeviceVector &v, A &...) const {
     DeviceVector out = DeviceVector::like(v);
@@ -308,6 +365,7 @@ struct DeviceHessian {
 // Riemannian::LinearOperator used as TNT's `precon`, backed by an mi_precon bound to X
 struct DevicePreconditioner {
   mi_precon *P = nullptr;
+  const void *owner = nullptr;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &, const DeviceVector &r, A &...) const {
     DeviceVector out = DeviceVector::like(r);

@@ -33,11 +33,11 @@ class RotationAveraging {
   size_t rotations() const { return N_; }
 
   Objective<Vector, double> objective() {
-    return [this](const Vector &R) {
-      double f = 0;
-      check(mi_so3n_objective(prob_, R.handle(), &f));
-      return f;
-    };
+    return DeviceObjective{this, [this](const Vector &R) {
+                             double f = 0;
+                             check(mi_so3n_objective(prob_, R.handle(), &f));
+                             return f;
+                           }};
   }
   // gradient in so(3)^N coordinates + the 3x3-block sparse Hessian assembled at R; also refreshes the
   // block-Jacobi preconditioner returned by preconditioner()
@@ -46,11 +46,37 @@ class RotationAveraging {
       if (grad.empty() || grad.size() != 3 * N_) grad = Vector(ctx_, 3 * N_);
       mi_op *op = nullptr;
       check(mi_so3n_model(prob_, R.handle(), grad.handle(), &op, &bj_));
-      Hess = DeviceHessian{op};
+      Hess = DeviceHessian{op, this};
     };
   }
   Riemannian::RiemannianMetric<Vector, Vector, double> metric() { return FrobeniusMetric{}; }
+  // R_i exp(hat(xi_i)) -- tagged: TNT evaluates a whole trial step (retraction, f at the trial point, the
+  // predicted-decrease terms, the model and both gradient norms at the trial point) through mi_so3n_trial, one read-back
   Riemannian::Retraction<Vector, Vector> retraction() {
+    DeviceTrialRetraction r;
+    r.owner = this;
+    r.retract = [this](const Vector &R, const Vector &xi) {
+      Vector Y = Vector::like(R);
+      check(mi_so3n_retract(prob_, R.handle(), xi.handle(), Y.handle()));
+      return Y;
+    };
+    r.trial = [this](const Vector &R, const Vector &h, const Vector &g, bool with_precon) {
+      DeviceTrialRetraction::Trial t;
+      t.x_trial = Vector::like(R);
+      double out[6];
+      check(mi_so3n_trial(prob_, R.handle(), h.handle(), g.handle(), with_precon ? 1 : 0, t.x_trial.handle(), out));
+      t.f_trial = out[0];
+      t.hh = out[1];
+      t.gh = out[2];
+      t.hHh = out[3];
+      t.grad_trial_sqnorm = out[4];
+      t.precon_grad_trial_sqnorm = out[5];
+      return t;
+    };
+    return r;
+  }
+  // the same without the tag (one call per statement of the reference's loop)
+  Riemannian::Retraction<Vector, Vector> plain_retraction() {
     return [this](const Vector &R, const Vector &xi) {
       Vector Y = Vector::like(R);
       check(mi_so3n_retract(prob_, R.handle(), xi.handle(), Y.handle()));
@@ -66,7 +92,7 @@ class RotationAveraging {
       mi_op *op = nullptr;
       check(mi_so3n_model(prob_, tmpR.handle(), tmpg.handle(), &op, &bj_));
     }
-    return DevicePreconditioner{bj_};
+    return DevicePreconditioner{bj_, this};
   }
 
  private:

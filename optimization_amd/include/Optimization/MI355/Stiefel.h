@@ -43,12 +43,14 @@ class StiefelRayleighQuotient {
   const Context &context() const { return ctx_; }
 
   // f(X) = 1/2 tr(X' A X)
+  // (tagged with this object as owner: TNT / GradientDescent fuse the trial step only when objective, model,
+  // gradient field and retraction all come from the same problem object -- MI355/Device.h)
   Objective<Vector, double> objective() {
-    return [this](const Vector &X) {
-      double f = 0;
-      check(mi_stiefel_rq_objective(prob_, X.handle(), &f));
-      return f;
-    };
+    return DeviceObjective{this, [this](const Vector &X) {
+                             double f = 0;
+                             check(mi_stiefel_rq_objective(prob_, X.handle(), &f));
+                             return f;
+                           }};
   }
   // grad f(X) = A X - X sym(X'AX);  Hess f(X)[V] = P_X(A V - V sym(X'AX)) as a device operator
   Riemannian::QuadraticModel<Vector, Vector> quadratic_model() {
@@ -56,7 +58,7 @@ class StiefelRayleighQuotient {
       if (grad.empty() || grad.size() != n_ * (size_t)p_) grad = Vector(ctx_, n_ * (size_t)p_);
       mi_op *op = nullptr;
       check(mi_stiefel_rq_model(prob_, X.handle(), grad.handle(), &op));
-      Hess = DeviceHessian{op};
+      Hess = DeviceHessian{op, this};
     };
   }
   Riemannian::RiemannianMetric<Vector, Vector, double> metric() { return FrobeniusMetric{}; }
@@ -64,12 +66,13 @@ class StiefelRayleighQuotient {
   // trial point, the predicted-decrease terms, the next gradient) through mi_stiefel_rq_trial, one read-back
   Riemannian::Retraction<Vector, Vector> retraction() {
     DeviceTrialRetraction r;
+    r.owner = this;
     r.retract = [this](const Vector &X, const Vector &V) {
       Vector Y = Vector::like(X);
       check(mi_stiefel_retract(ctx_.get(), n_, p_, X.handle(), V.handle(), Y.handle()));
       return Y;
     };
-    r.trial = [this](const Vector &X, const Vector &h, const Vector &g) {
+    r.trial = [this](const Vector &X, const Vector &h, const Vector &g, bool /*with_precon: none owned*/) {
       DeviceTrialRetraction::Trial t;
       t.x_trial = Vector::like(X);
       double out[5];
@@ -95,11 +98,11 @@ class StiefelRayleighQuotient {
   }
   // grad f(X) as a VectorField (GradientDescent's interface); after a fused trial at X it is already there
   Riemannian::VectorField<Vector, Vector> gradient() {
-    return [this](const Vector &X) {
-      Vector grad(ctx_, n_ * (size_t)p_);
-      check(mi_stiefel_rq_model(prob_, X.handle(), grad.handle(), nullptr));
-      return grad;
-    };
+    return DeviceGradientField{this, [this](const Vector &X) {
+                                 Vector grad(ctx_, n_ * (size_t)p_);
+                                 check(mi_stiefel_rq_model(prob_, X.handle(), grad.handle(), nullptr));
+                                 return grad;
+                               }};
   }
   // the same without the tag (one call per statement of the reference's loop)
   Riemannian::Retraction<Vector, Vector> plain_retraction() {

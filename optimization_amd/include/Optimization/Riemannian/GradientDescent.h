@@ -135,7 +135,9 @@ GradientDescentResult<Variable, Scalar> GradientDescent(
     bool sufficient = false;
     // Device path: a tagged retraction (MI355::DeviceTrialRetraction, Frobenius metric) evaluates a whole Armijo
     // trial -- h = -t g, the retraction, f at the trial point and, speculatively, the gradient norm there -- as one
-    // launch chain with one read-back.
+    // launch chain with one read-back.  Only when the objective and the gradient field name the SAME problem object
+    // as the retraction's owner: the chain evaluates the owner's f and gradient, and a wrapped / penalised / logging
+    // objective must get the calls the reference makes.
     bool fused_trial = false;
     Scalar trial_grad_sqnorm = 0;
 #if OPTIMIZATION_GD_HAVE_MI355
@@ -144,7 +146,11 @@ GradientDescentResult<Variable, Scalar> GradientDescent(
                   sizeof...(Args) == 0) {
       if (metric.template target<MI355::FrobeniusMetric>()) {
         armijo = retract.template target<MI355::DeviceTrialRetraction>();
-        if (armijo && !armijo->armijo) armijo = nullptr;
+        const auto *fo = f.template target<MI355::DeviceObjective>();
+        const auto *go = grad_f.template target<MI355::DeviceGradientField>();
+        if (armijo && !(armijo->armijo && armijo->owner && fo && fo->owner == armijo->owner && go &&
+                        go->owner == armijo->owner))
+          armijo = nullptr;
       }
     }
 #endif

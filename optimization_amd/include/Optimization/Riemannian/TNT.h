@@ -242,35 +242,60 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
       break;
     }
 
+    // Device path: a retraction whose owner evaluates the whole trial step (|h|, x_trial, f(x_trial), <g,h>,
+    // <h,Hess h> and the gradient norm(s) at x_trial) as one launch chain with one read-back -- :493-512 and :573-585
+    // in one call.  Taken only when the objective, the Hessian the model set and the retraction all name the SAME
+    // problem object as owner (the chain evaluates the owner's f and Hessian: a wrapped / penalised / logging
+    // objective, or callables of two problems, must keep the statement sequence below, which calls what was
+    // supplied), with the Frobenius metric.  A preconditioner does not matter to the chain; if it is the owner's,
+    // the chain also delivers |M^-1 grad| at the trial point.
+    bool step_scalars_batched = false, trial_done = false;
+    Scalar gh = 0, hHh = 0, trial_grad_sqnorm = 0, trial_precon_grad_sqnorm = -1;
+#if OPTIMIZATION_HAVE_MI355
+    const MI355::DeviceTrialRetraction *fused_trial = nullptr;
+    bool owners_precon = false;
+    if constexpr (device_types) {
+      const auto *tr = retract.template target<MI355::DeviceTrialRetraction>();
+      const auto *fo = f.template target<MI355::DeviceObjective>();
+      const auto *dh = Hess.template target<MI355::DeviceHessian>();
+      if (tr && tr->trial && tr->owner && fo && fo->owner == tr->owner && dh && dh->owner == tr->owner &&
+          metric.template target<MI355::FrobeniusMetric>())
+        fused_trial = tr;
+      if (fused_trial && precon)
+        if (const auto *dp = precon->template target<MI355::DevicePreconditioner>())
+          owners_precon = dp->owner == fused_trial->owner;
+    }
+    // with a fused trial step right behind it, the fused inner solve does not wait for the device either: one
+    // read-back serves both (MI355::DeferScope)
+    MI355::DeferScope defer(fused_trial != nullptr);
+#endif
+
     // inner solve                                                                   :488-493
     size_t inner_iterations;
     Tangent h = LA::STPCG<Tangent, Multiplier, Scalar, Args...>(
         grad, H, inner_product, args..., h_M_norm, inner_iterations, Delta, params.max_TPCG_iterations,
         params.kappa_fgr, params.theta, Pop);
-    // Device path (Frobenius metric, tagged Hessian): the three step scalars |h|^2, <g,h>, <h,Hess h> of
-    // :496,:511-512 come from ONE pass and ONE synchronisation instead of three (the Hessian application is a
-    // pure device operation, so evaluating it before the retraction is unobservable).
-    bool step_scalars_batched = false, trial_done = false;
-    Scalar gh = 0, hHh = 0, trial_grad_sqnorm = 0;
 #if OPTIMIZATION_HAVE_MI355
     if constexpr (device_types) {
-      // A retraction whose owner evaluates the whole trial step (|h|, x_trial, f(x_trial), <g,h>, <h,Hess h> and the
-      // gradient norm at x_trial) in one launch chain with one read-back: :493-512 and :573-585 in one call.
-      if (!precon && metric.template target<MI355::FrobeniusMetric>() &&
-          Hess.template target<MI355::DeviceHessian>()) {
-        if (const auto *tr = retract.template target<MI355::DeviceTrialRetraction>()) {
-          if (tr->trial) {
-            auto t = tr->trial(x, h, grad);
-            x_trial = std::move(t.x_trial);
-            fx_trial = t.f_trial;
-            h_norm = sqrt(t.hh);
-            gh = t.gh;
-            hHh = t.hHh;
-            trial_grad_sqnorm = t.grad_trial_sqnorm;
-            step_scalars_batched = trial_done = true;
-          }
-        }
+      if (fused_trial) {
+        auto t = fused_trial->trial(x, h, grad, owners_precon);
+        x_trial = std::move(t.x_trial);
+        fx_trial = t.f_trial;
+        h_norm = sqrt(t.hh);
+        gh = t.gh;
+        hHh = t.hHh;
+        trial_grad_sqnorm = t.grad_trial_sqnorm;
+        trial_precon_grad_sqnorm = t.precon_grad_trial_sqnorm;
+        step_scalars_batched = trial_done = true;
       }
+      if (defer.taken()) {  // |h|_M and the pass count of the inner solve (no wait: the trial's read-back was behind it)
+        const mi_stpcg_result sr = defer.collect();
+        h_M_norm = sr.update_step_M_norm;
+        inner_iterations = sr.num_iterations;
+      }
+      // Without such a retraction (Frobenius metric, tagged Hessian): the three step scalars |h|^2, <g,h>,
+      // <h,Hess h> of :496,:511-512 come from ONE pass and ONE synchronisation instead of three (the Hessian
+      // application is a pure device operation, so evaluating it before the retraction is unobservable).
       if (!trial_done && metric.template target<MI355::FrobeniusMetric>() &&
           Hess.template target<MI355::DeviceHessian>()) {
         const Tangent Hh = Hess(x, h, args...);
@@ -338,8 +363,16 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
       }
       QM(x, grad, Hess, args...);
       retag_for_device();
-      if (trial_done) {  // (|grad f(x_trial)|^2 came with the trial step; no preconditioner on this path)
-        grad_norm = precon_grad_norm = sqrt(trial_grad_sqnorm);
+      if (trial_done) {  // |grad f(x_trial)|^2 came with the trial step                  :575-585
+        grad_norm = sqrt(trial_grad_sqnorm);
+        if (!precon) {
+          precon_grad_norm = grad_norm;
+        } else if (trial_precon_grad_sqnorm >= 0) {  // ... and so did |M^-1 grad|^2 (the owner's preconditioner)
+          precon_grad_norm = sqrt(trial_precon_grad_sqnorm);
+        } else {
+          Tangent Pg = (*precon)(x, grad, args...);
+          precon_grad_norm = sqrt(metric(x, Pg, Pg, args...));
+        }
       } else {
         measure_gradient();
       }

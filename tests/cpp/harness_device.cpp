@@ -260,6 +260,12 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
   RM::RiemannianMetric<DeviceVector, DeviceVector> metric = prob.metric();
   RM::Retraction<DeviceVector, DeviceVector> retract = prob.retraction();
   if (mode == 2) retract = prob.plain_retraction();  // tagged model and metric, but no fused trial step
+  if (mode == 3) {
+    // a client's own objective on top of the problem's (here: + 1) with the problem's tagged model and retraction:
+    // TNT must call THIS f (the reference always calls the supplied f), i.e. keep the statement sequence
+    auto ft = prob.objective();
+    f = [ft](const DeviceVector &X) { return ft(X) + 1.0; };
+  }
   if (mode == 1) {  // hide the tags
     auto QMt = prob.quadratic_model();
     QM = [QMt](const DeviceVector &X, DeviceVector &g, RM::LinearOperator<DeviceVector, DeviceVector> &Hs) {
@@ -300,10 +306,17 @@ extern "C" int hd_tnt_so3n(size_t N, size_t E, const int32_t *ei, const int32_t 
         accepted += acc;
         return false;
       };
+  // with_precon: bit 0 = 3x3 block-Jacobi preconditioner, bit 1 = plain (untagged) retraction: no fused trial step
   std::optional<RM::LinearOperator<DeviceVector, DeviceVector>> pc;
-  if (with_precon) pc = prob.preconditioner();
+  if (with_precon & 1) pc = prob.preconditioner();
+  RM::Retraction<DeviceVector, DeviceVector> retract = prob.retraction();
+  if (with_precon & 2) retract = prob.plain_retraction();
+  size_t s0 = 0, s1 = 0;
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s0));
   RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector>(
-      prob.objective(), prob.quadratic_model(), prob.metric(), prob.retraction(), x0, pc, tp, uf);
+      prob.objective(), prob.quadratic_model(), prob.metric(), retract, x0, pc, tp, uf);
+  MI355::check(mi_ctx_sync_count(ctx.get(), &s1));
+  g_last_tnt_syncs = s1 - s0;
   export_result(r, accepted, res);
   HD_GUARD_END
 }

@@ -25,6 +25,8 @@ class DeviceHarness:
             raise FileNotFoundError(PATH + " (run __graft_entry__.build())")
         L = self.L = C.CDLL(PATH)
         L.hd_last_error.restype = C.c_char_p
+        L.hd_last_tnt_syncs.restype = C.c_size_t
+        L.hd_last_tnt_seconds.restype = C.c_double
         L.hd_stpcg_diag.restype = C.c_int
         L.hd_stpcg_diag.argtypes = [C.c_size_t, dp, dp, dp, C.c_double, C.c_size_t, C.c_double, C.c_double,
                                     C.c_int, dp, dp, sp]
@@ -77,6 +79,7 @@ class DeviceHarness:
                     outer_iterations=no, accepted=res.accepted,
                     objective_values=bufs["objective_values"][:nt].copy(),
                     gradient_norms=bufs["gradient_norms"][:nt].copy(),
+                    preconditioned_gradient_norms=bufs["preconditioned_gradient_norms"][:nt].copy(),
                     trust_region_radius=bufs["trust_region_radius"][:nt].copy(),
                     inner_iterations=bufs["inner_iterations"][:no].astype(np.int64),
                     update_step_norms=bufs["update_step_norms"][:no].copy(),

@@ -97,3 +97,59 @@ def test_so3n_full_size_cfg3(ctx, oracle):
     Y = prob.retract(R, r["s"])
     assert prob.objective(Y) < 0.2 * fo
     oracle.free(oprob)
+
+
+@pytest.mark.parametrize("with_precon", [False, True])
+def test_so3n_fused_trial_step_has_the_bits_of_the_separate_calls(ctx, with_precon):
+    """mi_so3n_trial (reference Riemannian/TNT.h:493-512,573-585 as one launch chain, one read-back) against the
+    separate calls it replaces -- Hessian product + dot products, retraction, objective, model and both gradient
+    norms at the trial point: bit for bit.  The speculative model is swapped in by the next model() call for the
+    SAME vector contents only (handle + serial + generation stamp)."""
+    N = 3000
+    ei, ej, Rt, w, _, Rinit = wl.pose_graph(N, seed=21)
+    prob = ctx.so3n(N, ei, ej, Rt, w)
+    R = ctx.upload(Rinit)
+    g, H, P = prob.model(R)
+    h = ctx.upload(np.random.default_rng(4).normal(size=3 * N) * 1e-2)
+    # separate calls
+    Hh = H.apply(h)
+    hh, gh, hHh = ctx.dot_batch([h, g, h], [h, h, Hh])
+    Rt_ref = prob.retract(R, h)
+    f_ref = prob.objective(Rt_ref)
+    # fused
+    Rtr, t = prob.trial(R, h, g, with_precon=with_precon)
+    assert np.array_equal(Rtr.numpy(), Rt_ref.numpy())
+    assert (t["f"], t["hh"], t["gh"], t["hHh"]) == (f_ref, hh, gh, hHh)
+    g2, H2, P2 = prob.model(Rtr)      # swaps the speculative model in
+    prob2 = ctx.so3n(N, ei, ej, Rt, w)
+    g2_ref, H2_ref, P2_ref = prob2.model(Rt_ref)
+    assert np.array_equal(g2.numpy(), g2_ref.numpy())
+    assert t["grad_sqnorm"] == g2_ref.dot(g2_ref)
+    if with_precon:
+        Pg = P2_ref.apply(g2_ref)
+        assert t["precon_grad_sqnorm"] == Pg.dot(Pg)
+    else:
+        assert t["precon_grad_sqnorm"] == -1.0
+    v = ctx.upload(np.random.default_rng(5).normal(size=3 * N))
+    assert np.array_equal(H2.apply(v).numpy(), H2_ref.apply(v).numpy())
+    assert np.array_equal(P2.apply(v).numpy(), P2_ref.apply(v).numpy())
+    r1 = ctx.stpcg(g2, H2, P2, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
+    r2 = ctx.stpcg(g2_ref, H2_ref, P2_ref, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
+    assert np.array_equal(r1["s"].numpy(), r2["s"].numpy())
+
+
+def test_so3n_speculative_model_is_dropped_when_the_trial_vector_changes(ctx):
+    """the speculation must not survive an in-place write to the trial vector, nor a recycled handle."""
+    N = 500
+    ei, ej, Rt, w, _, Rinit = wl.pose_graph(N, seed=2)
+    prob = ctx.so3n(N, ei, ej, Rt, w)
+    R = ctx.upload(Rinit)
+    g, H, P = prob.model(R)
+    h = ctx.upload(np.random.default_rng(1).normal(size=3 * N) * 1e-2)
+    Rtr, _ = prob.trial(R, h, g)
+    other = wl.pose_graph(N, seed=3)[5]
+    Rtr.set(other)                     # same handle, same device pointer, other contents
+    g2, _, _ = prob.model(Rtr)
+    prob2 = ctx.so3n(N, ei, ej, Rt, w)
+    g2_ref, _, _ = prob2.model(ctx.upload(other))
+    assert np.array_equal(g2.numpy(), g2_ref.numpy())

@@ -502,3 +502,62 @@ def test_fused_trial_step_has_the_bits_of_the_separate_calls(ctx, p):
     r1 = ctx.stpcg(g2, H2, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
     r2 = ctx.stpcg(g2_ref, H2_ref, Delta=10.0, max_iterations=8, kappa_fgr=1e-10, theta=1.0)
     assert np.array_equal(r1["s"].numpy(), r2["s"].numpy())
+
+
+def test_speculative_trial_model_is_keyed_on_the_vector_contents(ctx):
+    """mi_stiefel_rq_trial's cached A X+, S+, gradient must only serve a model() call for the SAME trial
+    vector contents -- not an in-place overwritten one, not a new vector that recycled the handle / pooled pointer."""
+    nx, ny, nz, p = 12, 10, 9, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    X = ctx.upload(wl.random_stiefel(n, p, seed=3))
+    g, H = prob.model(X)
+    h = ctx.stiefel_project(n, p, X, ctx.upload(np.random.default_rng(4).normal(size=(n, p)) * 1e-2))
+    other = wl.random_stiefel(n, p, seed=99)
+    prob2 = ctx.stiefel_rq(A, n, p)
+    g_ref, _ = prob2.model(ctx.upload(other))
+    # (i) in-place write to the trial vector
+    Xt, _ = prob.trial(X, h, g)
+    Xt.set(other)
+    g2, _ = prob.model(Xt)
+    assert np.array_equal(g2.numpy(), g_ref.numpy())
+    # (ii) the trial vector dies; new vectors of the same size recycle its pooled storage (and maybe its handle)
+    g, H = prob.model(X)
+    Xt, _ = prob.trial(X, h, g)
+    del Xt
+    for _ in range(4):
+        Y = ctx.upload(other)
+        g3, _ = prob.model(Y)
+        assert np.array_equal(g3.numpy(), g_ref.numpy())
+        del Y, g3
+
+
+def test_deferred_stpcg_result(ctx):
+    """mi_stpcg with defer_result: no wait at the exit, s valid in stream order, scalars through mi_stpcg_collect --
+    identical to the blocking call; collect after another read-back does not wait again."""
+    nx, ny, nz, p = 16, 15, 14, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
+    X = ctx.upload(Xb)
+    g, H = prob.model(X)
+    kw = dict(Delta=1e3, max_iterations=25, kappa_fgr=1e-9, theta=1.0)
+    a = ctx.stpcg(g, H, **kw)
+    c0 = ctx.sync_count()
+    b = ctx.stpcg(g, H, defer=True, **kw)
+    assert ctx.sync_count() == c0            # the solve itself did not wait
+    nrm = b["s"].dot(b["s"])                 # a read-back behind the solve ...
+    c1 = ctx.sync_count()
+    r = ctx.stpcg_collect()                  # ... so collecting costs no further wait
+    assert ctx.sync_count() == c1
+    assert (r["iterations"], r["exit_reason"], r["M_norm"]) == (a["iterations"], a["exit_reason"], a["M_norm"])
+    assert np.array_equal(a["s"].numpy(), b["s"].numpy()) and nrm > 0
+    # collect straight away: waits once
+    b = ctx.stpcg(g, H, defer=True, **kw)
+    r = ctx.stpcg_collect()
+    assert ctx.sync_count() == c1 + 1
+    assert r["iterations"] == a["iterations"] and r["M_norm"] == a["M_norm"]

@@ -370,3 +370,79 @@ def test_example_client_program_runs():
     r = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "smallest eigenvalues" in r.stdout
+
+
+# ----------------------------------------------------------------------------------------------
+# TNT outer loop on the device: fused trial step + deferred inner-solve result
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pre", [0, 1], ids=["plain", "block_jacobi"])
+def test_tnt_so3n_fused_trial_equals_statement_sequence(harness, oracle, pre):
+    """cfg3 recipe (N = 4000): TNT with the tagged retraction (mi_so3n_trial: one chain, one read-back per outer
+    iteration, also WITH the block-Jacobi preconditioner -- the preconditioned TNT of BASELINE cfg3) against the
+    same run with the plain retraction (the reference's statement sequence, Riemannian/TNT.h:493-587): identical
+    bits in every trace, <= 1.2 host synchronisations per outer iteration instead of ~5."""
+    N = 4000
+    ei, ej, Rt, w, _, Rinit = wl.pose_graph(N, seed=13)
+    prm = oracle.default_params(gradient_tolerance=1e-7, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=60)
+    runs, syncs = {}, {}
+    for plain in (0, 1):
+        r = harness.tnt_so3n(N, ei, ej, Rt, w, Rinit, prm, pre | (2 * plain))
+        assert r["rc"] == 0, r.get("err")
+        runs[plain], syncs[plain] = r, harness.L.hd_last_tnt_syncs()
+    a, b = runs[0], runs[1]
+    assert a["status"] == b["status"] == 0
+    assert a["outer_iterations"] == b["outer_iterations"] and a["accepted"] == b["accepted"]
+    for k in ("inner_iterations", "objective_values", "gradient_norms", "preconditioned_gradient_norms",
+              "trust_region_radius", "update_step_norms", "update_step_M_norms", "gain_ratios", "x"):
+        assert np.array_equal(a[k], b[k]), k
+    outer = a["outer_iterations"]
+    print("so3n pre", pre, "outer", outer, "syncs fused", syncs[0], "plain", syncs[1])
+    assert syncs[0] <= 1.2 * outer + 3
+    assert syncs[1] >= 3 * outer
+
+
+def test_tnt_stiefel_syncs_per_outer_iteration(harness, oracle):
+    """cfg2 recipe (40x36x32): one read-back per outer iteration (the inner solve's result travels with the trial
+    step's, MI355::DeferScope / mi_stpcg_collect) -- and the same bits as the run without the fused trial step."""
+    nx, ny, nz, p = 40, 36, 32, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = wl.random_stiefel(n, p, seed=11)
+    prm = oracle.default_params(gradient_tolerance=1e-6, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=14,
+                                max_TPCG_iterations=50)
+    a = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 0)
+    sa = harness.L.hd_last_tnt_syncs()
+    b = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 2)
+    sb = harness.L.hd_last_tnt_syncs()
+    assert a["rc"] == 0 and b["rc"] == 0
+    for k in ("inner_iterations", "objective_values", "gradient_norms", "trust_region_radius", "gain_ratios", "x"):
+        assert np.array_equal(a[k], b[k]), k
+    outer = a["outer_iterations"]
+    print("stiefel outer", outer, "syncs fused", sa, "plain retraction", sb)
+    assert sa <= 1.2 * outer + 3
+    assert sb >= 2 * outer
+
+
+def test_tnt_supplied_objective_is_the_one_called(harness, oracle):
+    """a client objective that is NOT the problem's own (here f + 1 in a plain lambda) next to the
+    problem's tagged model and retraction.  The reference always calls the supplied f; the fused trial step would
+    evaluate the owner's f instead -- so TNT must keep the statement sequence: every recorded objective value is
+    the owner's + 1, and the iterates are those of the plain run."""
+    nx, ny, nz, p = 10, 9, 8, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = wl.random_stiefel(n, p, seed=5)
+    prm = oracle.default_params(gradient_tolerance=1e-7, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=30,
+                                max_TPCG_iterations=50)
+    a = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 0)
+    c = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 3)
+    assert a["rc"] == 0 and c["rc"] == 0
+    assert c["objective_values"][0] == a["objective_values"][0] + 1.0
+    assert np.all(c["objective_values"] > 1.0)
+    assert abs(c["f"] - (a["f"] + 1.0)) < 1e-12
+    # same decisions while df is far above the rounding of (f + 1)
+    k = 5
+    assert list(c["inner_iterations"][:k]) == list(a["inner_iterations"][:k])
