@@ -12,10 +12,11 @@ region also contains each solve's initialisation and final read-back.
 value = steps x (compulsory HBM bytes of the three kernels an iteration runs) / time: a bandwidth that can be
 held against the 8 TB/s HBM peak (hbm_roofline_frac_whole_step = value / n_gpus / 8000).  The fused kernels
 move far fewer bytes than SURVEY.md 8(d)'s accounting of the reference schedule (88 N + 12 nnz + 4 (n+1) +
-16 n p + 56 N per iteration); the same time priced by those bytes is reported as survey_8d_equivalent_GBps.
+16 n p + 56 N per iteration); the same time priced by those bytes is kept only as
+reference_schedule_bytes_per_second_not_a_bandwidth.
 
 Extra legs (rank 0 of a 1-GPU run, each with its own moved-bytes fraction): the same workload with the
-matrix in plain 12-byte entries instead of the 4-byte value-indexed copy (`plain_matrix_leg`), St(8e6,3) on
+matrix in plain 12-byte entries instead of the 4-byte value-indexed copy (`generic_csr_leg`, with its own roofline block), St(8e6,3) on
 one GPU -- beyond the 256 MiB Infinity Cache -- (`beyond_cache_leg`), and the CPU baselines: the reference's
 own single-threaded path and the oracle's OpenMP build on all host cores this process may use.
 
@@ -138,10 +139,21 @@ def extra_leg(ctx, nx, p, steps, warmup, packed, label):
     per, moved = timed_kernels(ctx, g, H, s_out, min(steps, 100), kb)
     N = n * p
     ws = 6 * 8 * N + (4 if packed else 12) * nnz
+    ran = [k for k in HOT if per[k]["launches"]]
+    dom = max(ran, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
     out = {"workload": label, "rows": n, "nnz": nnz, "packed_matrix": packed, "steps": steps,
            "us_per_step": 1e6 * dt / steps, "moved_bytes_per_step": moved,
-           "moved_GBps": steps * moved / dt / 1e9, "hbm_roofline_frac": steps * moved / dt / 1e9 / HBM_PEAK_GBS,
+           "value": steps * moved / dt / 1e9, "unit": "GB/s",
+           "hbm_roofline_frac_whole_step": steps * moved / dt / 1e9 / HBM_PEAK_GBS,
            "working_set_MB": ws / 1e6, "infinity_cache_MB": 268.4,
+           # the dominant kernel of THIS leg on its own compulsory bytes, raw HIP event pairs (each pair also times
+           # its two records, ~1.7 us: the figure is a lower bound on the kernel's rate)
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": per[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": per[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": kb[dom], "avg_launch_us_event_pairs": per[dom]["avg_us"],
+                        "timing": "raw HIP event pairs around every launch"},
+           "sum_kernel_us_over_step_us": sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / min(steps, 100)
+                                         / (1e6 * dt / steps),
            "kernels": {k: v for k, v in per.items() if v["launches"]}}
     del g, H, s_out, X, prob, A
     return out
@@ -242,7 +254,7 @@ def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
     (b) the oracle's OpenMP build (its vector and row loops as `omp parallel for`) on all the host CPUs this
     process may use -- both on a bounded sample of the same workload, same iteration counts asserted.
     `value` prices a CPU step with the same bytes as the GPU's `value` (so the ratio of the two is the ratio of
-    steps per second); the SURVEY 8(d) figure of the reference schedule is next to it."""
+    steps per second)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     n = nx * ny * nz
@@ -273,7 +285,7 @@ def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
                     "sample": f"{solves} STPCG solves x {TPCG} inner iterations of the same St({n},{p}) workload "
                               f"({iters} steps, {dt:.1f} s)" + (", OpenMP loops (oracle/liboracle_omp.so)" if omp else ""),
                     "ms_per_step": 1e3 * dt / max(iters, 1),
-                    "survey_8d_GBps": iters * bytes_8d / dt / 1e9,
+                    "reference_schedule_bytes_per_second_not_a_bandwidth": iters * bytes_8d / dt,
                     "cpu": cpu_model(), "host_cores_visible": os.cpu_count(), "host_cores_usable": ncpu})
     return out[0], out[1]
 
@@ -407,23 +419,27 @@ def main():
             ev_overhead = 0.0
         net_us = per[dom]["avg_us"] - ev_overhead
         achieved = kb[dom] / (net_us * 1e-6) / 1e9
-        traffic = None
+        # `traffic` is NOT measured in this run: PMC counters need separate rocprofv3 passes (tools/pmc_bytes.sh);
+        # the figure is the last committed measurement of the same kernel on the same workload, labelled as such
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
             try:
                 traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_bytes.sh on this " \
+                                 "workload; not collected in this run)"
             except Exception:  # noqa
                 traffic = None
-        # SURVEY 8(d) prices the whole Stiefel HVP (SpMM + Gram pass + finish pass, 12-byte matrix entries) at
-        # stiefel_hvp_bytes; the one-pass kernel performs all of it.  `achieved`/`frac` use the bytes THIS kernel
-        # must move; the 8(d) variant is reported next to it.
-        a8d = wl.stiefel_hvp_bytes(n, nnz, p) if dom == "stiefel_hess_fused" else kb[dom]
+        sum_kernel_us = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": kb[dom],
-                    "survey_8d_bytes_per_launch": a8d,
-                    "achieved_survey_8d": a8d / (net_us * 1e-6) / 1e9,
                     "avg_launch_us": net_us,
+                    # sum of the kernels' durations over the un-instrumented step: 1.0 = no gaps between kernels
+                    "sum_kernel_us_over_step_us": (sum_kernel_us - ev_overhead * launches_per_step)
+                                                  / (dt / args.steps * 1e6),
+                    "sum_kernel_us_over_step_us_event_pairs": sum_kernel_us / (dt / args.steps * 1e6),
                     "avg_launch_us_event_pairs": per[dom]["avg_us"],
                     "event_record_overhead_us_per_launch": ev_overhead,
                     "timing": "HIP event pair around every launch on the launch stream, minus the pairs' own cost "
@@ -441,8 +457,9 @@ def main():
         if not args.no_legs:
             try:
                 plain_leg = extra_leg(ctx, nx, p, min(args.steps, 200), 20, packed=not packed,
-                                      label=f"cfg2 St({n},{p}) with the matrix in " +
-                                            ("plain 12-byte entries" if packed else "4-byte value-indexed entries"))
+                                      label=f"cfg2 St({n},{p}), generic CSR path: the matrix in " +
+                                            ("plain 12-byte entries (what any sparse SPD matrix gets)" if packed
+                                             else "4-byte value-indexed entries"))
                 big_leg = extra_leg(ctx, 200, p, 50, 10, packed=packed,
                                     label=f"St(8000000,{p}), 200^3 grid, one GPU: beyond the Infinity Cache")
             except capi.MiError as e:  # an extra leg must never take the headline down with it
@@ -461,7 +478,7 @@ def main():
                                    f"iterations at a near-optimal iterate (modes {modes})",
                        "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
                        "moved_bytes_per_step_per_gpu": moved_bytes,
-                       "survey_8d_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
+                       "reference_schedule_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
                        "packed_matrix": packed,
                        "parallelism": (f"row-sharded z-slabs x{world}, comm: " +
                                        ("peer-memory layer (hipIpc-mapped arenas over xGMI: scalar all-reduce and "
@@ -476,11 +493,13 @@ def main():
                            "cg_update 24 N; cg_pupdate 40 N) per second; working set "
                            f"{(6 * 8 * N + (4 if packed else 12) * nnz) / 1e6:.0f} MB per GPU (Infinity Cache: 268 MB)",
             "packed_matrix": packed,
-            "survey_8d_equivalent_GBps": world * args.steps * bytes_per_step / dt / 1e9,
-            "survey_8d_basis": "the same time priced by SURVEY.md 8(d)'s bytes of the reference schedule "
-                               "(88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration): exceeds the HBM peak "
-                               "because the fused kernels never move those bytes",
-            "roofline": roofline, "plain_matrix_leg": plain_leg, "beyond_cache_leg": big_leg,
+            # NOT a bandwidth: the same time priced by the bytes SURVEY.md 8(d) attributes to the reference's schedule
+            # (88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration); the fused kernels never move those bytes
+            "reference_schedule_bytes_per_second_not_a_bandwidth": world * args.steps * bytes_per_step / dt,
+            "roofline": roofline,
+            # the second first-class number: the SAME workload through the generic path any CSR matrix takes
+            # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
+            "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
         }
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())

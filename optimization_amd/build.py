@@ -52,7 +52,11 @@ def _compile(src, force):
 # Host-only sources (csrc/*.cpp): g++ with AVX2, fused multiply-adds OFF (bit-identical to a scalar build; see
 # csrc/rr_host.cpp); hipcc's host pass when there is no g++
 HOST_CXX = os.environ.get("CXX", "g++")
-HOST_CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-mavx2", "-ffp-contract=off", "-Wall",
+# No -mavx2 on the command line: csrc/rr_host.cpp carries its own `target_clones("avx2","default")` on the hot solver,
+# so the library also loads (and gives the same bits: no FMA, no reassociation) on a host CPU without AVX2.
+# -ffp-contract=off is REQUIRED for the documented bit-for-bit agreement of the host and device Rayleigh-Ritz paths; a
+# client that compiles DenseSymmetricEigen.h itself (the generic LOBPCG path) needs the same flag for that claim.
+HOST_CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", os.path.join(HERE, "include")]
 
 
@@ -61,9 +65,14 @@ def _compile_host(src, force):
     deps = glob.glob(os.path.join(HERE, "include", "Optimization", "LinearAlgebra", "*.h"))
     if not force and not _newer(src, obj, deps):
         return obj, False, ""
-    r = subprocess.run([HOST_CXX] + HOST_CFLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
+    import shutil
+    if shutil.which(HOST_CXX):
+        cmd = [HOST_CXX] + HOST_CFLAGS
+    else:  # no g++ on this machine: hipcc's host pass (clang), same flags, no device code
+        cmd = [HIPCC, "-x", "c++"] + HOST_CFLAGS
+    r = subprocess.run(cmd + ["-c", src, "-o", obj], capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError(f"{HOST_CXX} failed on {src}:\n{r.stderr[-6000:]}")
+        raise RuntimeError(f"{cmd[0]} failed on {src}:\n{r.stderr[-6000:]}")
     return obj, True, r.stderr
 
 

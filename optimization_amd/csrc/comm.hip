@@ -224,6 +224,24 @@ int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
 }
 
 int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k) {
+  // A uniform-grid context (every multi-rank context) leaves exactly kMaxGrid partial rows per component; rows
+  // kMaxGrid..kMaxRows of the component-major buffer are never written there.  Reduce the live half only: k strided
+  // segments of kMaxGrid doubles in one RCCL group (one launch), half the payload of the per-iteration exchanges.
+  Comm *c = (Comm *)ctx->comm;
+  if (c && c->nccl && ctx->uniform_grid && k > 0) {
+    if (k == 1) return comm_allreduce(ctx, partials, kMaxGrid);
+    MI_NCCL(ncclGroupStart());
+    for (int j = 0; j < k; ++j) {
+      double *seg = partials + (size_t)j * kMaxRows;
+      ncclResult_t r = ncclAllReduce(seg, seg, (size_t)kMaxGrid, ncclDouble, ncclSum, c->nccl, ctx->stream);
+      if (r != ncclSuccess) {
+        (void)ncclGroupEnd();
+        MI_NCCL(r);
+      }
+    }
+    MI_NCCL(ncclGroupEnd());
+    return MI_OK;
+  }
   return comm_allreduce(ctx, partials, k * kMaxRows);
 }
 

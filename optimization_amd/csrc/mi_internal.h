@@ -360,6 +360,10 @@ struct mi_csr {
   size_t n = 0;        // local rows
   size_t ncols = 0;    // local columns incl. halo (== n when not sharded)
   size_t nnz = 0;      // true non-zeros (algorithmic byte accounting uses this)
+  // A == A' entry by entry (same bits), checked once at creation (sparse.hip csr_is_symmetric; a row shard checks its
+  // diagonal block).  The one-pass Stiefel Hessian rests on X'(A p) = (A X)'p: without symmetry the operator keeps
+  // its two-pass form (stiefel.hip mi_stiefel_rq_model).
+  bool symmetric = false;
   size_t padded = 0;   // stored entries
   size_t nslices = 0;
   long long *slice_ptr = nullptr;  // device, nslices + 1
@@ -389,8 +393,14 @@ struct mi_csr {
   size_t win_far_pure = 0;         // D when EVERY far entry is at row +- D (slot 0: +D, slot 1: -D), else 0
   // workgroup -> first tile table of the window kernels (stiefel.hip window_bounds), built on first use for one
   // workgroup budget: win_bounds_n + 1 device ints
-  mutable int *win_bounds = nullptr;
-  mutable int win_bounds_n = 0, win_bounds_for = 0;
+  // One plan per workgroup budget (the Hessian pass and the column-major panel product ask with different budgets on
+  // the same matrix: a single slot would be rebuilt -- hipFree + hipMalloc + blocking copy -- on every alternation);
+  // plans live as long as the matrix, an entry appears only after its table is on the device.
+  struct WinPlan {
+    int *bounds = nullptr;  // device, n + 1 ints
+    int n = 0;
+  };
+  mutable std::map<int, WinPlan> win_plans;
   // row-sharded operation (world_size > 1).  Local column index c < n addresses the local rows of
   // V; c >= n addresses the halo buffer: [n, n+halo_lo) = last halo_lo rows of rank-1,
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.

@@ -521,17 +521,21 @@ int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, 
   const char *off_env = getenv("MI355OPT_NO_WIN_BOUNDS");  // (per call: tests compare the plans in one process)
   const bool off = off_env && off_env[0] == '1';
   const int key = off ? -wgs : wgs;
-  if (A->win_bounds_for != key) {
-    A->win_bounds_for = key;
+  auto it = A->win_plans.find(key);
+  if (it == A->win_plans.end()) {
     const std::vector<int> b = window_runs(ntiles, wgs, ctx->num_cu, off ? 0 : A->win_far_stride);
-    if (A->win_bounds) (void)hipFree(A->win_bounds);
-    A->win_bounds = nullptr;
-    A->win_bounds_n = (int)b.size() - 1;
-    MI_HIP(hipMalloc((void **)&A->win_bounds, b.size() * sizeof(int)));
-    MI_HIP(hipMemcpy(A->win_bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice));
+    mi_csr::WinPlan plan;
+    plan.n = (int)b.size() - 1;
+    MI_HIP(hipMalloc((void **)&plan.bounds, b.size() * sizeof(int)));
+    const hipError_t e = hipMemcpy(plan.bounds, b.data(), b.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(plan.bounds);
+      MI_HIP(e);
+    }
+    it = A->win_plans.emplace(key, plan).first;  // (only a complete plan is ever recorded)
   }
-  *grid = A->win_bounds_n;
-  *bounds_out = A->win_bounds;
+  *grid = it->second.n;
+  *bounds_out = it->second.bounds;
   return MI_OK;
 }
 int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
@@ -626,6 +630,35 @@ int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, c
   return MI_OK;
 }
 
+// A == A' with bitwise-equal values, on the square block of columns [0, n) (all of a single-GPU matrix; the diagonal
+// block of a row shard, whose halo columns >= n are skipped).  O(nnz): counting-sort transpose, then the (column, value)
+// lists of every row are compared after sorting them (rows are short).
+bool csr_is_symmetric(size_t n, const int32_t *rowptr, const int32_t *col, const double *val) {
+  std::vector<size_t> tp(n + 1, 0);
+  size_t inside = 0;
+  for (size_t i = 0; i < n; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if ((size_t)col[k] < n) { ++tp[(size_t)col[k] + 1]; ++inside; }
+  for (size_t i = 0; i < n; ++i) tp[i + 1] += tp[i];
+  std::vector<std::pair<int32_t, uint64_t>> t(inside);
+  std::vector<size_t> fill(tp.begin(), tp.end() - 1);
+  auto bits = [](double v) { uint64_t b; std::memcpy(&b, &v, sizeof b); return b; };
+  for (size_t i = 0; i < n; ++i)
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if ((size_t)col[k] < n) t[fill[(size_t)col[k]]++] = {(int32_t)i, bits(val[k])};
+  std::vector<std::pair<int32_t, uint64_t>> row;
+  for (size_t i = 0; i < n; ++i) {
+    row.clear();
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
+      if ((size_t)col[k] < n) row.push_back({col[k], bits(val[k])});
+    if (row.size() != tp[i + 1] - tp[i]) return false;
+    std::sort(row.begin(), row.end());
+    std::sort(t.begin() + tp[i], t.begin() + tp[i + 1]);  // (already ordered by row of origin; ties by value)
+    if (!std::equal(row.begin(), row.end(), t.begin() + tp[i])) return false;
+  }
+  return true;
+}
+
 }  // namespace mi
 
 extern "C" {
@@ -638,7 +671,9 @@ int mi_csr_create(mi_ctx *ctx, size_t n, size_t nnz, const int32_t *rowptr, cons
   for (size_t i = 0; i < n; ++i) MI_REQUIRE(rowptr[i + 1] >= rowptr[i], "rowptr not monotone at row %zu", i);
   for (size_t k = 0; k < nnz; ++k)
     MI_REQUIRE(col[k] >= 0 && (size_t)col[k] < n, "column index out of range at entry %zu", k);
-  return build_sell(ctx, n, n, nnz, rowptr, col, val, out);
+  MI_TRY(build_sell(ctx, n, n, nnz, rowptr, col, val, out));
+  (*out)->symmetric = csr_is_symmetric(n, rowptr, col, val);
+  return MI_OK;
 }
 
 int mi_csr_destroy(mi_csr *A) {
@@ -651,7 +686,7 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->wk);
   (void)hipFree(A->wfar);
   (void)hipFree(A->wk16);
-  if (A->win_bounds) (void)hipFree(A->win_bounds);
+  for (auto &kv : A->win_plans) (void)hipFree(kv.second.bounds);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
   delete A;
   return MI_OK;
@@ -724,6 +759,7 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
                            &need_hi));
   mi_csr *A = nullptr;
   MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A));
+  A->symmetric = csr_is_symmetric(n, rowptr, lcol.data(), val);  // the diagonal block (the couplings are the caller's word)
   A->halo_lo = need_lo;
   A->halo_hi = need_hi;
   // what we must SEND equals what the neighbours need; exchanged once through the communicator

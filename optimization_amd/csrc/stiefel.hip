@@ -600,6 +600,7 @@ struct mi_stiefel_rq {
   const mi_vec *trial_X = nullptr;
   const double *trial_d = nullptr;
   uint64_t trial_serial = 0, trial_gen = 0;
+  bool warned_unsymmetric = false;
   void remember_trial(const mi_vec *Xt) {
     trial_X = Xt;
     trial_d = Xt->d;
@@ -906,8 +907,14 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   q->dg.X = X->d;
   q->dg.Y = q->Y->d;
   q->dg.S = q->S_dev;
-  // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator
-  q->hess.dirgram = sell_stream_ok(q->A, q->p) ? &q->dg : nullptr;
+  // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator -- and so does
+  // a matrix that is not symmetric (checked at creation): the one-pass form replaces X'(A p) by (A X)'p
+  q->hess.dirgram = (sell_stream_ok(q->A, q->p) && q->A->symmetric) ? &q->dg : nullptr;
+  if (!q->A->symmetric && !q->warned_unsymmetric) {
+    q->warned_unsymmetric = true;
+    fprintf(stderr, "mi355opt: the matrix of this Stiefel Rayleigh-quotient problem is not symmetric: the Hessian "
+                    "operator keeps its two-pass form (P_X(A V - V S) with A as given)\n");
+  }
   if (hess) *hess = &q->hess;
   return MI_OK;
 }

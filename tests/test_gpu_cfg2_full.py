@@ -1,0 +1,186 @@
+"""Parity at bench.py's own operating point: BASELINE cfg2 at its full size, St(1e6,3) on the
+100^3 grid.
+
+  * the exact solve bench.py times (50 STPCG iterations, kappa_fgr 1e-12, theta 1, Delta 1e3, at the bench iterate)
+    in every matrix format the library has, against the reference: iteration count, alpha / beta / kappa / <r,v>
+    traces, |s|_M and the step s;
+  * a whole TNT run from a random start (max_TPCG_iterations = 50) against the trace the REAL reference produced
+    here (tests/golden/cfg2_full.json, written by tests/golden/make_golden_full.py from oracle/_ref/libref.so).
+
+The fixture holds scalars and checksums only (24 MB vectors do not travel).  The vectors the device results are
+compared with come from the plain-C oracle re-run on the GPU box's host on the same inputs; its outputs must hash
+(SHA-256 of the bytes) to what the real reference produced, so "against the oracle" IS "against the reference",
+bit for bit, at full size.
+
+Tolerance: BASELINE.json asks for iterates within 1e-10 relative.  Where that is not reachable the test says why in
+numbers: the SAME reference algorithm with its sums re-associated (the oracle's OpenMP build: identical statements,
+per-thread partial sums) moves away from the sequential-sum reference by `floor`; no implementation whose reduction
+order differs from the reference's can be asked to do better than a small multiple of that.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from optimization_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+NX = NY = NZ = 100
+P = 3
+N = NX * NY * NZ
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def cfg2(oracle, golden):
+    import oracle_py
+    fx = golden("cfg2_full.json")
+    assert fx["grid"] == [NX, NY, NZ] and fx["p"] == P
+    rowptr, col, val = wl.laplacian_3d(NX, NY, NZ)
+    oprob = oracle.stiefel_rq(N, P, rowptr, col, val)
+    omp = None
+    try:
+        omp = oracle_py.Oracle(omp=True)
+        omp.set_threads(4)
+        omp_prob = omp.stiefel_rq(N, P, rowptr, col, val)
+    except OSError:
+        omp_prob = None
+    yield dict(fx=fx, csr=(rowptr, col, val), oprob=oprob, omp=omp, omp_prob=omp_prob)
+    oracle.free(oprob)
+    if omp_prob is not None:
+        omp.free(omp_prob)
+
+
+@pytest.fixture(scope="module")
+def bench_solve(oracle, cfg2):
+    """The oracle's (= the reference's, by SHA-256) bench solve, and the re-associated run that gives the floor."""
+    fx = cfg2["fx"]["bench_stpcg"]
+    it = fx["iterate"]
+    Xb, modes = wl.stiefel_bench_iterate(NX, NY, NZ, P, eps=it["eps"], seed=it["seed"])
+    assert [list(m) for m in modes] == it["modes"]
+    prm = fx["params"]
+    g = oracle.eval_grad(cfg2["oprob"], Xb.ravel())
+    assert _sha(g) == fx["g"]["sha256"], "the oracle's gradient at full size is not the reference's, bit for bit"
+    o = oracle.stpcg_problem(cfg2["oprob"], Xb.ravel(), g, prm["Delta"], max_iterations=prm["max_iterations"],
+                             kappa_fgr=prm["kappa_fgr"], theta=prm["theta"], trace_cap=64)
+    assert o["iterations"] == fx["iterations"] == 50 and o["exit_reason"] == fx["exit_reason"]
+    assert _sha(o["s"]) == fx["s"]["sha256"], "the oracle's step at full size is not the reference's, bit for bit"
+    assert o["M_norm"] == fx["M_norm"]
+    for k in ("alpha", "beta", "kappa", "rv"):
+        assert list(o["trace"][k]) == fx["trace"][k]
+    floor = None
+    if cfg2["omp_prob"] is not None:
+        omp = cfg2["omp"]
+        gm = omp.eval_grad(cfg2["omp_prob"], Xb.ravel())
+        m = omp.stpcg_problem(cfg2["omp_prob"], Xb.ravel(), gm, prm["Delta"], max_iterations=prm["max_iterations"],
+                              kappa_fgr=prm["kappa_fgr"], theta=prm["theta"], trace_cap=64)
+        floor = dict(s=rel_err(m["s"], o["s"]), iterations=m["iterations"],
+                     alpha=float(np.max(np.abs(m["trace"]["alpha"] / o["trace"]["alpha"] - 1))),
+                     beta=float(np.max(np.abs(m["trace"]["beta"] / o["trace"]["beta"] - 1))))
+    return dict(Xb=Xb, g=g, o=o, prm=prm, floor=floor)
+
+
+FORMATS = {
+    "default_window_packed": {},
+    "generic_csr_12_byte_entries": {"MI355OPT_NO_PACKED": "1"},
+    "words16": {"MI355OPT_WORDS16": "1"},
+    "packed_streaming_no_window": {"MI355OPT_NO_WINDOW": "1"},
+    "two_pass_operator": {"MI355OPT_NO_DIRGRAM": "1"},
+}
+
+
+@pytest.mark.parametrize("fmt", list(FORMATS))
+def test_bench_solve_matches_the_reference(cfg2, bench_solve, monkeypatch, fmt):
+    """bench.py's solve, N = 3e6, 50 iterations, in every matrix format, against the reference's."""
+    from optimization_amd import capi
+    for k, v in FORMATS[fmt].items():
+        monkeypatch.setenv(k, v)
+    c = capi.Context(0)  # (MI355OPT_NO_DIRGRAM is read at context creation, MI355OPT_NO_PACKED at matrix creation)
+    try:
+        rowptr, col, val = cfg2["csr"]
+        A = c.csr(N, rowptr, col, val)
+        prob = c.stiefel_rq(A, N, P)
+        X = c.upload(bench_solve["Xb"])
+        g, H = prob.model(X)
+        assert rel_err(g.numpy(), bench_solve["g"]) < 1e-12
+        prm, o = bench_solve["prm"], bench_solve["o"]
+        c.ktime_enable("stiefel_hess_fused", True)
+        c.ktime_enable("stiefel_finish_dots", True)
+        r = c.stpcg(g, H, Delta=prm["Delta"], max_iterations=prm["max_iterations"], kappa_fgr=prm["kappa_fgr"],
+                    theta=prm["theta"], trace_cap=64)
+        one_pass = c.ktime_read("stiefel_hess_fused")[0]
+        two_pass = c.ktime_read("stiefel_finish_dots")[0]
+        assert (two_pass > 0) == (fmt == "two_pass_operator") and (one_pass > 0) == (fmt != "two_pass_operator")
+        assert r["iterations"] == o["iterations"] == 50
+        assert r["exit_reason"] == o["exit_reason"]
+        ea = float(np.max(np.abs(r["trace"]["alpha"] / o["trace"]["alpha"] - 1)))
+        eb = float(np.max(np.abs(r["trace"]["beta"] / o["trace"]["beta"] - 1)))
+        ek = float(np.max(np.abs(r["trace"]["kappa"] / o["trace"]["kappa"] - 1)))
+        es = rel_err(r["s"].numpy(), o["s"])
+        em = abs(r["M_norm"] - o["M_norm"]) / o["M_norm"]
+        fl = bench_solve["floor"] or dict(s=0.0, alpha=0.0, beta=0.0)
+        print(f"{fmt}: s {es:.2e} (re-associated reference: {fl['s']:.2e}), alpha {ea:.2e} ({fl['alpha']:.2e}), "
+              f"beta {eb:.2e} ({fl['beta']:.2e}), kappa {ek:.2e}, |s|_M {em:.2e}")
+        # BASELINE.json: 1e-10 relative on the iterate; the per-iteration scalars are ratios of two sums of 3e6
+        # terms each and get the slack the re-associated reference itself needs
+        assert es <= max(1e-10, 3 * fl["s"]), (es, fl)
+        assert em <= 1e-11
+        assert ea <= max(1e-10, 3 * fl["alpha"]) and eb <= max(1e-9, 3 * fl["beta"]), (ea, eb, fl)
+    finally:
+        c.close()
+
+
+def test_full_cfg2_tnt_run_matches_the_reference_trace(cfg2, oracle):
+    """A whole TNT run on cfg2 at full size through the drop-in templates on DeviceVector (fused inner solves, fused
+    trial steps), against what the REAL reference did on the same inputs: status, outer / inner iteration counts,
+    the accept sequence, the f / |g| / radius traces -- and the final iterate against the oracle's (= the
+    reference's, by SHA-256), as a subspace (the minimiser of a Rayleigh quotient is one)."""
+    import harness_py
+    fx = cfg2["fx"]["tnt"]
+    rowptr, col, val = cfg2["csr"]
+    X0 = wl.random_stiefel(N, P, seed=fx["seed"])
+    assert _sha(X0) == fx["x0"]["sha256"]
+    prm = oracle.default_params(**fx["params"])
+    hz = harness_py.DeviceHarness()
+    r = hz.tnt_stiefel(N, P, rowptr, col, val, X0, prm, 0)
+    assert r["rc"] == 0, r.get("err")
+    syncs = hz.L.hd_last_tnt_syncs()
+    assert r["status"] == fx["status"]
+    assert r["outer_iterations"] == fx["outer_iterations"]
+    assert list(r["inner_iterations"]) == fx["inner_iterations"]
+    assert r["accepted"] == fx["accepted"]
+    rho, rho_ref = np.array(r["gain_ratios"]), np.array(fx["gain_ratios"])
+    assert list(rho > 0.05) == list(rho_ref > 0.05) and list(rho >= 0.9) == list(rho_ref >= 0.9)  # eta1, eta2
+    assert np.allclose(r["objective_values"], fx["objective_values"], rtol=1e-11)
+    assert np.allclose(r["trust_region_radius"], fx["trust_region_radius"], rtol=1e-10)
+    assert np.allclose(r["update_step_M_norms"], fx["update_step_M_norms"], rtol=1e-9)
+    assert np.allclose(r["gradient_norms"], fx["gradient_norms"], rtol=1e-6)
+    assert abs(r["f"] - fx["f"]) <= 1e-12 * abs(fx["f"])
+    print("cfg2 TNT: outer", r["outer_iterations"], "inner", int(np.sum(r["inner_iterations"])), "host syncs", syncs,
+          "max |f - f_ref| / f", float(np.max(np.abs(np.array(r["objective_values"]) / np.array(fx["objective_values"]) - 1))))
+    assert syncs <= 1.2 * r["outer_iterations"] + 3
+    # final iterate: the oracle's run (bitwise the reference's) on this host
+    o = oracle.tnt(cfg2["oprob"], X0.ravel(), prm)
+    assert _sha(o["x"]) == fx["x"]["sha256"], "the oracle's TNT iterate at full size is not the reference's, bit for bit"
+    X, Xr = r["x"].reshape(N, P), o["x"].reshape(N, P)
+    assert np.abs(X.T @ X - np.eye(P)).max() < 1e-12
+    # distance of the subspaces: |(I - Xr Xr') X|_F = |sin Theta|_F  (= |X X' - Xr Xr'|_F / sqrt 2), no cancellation
+    dist = np.linalg.norm(X - Xr @ (Xr.T @ X))
+    # ... and of the iterates themselves
+    ex = rel_err(X, Xr)
+    floor = None
+    if cfg2["omp_prob"] is not None:
+        m = cfg2["omp"].tnt(cfg2["omp_prob"], X0.ravel(), prm)
+        Xm = m["x"].reshape(N, P)
+        floor = dict(x=rel_err(Xm, Xr), subspace=float(np.linalg.norm(Xm - Xr @ (Xr.T @ Xm))),
+                     outer=int(m["outer_iterations"]))
+    print(f"cfg2 TNT final iterate: rel err {ex:.2e}, subspace distance {dist:.2e}; re-associated reference: {floor}")
+    fx_floor = floor or dict(x=0.0, subspace=0.0)
+    assert dist <= max(1e-10, 3 * fx_floor["subspace"])
+    assert ex <= max(1e-10, 3 * fx_floor["x"])

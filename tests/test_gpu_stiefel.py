@@ -561,3 +561,42 @@ def test_deferred_stpcg_result(ctx):
     r = ctx.stpcg_collect()
     assert ctx.sync_count() == c1 + 1
     assert r["iterations"] == a["iterations"] and r["M_norm"] == a["M_norm"]
+
+
+def test_unsymmetric_matrix_keeps_the_two_pass_hessian(ctx, oracle):
+    """the one-pass Hessian replaces X'(A p) by (A X)'p, i.e. presupposes A = A'.  Symmetry is checked
+    when the matrix is created; an unsymmetric CSR keeps the two-pass operator P_X(A V - V S) with A as given --
+    the operator the oracle (and the reference's user callable) would apply."""
+    n, p = 700, 3
+    rowptr, col, val = _random_csr(n, seed=42)            # unsymmetric pattern and values
+    Xb = wl.random_stiefel(n, p, seed=8)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    g, H = prob.model(ctx.upload(Xb))
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    assert rel_err(g.numpy(), go) < 1e-12
+    ctx.ktime_enable("stiefel_hess_fused", True)
+    ctx.ktime_enable("stiefel_finish_dots", True)
+    ctx.ktime_reset()
+    r = ctx.stpcg(g, H, Delta=0.5, max_iterations=6, kappa_fgr=1e-8, theta=1.0)
+    assert ctx.ktime_read("stiefel_hess_fused")[0] == 0 and ctx.ktime_read("stiefel_finish_dots")[0] > 0
+    ctx.ktime_enable("stiefel_hess_fused", False)
+    ctx.ktime_enable("stiefel_finish_dots", False)
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 0.5, max_iterations=6, kappa_fgr=1e-8, theta=1.0)
+    assert (r["iterations"], r["exit_reason"]) == (o["iterations"], o["exit_reason"])
+    assert rel_err(r["s"].numpy(), o["s"]) < 1e-10
+    oracle.free(oprob)
+    # the symmetrised matrix takes the one-pass kernel again
+    import scipy.sparse as sps
+    M = sps.csr_matrix((val, col, rowptr), shape=(n, n))
+    S = sps.csr_matrix(M + M.T)
+    S.sort_indices()
+    A2 = ctx.csr(n, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    prob2 = ctx.stiefel_rq(A2, n, p)
+    g2, H2 = prob2.model(ctx.upload(Xb))
+    ctx.ktime_enable("stiefel_hess_fused", True)
+    ctx.ktime_reset()
+    ctx.stpcg(g2, H2, Delta=0.5, max_iterations=3, kappa_fgr=1e-8, theta=1.0)
+    assert ctx.ktime_read("stiefel_hess_fused")[0] > 0
+    ctx.ktime_enable("stiefel_hess_fused", False)
