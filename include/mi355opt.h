@@ -156,6 +156,17 @@ MI_API int mi_precon_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void
 MI_API int mi_precon_create_diag(mi_ctx *ctx, const mi_vec *dinv, mi_precon **out); /* v = dinv .* r */
 /* 3x3 block-Jacobi: blocks holds N row-major 3x3 INVERSE diagonal blocks (9N doubles) */
 MI_API int mi_precon_create_block3(mi_ctx *ctx, const mi_vec *inv_blocks, mi_precon **out);
+/* Constraint preconditioner of the PROJECTED solve (IterativeSolvers.h:83-85, applied at :229-253 and :381-405;
+ * tests/IterativeSolvers_unit_test.cpp:316-496): P(r) = (v, lambda) with [M A'; A 0][v; lambda] = [r; 0] for a
+ * DIAGONAL M (Minv = its inverse, n doubles) and a dense m x n constraint matrix A (row-major, m <= 512 <= n).
+ * S = A M^-1 A' is formed, factored and inverted once on the device (sync); every application is two launches.
+ * mi_precon_apply gives v; mi_precon_constraint_solve also lambda; mi_precon_constraint_At is A' (the `At` argument
+ * of STPCG).  Handed to mi_stpcg with params.constraint_At != 0 the solve takes the reference's `At` branch
+ * (r -= A' lambda after every preconditioner application, :251,403) inside the same pass.  A and Minv must outlive P. */
+MI_API int mi_precon_create_constraint(mi_ctx *ctx, size_t n, size_t m, const mi_vec *A_rowmajor,
+                                       const mi_vec *Minv_diag, mi_precon **out);
+MI_API int mi_precon_constraint_solve(mi_precon *P, const mi_vec *r, mi_vec *v, mi_vec *lambda /*nullable*/);
+MI_API int mi_precon_constraint_At(mi_precon *P, const mi_vec *lambda, mi_vec *out);
 MI_API int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v);
 MI_API int mi_precon_destroy(mi_precon *P);
 
@@ -172,6 +183,8 @@ typedef struct mi_stpcg_params {
   double theta;          /* :172 (.5) */
   double epsilon;        /* :179 (1e-8) */
   int run_ahead;         /* iterations the host may enqueue beyond the last one known complete (0 -> default 3) */
+  int constraint_At;     /* nonzero: P is a constraint preconditioner (mi_precon_create_constraint) and the solve was given
+                            `At` (IterativeSolvers.h:178): r -= A' lambda after every application of P (:251,403) */
   int defer_result;      /* nonzero: do NOT wait for the device at the exit.  s_out is valid in stream order (anything
                             enqueued afterwards sees it); `result` only receives hvp_calls, the other fields arrive
                             through mi_stpcg_collect.  Lets a caller put its next launch chain (e.g. the trust-region

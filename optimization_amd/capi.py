@@ -40,7 +40,7 @@ class MiError(RuntimeError):
 class StpcgParams(C.Structure):
     _fields_ = [("Delta", C.c_double), ("max_iterations", C.c_size_t), ("kappa_fgr", C.c_double),
                 ("theta", C.c_double), ("epsilon", C.c_double), ("run_ahead", C.c_int),
-                ("defer_result", C.c_int)]
+                ("constraint_At", C.c_int), ("defer_result", C.c_int)]
 
 
 class StpcgResult(C.Structure):
@@ -133,6 +133,9 @@ def load():
         "mi_precon_create_diag": [vp, vp, C.POINTER(vp)],
         "mi_precon_create_block3": [vp, vp, C.POINTER(vp)],
         "mi_precon_apply": [vp, vp, vp],
+        "mi_precon_create_constraint": [vp, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(vp)],
+        "mi_precon_constraint_solve": [vp, vp, vp, vp],
+        "mi_precon_constraint_At": [vp, vp, vp],
         "mi_precon_destroy": [vp],
         "mi_stpcg": [vp, vp, vp, vp, C.POINTER(StpcgParams), vp, C.POINTER(StpcgResult),
                      C.POINTER(StpcgTrace)],
@@ -380,10 +383,11 @@ class Context:
 
     # fused STPCG ------------------------------------------------------------------------------
     def stpcg(self, g, H, P=None, Delta=1.0, max_iterations=1000, kappa_fgr=.1, theta=.5,
-              epsilon=1e-8, run_ahead=0, trace_cap=0, s_out=None, defer=False):
+              epsilon=1e-8, run_ahead=0, trace_cap=0, s_out=None, defer=False, constraint_At=False):
         """defer=True: mi_stpcg returns without waiting for the device (s is valid in stream order); the scalar
         results come from stpcg_collect()."""
-        prm = StpcgParams(Delta, max_iterations, kappa_fgr, theta, epsilon, run_ahead, int(defer))
+        prm = StpcgParams(Delta, max_iterations, kappa_fgr, theta, epsilon, run_ahead, int(constraint_At),
+                          int(defer))
         res = StpcgResult()
         s = s_out if s_out is not None else Vec(self, g.n)
         tr = None

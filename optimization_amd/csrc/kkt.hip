@@ -1,0 +1,279 @@
+// kkt.hip -- the constraint preconditioner of the PROJECTED Steihaug-Toint CG (reference
+// LinearAlgebra/IterativeSolvers.h:83-85 `STPCGPreconditioner`, applied at :229-253 and :381-405; the reference's
+// own cases: tests/IterativeSolvers_unit_test.cpp:316-496, n = 1000, m = 100 dense constraints, diagonal M):
+//        [M  A'][v]   [r]
+//        [A  0 ][l] = [0]        <=>   l = S^-1 A M^-1 r,   v = M^-1 (r - A' l),   S = A M^-1 A'
+// followed (when STPCG was given `At`) by the residual correction r -= A' l of :251,403.
+//
+// Device form (small m, the case the reference tests): S is formed, Cholesky-factored and inverted ONCE, on the
+// device, when the preconditioner is created.  Every application is two launches and no scalar kernel:
+//   k_kkt_b       per-workgroup partial rows of b = A (M^-1 r): one wave per constraint row over the workgroup's
+//                 column chunk (coalesced reads of A's rows), fixed-shape wave reductions
+//   k_kkt_finish  EVERY workgroup re-reduces b from the partial rows and forms l = S^-1 b in its prologue (identical
+//                 code on identical data: identical bits everywhere, no atomics, no one-workgroup kernel); body:
+//                 w_i = sum_a A[a,i] l_a (coalesced over i), v_i = M^-1_i (r_i - w_i) and, if asked, r_i -= w_i
+// A is m x n row-major (a constraint row contiguous), i.e. the column-major n x m panel of A'.
+#include "mi_internal.h"
+
+using namespace mi;
+
+namespace {
+
+constexpr int kKktMaxM = 512;  // constraints (the prologue holds b and l in LDS; the one-off inversion is O(m^2) per thread)
+
+struct KktImpl {
+  size_t n = 0, m = 0;
+  const double *A = nullptr;     // m x n row-major, caller-owned
+  const double *Minv = nullptr;  // n, caller-owned
+  double *Sinv = nullptr;        // m x m
+  double *bpart = nullptr;       // m x kMaxGrid partial sums of b
+  double *lambda = nullptr;      // m (the multiplier estimate of the last application)
+};
+
+__global__ __launch_bounds__(256) void k_kkt_schur(size_t n, int m, const double *__restrict__ A,
+                                                   const double *__restrict__ Minv, double *__restrict__ S) {
+  // workgroup t <-> pair (a, b <= a)
+  __shared__ double lds[4];
+  int a = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((size_t)(a + 1) * (a + 2) / 2 <= blockIdx.x) ++a;
+  while ((size_t)a * (a + 1) / 2 > blockIdx.x) --a;
+  const int b = (int)(blockIdx.x - (size_t)a * (a + 1) / 2);
+  const double *ra = A + (size_t)a * n, *rb = A + (size_t)b * n;
+  double acc = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) acc += ra[i] * Minv[i] * rb[i];
+  acc = wave_reduce_sum(acc);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    S[(size_t)a * m + b] = s;
+    S[(size_t)b * m + a] = s;
+  }
+}
+
+// one workgroup: S -> L (lower Cholesky, in place), then Sinv column by column (thread c solves L L' x = e_c)
+__global__ __launch_bounds__(kBlock) void k_kkt_invert(int m, double *__restrict__ S, double *__restrict__ Sinv,
+                                                       int *__restrict__ fail) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < m; ++j) {
+    if (threadIdx.x == 0) {
+      const double d = S[(size_t)j * m + j];
+      if (!(d > 0)) bad = 1;
+      S[(size_t)j * m + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (bad) break;
+    const double ljj = S[(size_t)j * m + j];
+    for (int i = j + 1 + threadIdx.x; i < m; i += kBlock) S[(size_t)i * m + j] /= ljj;
+    __syncthreads();
+    // trailing update of the lower triangle: S[i][k] -= L[i][j] L[k][j], j < k <= i
+    const int t = m - j - 1;
+    for (int e = threadIdx.x; e < t * t; e += kBlock) {
+      const int i = j + 1 + e / t, k = j + 1 + e % t;
+      if (k <= i) S[(size_t)i * m + k] -= S[(size_t)i * m + j] * S[(size_t)k * m + j];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (threadIdx.x == 0) *fail = 1;
+    return;
+  }
+  for (int c = threadIdx.x; c < m; c += kBlock) {
+    double *x = Sinv + (size_t)c * m;  // row c of the (symmetric) inverse
+    for (int i = 0; i < m; ++i) {      // L y = e_c
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= S[(size_t)i * m + k] * x[k];
+      x[i] = s / S[(size_t)i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {  // L' x = y
+      double s = x[i];
+      for (int k = i + 1; k < m; ++k) s -= S[(size_t)k * m + i] * x[k];
+      x[i] = s / S[(size_t)i * m + i];
+    }
+  }
+}
+
+__device__ __forceinline__ void kkt_chunk(size_t n, size_t &c0, size_t &c1) {
+  // contiguous column chunk of this workgroup, a multiple of 64 columns
+  const size_t per = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+  c0 = (size_t)blockIdx.x * per;
+  c1 = c0 + per < n ? c0 + per : n;
+  if (c0 > n) c0 = n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_kkt_b(size_t n, int m, const double *__restrict__ A,
+                                                  const double *__restrict__ Minv, const double *__restrict__ r,
+                                                  double *__restrict__ bpart) {
+  size_t c0, c1;
+  kkt_chunk(n, c0, c1);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int a = w; a < m; a += kWaves) {
+    const double *row = A + (size_t)a * n;
+    double acc = 0;
+    for (size_t i = c0 + lane; i < c1; i += 64) acc += row[i] * (Minv[i] * r[i]);
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) bpart[(size_t)a * kMaxGrid + blockIdx.x] = acc;
+  }
+}
+
+template <bool SUBTRACT>
+__global__ __launch_bounds__(kBlock) void k_kkt_finish(size_t n, int m, int nparts, const double *__restrict__ A,
+                                                       const double *__restrict__ Minv,
+                                                       const double *__restrict__ Sinv,
+                                                       const double *__restrict__ bpart, double *__restrict__ r,
+                                                       double *__restrict__ v, double *__restrict__ lambda_out) {
+  __shared__ double bs[kKktMaxM], ls[kKktMaxM];
+  for (int a = threadIdx.x; a < m; a += kBlock) {
+    const double *src = bpart + (size_t)a * kMaxGrid;
+    double s = 0;
+    for (int j = 0; j < nparts; ++j) s += src[j];
+    bs[a] = s;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < m; a += kBlock) {
+    const double *row = Sinv + (size_t)a * m;
+    double s = 0;
+    for (int b = 0; b < m; ++b) s += row[b] * bs[b];
+    ls[a] = s;
+    if (blockIdx.x == 0) lambda_out[a] = s;
+  }
+  __syncthreads();
+  size_t c0, c1;
+  kkt_chunk(n, c0, c1);
+  for (size_t i = c0 + threadIdx.x; i < c1; i += kBlock) {
+    double w = 0;
+    for (int a = 0; a < m; ++a) w += A[(size_t)a * n + i] * ls[a];
+    const double ri = r[i], d = ri - w;
+    v[i] = Minv[i] * d;
+    if (SUBTRACT) r[i] = d;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_kkt_At(size_t n, int m, const double *__restrict__ A,
+                                                   const double *__restrict__ l, double *__restrict__ out) {
+  __shared__ double ls[kKktMaxM];
+  for (int a = threadIdx.x; a < m; a += kBlock) ls[a] = l[a];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    double w = 0;
+    for (int a = 0; a < m; ++a) w += A[(size_t)a * n + i] * ls[a];
+    out[i] = w;
+  }
+}
+
+int kkt_run(mi_precon *self, mi_vec *r, mi_vec *v, int subtract) {
+  KktImpl *k = (KktImpl *)self->impl;
+  mi_ctx *ctx = self->ctx;
+  const int grid = grid_for(ctx, k->n, 1);
+  hipLaunchKernelGGL(k_kkt_b, dim3(grid), dim3(kBlock), 0, ctx->stream, k->n, (int)k->m, k->A, k->Minv,
+                     (const double *)r->d, k->bpart);
+  if (subtract)
+    hipLaunchKernelGGL(k_kkt_finish<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, k->n, (int)k->m, grid, k->A,
+                       k->Minv, (const double *)k->Sinv, (const double *)k->bpart, r->d, v->d, k->lambda);
+  else
+    hipLaunchKernelGGL(k_kkt_finish<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, k->n, (int)k->m, grid, k->A,
+                       k->Minv, (const double *)k->Sinv, (const double *)k->bpart, r->d, v->d, k->lambda);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+int kkt_apply(mi_precon *self, const mi_vec *r, mi_vec *v) { return kkt_run(self, const_cast<mi_vec *>(r), v, 0); }
+void kkt_destroy(mi_precon *self) {
+  KktImpl *k = (KktImpl *)self->impl;
+  (void)hipStreamSynchronize(self->ctx->stream);
+  (void)hipFree(k->Sinv);
+  (void)hipFree(k->bpart);
+  (void)hipFree(k->lambda);
+  delete k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_precon_create_constraint(mi_ctx *ctx, size_t n, size_t m, const mi_vec *A, const mi_vec *Minv,
+                                mi_precon **out) {
+  MI_REQUIRE(ctx && A && Minv && out, "null argument");
+  MI_REQUIRE(A->ctx == ctx && Minv->ctx == ctx, "vector belongs to another context");
+  MI_REQUIRE(m >= 1 && m <= (size_t)kKktMaxM, "number of constraints must be in [1,%d], got %zu", kKktMaxM, m);
+  MI_REQUIRE(n >= m && A->n == n * m && Minv->n == n, "constraint matrix must be m x n row-major (m <= n), M^-1 of length n");
+  MI_TRY(ensure_device());
+  KktImpl *k = new KktImpl();
+  k->n = n;
+  k->m = m;
+  k->A = A->d;
+  k->Minv = Minv->d;
+  double *S = nullptr;
+  int *fail = nullptr;
+  int st = MI_OK, failed = 0;
+  auto hipok = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && st == MI_OK) st = hip_fail(e, what, __FILE__, __LINE__);
+  };
+  hipok(hipMalloc((void **)&k->Sinv, m * m * sizeof(double)), "hipMalloc Sinv");
+  hipok(hipMalloc((void **)&k->bpart, m * kMaxGrid * sizeof(double)), "hipMalloc bpart");
+  hipok(hipMalloc((void **)&k->lambda, m * sizeof(double)), "hipMalloc lambda");
+  hipok(hipMalloc((void **)&S, m * m * sizeof(double)), "hipMalloc S");
+  hipok(hipMalloc((void **)&fail, sizeof(int)), "hipMalloc flag");
+  if (st == MI_OK) {
+    hipok(hipMemsetAsync(fail, 0, sizeof(int), ctx->stream), "memset");
+    hipLaunchKernelGGL(k_kkt_schur, dim3((unsigned)(m * (m + 1) / 2)), dim3(256), 0, ctx->stream, n, (int)m, k->A,
+                       k->Minv, S);
+    hipLaunchKernelGGL(k_kkt_invert, dim3(1), dim3(kBlock), 0, ctx->stream, (int)m, S, k->Sinv, fail);
+    hipok(hipGetLastError(), "kkt setup launch");
+    hipok(hipMemcpyAsync(&failed, fail, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "flag copy");
+    hipok(hipStreamSynchronize(ctx->stream), "kkt setup");
+  }
+  (void)hipFree(S);
+  (void)hipFree(fail);
+  if (st == MI_OK && failed) {
+    set_error("A M^-1 A' is not positive definite: the constraint rows are linearly dependent (or M^-1 is not positive)");
+    st = MI_ERR_INVALID_ARGUMENT;
+  }
+  if (st != MI_OK) {
+    (void)hipFree(k->Sinv);
+    (void)hipFree(k->bpart);
+    (void)hipFree(k->lambda);
+    delete k;
+    return st;
+  }
+  mi_precon *P = new mi_precon();
+  P->ctx = ctx;
+  P->n = n;
+  P->kind = 3;
+  P->apply = kkt_apply;
+  P->apply_project = kkt_run;
+  P->destroy = kkt_destroy;
+  P->impl = k;
+  *out = P;
+  return MI_OK;
+}
+
+int mi_precon_constraint_solve(mi_precon *P, const mi_vec *r, mi_vec *v, mi_vec *lambda) {
+  MI_REQUIRE(P && r && v, "null argument");
+  MI_REQUIRE(P->kind == 3, "not a constraint preconditioner");
+  KktImpl *k = (KktImpl *)P->impl;
+  MI_REQUIRE(r->n == k->n && v->n == k->n && (!lambda || lambda->n == k->m), "dimension mismatch");
+  touch(v);
+  MI_TRY(kkt_run(P, const_cast<mi_vec *>(r), v, 0));
+  if (lambda) {
+    touch(lambda);
+    MI_HIP(hipMemcpyAsync(lambda->d, k->lambda, k->m * sizeof(double), hipMemcpyDeviceToDevice, P->ctx->stream));
+  }
+  return MI_OK;
+}
+
+int mi_precon_constraint_At(mi_precon *P, const mi_vec *lambda, mi_vec *out) {
+  MI_REQUIRE(P && lambda && out, "null argument");
+  MI_REQUIRE(P->kind == 3, "not a constraint preconditioner");
+  KktImpl *k = (KktImpl *)P->impl;
+  MI_REQUIRE(lambda->n == k->m && out->n == k->n, "dimension mismatch");
+  touch(out);
+  hipLaunchKernelGGL(k_kkt_At, dim3(grid_for(P->ctx, k->n, 1)), dim3(kBlock), 0, P->ctx->stream, k->n, (int)k->m,
+                     k->A, (const double *)lambda->d, out->d);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+}  // extern "C"

@@ -489,9 +489,12 @@ struct mi_dirgram {
 struct mi_precon {
   mi_ctx *ctx = nullptr;
   size_t n = 0;
-  int kind = 0;  // 0 callback/generic, 1 diag (fusable), 2 block3 (fusable)
+  int kind = 0;  // 0 callback/generic, 1 diag (fusable), 2 block3 (fusable), 3 constraint (kkt.hip)
   const double *data = nullptr;  // dinv (n) or inverse blocks (9 * n/3)
   int (*apply)(mi_precon *self, const mi_vec *r, mi_vec *v) = nullptr;
+  // constraint preconditioner (IterativeSolvers.h:229-253,381-405): (v, lambda) = P(r) and, if subtract, the
+  // residual correction r -= A' lambda of the `At` branch in the same pass
+  int (*apply_project)(mi_precon *self, mi_vec *r, mi_vec *v, int subtract) = nullptr;
   void (*destroy)(mi_precon *self) = nullptr;
   void *impl = nullptr;
   bool borrowed = false;

@@ -664,6 +664,7 @@ void mi_stpcg_default_params(mi_stpcg_params *p) {
   p->theta = .5;
   p->epsilon = 1e-8;  // :179
   p->run_ahead = 3;
+  p->constraint_At = 0;
   p->defer_result = 0;
 }
 
@@ -701,6 +702,8 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   MI_REQUIRE(g->d != s_out->d, "g and s_out must not alias");
   touch(s_out);
   MI_REQUIRE(!P || (P->ctx == ctx && P->n == g->n), "preconditioner dimension/context mismatch");
+  MI_REQUIRE(!prm->constraint_At || (P && P->apply_project),
+             "constraint_At needs a constraint preconditioner (mi_precon_create_constraint)");
   // reference argument checks, IterativeSolvers.h:183-205
   MI_REQUIRE(prm->Delta > 0, "Trust-region radius (Delta) must be a positive real value");
   MI_REQUIRE(prm->kappa_fgr >= 0 && prm->kappa_fgr < 1,
@@ -799,7 +802,8 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     LAUNCH_PRE(k_cg_init, n, (const double *)g->d, pred, r->d, vd, p->d, s_out->d, ctx->partials_b);
   }
   if (pre == PRE_EXTERNAL) {
-    CG_CHECK(P->apply(P, r, v));
+    if (P->apply_project) CG_CHECK(P->apply_project(P, r, v, prm->constraint_At));  // (v, lambda) = P(r); r -= A' lambda
+    else CG_CHECK(P->apply(P, r, v));
     hipLaunchKernelGGL(k_cg_dot_rv<true>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st0,
                        (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
   }
@@ -895,7 +899,8 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       }
 #undef UPD_ARGS
       if (pre == PRE_EXTERNAL) {
-        CG_CHECK(P->apply(P, r, v));  // v = P(r) (:386)
+        if (P->apply_project) CG_CHECK(P->apply_project(P, r, v, prm->constraint_At));  // :386,403
+        else CG_CHECK(P->apply(P, r, v));  // v = P(r) (:386)
         hipLaunchKernelGGL(k_cg_dot_rv<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1,
                            (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
       }

@@ -66,6 +66,7 @@ template <typename Vector, typename Multiplier, typename Scalar, typename... Arg
 bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args...> &H,
                      const InnerProduct<Vector, Scalar, Args...> &inner_product,
                      const std::optional<STPCGPreconditioner<Vector, Multiplier, Args...>> &P,
+                     const std::optional<LinearOperator<Multiplier, Vector, Args...>> &At,
                      Scalar Delta, size_t max_iterations, Scalar kappa_fgr, Scalar theta, Scalar epsilon,
                      Vector &s_out, Scalar &update_step_M_norm, size_t &num_iterations) {
   if constexpr (!MI355::is_device_vector<Vector>::value || !std::is_same<Scalar, double>::value) {
@@ -77,10 +78,26 @@ bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args
     const DeviceOperator *dop = H.template target<DeviceOperator>();
     if (!dop || !dop->op) return false;
     mi_precon *prec = nullptr;
+    bool constraint_At = false;
     if (P) {
-      const auto *dp = P->template target<DeviceSTPCGPreconditioner<Multiplier>>();
-      if (!dp || !dp->P) return false;
-      prec = dp->P;
+      if (const auto *dp = P->template target<DeviceSTPCGPreconditioner<Multiplier>>()) {
+        if (!dp->P || At) return false;  // (an ordinary preconditioner has no multipliers for `At` to act on)
+        prec = dp->P;
+      } else if constexpr (is_device_vector<Multiplier>::value) {
+        // projected solve (:229-253,381-405): constraint preconditioner and A' of ONE device KKT object
+        const auto *cp = P->template target<DeviceConstraintPreconditioner>();
+        if (!cp || !cp->P) return false;
+        if (At) {
+          const auto *ct = At->template target<DeviceConstraintTranspose>();
+          if (!ct || ct->P != cp->P) return false;
+          constraint_At = true;
+        }
+        prec = cp->P;
+      } else {
+        return false;
+      }
+    } else if (At) {
+      return false;
     }
     mi_stpcg_params prm;
     mi_stpcg_default_params(&prm);
@@ -89,6 +106,7 @@ bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args
     prm.kappa_fgr = kappa_fgr;
     prm.theta = theta;
     prm.epsilon = epsilon;
+    prm.constraint_At = constraint_At ? 1 : 0;
     // a caller that reads the result together with its own next chain (TNT's fused trial step): no wait here
     DeferScope *defer = DeferScope::active();
     prm.defer_result = defer ? 1 : 0;
@@ -176,9 +194,9 @@ Vector STPCG(const Vector &g, const SymmetricLinearOperator<Vector, Args...> &H,
 
 #if OPTIMIZATION_HAVE_MI355
   if constexpr (sizeof...(Args) == 0) {
-    if (!At && !user_function) {
+    if (!user_function) {
       Vector s_dev;
-      if (detail::stpcg_on_device<Vector, Multiplier, Scalar>(g, H, inner_product, P, Delta, max_iterations,
+      if (detail::stpcg_on_device<Vector, Multiplier, Scalar>(g, H, inner_product, P, At, Delta, max_iterations,
                                                               kappa_fgr, theta, epsilon, s_dev,
                                                               update_step_M_norm, num_iterations))
         return s_dev;

@@ -385,5 +385,31 @@ struct DeviceSTPCGPreconditioner {
   }
 };
 
+// The constraint preconditioner of the PROJECTED solve and the transposed constraint operator handed to STPCG as
+// `P` and `At` (reference IterativeSolvers.h:83-85,178, used at :229-253,381-405), both backed by ONE mi_precon made
+// by mi_precon_create_constraint (diagonal M, dense m x n constraints): STPCG<DeviceVector, DeviceVector> recognises
+// the pair and runs the whole projected solve through the fused device loop (mi_stpcg with constraint_At); used as
+// plain callables they do what the reference's callables do.
+struct DeviceConstraintPreconditioner {
+  mi_precon *P = nullptr;
+  size_t multipliers = 0;  // m
+  template <typename... A>
+  std::pair<DeviceVector, DeviceVector> operator()(const DeviceVector &r, A &...) const {
+    DeviceVector v = DeviceVector::like(r), l = DeviceVector::on(r.context(), multipliers);
+    check(mi_precon_constraint_solve(P, r.handle(), v.handle(), l.handle()));
+    return std::make_pair(std::move(v), std::move(l));
+  }
+};
+struct DeviceConstraintTranspose {
+  mi_precon *P = nullptr;
+  size_t n = 0;
+  template <typename... A>
+  DeviceVector operator()(const DeviceVector &l, A &...) const {
+    DeviceVector out = DeviceVector::on(l.context(), n);
+    check(mi_precon_constraint_At(P, l.handle(), out.handle()));
+    return out;
+  }
+};
+
 }  // namespace MI355
 }  // namespace Optimization

@@ -198,17 +198,50 @@ extern "C" int hd_stpcg_diag_stop(size_t n, const double *g, const double *D, co
 // do their dense algebra on the host (oracle/kkt_dense.h, the same code as the reference-side driver) and hand
 // device vectors back -- the solver's own work (every vector statement, the r -= A'lambda correction) is on the GPU.
 // ------------------------------------------------------------------------------------------------
+// mode 0: as described above (generic loop, host KKT algebra);  mode 1: the DEVICE constraint preconditioner
+// (mi_precon_create_constraint: S = A M^-1 A' formed, factored and inverted on the GPU) as tagged P / At callables ->
+// the whole projected solve runs through the fused loop (mi_stpcg with constraint_At);  mode 2: the same device
+// callables hidden in plain lambdas -> generic loop, device KKT algebra.
 extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const double *Pdiag, const double *Mdiag,
                                   const double *A, double Delta, size_t max_iterations, double kappa_fgr,
-                                  double theta, double *s_out, double *M_norm, size_t *iterations) {
+                                  double theta, int mode, double *s_out, double *M_norm, size_t *iterations) {
   HD_GUARD_BEGIN
   Context ctx(0);
-  const KktDense K(n, m, A, Mdiag);
   DeviceVector gd(ctx, g, n), Pd(ctx, Pdiag, n);
   mi_op *op = nullptr;
   MI355::check(mi_op_create_diag(ctx.get(), Pd.handle(), &op));
   LA::SymmetricLinearOperator<DeviceVector> H = MI355::DeviceOperator{op};
   LA::InnerProduct<DeviceVector> ip = MI355::FrobeniusInnerProduct{};
+  if (mode != 0) {
+    std::vector<double> mi(n);
+    for (size_t i = 0; i < n; ++i) mi[i] = 1.0 / Mdiag[i];
+    DeviceVector Ad(ctx, A, n * m), Mi(ctx, mi);
+    mi_precon *kkt = nullptr;
+    MI355::check(mi_precon_create_constraint(ctx.get(), n, m, Ad.handle(), Mi.handle(), &kkt));
+    const MI355::DeviceConstraintPreconditioner cp{kkt, m};
+    const MI355::DeviceConstraintTranspose ct{kkt, n};
+    std::optional<LA::STPCGPreconditioner<DeviceVector, DeviceVector>> P = LA::STPCGPreconditioner<DeviceVector, DeviceVector>(cp);
+    std::optional<LA::LinearOperator<DeviceVector, DeviceVector>> At = LA::LinearOperator<DeviceVector, DeviceVector>(ct);
+    if (mode == 2) {
+      P = LA::STPCGPreconditioner<DeviceVector, DeviceVector>([cp](const DeviceVector &r) { return cp(r); });
+      At = LA::LinearOperator<DeviceVector, DeviceVector>([ct](const DeviceVector &l) { return ct(l); });
+    }
+    double mn = 0;
+    size_t it = 0, c0 = 0, c1 = 0;
+    MI355::check(mi_ctx_sync_count(ctx.get(), &c0));
+    DeviceVector s = LA::STPCG<DeviceVector, DeviceVector>(gd, H, ip, mn, it, Delta, max_iterations, kappa_fgr, theta,
+                                                           P, At);
+    MI355::check(mi_ctx_sync_count(ctx.get(), &c1));
+    g_last_tnt_syncs = c1 - c0;
+    const std::vector<double> sh = s.to_host();
+    std::memcpy(s_out, sh.data(), n * sizeof(double));
+    *M_norm = mn;
+    *iterations = it;
+    mi_precon_destroy(kkt);
+    mi_op_destroy(op);
+    return 0;
+  }
+  const KktDense K(n, m, A, Mdiag);
   std::optional<LA::STPCGPreconditioner<DeviceVector, DeviceVector>> P =
       LA::STPCGPreconditioner<DeviceVector, DeviceVector>([&](const DeviceVector &r) {
         const std::vector<double> rh = r.to_host();

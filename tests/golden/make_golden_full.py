@@ -6,9 +6,11 @@
   (b) for a whole TNT run from a random start (reference Riemannian/TNT.h:242-689), max_TPCG_iterations = 50.
 
 Only scalars travel: per-iteration traces, counts, the accept sequence and checksums of the 24 MB vectors (sums,
-projections on analytic eigenvectors, SHA-256 of the bytes).  The GPU tests re-run the plain-C oracle on the same
-inputs on the GPU box's host, require ITS vectors to hash to the values recorded here (oracle == reference bit for
-bit at full size) and compare the device results with them.
+projections on analytic eigenvectors, SHA-256 of the bytes).  On THIS machine the plain-C oracle reproduces the
+hashes (tests/test_cpu_oracle_templates.py::test_oracle_is_the_reference_on_the_full_size_bench_solve: oracle ==
+reference bit for bit at full size); on the GPU box, whose numpy generates the inputs with other last bits, the
+tests re-run the oracle on the same arrays as the device, hold it against the scalars recorded here with a
+tolerance and compare the device results with its vectors (tests/test_gpu_cfg2_full.py).
 
 Run here (where /root/reference is mounted; ~4 minutes):  python tests/golden/make_golden_full.py
 """
@@ -16,6 +18,11 @@ import hashlib
 import json
 import os
 import sys
+
+# (the inputs come out of numpy's QR: its BLAS must run with the thread count the tests use -- tests/conftest.py --
+# or the last bits of X differ)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ[_v] = "1"
 
 import numpy as np
 

@@ -96,17 +96,18 @@ class DeviceHarness:
                                    C.byref(params), mode, C.byref(res))
         return self._unpack(rc, bufs, res, self.err() if rc else "")
 
-    def stpcg_projected(self, pr):
+    def stpcg_projected(self, pr, mode=0):
         """hd_stpcg_projected on the inputs of oracle_py.projected_stpcg_problem"""
         self.L.hd_stpcg_projected.restype = C.c_int
         self.L.hd_stpcg_projected.argtypes = [C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_double, C.c_size_t,
-                                              C.c_double, C.c_double, dp, dp, C.POINTER(C.c_size_t)]
+                                              C.c_double, C.c_double, C.c_int, dp, dp, C.POINTER(C.c_size_t)]
         s = np.zeros(pr["n"])
         mn, it = C.c_double(0), C.c_size_t(0)
         rc = self.L.hd_stpcg_projected(pr["n"], pr["m"], _dp(pr["g"]), _dp(pr["P"]), _dp(pr["M"]),
                                        _dp(np.ascontiguousarray(pr["A"])), pr["Delta"], pr["max_iterations"],
-                                       pr["kappa"], pr["theta"], _dp(s), C.byref(mn), C.byref(it))
-        return dict(rc=rc, err=self.err() if rc else "", s=s, M_norm=mn.value, iterations=it.value)
+                                       pr["kappa"], pr["theta"], mode, _dp(s), C.byref(mn), C.byref(it))
+        return dict(rc=rc, err=self.err() if rc else "", s=s, M_norm=mn.value, iterations=it.value,
+                    syncs=self.L.hd_last_tnt_syncs())
 
     def tnt_rosenbrock(self, n, precon_kind, x0, params, mode=0):
         """BASELINE cfg1 through EuclideanTNT<DeviceVector> (hd_tnt_rosenbrock)"""

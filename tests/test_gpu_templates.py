@@ -94,17 +94,22 @@ def test_stpcg_user_function_stop_on_device_vectors(harness, golden):
         assert abs(r["M_norm"] - c["M_norm"]) <= tol * max(1e-300, c["M_norm"])
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["generic_host_kkt", "fused_device_kkt", "generic_device_kkt"])
 @pytest.mark.parametrize("case", ["exact", "truncated"])
-def test_projected_stpcg_on_device_vectors(harness, golden, case):
+def test_projected_stpcg_on_device_vectors(harness, golden, case, mode):
     """The `At` + constraint-preconditioner branch of STPCG (reference IterativeSolvers.h:229-253,381-405) with
     Vector = Multiplier = DeviceVector, on the reference's two equality-constrained cases
     (tests/IterativeSolvers_unit_test.cpp:316-496, n = 1000, 100 constraints), against the fixture the REAL
-    reference produced (tests/golden/stpcg_projected.json): same iteration count, iterate to 1e-10, |A s| < 1e-6."""
+    reference produced (tests/golden/stpcg_projected.json): same iteration count, iterate to 1e-10, |A s| < 1e-6.
+    fused_device_kkt: tagged constraint preconditioner + A' of one device KKT object (mi_precon_create_constraint)
+    -> the whole projected solve is ONE mi_stpcg call, one host synchronisation."""
     import oracle_py
     pr = oracle_py.projected_stpcg_problem(case)
     fx = golden("stpcg_projected.json")[case]
-    r = harness.stpcg_projected(pr)
+    r = harness.stpcg_projected(pr, mode)
     assert r["rc"] == 0, r["err"]
+    if mode == 1:
+        assert r["syncs"] == 1, r["syncs"]
     assert r["iterations"] == fx["iterations"]
     assert rel_err(r["s"], np.array(fx["s"])) < 1e-10
     assert abs(r["M_norm"] - fx["M_norm"]) < 1e-10 * fx["M_norm"]
