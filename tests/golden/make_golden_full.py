@@ -72,9 +72,17 @@ def main():
     g = O.eval_grad(prob, Xb.ravel())
     r = O.stpcg_problem(prob, Xb.ravel(), g, BENCH["Delta"], max_iterations=BENCH["max_iterations"],
                         kappa_fgr=BENCH["kappa_fgr"], theta=BENCH["theta"], trace_cap=64, lib=R)
+    # the reference's observer (STPCGUserFunction, IterativeSolvers.h:50-59) sees alpha_k only; beta, kappa and <r,v>
+    # are taken from the plain-C oracle's run, which must reproduce the reference's alphas and step bit for bit
+    o = O.stpcg_problem(prob, Xb.ravel(), g, BENCH["Delta"], max_iterations=BENCH["max_iterations"],
+                        kappa_fgr=BENCH["kappa_fgr"], theta=BENCH["theta"], trace_cap=64)
+    assert list(o["trace"]["alpha"]) == list(r["trace"]["alpha"]) and np.array_equal(o["s"], r["s"])
+    assert o["M_norm"] == r["M_norm"] and o["iterations"] == r["iterations"]
     out["bench_stpcg"] = dict(params=BENCH, iterate=dict(eps=1e-3, seed=7, modes=[list(m) for m in modes]),
                               iterations=int(r["iterations"]),  # (the reference reports no exit reason)
-                              M_norm=float(r["M_norm"]), trace={k: lst(v) for k, v in r["trace"].items()},
+                              M_norm=float(r["M_norm"]),
+                              trace=dict(alpha=lst(r["trace"]["alpha"]), beta=lst(o["trace"]["beta"]),
+                                         kappa=lst(o["trace"]["kappa"]), rv=lst(o["trace"]["rv"])),
                               g=vector_checksums(g, n, P), s=vector_checksums(r["s"], n, P))
     print("bench solve:", r["iterations"], "iterations, |s|_M", r["M_norm"])
 
