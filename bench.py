@@ -324,9 +324,10 @@ def main():
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(world, rank, uid[0])
-        # RCCL carries every exchange by default.  MI355OPT_COMM=peer opts into the peer-memory layer (scalar
-        # all-reduces and halo rows by xGMI peer stores), enabled only when every rank's bring-up + self-test
-        # succeeds; the one-GPU rehearsal needs it (RCCL refuses duplicate devices).
+        # The peer-memory layer (scalar all-reduces and halo rows by xGMI peer stores) carries the small exchanges
+        # whenever every rank's bring-up + self-test succeeds AND the sharded data path verifies through it below;
+        # otherwise -- or with MI355OPT_COMM=rccl -- RCCL does.  The one-GPU rehearsal needs it (RCCL refuses
+        # duplicate devices).
         peer_memory = ctx.enable_peer_memory(world, rank, dist, force=one_gpu)
         if one_gpu and not peer_memory:
             raise SystemExit("one-GPU rehearsal needs the peer-memory layer")

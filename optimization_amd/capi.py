@@ -544,9 +544,9 @@ class Context:
         """Collective bring-up of the peer-memory layer over a torch.distributed (gloo) control plane: export,
         gather handles, map, self-test; enabled only if EVERY rank succeeded at every step, else it stays off
         (RCCL then does the small exchanges).  Returns True when enabled.
-        OPT-IN: RCCL is the default exchange layer; the peer-memory layer is only brought up with
-        MI355OPT_COMM=peer (or force=True: the one-GPU multi-process tests, where RCCL cannot run) -- it has never
-        executed across real xGMI links yet."""
+        DEFAULT since r03: the layer is brought up and used whenever its collective self-test passes on every rank
+        (bench.py additionally verifies the sharded data path through it and falls back to RCCL on any failure);
+        MI355OPT_COMM=rccl keeps RCCL in charge.  force=True: the one-GPU multi-process tests, where RCCL cannot run."""
         import os
 
         def all_ok(flag, payload=None):
@@ -554,7 +554,7 @@ class Context:
             dist.all_gather_object(lst, (bool(flag), payload))
             return all(f for f, _ in lst), [pl for _, pl in lst]
 
-        if not force and os.environ.get("MI355OPT_COMM", "rccl") != "peer":
+        if not force and os.environ.get("MI355OPT_COMM", "peer") == "rccl":
             return False
         try:
             handle, ok = self.comm_ipc_export(), True

@@ -1,0 +1,61 @@
+"""One rank of the BASELINE cfg4 rehearsal on ONE GPU (tests/test_gpu_comm.py): Stiefel(8e6, 3) on the 200^3 grid,
+row-sharded in z-slabs over W processes that all sit on GPU 0 and exchange through the peer-memory layer (RCCL
+refuses duplicate devices).  Every rank builds its slab of the matrix and its rows of the bench iterate, runs the
+exact solve bench.py times (50 fused STPCG iterations, kappa_fgr 1e-12, theta 1, Delta 1e3) and writes its rows of
+the step plus the replicated scalars; the test compares them with the single-context solve of the whole problem."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from optimization_amd import capi, workloads as wl  # noqa: E402  (ROCm before torch)
+
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out_dir = os.environ["CFG4_WORKER_OUT"]
+    nx, ny, nz = (int(v) for v in os.environ.get("CFG4_GRID", "200,200,200").split(","))
+    p = 3
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = capi.Context(0)
+    enabled = c.enable_peer_memory(world, rank, dist, force=True)
+    out = {"rank": rank, "enabled": enabled}
+    if enabled:
+        z0, z1 = wl.shard_rows(nz, world)[rank]
+        n_glob, n = nx * ny * nz, nx * ny * (z1 - z0)
+        r0 = nx * ny * z0
+        Xb = np.load(os.path.join(out_dir, "Xb.npy"), mmap_mode="r")[r0:r0 + n]
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
+        starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
+        dist.barrier()
+        A = c.csr_sharded(n_glob, r0, r0 + n, rowptr, col, val, starts)
+        prob = c.stiefel_rq(A, n, p)
+        X = c.upload(np.ascontiguousarray(Xb))
+        out["f"] = prob.objective(X)
+        g, H = prob.model(X)
+        c.ktime_enable("stiefel_hess_fused", True)
+        r = c.stpcg(g, H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
+        out["one_pass_launches"] = c.ktime_read("stiefel_hess_fused")[0]
+        np.save(os.path.join(out_dir, f"s_rank{rank}.npy"), r["s"].numpy())
+        np.save(os.path.join(out_dir, f"g_rank{rank}.npy"), g.numpy())
+        out.update(rows=[r0, r0 + n], iters=r["iterations"], exit=r["exit_reason"], M=float(r["M_norm"]).hex(),
+                   rv=float(r["rv_final"]).hex(), hvp=r["hvp_calls"],
+                   alpha=[float(a).hex() for a in r["trace"]["alpha"]],
+                   beta=[float(a).hex() for a in r["trace"]["beta"]], ipc_error=c.comm_ipc_error())
+        dist.barrier()
+        c.comm_finalize()
+    c.close()
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

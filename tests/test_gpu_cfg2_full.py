@@ -108,7 +108,7 @@ def test_bench_solve_matches_the_reference(cfg2, bench_solve, monkeypatch, fmt):
         prob = c.stiefel_rq(A, N, P)
         X = c.upload(bench_solve["Xb"])
         g, H = prob.model(X)
-        assert rel_err(g.numpy(), bench_solve["g"]) < 1e-12
+        assert rel_err(g.numpy(), bench_solve["g"]) < 1e-11  # (|g| is 1e-3 of |A X| at this near-optimal iterate)
         prm, o = bench_solve["prm"], bench_solve["o"]
         c.ktime_enable("stiefel_hess_fused", True)
         c.ktime_enable("stiefel_finish_dots", True)

@@ -250,7 +250,7 @@ def test_bench_two_ranks_on_one_gpu_functional_rehearsal():
 
 
 def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification():
-    # (the peer-memory layer is opt-in: RCCL is the default exchange layer)
+    # (the peer-memory layer is the default exchange layer; RCCL the fallback)
     env = dict(os.environ, MI355OPT_BENCH_FORCE_COMM="1", MI355OPT_BENCH_INJECT_VERIFY_FAILURE="1",
                MI355OPT_COMM="peer")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
@@ -275,3 +275,59 @@ def test_peer_memory_wait_is_bounded_and_fails_loudly():
     assert o["first"] == 2000.0
     assert o["err"] != 0 and 0.2 < o["waited_s"] < 5.0, o
     assert o["stpcg"].startswith("MiError"), o
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world):
+    """BASELINE cfg4 (St(8e6,3), 200^3 grid) at its full size, row-sharded over `world` real processes on GPU 0
+    through the (default) peer-memory layer: the solve bench.py times -- 50 fused STPCG iterations -- against the
+    single-context solve of the same problem: same iteration count and exit, |s|_M and the alpha / beta traces to
+    rounding of the re-partitioned sums, the step to 1e-10 relative, every replicated scalar bit-identical on all
+    ranks, the one-pass (recurrence-form) Hessian on every rank."""
+    import tempfile
+    from optimization_amd import capi, workloads as wl
+    nx = ny = nz = 200
+    p, n = 3, nx * ny * nz
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "Xb.npy"), Xb)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29580 + world),
+               os.path.join(ROOT, "tests", "cfg4_worker.py")]
+        r = subprocess.run(cmd, env=dict(os.environ, CFG4_WORKER_OUT=tmp, CFG4_GRID=f"{nx},{ny},{nz}"),
+                           capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
+        s_sh = np.concatenate([np.load(os.path.join(tmp, f"s_rank{k}.npy")) for k in range(world)])
+        g_sh = np.concatenate([np.load(os.path.join(tmp, f"g_rank{k}.npy")) for k in range(world)])
+    assert all(o["enabled"] and o["ipc_error"] == 0 for o in outs), outs
+    assert outs[0]["rows"][0] == 0 and outs[-1]["rows"][1] == n
+    for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):  # replicated: the same bits on every rank
+        assert all(o[k] == outs[0][k] for o in outs), k
+    assert all(o["one_pass_launches"] >= 50 for o in outs)
+    # the single-context solve
+    c = capi.Context(0)
+    try:
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+        A = c.csr(n, rowptr, col, val)
+        del rowptr, col, val
+        prob = c.stiefel_rq(A, n, p)
+        g, H = prob.model(c.upload(Xb))
+        one = c.stpcg(g, H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
+        f1 = prob.objective(c.upload(Xb))
+        s1, g1 = one["s"].numpy(), g.numpy()
+    finally:
+        c.close()
+    o = outs[0]
+    assert (o["iters"], o["exit"]) == (one["iterations"], one["exit_reason"]) and o["iters"] == 50
+    assert abs(o["f"] - f1) <= 1e-12 * abs(f1)
+    assert np.abs(g_sh - g1).max() <= 1e-12 * np.abs(g1).max()
+    M = float.fromhex(o["M"])
+    assert abs(M - one["M_norm"]) <= 1e-11 * one["M_norm"]
+    al = np.array([float.fromhex(a) for a in o["alpha"]])
+    be = np.array([float.fromhex(a) for a in o["beta"]])
+    ea = float(np.max(np.abs(al / one["trace"]["alpha"] - 1)))
+    eb = float(np.max(np.abs(be / one["trace"]["beta"] - 1)))
+    es = float(np.linalg.norm(s_sh - s1) / np.linalg.norm(s1))
+    print(f"cfg4 on one GPU, {world} ranks: s {es:.2e}, alpha {ea:.2e}, beta {eb:.2e}, |s|_M {abs(M - one['M_norm']) / M:.2e}")
+    assert es <= 1e-10 and ea <= 1e-9 and eb <= 1e-8
