@@ -25,6 +25,8 @@ using namespace mi;
 
 namespace {
 
+constexpr bool kBsr3NtDefault = false;
+
 struct IncView {
   size_t N, nslices;
   const long long *__restrict__ slice_ptr;
@@ -152,7 +154,18 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
 }
 
 // h = D xi - sum B_ij xi_j, fused with the three curvature dots (one 256-thread workgroup = 4 slices)
-template <bool DOTS>
+// NT: the matrix streams (diagonal blocks, off-diagonal blocks, neighbour indices -- read exactly once per pass) are
+// loaded with the non-temporal policy, so that they do not evict the 12 MB of xi that the random chord gathers re-visit
+// from the XCD's 4 MB L2 (A/B switch MI355OPT_BSR3_NT, measured in DESIGN 5.1).
+template <bool NT>
+__device__ __forceinline__ double ld_stream(const double *p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ int ld_stream(const int *p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool DOTS, bool NT>
 __global__ __launch_bounds__(kBlock) void k_bsr3_spmv(IncView inc, const CgState *__restrict__ st,
                                                       const double *__restrict__ Dsl,
                                                       const double *__restrict__ Bblk,
@@ -173,18 +186,18 @@ __global__ __launch_bounds__(kBlock) void k_bsr3_spmv(IncView inc, const CgState
     const size_t i = (size_t)node;  // degree-sorted inside the workgroup's 1024-node window
     const double x0 = xi[3 * i], x1 = xi[3 * i + 1], x2 = xi[3 * i + 2];
     const double *D = Dsl + slice * 9 * 64 + lane;
-    double h0 = D[0] * x0 + D[64] * x1 + D[128] * x2;
-    double h1 = D[192] * x0 + D[256] * x1 + D[320] * x2;
-    double h2 = D[384] * x0 + D[448] * x1 + D[512] * x2;
+    double h0 = ld_stream<NT>(D) * x0 + ld_stream<NT>(D + 64) * x1 + ld_stream<NT>(D + 128) * x2;
+    double h1 = ld_stream<NT>(D + 192) * x0 + ld_stream<NT>(D + 256) * x1 + ld_stream<NT>(D + 320) * x2;
+    double h2 = ld_stream<NT>(D + 384) * x0 + ld_stream<NT>(D + 448) * x1 + ld_stream<NT>(D + 512) * x2;
     const long long b0 = inc.slice_ptr[slice], b1 = inc.slice_ptr[slice + 1];
     for (long long k = b0; k < b1; ++k) {
       const size_t e0 = (size_t)k * 64 + lane;
-      const size_t j = (size_t)inc.nbr[e0];
+      const size_t j = (size_t)ld_stream<NT>(inc.nbr + e0);
       const double y0 = xi[3 * j], y1 = xi[3 * j + 1], y2 = xi[3 * j + 2];
       const double *B = Bblk + (size_t)k * 9 * 64 + lane;
-      h0 -= B[0] * y0 + B[64] * y1 + B[128] * y2;
-      h1 -= B[192] * y0 + B[256] * y1 + B[320] * y2;
-      h2 -= B[384] * y0 + B[448] * y1 + B[512] * y2;
+      h0 -= ld_stream<NT>(B) * y0 + ld_stream<NT>(B + 64) * y1 + ld_stream<NT>(B + 128) * y2;
+      h1 -= ld_stream<NT>(B + 192) * y0 + ld_stream<NT>(B + 256) * y1 + ld_stream<NT>(B + 320) * y2;
+      h2 -= ld_stream<NT>(B + 384) * y0 + ld_stream<NT>(B + 448) * y1 + ld_stream<NT>(B + 512) * y2;
     }
     h[3 * i] = h0; h[3 * i + 1] = h1; h[3 * i + 2] = h2;
     if (DOTS) {
@@ -299,14 +312,18 @@ int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int 
   const size_t ngroups = (q->nslices + kWaves - 1) / kWaves;
   const int grid = uniform_grid(ctx, ngroups);
   KScope ks(ctx, MI_K_BSR3_SPMV_DOTS);
-  if (dots)
-    hipLaunchKernelGGL(k_bsr3_spmv<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), ctx->cg_live,
-                       (const double *)q->Dsl, (const double *)q->Bblk, (const double *)in->d, out->d,
-                       ctx->partials);
-  else
-    hipLaunchKernelGGL(k_bsr3_spmv<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, view(q),
-                       (const CgState *)nullptr, (const double *)q->Dsl, (const double *)q->Bblk,
-                       (const double *)in->d, out->d, (double *)nullptr);
+  const char *nt_env = getenv("MI355OPT_BSR3_NT");  // (per call: A/B runs in one process)
+  const bool nt = nt_env ? nt_env[0] == '1' : kBsr3NtDefault;
+#define BSR3(DV, NTV, STATE, PART)                                                                               \
+  hipLaunchKernelGGL((k_bsr3_spmv<DV, NTV>), dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), STATE,          \
+                     (const double *)q->Dsl, (const double *)q->Bblk, (const double *)in->d, out->d, PART)
+  if (dots) {
+    if (nt) BSR3(true, true, ctx->cg_live, ctx->partials); else BSR3(true, false, ctx->cg_live, ctx->partials);
+  } else {
+    if (nt) BSR3(false, true, (const CgState *)nullptr, (double *)nullptr);
+    else BSR3(false, false, (const CgState *)nullptr, (double *)nullptr);
+  }
+#undef BSR3
   if (nparts) *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
