@@ -317,6 +317,9 @@ def main():
     # MI355OPT_BENCH_ONE_GPU=1: functional rehearsal of the N-rank flow with all ranks on GPU 0 and WITHOUT RCCL
     # (which refuses duplicate devices): the peer-memory layer carries every exchange.  Timings are meaningless.
     one_gpu = os.environ.get("MI355OPT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        # the consumers wait for their peers inside their prologue: all ranks' kernels must fit on the one GPU together
+        os.environ.setdefault("MI355OPT_MAX_GRID", str(max(32, 384 // max(world, 1))))
     ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
     if use_comm:

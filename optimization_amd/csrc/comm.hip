@@ -10,6 +10,7 @@
 
 #include <cstdlib>
 
+#include "comm_ipc.h"
 #include "mi_internal.h"
 
 using namespace mi;
@@ -25,27 +26,16 @@ namespace {
 // summation order on every rank => replicated, deterministic results.  Waits are bounded (timeout ->
 // error word, never a hang); the layer is switched on only after a collective self-test passed on
 // every rank, else RCCL stays in charge.
-constexpr int kIpcMaxRanks = 8;
-constexpr int kIpcRing = 4;            // mailbox slots in flight (2 would do: a rank is never >1 exchange ahead)
-constexpr int kIpcVals = 16;           // doubles per rank per exchange
-constexpr size_t kIpcMailboxBytes = 64 * 1024;
+// (mailbox layout and the device-side wait / folded exchange: comm_ipc.h)
 constexpr size_t kIpcArenaBytes = 16u << 20;   // mailbox + halo regions
 constexpr uint64_t kIpcTimeoutTicks = 2000000000ull;  // default: 20 s of the 100 MHz wall clock (MI355OPT_IPC_TIMEOUT_MS)
-
-struct IpcMailbox {  // lives at offset 0 of every arena
-  uint64_t flag[kIpcRing][kIpcMaxRanks];             // flag[q][r] == seq: rank r's values of exchange seq are in
-  double val[kIpcRing][kIpcMaxRanks][kIpcVals];
-  uint64_t halo_flag[2];                              // [0]: from rank-1, [1]: from rank+1
-  unsigned int halo_count;                            // "last workgroup" counter of k_ipc_halo_push
-  unsigned int pad;
-};
-static_assert(sizeof(IpcMailbox) <= kIpcMailboxBytes, "mailbox too large");
 
 struct Comm {
   ncclComm_t nccl = nullptr;
   double *scratch = nullptr;  // device, small all-gather buffer
   // IPC layer
   bool ipc_mapped = false, ipc_enabled = false;
+  bool fold = true;                      // exchanges folded into the consumers' prologues (MI355OPT_NO_FOLD=1: off)
   char *arena = nullptr;                 // my arena (fine-grained device memory)
   char *peer[kIpcMaxRanks] = {nullptr};  // mapped arenas, peer[rank] == arena
   char **peer_dev = nullptr;             // device copy of peer[]
@@ -65,20 +55,6 @@ int nccl_fail(ncclResult_t r, const char *what) {
     ncclResult_t _r = (expr);                           \
     if (_r != ncclSuccess) return nccl_fail(_r, #expr); \
   } while (0)
-
-__device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err, uint64_t timeout) {
-  const uint64_t t0 = wall_clock64();
-  // sequence numbers only grow: ">= want", so that a peer that is already one exchange further on (it may raise
-  // this flag again before a descheduled waiter has looked) still releases the wait
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (wall_clock64() - t0 > timeout) {
-      __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return true;
-}
 
 // One workgroup.  vals: K values per rank, either the fixed-order sums of `count` partial rows
 // (partials != null) or in_vals[0..K).  SUM: out[0..K) = sum over ranks in rank order; else
@@ -198,6 +174,23 @@ int ipc_exchange(mi_ctx *ctx, Comm *c, const double *partials, int count, const 
 namespace mi {
 
 bool comm_ipc_enabled(const mi_ctx *ctx) { return ctx->comm && ((const Comm *)ctx->comm)->ipc_enabled; }
+
+FoldArgs comm_fold_next(mi_ctx *ctx) {
+  FoldArgs f;
+  Comm *c = (Comm *)ctx->comm;
+  if (!c || !c->ipc_enabled || !c->fold) return f;
+  f.peers = (char *const *)c->peer_dev;
+  f.err = c->err_dev;
+  f.seq = ++c->seq;
+  f.timeout = c->timeout;
+  f.P = ctx->world_size;
+  f.rank = ctx->rank;
+  return f;
+}
+bool comm_fold_enabled(const mi_ctx *ctx) {
+  const Comm *c = (const Comm *)ctx->comm;
+  return c && c->ipc_enabled && c->fold;
+}
 
 int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
   // a communicator of size 1 still goes through RCCL: the single-GPU box then exercises exactly the
@@ -396,6 +389,7 @@ int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTE
   }
   MI_REQUIRE(!c->arena, "arena already exported");
   if (const char *e = getenv("MI355OPT_IPC_TIMEOUT_MS")) c->timeout = (uint64_t)std::max(1L, atol(e)) * 100000ull;
+  if (const char *e = getenv("MI355OPT_NO_FOLD")) c->fold = !(e[0] == '1');
   MI_HIP(hipSetDevice(ctx->device));
   MI_HIP(hipExtMallocWithFlags((void **)&c->arena, kIpcArenaBytes, hipDeviceMallocFinegrained));
   MI_HIP(hipMemset(c->arena, 0, kIpcArenaBytes));

@@ -197,6 +197,7 @@ static int ctx_init(mi_ctx *ctx, int device) {
   memset((void *)ctx->status, 0, sizeof(HostStatus));
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
   { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
+  if (const char *e = getenv("MI355OPT_MAX_GRID")) ctx->max_grid = std::min(kMaxGrid, std::max(1, atoi(e)));
   { const char *e = getenv("MI355OPT_FORCE_LOCKSTEP"); ctx->force_lockstep = e && e[0] == '1'; }
   { const char *e = getenv("MI355OPT_NO_DIRGRAM"); ctx->no_dirgram = e && e[0] == '1'; }
   { const char *e = getenv("MI355OPT_DIRGRAM_DIRECT"); ctx->dirgram_direct = e && e[0] == '1'; }

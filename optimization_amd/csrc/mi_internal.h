@@ -103,6 +103,10 @@ struct mi_ctx {
   char device_name[128] = {0};
   int num_cu = 256;
   bool uniform_grid = false;  // see uniform_grid() below
+  // cap of the streaming kernels' grids (default kMaxGrid; MI355OPT_MAX_GRID).  Several processes rehearsing a
+  // multi-GPU run on ONE GPU need it: the consumer kernels WAIT for their peers in their prologue (comm_ipc.h), so
+  // the kernels of all ranks must be resident at the same time.
+  int max_grid = 512;
   // memory pool: free lists keyed by byte size
   std::multimap<size_t, void *> pool_free;
   std::map<void *, size_t> pool_all;
@@ -185,7 +189,7 @@ int ensure_device();
 inline int uniform_grid(const mi_ctx *ctx, size_t blocks) {
   if (ctx->uniform_grid) return kMaxGrid;
   if (blocks < 1) blocks = 1;
-  if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
+  if (blocks > (size_t)ctx->max_grid) blocks = ctx->max_grid;
   return (int)blocks;
 }
 
@@ -193,7 +197,7 @@ inline int grid_for(const mi_ctx *ctx, size_t n, int per_thread) {
   if (ctx->uniform_grid) return kMaxGrid;
   size_t blocks = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
   if (blocks < 1) blocks = 1;
-  if (blocks > (size_t)kMaxGrid) blocks = kMaxGrid;
+  if (blocks > (size_t)ctx->max_grid) blocks = ctx->max_grid;
   return (int)blocks;
 }
 
@@ -221,6 +225,8 @@ int comm_allreduce(mi_ctx *ctx, double *buf, int count);
 // every rank).  rows_mode(): a communicator is attached and the slot path is not forced.
 int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k);
 bool comm_ipc_enabled(const mi_ctx *ctx);
+// the peer-memory layer carries the exchanges AND they are folded into the consumers' prologues (comm_ipc.h)
+bool comm_fold_enabled(const mi_ctx *ctx);
 inline bool rows_mode(const mi_ctx *ctx) {
   return ctx->comm != nullptr && !ctx->force_slot_path && !comm_ipc_enabled(ctx);
 }

@@ -23,6 +23,7 @@
 //   k_cg_pupdate  B-step prologue (beta, M-norm recurrences, loop control :408-417,285,290) +
 //                 p = -v + beta p (:420)                                                [3N]
 // and the operator supplies <p,Hp>, <Hp,Hp>, <p,p> partials from its last pass (else k_cg_dot3, 2N).
+#include "comm_ipc.h"
 #include "mi_internal.h"
 #include "stiefel_core.h"
 
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
                                                       const double *__restrict__ pre,
                                                       double *__restrict__ s, double *__restrict__ r,
                                                       double *__restrict__ v,
-                                                      double *__restrict__ partials_b, DirGramArgs dg) {
+                                                      double *__restrict__ partials_b, DirGramArgs dg,
+                                                      FoldArgs fold) {
   __shared__ double lds[3 * (kWaves + 1)];
   static_assert(KC >= 3 && KC <= kWaves, "3 curvature dots + at most 13 Gram components");
   CgState cs = load_state(st_in);
@@ -330,6 +332,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
     for (int i = 0; i < KC; ++i) d[i] = slots[i];
   } else {
     reduce_rows<KC>(partials_a, nparts_a, d, lds, prefetch);
+    // several ranks, peer-memory layer: the sum over the ranks completes HERE instead of in an exchange kernel of its
+    // own in front of this one (comm_ipc.h; every rank runs this kernel with the same replicated state)
+    if (fold.peers) fold_exchange_sum<KC>(d, fold, lds);
   }
   step_a(cs, cc, d[0], d[1], d[2]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -428,8 +433,9 @@ struct DirGramLds {
 };
 template <>
 struct DirGramLds<0> {
-  static constexpr int value = kWaves + 1;
+  static constexpr int value = kWaves + 1;  // (>= kIpcVals: the folded exchange's staging)
 };
+static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 
 template <bool FROM_SLOTS, int SP>
 __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
                                                        const double *__restrict__ v,
                                                        double *__restrict__ p, double *__restrict__ s,
                                                        HostStatus *hs, double *__restrict__ trace,
-                                                       size_t trace_cap, DirGramArgs dg) {
+                                                       size_t trace_cap, DirGramArgs dg, FoldArgs fold) {
   __shared__ double lds[DirGramLds<SP>::value];
   CgState cs = load_state(st_in);
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
   double red[1] = {0};
   if (mode_in != CG_APPLY_SIGMA && !FROM_SLOTS) {
     reduce_rows<1>(partials_b, nparts_b, red, lds, prefetch);
+    if (fold.peers) fold_exchange_sum<1>(red, fold, lds);  // (as in k_cg_update)
   } else {
     prefetch();
     if (mode_in != CG_APPLY_SIGMA) red[0] = slots[0];
@@ -769,6 +776,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   double *slots_g = ctx->scalars + SLOT_GRAM;    // slot file of the recurrence form (kc <= 16 doubles)
   double *slots_a = ctx->scalars + SLOT_CG, *slots_b = ctx->scalars + SLOT_CG + 4;
   CgState *st0 = ctx->cg, *st1 = ctx->cg1;
+  // Several ranks through the peer-memory layer, unpreconditioned recurrence form (the cfg2 / cfg4 hot loop): the two
+  // scalar exchanges of an iteration are folded into the prologues of their consumers (no exchange kernels).  Every
+  // other combination keeps the separate exchange kernels.
+  const bool folded = sharded && recur && comm_fold_enabled(ctx) && !ctx->force_slot_path;
+  FoldArgs fold_a, fold_b;
   double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
   ctx->cg_live = st0;
@@ -868,7 +880,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 #define UPD_ARGS                                                                                      \
   n, cc, (const CgState *)st0, st1, (const double *)ctx->partials, nparts,                              \
       (const double *)(recur ? slots_g : slots_a), (const double *)p->d, (const double *)Hp->d, pred,  \
-      s_out->d, r->d, vd, ctx->partials_b, dga
+      s_out->d, r->d, vd, ctx->partials_b, dga, fold_a
       if (recur) {
         // 3 dots + the Gram rows of Hp in one reduction (and one exchange across ranks)
 #define UPD_RECUR(FS)                                                                                      \
@@ -878,7 +890,13 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 9: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 9>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
     default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 16>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break; \
   }
-        if (sharded) {
+        if (sharded && folded) {
+          // the sum over the ranks completes in the kernel's own prologue (comm_ipc.h): no exchange kernel
+          fold_a = comm_fold_next(ctx);
+          KScope ks(ctx, MI_K_CG_UPDATE);
+          UPD_RECUR(false);
+          fold_a = FoldArgs{};
+        } else if (sharded) {
           CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, kc, slots_g));
           KScope ks(ctx, MI_K_CG_UPDATE);
           UPD_RECUR(true);
@@ -907,7 +925,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 #define PUPD(FS, SPV)                                                                                          \
   hipLaunchKernelGGL((k_cg_pupdate<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0, \
                      (const double *)ctx->partials_b, grid, (const double *)slots_b, (const double *)vd, p->d,  \
-                     s_out->d, ctx->status_dev, tr, tcap, dga)
+                     s_out->d, ctx->status_dev, tr, tcap, dga, fold_b)
 #define LAUNCH_PUPD(FS)                 \
   switch (sp) {                         \
     case 0: PUPD(FS, 0); break;         \
@@ -916,7 +934,12 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 3: PUPD(FS, 3); break;         \
     default: PUPD(FS, 4); break;        \
   }
-      if (sharded) {
+      if (sharded && folded) {
+        fold_b = comm_fold_next(ctx);
+        KScope ks(ctx, MI_K_CG_PUPDATE);
+        LAUNCH_PUPD(false);
+        fold_b = FoldArgs{};
+      } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
         LAUNCH_PUPD(true);

@@ -23,6 +23,9 @@ def main():
     nx, ny, nz = (int(v) for v in os.environ.get("CFG4_GRID", "200,200,200").split(","))
     p = 3
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # all ranks share ONE GPU and the consumer kernels wait for their peers in their prologue: every rank's kernels
+    # must be resident at once, so cap the streaming grids (512 resident workgroups of 1024 threads per MI355X)
+    os.environ.setdefault("MI355OPT_MAX_GRID", str(384 // world))
     c = capi.Context(0)
     enabled = c.enable_peer_memory(world, rank, dist, force=True)
     out = {"rank": rank, "enabled": enabled}

@@ -277,6 +277,41 @@ def test_peer_memory_wait_is_bounded_and_fails_loudly():
     assert o["stpcg"].startswith("MiError"), o
 
 
+def _run_cfg4_workers(world, grid, Xb, extra_env=None, port=29580):
+    """W processes of tests/cfg4_worker.py on GPU 0 -> (per-rank records, concatenated step, concatenated gradient)"""
+    import tempfile
+    nx, ny, nz = grid
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "Xb.npy"), Xb)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port + world),
+               os.path.join(ROOT, "tests", "cfg4_worker.py")]
+        env = dict(os.environ, CFG4_WORKER_OUT=tmp, CFG4_GRID=f"{nx},{ny},{nz}")
+        env.update(extra_env or {})
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
+        s_sh = np.concatenate([np.load(os.path.join(tmp, f"s_rank{k}.npy")) for k in range(world)])
+        g_sh = np.concatenate([np.load(os.path.join(tmp, f"g_rank{k}.npy")) for k in range(world)])
+    return outs, s_sh, g_sh
+
+
+def test_folded_exchanges_give_the_bits_of_the_exchange_kernels():
+    """The scalar exchanges of a sharded STPCG iteration folded into the prologues of their consumer kernels
+    (comm_ipc.h fold_exchange_sum: 4 launches per iteration instead of 6) against the separate one-workgroup
+    exchange kernels (MI355OPT_NO_FOLD=1): the same local reduction, the same rank-order sum -- bit-identical
+    scalars and steps, with 3 real peers on one GPU."""
+    from optimization_amd import workloads as wl
+    grid = (60, 50, 48)
+    Xb, _ = wl.stiefel_bench_iterate(*grid, 3, eps=1e-3, seed=7)
+    a, sa, _ = _run_cfg4_workers(3, grid, Xb, port=29590)
+    b, sb, _ = _run_cfg4_workers(3, grid, Xb, extra_env={"MI355OPT_NO_FOLD": "1"}, port=29594)
+    assert all(o["enabled"] and o["ipc_error"] == 0 for o in a + b)
+    for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):
+        assert a[0][k] == b[0][k], k
+    assert np.array_equal(sa, sb)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world):
     """BASELINE cfg4 (St(8e6,3), 200^3 grid) at its full size, row-sharded over `world` real processes on GPU 0
@@ -284,22 +319,11 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world):
     single-context solve of the same problem: same iteration count and exit, |s|_M and the alpha / beta traces to
     rounding of the re-partitioned sums, the step to 1e-10 relative, every replicated scalar bit-identical on all
     ranks, the one-pass (recurrence-form) Hessian on every rank."""
-    import tempfile
     from optimization_amd import capi, workloads as wl
     nx = ny = nz = 200
     p, n = 3, nx * ny * nz
     Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)
-    with tempfile.TemporaryDirectory() as tmp:
-        np.save(os.path.join(tmp, "Xb.npy"), Xb)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(29580 + world),
-               os.path.join(ROOT, "tests", "cfg4_worker.py")]
-        r = subprocess.run(cmd, env=dict(os.environ, CFG4_WORKER_OUT=tmp, CFG4_GRID=f"{nx},{ny},{nz}"),
-                           capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-        outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
-        s_sh = np.concatenate([np.load(os.path.join(tmp, f"s_rank{k}.npy")) for k in range(world)])
-        g_sh = np.concatenate([np.load(os.path.join(tmp, f"g_rank{k}.npy")) for k in range(world)])
+    outs, s_sh, g_sh = _run_cfg4_workers(world, (nx, ny, nz), Xb)
     assert all(o["enabled"] and o["ipc_error"] == 0 for o in outs), outs
     assert outs[0]["rows"][0] == 0 and outs[-1]["rows"][1] == n
     for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):  # replicated: the same bits on every rank
