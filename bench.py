@@ -318,8 +318,10 @@ def main():
     # (which refuses duplicate devices): the peer-memory layer carries every exchange.  Timings are meaningless.
     one_gpu = os.environ.get("MI355OPT_BENCH_ONE_GPU") == "1"
     if one_gpu:
-        # the consumers wait for their peers inside their prologue: all ranks' kernels must fit on the one GPU together
-        os.environ.setdefault("MI355OPT_MAX_GRID", str(max(32, 384 // max(world, 1))))
+        # the consumers wait for their peers inside their prologue, and the push they wait for comes from workgroup 0
+        # of every other rank's kernel: (world - 1) * grid + 1 <= 256 resident 1024-thread workgroups on the one GPU
+        os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // max(world, 1))))
+        os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
     ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
     if use_comm:

@@ -29,15 +29,21 @@ struct FoldArgs {
   int P = 1, rank = 0;
 };
 
+// Once ANY wait of this rank has timed out the error word is sticky and every later wait gives up after 1 ms instead
+// of its full bound: a broken exchange fails the solve in about one timeout, not in (exchanges left) x timeout.
+__device__ __forceinline__ bool ipc_give_up(uint64_t waited, unsigned int *err, uint64_t timeout) {
+  if (waited > timeout) {
+    __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+  }
+  return waited > 100000ull && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
 __device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, unsigned int *err, uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
   // sequence numbers only grow: ">= want", so that a peer that is already one exchange further on (it may raise
   // this flag again before a descheduled waiter has looked) still releases the wait
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (wall_clock64() - t0 > timeout) {
-      __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return false;
-    }
+    if (ipc_give_up(wall_clock64() - t0, err, timeout)) return false;
     __builtin_amdgcn_s_sleep(2);
   }
   return true;
@@ -49,10 +55,7 @@ __device__ __forceinline__ bool ipc_wait_relaxed(const uint64_t *flag, uint64_t 
                                                  uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (wall_clock64() - t0 > timeout) {
-      __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return false;
-    }
+    if (ipc_give_up(wall_clock64() - t0, err, timeout)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
   return true;

@@ -23,9 +23,12 @@ def main():
     nx, ny, nz = (int(v) for v in os.environ.get("CFG4_GRID", "200,200,200").split(","))
     p = 3
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # all ranks share ONE GPU and the consumer kernels wait for their peers in their prologue: every rank's kernels
-    # must be resident at once, so cap the streaming grids (512 resident workgroups of 1024 threads per MI355X)
-    os.environ.setdefault("MI355OPT_MAX_GRID", str(384 // world))
+    # All ranks share ONE GPU and the consumer kernels wait for their peers in their prologue; the push a waiter needs
+    # comes from workgroup 0 of the SAME kernel of every other rank, so that workgroup must get a slot while the
+    # kernels of all the other ranks sit resident and waiting: (world - 1) * grid + 1 <= 256 (one 1024-thread workgroup
+    # of these kernels per CU).  On a real node every rank has a GPU to itself.
+    os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // world)))
+    os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
     c = capi.Context(0)
     enabled = c.enable_peer_memory(world, rank, dist, force=True)
     out = {"rank": rank, "enabled": enabled}

@@ -29,7 +29,7 @@ def emit(out):
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    os.environ.setdefault("MI355OPT_MAX_GRID", str(384 // world))  # (see tests/cfg4_worker.py)
+    os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // world)))  # (see tests/cfg4_worker.py)
     c = capi.Context(0)
     enabled = c.enable_peer_memory(world, rank, dist, force=True)
     out = {"rank": rank, "enabled": enabled}
