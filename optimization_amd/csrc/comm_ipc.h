@@ -93,6 +93,17 @@ __device__ __forceinline__ void fold_exchange_sum(double (&d)[K], const FoldArgs
   __syncthreads();
 }
 
+// The kernels that can fold an exchange are instantiated twice: with FoldArgs (several ranks, peer-memory layer) and
+// with NoFold, an EMPTY parameter whose fold_maybe() is nothing at all -- the single-GPU kernels must not carry the
+// extra kernel arguments and the branch (measured: +3 us on k_cg_update when they did).
+struct NoFold {};
+template <int K>
+__device__ __forceinline__ void fold_maybe(double (&)[K], const NoFold &, double *) {}
+template <int K>
+__device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldArgs &f, double *lds) {
+  if (f.peers) fold_exchange_sum<K>(d, f, lds);
+}
+
 // host: arguments of the next folded exchange on this context (comm.hip).  peers == nullptr when the peer-memory
 // layer is not carrying the exchanges or folding is switched off (MI355OPT_NO_FOLD=1): separate exchange kernels.
 FoldArgs comm_fold_next(mi_ctx *ctx);

@@ -294,7 +294,7 @@ struct DirGramArgs {
 //   CG_RUN:            r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)   [s += alpha p: see k_cg_pupdate]
 //   CG_APPLY_SIGMA:    s += sigma p (:360)
 //   CG_KERNEL_PENDING: partial <p,r> (:320)
-template <int PRE, bool FROM_SLOTS, int KC = 3>
+template <int PRE, bool FROM_SLOTS, int KC = 3, class FOLD = NoFold>
 __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                       CgState *__restrict__ st_out,
                                                       const double *__restrict__ partials_a, int nparts_a,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
                                                       double *__restrict__ s, double *__restrict__ r,
                                                       double *__restrict__ v,
                                                       double *__restrict__ partials_b, DirGramArgs dg,
-                                                      FoldArgs fold) {
+                                                      FOLD fold) {
   __shared__ double lds[3 * (kWaves + 1)];
   static_assert(KC >= 3 && KC <= kWaves, "3 curvature dots + at most 13 Gram components");
   CgState cs = load_state(st_in);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, cons
     reduce_rows<KC>(partials_a, nparts_a, d, lds, prefetch);
     // several ranks, peer-memory layer: the sum over the ranks completes HERE instead of in an exchange kernel of its
     // own in front of this one (comm_ipc.h; every rank runs this kernel with the same replicated state)
-    if (fold.peers) fold_exchange_sum<KC>(d, fold, lds);
+    fold_maybe<KC>(d, fold, lds);
   }
   step_a(cs, cc, d[0], d[1], d[2]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -437,7 +437,7 @@ struct DirGramLds<0> {
 };
 static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 
-template <bool FROM_SLOTS, int SP>
+template <bool FROM_SLOTS, int SP, class FOLD = NoFold>
 __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
                                                        CgState *__restrict__ st_out,
                                                        const double *__restrict__ partials_b, int nparts_b,
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
                                                        const double *__restrict__ v,
                                                        double *__restrict__ p, double *__restrict__ s,
                                                        HostStatus *hs, double *__restrict__ trace,
-                                                       size_t trace_cap, DirGramArgs dg, FoldArgs fold) {
+                                                       size_t trace_cap, DirGramArgs dg, FOLD fold) {
   __shared__ double lds[DirGramLds<SP>::value];
   CgState cs = load_state(st_in);
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
   double red[1] = {0};
   if (mode_in != CG_APPLY_SIGMA && !FROM_SLOTS) {
     reduce_rows<1>(partials_b, nparts_b, red, lds, prefetch);
-    if (fold.peers) fold_exchange_sum<1>(red, fold, lds);  // (as in k_cg_update)
+    fold_maybe<1>(red, fold, lds);  // (as in k_cg_update)
   } else {
     prefetch();
     if (mode_in != CG_APPLY_SIGMA) red[0] = slots[0];
@@ -780,7 +780,6 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // scalar exchanges of an iteration are folded into the prologues of their consumers (no exchange kernels).  Every
   // other combination keeps the separate exchange kernels.
   const bool folded = sharded && recur && comm_fold_enabled(ctx) && !ctx->force_slot_path;
-  FoldArgs fold_a, fold_b;
   double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
   ctx->cg_live = st0;
@@ -802,10 +801,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
 #define LAUNCH_UPDATE(FS)                                                                              \
   switch (pre) {                                                                                       \
-    case PRE_NONE: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;     \
-    case PRE_DIAG: hipLaunchKernelGGL((k_cg_update<PRE_DIAG, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;     \
-    case PRE_BLOCK3: hipLaunchKernelGGL((k_cg_update<PRE_BLOCK3, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break; \
-    default: hipLaunchKernelGGL((k_cg_update<PRE_EXTERNAL, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;       \
+    case PRE_NONE: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break;     \
+    case PRE_DIAG: hipLaunchKernelGGL((k_cg_update<PRE_DIAG, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break;     \
+    case PRE_BLOCK3: hipLaunchKernelGGL((k_cg_update<PRE_BLOCK3, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break; \
+    default: hipLaunchKernelGGL((k_cg_update<PRE_EXTERNAL, FS>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break;       \
   }
 
   // --- initialisation -----------------------------------------------------------------------
@@ -880,30 +879,29 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 #define UPD_ARGS                                                                                      \
   n, cc, (const CgState *)st0, st1, (const double *)ctx->partials, nparts,                              \
       (const double *)(recur ? slots_g : slots_a), (const double *)p->d, (const double *)Hp->d, pred,  \
-      s_out->d, r->d, vd, ctx->partials_b, dga, fold_a
+      s_out->d, r->d, vd, ctx->partials_b, dga
       if (recur) {
         // 3 dots + the Gram rows of Hp in one reduction (and one exchange across ranks)
-#define UPD_RECUR(FS)                                                                                      \
-  switch (kc) {                                                                                            \
-    case 4: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 4>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
-    case 6: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 6>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
-    case 9: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 9>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break;  \
-    default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 16>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS); break; \
+#define UPD_RECUR(FS, FT, FV)                                                                                      \
+  switch (kc) {                                                                                                    \
+    case 4: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 4, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
+    case 6: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 6, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
+    case 9: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 9, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
+    default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
   }
         if (sharded && folded) {
           // the sum over the ranks completes in the kernel's own prologue (comm_ipc.h): no exchange kernel
-          fold_a = comm_fold_next(ctx);
+          const FoldArgs fold_a = comm_fold_next(ctx);
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(false);
-          fold_a = FoldArgs{};
+          UPD_RECUR(false, FoldArgs, fold_a);
         } else if (sharded) {
           CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, kc, slots_g));
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(true);
+          UPD_RECUR(true, NoFold, NoFold{});
         } else {
           if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials, kc));
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(false);
+          UPD_RECUR(false, NoFold, NoFold{});
         }
 #undef UPD_RECUR
       } else if (sharded) {
@@ -922,10 +920,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         hipLaunchKernelGGL(k_cg_dot_rv<false>, dim3(grid), dim3(kBlock), 0, st, n, (const CgState *)st1,
                            (const double *)r->d, (const double *)v->d, p->d, ctx->partials_b);
       }
-#define PUPD(FS, SPV)                                                                                          \
-  hipLaunchKernelGGL((k_cg_pupdate<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0, \
-                     (const double *)ctx->partials_b, grid, (const double *)slots_b, (const double *)vd, p->d,  \
-                     s_out->d, ctx->status_dev, tr, tcap, dga, fold_b)
+#define PUPD_ARGS                                                                                          \
+  n, cc, (const CgState *)st1, st0, (const double *)ctx->partials_b, grid, (const double *)slots_b,        \
+      (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap, dga
+#define PUPD(FS, SPV) \
+  hipLaunchKernelGGL((k_cg_pupdate<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, NoFold{})
 #define LAUNCH_PUPD(FS)                 \
   switch (sp) {                         \
     case 0: PUPD(FS, 0); break;         \
@@ -935,10 +934,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     default: PUPD(FS, 4); break;        \
   }
       if (sharded && folded) {
-        fold_b = comm_fold_next(ctx);
+        const FoldArgs fold_b = comm_fold_next(ctx);  // (folded <=> recurrence form <=> sp == 0)
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        LAUNCH_PUPD(false);
-        fold_b = FoldArgs{};
+        hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
       } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
@@ -950,6 +948,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       }
 #undef LAUNCH_PUPD
 #undef PUPD
+#undef PUPD_ARGS
     }
     result->hvp_calls = hvp;
   }
