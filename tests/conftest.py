@@ -28,6 +28,27 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_omp():
+    """The oracle's OpenMP build (oracle/liboracle_omp.so) on 4 threads: the SAME statements as the bit-for-bit
+    restatement with every sum split into per-thread partial sums.  Used only to measure the CONDITIONING FLOOR of a
+    comparison: how far the reference algorithm itself moves when nothing but the association of its sums changes.
+    A device (or sharded) run, whose reductions are necessarily grouped differently from the reference's sequential
+    loops, cannot be held to less than a small multiple of that.  None when the library is missing."""
+    import oracle_py
+    try:
+        o = oracle_py.Oracle(omp=True)
+        o.set_threads(4)
+        return o
+    except OSError:
+        return None
+
+
+def floor_or(tol, floor, factor=3.0):
+    """the tolerance BASELINE.json states (1e-10 relative), or `factor` x the measured conditioning floor if larger"""
+    return max(tol, factor * (floor or 0.0))
+
+
+@pytest.fixture(scope="session")
 def reference():
     """The real reference templates (oracle/_ref/libref.so), when prebuilt."""
     import oracle_py

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, rel_err
+from conftest import ROOT, floor_or, rel_err
 from optimization_amd import capi, workloads as wl
 
 
@@ -40,7 +40,7 @@ def _run_workers(world, tmp_path):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_stpcg_matches_unsharded(oracle, tmp_path, world):
+def test_sharded_stpcg_matches_unsharded(oracle, oracle_omp, tmp_path, world):
     d = _run_workers(world, tmp_path)
     nx, ny, nz, p = 6, 5, 8, 3
     n = nx * ny * nz
@@ -53,12 +53,29 @@ def test_sharded_stpcg_matches_unsharded(oracle, tmp_path, world):
     assert d["same_scalars"]                       # every rank saw identical all-reduced scalars
     assert d["it1"] == o1["iterations"] and d["exit1"] == o1["exit_reason"]
     assert d["it2"] == o2["iterations"] and d["exit2"] == o2["exit_reason"]
-    # the Hessian near the minimiser is nearly singular: CG amplifies the different summation grouping
-    # (per-slab partial sums) to ~1e-8; iteration counts and exit branches must still agree exactly
-    assert abs(d["M1"] - o1["M_norm"]) <= 1e-6 * o1["M_norm"]
-    assert rel_err(d["s1"], o1["s"]) < 1e-6
-    assert rel_err(d["s2"], o2["s"]) < 1e-6
-    assert np.allclose(d["alpha2"], o2["trace"]["alpha"], rtol=1e-6)
+    # Iteration counts and exit branches agree exactly.  The iterates: 1e-10 relative, or the conditioning floor of
+    # these two solves -- the Hessian near the minimiser is nearly singular and CG amplifies ANY regrouping of the
+    # sums; per-slab partial sums are one such regrouping, the oracle's OpenMP build (conftest.oracle_omp: the same
+    # statements, per-thread partial sums) another, and the latter's distance from the sequential reference is what no
+    # sharded run can be asked to beat by much
+    f1 = f2 = fa = fM = None
+    if oracle_omp is not None:
+        pm = oracle_omp.stiefel_rq(n, p, rowptr, col, val)
+        gm = oracle_omp.eval_grad(pm, Xb.ravel())
+        m1 = oracle_omp.stpcg_problem(pm, Xb.ravel(), gm, 0.05, max_iterations=40, kappa_fgr=1e-6, theta=.5)
+        m2 = oracle_omp.stpcg_problem(pm, Xb.ravel(), gm, 1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0,
+                                      trace_cap=64)
+        oracle_omp.free(pm)
+        f1, f2 = rel_err(m1["s"], o1["s"]), rel_err(m2["s"], o2["s"])
+        fM = abs(m1["M_norm"] - o1["M_norm"]) / o1["M_norm"]
+        fa = float(np.max(np.abs(m2["trace"]["alpha"] / o2["trace"]["alpha"] - 1)))
+    e1, e2 = rel_err(d["s1"], o1["s"]), rel_err(d["s2"], o2["s"])
+    ea = float(np.max(np.abs(np.array(d["alpha2"]) / o2["trace"]["alpha"] - 1)))
+    print(f"sharded x{world}: s1 {e1:.2e} (floor {f1}), s2 {e2:.2e} (floor {f2}), alpha {ea:.2e} (floor {fa})")
+    assert abs(d["M1"] - o1["M_norm"]) <= floor_or(1e-10, fM, 10) * o1["M_norm"]
+    assert e1 <= floor_or(1e-10, f1, 10)
+    assert e2 <= floor_or(1e-10, f2, 10)
+    assert ea <= floor_or(1e-10, fa, 10)
     # halo = one grid plane from each neighbour, symmetric send/receive counts
     plane = nx * ny
     for r, (need_lo, need_hi, send_lo, send_hi) in enumerate(d["halo"]):

@@ -212,7 +212,7 @@ def test_peer_memory_layer_with_real_peers_on_one_gpu(world):
         assert o["ipc_error"] == 0
         assert o["dot_err"] < 1e-13 and o["spmm_err"] == 0.0 and o["spmm2_err"] == 0.0, o
         assert abs(o["f"] - o["f_ref"]) <= 1e-12 * abs(o["f_ref"])
-        assert o["g_err"] < 1e-12 and o["s_err"] < 1e-9 and o["retract_err"] < 1e-12, o
+        assert o["g_err"] < 1e-12 and o["s_err"] < 1e-10 and o["retract_err"] < 1e-12, o
         assert (o["iters"], o["exit"]) == (o["iters_ref"], o["exit_ref"])
         assert (o["b_iters"], o["b_exit"]) == (o["b_iters_ref"], o["b_exit_ref"])
         assert abs(o["M"] - o["M_ref"]) <= 1e-10 * abs(o["M_ref"]) and o["same_s"]
