@@ -367,6 +367,17 @@ class Context:
         check(self.L.mi_precon_create_block3(self.h, inv_blocks.h, C.byref(h)))
         return Precon(self, h, keep=[inv_blocks])
 
+    def precon_constraint(self, A, Minv):
+        """mi_precon_create_constraint: A (m x n numpy, dense constraints), Minv (n, inverse of the diagonal M)"""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        m, n = A.shape
+        Ad, Md = self.upload(A), self.upload(Minv)
+        h = vp()
+        check(self.L.mi_precon_create_constraint(self.h, n, m, Ad.h, Md.h, C.byref(h)))
+        P = ConstraintPrecon(self, h, keep=[Ad, Md])
+        P.m, P.n = m, n
+        return P
+
     def precon_callback(self, n, fn):
         def cb(_u, pin, pout):
             try:
@@ -726,6 +737,21 @@ class Precon:
                 self.L.mi_precon_destroy(self.h)
         except Exception:  # noqa
             pass
+
+
+class ConstraintPrecon(Precon):
+    """The constraint preconditioner of the projected STPCG (mi_precon_create_constraint)."""
+
+    def solve(self, r):
+        """(v, lambda) = P(r)"""
+        v, lam = Vec(self.ctx, self.n), Vec(self.ctx, self.m)
+        check(self.L.mi_precon_constraint_solve(self.h, r.h, v.h, lam.h))
+        return v, lam
+
+    def At(self, lam):
+        out = Vec(self.ctx, self.n)
+        check(self.L.mi_precon_constraint_At(self.h, lam.h, out.h))
+        return out
 
 
 class _BorrowedPrecon(Precon):

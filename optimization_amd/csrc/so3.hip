@@ -286,7 +286,8 @@ struct mi_so3n {
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
   mi_op hess;
   mi_precon bj;
-  const mi_vec *R = nullptr;                // the point the model is bound to (mi_so3n_model)
+  const mi_vec *R = nullptr;                // the point the model is bound to (mi_so3n_model) ...
+  uint64_t R_serial = 0;                    // ... by handle AND serial (handles are recycled)
   // mi_so3n_trial: the model assembled speculatively at the trial point (a second set of the arrays above plus the
   // gradient), swapped in by the next mi_so3n_model call if that call is for the same vector -- keyed on the
   // handle AND the identity of its contents (mi_vec::serial / gen), as in stiefel.hip
@@ -494,6 +495,7 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
   }
   q->trial_R = nullptr;
   q->R = R;
+  q->R_serial = R->serial;
   if (hess) *hess = &q->hess;
   if (block_jacobi) *block_jacobi = &q->bj;
   return MI_OK;
@@ -518,7 +520,8 @@ int mi_so3n_retract(mi_so3n *q, const mi_vec *R, const mi_vec *xi, mi_vec *Y) {
 int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g, int with_precon, mi_vec *R_trial,
                   double out[6]) {
   MI_REQUIRE(q && R && h && g && R_trial && out, "null argument");
-  MI_REQUIRE(q->R == R, "mi_so3n_trial: the model is not bound to this R (call mi_so3n_model first)");
+  MI_REQUIRE(q->R == R && q->R_serial == R->serial,
+             "mi_so3n_trial: the model is not bound to this R (call mi_so3n_model first)");
   MI_REQUIRE(R->n == 9 * q->N && R_trial->n == 9 * q->N && h->n == 3 * q->N && g->n == 3 * q->N, "dimension mismatch");
   MI_REQUIRE(R_trial->d != R->d, "the trial point must not alias the current one");
   mi_ctx *ctx = q->ctx;

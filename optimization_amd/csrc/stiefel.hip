@@ -591,6 +591,8 @@ struct mi_stiefel_rq {
   mi_dirgram dg;
   mi_op hess;     // borrowed operator object bound to X
   const mi_vec *X;
+  uint64_t X_serial = 0;  // (handles are recycled: "bound to this X" means this handle AND this vector's serial)
+  bool bound_to(const mi_vec *x) const { return X == x && x && X_serial == x->serial; }
   // mi_stiefel_rq_trial: what it already worked out at the trial point (A X+, sym(X+'A X+), the gradient), handed
   // to the next mi_stiefel_rq_model call if that call is for the same vector
   double *S_next = nullptr;
@@ -902,6 +904,7 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   }
   q->trial_X = nullptr;
   q->X = X;
+  q->X_serial = X->serial;
   q->dg.p = q->p;
   q->dg.n = q->n;
   q->dg.X = X->d;
@@ -929,7 +932,7 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
 int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, const mi_vec *g, mi_vec *X_trial,
                         double out[5]) {
   MI_REQUIRE(q && X && h && g && X_trial && out, "null argument");
-  MI_REQUIRE(q->X == X, "mi_stiefel_rq_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
+  MI_REQUIRE(q->bound_to(X), "mi_stiefel_rq_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, h, g));
   MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;
@@ -986,7 +989,8 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
 int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *g, double t, mi_vec *h_out,
                                mi_vec *X_trial, double out[2]) {
   MI_REQUIRE(q && X && g && h_out && X_trial && out, "null argument");
-  MI_REQUIRE(q->X == X, "mi_stiefel_rq_armijo_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
+  MI_REQUIRE(q->bound_to(X),
+             "mi_stiefel_rq_armijo_trial: the model is not bound to this X (call mi_stiefel_rq_model first)");
   MI_TRY(check_np(q->ctx, q->n, q->p, X, g, h_out));
   MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;

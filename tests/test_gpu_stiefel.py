@@ -600,3 +600,52 @@ def test_unsymmetric_matrix_keeps_the_two_pass_hessian(ctx, oracle):
     ctx.stpcg(g2, H2, Delta=0.5, max_iterations=3, kappa_fgr=1e-8, theta=1.0)
     assert ctx.ktime_read("stiefel_hess_fused")[0] > 0
     ctx.ktime_enable("stiefel_hess_fused", False)
+
+
+def test_trial_entry_points_refuse_a_point_the_model_is_not_bound_to(ctx):
+    """mi_stiefel_rq_trial / _armijo_trial / mi_so3n_trial work at the point of the LAST model() call, identified by
+    handle and serial number: another vector -- also one that recycled the old handle -- is an error, not a silent
+    evaluation of the old model."""
+    from optimization_amd import capi
+    nx, ny, nz, p = 8, 7, 6, 2
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    X = ctx.upload(wl.random_stiefel(n, p, seed=1))
+    g, H = prob.model(X)
+    h = ctx.stiefel_project(n, p, X, ctx.upload(np.random.default_rng(2).normal(size=(n, p)) * 1e-2))
+    other = ctx.upload(wl.random_stiefel(n, p, seed=2))
+    with pytest.raises(capi.MiError):
+        prob.trial(other, h, g)
+    # deferred result + a trace request: the trace needs the wait, the call stays synchronous and still correct
+    r0 = ctx.stpcg(g, H, Delta=1.0, max_iterations=5, kappa_fgr=1e-6, theta=1.0, trace_cap=8)
+    r1 = ctx.stpcg(g, H, Delta=1.0, max_iterations=5, kappa_fgr=1e-6, theta=1.0, trace_cap=8, defer=True)
+    assert r1["iterations"] == r0["iterations"] and np.array_equal(r0["trace"]["alpha"], r1["trace"]["alpha"])
+    with pytest.raises(capi.MiError):
+        ctx.stpcg_collect()  # nothing pending
+
+
+def test_symmetry_check_edge_cases(ctx, oracle):
+    """csr_is_symmetric at matrix creation: empty rows, an explicit zero mirrored by a missing entry (NOT symmetric
+    as stored: the entry lists differ), duplicates stored in different orders (symmetric), -0.0 vs 0.0 (different
+    bits: not symmetric).  Observable through which Hessian form STPCG takes."""
+    def one_pass(rowptr, col, val, n):
+        A = ctx.csr(n, np.array(rowptr, np.int32), np.array(col, np.int32), np.array(val, np.float64))
+        prob = ctx.stiefel_rq(A, n, 1)
+        x = np.zeros((n, 1)); x[0] = 1.0
+        g, H = prob.model(ctx.upload(x))
+        ctx.ktime_enable("stiefel_hess_fused", True)
+        ctx.ktime_reset()
+        ctx.stpcg(g, H, Delta=1.0, max_iterations=2, kappa_fgr=1e-3, theta=1.0)
+        k = ctx.ktime_read("stiefel_hess_fused")[0]
+        ctx.ktime_enable("stiefel_hess_fused", False)
+        return k > 0
+    # 4 x 4: row 2 empty; symmetric
+    assert one_pass([0, 2, 4, 4, 5], [0, 1, 0, 1, 3], [2.0, -1.0, -1.0, 2.0, 1.0], 4)
+    # (0,1) = 0.0 stored, (1,0) not stored
+    assert not one_pass([0, 2, 3, 4], [0, 1, 1, 2], [2.0, 0.0, 2.0, 1.0], 3)
+    # -0.0 against +0.0
+    assert not one_pass([0, 2, 4, 5], [0, 1, 0, 1, 2], [2.0, 0.0, -0.0, 2.0, 1.0], 3)
+    # value asymmetry in the last bit
+    assert not one_pass([0, 2, 4], [0, 1, 0, 1], [2.0, -1.0, np.nextafter(-1.0, 0), 2.0], 2)
