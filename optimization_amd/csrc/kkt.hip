@@ -55,12 +55,15 @@ __global__ __launch_bounds__(256) void k_kkt_schur(size_t n, int m, const double
 __global__ __launch_bounds__(kBlock) void k_kkt_invert(int m, double *__restrict__ S, double *__restrict__ Sinv,
                                                        int *__restrict__ fail) {
   __shared__ int bad;
+  __shared__ double d0[kKktMaxM];  // the diagonal before elimination: a pivot that cancelled to rounding level relative
+                                   // to it means linearly dependent constraint rows, not a tiny positive number
   if (threadIdx.x == 0) bad = 0;
+  for (int j = threadIdx.x; j < m; j += kBlock) d0[j] = S[(size_t)j * m + j];
   __syncthreads();
   for (int j = 0; j < m; ++j) {
     if (threadIdx.x == 0) {
       const double d = S[(size_t)j * m + j];
-      if (!(d > 0)) bad = 1;
+      if (!(d > 1e-12 * d0[j]) || !(d0[j] > 0)) bad = 1;
       S[(size_t)j * m + j] = sqrt(d);
     }
     __syncthreads();
