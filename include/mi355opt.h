@@ -348,6 +348,12 @@ MI_API int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, c
 MI_API int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C);
 /* Y (n x k column-major) = A X : the sparse operator of LOBPCG clients (called at LOBPCG.h:213,218,267,281) */
 MI_API int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y);
+/* AX (n x nx) = A X (LOBPCG.h:281) together with R = AX - X diag(theta) (:285, B absent so BX = X) and the column norms
+ * of R and X (:293,302; host, sync): when the matrix takes the LDS-window form the residual is finished in the
+ * product's own pass (the row's X values are in the ring), otherwise this is mi_csr_spmm_colmajor followed by
+ * mi_lobpcg_residual.  R has the same bits either way. */
+MI_API int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, const double *theta_host,
+                                         mi_vec *AX, mi_vec *R, double *rnorm, double *xnorm);
 /* Y[r,c] = d[r] X[r,c] : diagonal operator / Jacobi preconditioner on a column-major panel
  * (the operators of tests/LOBPCG_unit_test.cpp:56-74) */
 MI_API int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_vec *X, mi_vec *Y);

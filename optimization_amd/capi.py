@@ -164,6 +164,7 @@ def load():
                                c_double_p],
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
         "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
+        "mi_csr_spmm_colmajor_residual": [vp, C.c_int, vp, c_double_p, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_split": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p],
         "mi_debug_window_runs": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)],
         "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
@@ -690,6 +691,14 @@ class Csr:
         Y = Y if Y is not None else Vec(self.ctx, self.n * k)
         check(self.L.mi_csr_spmm_colmajor(self.h, k, X.h, Y.h))
         return Y
+
+    def spmm_colmajor_residual(self, nx, X, theta):
+        """mi_csr_spmm_colmajor_residual: (AX, R, rnorm, xnorm)"""
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        AX, R = Vec(self.ctx, self.n * nx), Vec(self.ctx, self.n * nx)
+        rn, xn = np.zeros(nx), np.zeros(nx)
+        check(self.L.mi_csr_spmm_colmajor_residual(self.h, nx, X.h, _dp(theta), AX.h, R.h, _dp(rn), _dp(xn)))
+        return AX, R, rn, xn
 
     def __del__(self):
         try:

@@ -538,11 +538,11 @@ __global__ __launch_bounds__(kBlock) void k_residual(size_t m, int nx, int c0, c
     for (int c = 0; c < 8; ++c) {
       if (c0 + c < nx) {
         const size_t idx = (size_t)(c0 + c) * m + r;
-        const double res = AX[idx] - BX[idx] * th[c];
+        const double res = __builtin_fma(-BX[idx], th[c], AX[idx]);  // (explicit: k_spmm_colmajor_win<.., RES> does the same)
         const double xv = X[idx];
         R[idx] = res;
-        a[c] += res * res;
-        a[8 + c] += xv * xv;
+        a[c] = __builtin_fma(res, res, a[c]);
+        a[8 + c] = __builtin_fma(xv, xv, a[8 + c]);
       }
     }
   }
@@ -633,12 +633,30 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslic
 // cfg5; 180 us when all seven hit L1).  Far rows are gathered one tile ahead (they are then in flight while their
 // owner stages them: one fetch into the XCD's L2) and enter the entry loop from registers, selected per lane, in
 // storage order: the same fused multiply-adds in the same order as the kernels above.
-template <int KC, int HW, int WC, bool FARD>
+// RES (r03): the product is LOBPCG's A(X) of the NEW Ritz block (LOBPCG.h:281) and B is absent: the residual
+// R = AX - X diag(theta) (:285) and the partial rows of |R_j|^2, |X_j|^2 (:293,302) are finished in the same pass -- the
+// row's own X values are in the ring anyway -- instead of a pass of their own that re-reads AX and X (k_residual).
+// Same operations on the same operands as k_residual (one fused multiply-add per element, squares accumulated by fma):
+// R has its bits; the norms differ from its by the grouping of their sums only.
+template <int KC, int HW, int WC, bool FARD, bool RES = false>
 __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c0,
                                                                  const double *__restrict__ X,
-                                                                 double *__restrict__ Y) {
+                                                                 double *__restrict__ Y,
+                                                                 const double *__restrict__ theta = nullptr,
+                                                                 double *__restrict__ R = nullptr,
+                                                                 double *__restrict__ partials = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double ring_dyn[];  // KC x (ring rows + zero row)
   __shared__ double vt[256];
+  __shared__ double red[RES ? 2 * KC * kWinWaves : 1];
+  double nr[RES ? KC : 1], nxs[RES ? KC : 1], th[RES ? KC : 1];
+  if (RES) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      nr[c] = 0;
+      nxs[c] = 0;
+      th[c] = (c0 + c < k) ? theta[c0 + c] : 0.0;
+    }
+  }
   constexpr int NW = kWinWaves;
   static_assert(kWinBlock == 256 && kFarCap == 2, "table fill and far-slot decoding");
   vt[threadIdx.x] = A.vtab[threadIdx.x];
@@ -650,7 +668,15 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
     t0 = scalar_int(W.bounds, lb);
     t1 = scalar_int(W.bounds, lb + 1);
   }
-  if (t0 >= t1) return;
+  if (t0 >= t1) {
+    if constexpr (RES) {  // an idle workgroup still owns a partial row: zeros
+      double z[2 * KC];
+#pragma unroll
+      for (int c = 0; c < 2 * KC; ++c) z[c] = 0;
+      block_partials_store_nw<2 * KC, kWinWaves>(z, red, partials);
+    }
+    return;
+  }
   // (the half-width is a template parameter: the column offsets c * RR of the ring are then immediates of the LDS
   // instructions instead of eight address additions per entry)
   constexpr int wc = WC, nc = 2 * NW + 2 * WC, zrow = nc * 64;
@@ -797,6 +823,18 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
 #pragma unroll
         for (int c = 0; c < KC; ++c)
           if (c0 + c < k) __builtin_nontemporal_store(acc[c], Y + (size_t)(c0 + c) * m + row);
+        if constexpr (RES) {
+          const LdsDouble *own = L + (unsigned)slot_own * 64u + (unsigned)lane;
+#pragma unroll
+          for (int c = 0; c < KC; ++c)
+            if (c0 + c < k) {
+              const double xv = own[(unsigned)c * RR];
+              const double res = __builtin_fma(-xv, th[c], acc[c]);   // AX - BX theta with BX = X, as k_residual
+              R[(size_t)(c0 + c) * m + row] = res;
+              nr[c] = __builtin_fma(res, res, nr[c]);
+              nxs[c] = __builtin_fma(xv, xv, nxs[c]);
+            }
+        }
       }
 #pragma unroll
       for (int s_ = 0; s_ < kFarCap; ++s_)
@@ -814,6 +852,15 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
     slot_job += NW;
     slot_job = slot_job >= nc ? slot_job - nc : slot_job;
     if (t + 1 < t1) lds_barrier();
+  }
+  if constexpr (RES) {  // components 0..KC-1: |R_j|^2, KC..2KC-1: |X_j|^2 (the layout k_residual leaves)
+    double a[2 * KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      a[c] = nr[c];
+      a[KC + c] = nxs[c];
+    }
+    block_partials_store_nw<2 * KC, kWinWaves>(a, red, partials);
   }
 }
 
@@ -1217,6 +1264,106 @@ int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_ve
   return MI_OK;
 }
 
+namespace {
+// the window form of the panel product applies (matrices that qualify, sparse.hip build_window; one context, no halo)
+bool spmm_win_ok(const mi_csr *A) {
+  const char *no_win_env = getenv("MI355OPT_NO_SPMM_WIN");  // (read per call: the tests compare both forms in one process)
+  const bool no_win = no_win_env && no_win_env[0] == '1';
+  return A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !no_win && !A->ctx->uniform_grid &&
+         A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n * 8 < ((size_t)1 << 32);
+}
+
+// Y = A X in window form, 8 columns per pass.  theta_dev != nullptr: the fused residual form (k_spmm_colmajor_win<..,
+// RES>): R = Y - X diag(theta) and, per pass, the 16 column sums |R_j|^2, |X_j|^2 reduced into sums_dev + 16 * pass.
+int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const double *theta_dev, double *Rd,
+                    double *sums_dev) {
+  mi_ctx *ctx = A->ctx;
+  // 49 KB of ring at a half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 columns per pass: 313 us
+  // per 24 columns, 8: 251)
+  constexpr int kSpmmWinCols = 8;
+  const int nc = 2 * kWinWaves + 2 * A->win_chunks;
+  const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
+  const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1, res = theta_dev != nullptr;
+  const void *fn = nullptr;
+  const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
+  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
+                    !(no_fard_env && no_fard_env[0] == '1');
+#define PICK3(HWV, WCV, FV, RV) fn = (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, FV, RV>
+#define PICK(HWV, WCV)                                                        \
+  if (res) { if (fard) PICK3(HWV, WCV, true, true); else PICK3(HWV, WCV, false, true); } \
+  else { if (fard) PICK3(HWV, WCV, true, false); else PICK3(HWV, WCV, false, false); }
+  if (wc1) { if (hw7) { PICK(7, 1) } else { PICK(8, 1) } }
+  else { if (hw7) { PICK(7, 2) } else { PICK(8, 2) } }
+#undef PICK
+#undef PICK3
+  static int occ_cache[2][2][2][2] = {};
+  int &occ = occ_cache[hw7 ? 0 : 1][wc1 ? 0 : 1][fard ? 1 : 0][res ? 1 : 0];
+  if (occ == 0) {
+    int nbk = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fn, kWinBlock, lds);
+    occ = (e == hipSuccess && nbk > 0) ? nbk : 1;
+    (void)hipGetLastError();
+  }
+  const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
+  int wgrid = 0;
+  const int *bounds = nullptr;
+  static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
+  MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
+  SellView view = sell_view(A);
+  WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
+             nullptr};
+  double *partials = res ? ctx->partials2 : nullptr;
+  for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
+    void *args[] = {&view, &wv, &k, &c0, &Xd, &Yd, &theta_dev, &Rd, &partials};
+    MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
+    if (res) MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, wgrid, 16, sums_dev + 16 * (c0 / kSpmmWinCols)));
+  }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+}  // namespace
+
+// AX = A X (LOBPCG.h:281) with R = AX - X diag(theta) (:285, B absent: BX = X) and the column norms of R and X
+// (:293,302) in the same pass over X when the matrix takes the window form; otherwise the product followed by
+// mi_lobpcg_residual -- the same R bits either way.  sync (one read-back of the 2 nx sums)
+int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, const double *theta_host, mi_vec *AX,
+                                  mi_vec *R, double *rnorm, double *xnorm) {
+  MI_REQUIRE(A && X && theta_host && AX && R && rnorm && xnorm, "null argument");
+  MI_REQUIRE(nx >= 1 && nx <= kGramMaxK, "block size must be in [1,%d]", kGramMaxK);
+  mi_ctx *ctx = A->ctx;
+  MI_TRY(check_panel(ctx, A->n, nx, X, "X"));
+  MI_TRY(check_panel(ctx, A->n, nx, AX, "AX"));
+  MI_TRY(check_panel(ctx, A->n, nx, R, "R"));
+  MI_REQUIRE(X->d != AX->d && X->d != R->d && AX->d != R->d, "X, AX and R must not alias");
+  if (!spmm_win_ok(A) || A->n == 0) {
+    MI_TRY(mi_csr_spmm_colmajor(A, nx, X, AX));
+    return mi_lobpcg_residual(ctx, A->n, nx, AX, X, X, theta_host, R, rnorm, xnorm);
+  }
+  touch(AX);
+  touch(R);
+  const int nchunks = (nx + 7) / 8;
+  void *thdev = nullptr, *sums = nullptr;
+  MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
+  MI_TRY(pool_alloc(ctx, (size_t)nchunks * 16 * sizeof(double), &sums));
+  MI_TRY(stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev));  // (no host wait)
+  {
+    KScope ks(ctx, MI_K_SPMM);
+    MI_TRY(spmm_win_launch(A, nx, X->d, AX->d, (const double *)thdev, R->d, (double *)sums));
+  }
+  std::vector<double> out((size_t)nchunks * 16);
+  hipError_t e = hipMemcpyAsync(out.data(), sums, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ctx->host_syncs++;
+  pool_free(ctx, sums);
+  pool_free(ctx, thdev);
+  if (e != hipSuccess) return hip_fail(e, "residual norms read-back", __FILE__, __LINE__);
+  for (int c = 0; c < nx; ++c) {
+    rnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + c % 8]);
+    xnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + 8 + c % 8]);
+  }
+  return MI_OK;
+}
+
 int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   MI_REQUIRE(A && X && Y, "null argument");
   MI_REQUIRE(k >= 1 && k <= kGramMaxK, "panel width must be in [1,%d]", kGramMaxK);
@@ -1250,51 +1397,7 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   }
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
-  const char *no_win_env = getenv("MI355OPT_NO_SPMM_WIN");  // (read per call: the tests compare both forms in one process)
-  const bool no_win = no_win_env && no_win_env[0] == '1';
-  if (A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !no_win && !ctx->uniform_grid &&
-      A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n * 8 < ((size_t)1 << 32)) {
-    // the window form (matrices that qualify, sparse.hip build_window), 8 columns per pass: 49 KB of ring at a
-    // half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 per pass: 313 us per 24 columns, 8: 251)
-    constexpr int kSpmmWinCols = 8;
-    const int nc = 2 * kWinWaves + 2 * A->win_chunks;
-    const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
-    const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1;
-    const void *fn = nullptr;
-    const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
-    const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
-                      !(no_fard_env && no_fard_env[0] == '1');
-#define PICK(HWV, WCV) \
-  fn = fard ? (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, true> \
-            : (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, false>
-    if (wc1) { if (hw7) { PICK(7, 1); } else { PICK(8, 1); } }
-    else { if (hw7) { PICK(7, 2); } else { PICK(8, 2); } }
-#undef PICK
-    static int occ_cache[2][2][2] = {};
-    int &occ = occ_cache[hw7 ? 0 : 1][wc1 ? 0 : 1][fard ? 1 : 0];
-    if (occ == 0) {
-      int nbk = 0;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, fn, kWinBlock, lds);
-      occ = (e == hipSuccess && nbk > 0) ? nbk : 1;
-      (void)hipGetLastError();
-    }
-    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
-    int wgrid = 0;
-    const int *bounds = nullptr;
-    static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
-    MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
-    SellView view = sell_view(A);
-    WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
-               nullptr};
-    const double *Xd = X->d;
-    double *Yd = Y->d;
-    for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
-      void *args[] = {&view, &wv, &k, &c0, &Xd, &Yd};
-      MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
-    }
-    MI_HIP(hipGetLastError());
-    return MI_OK;
-  }
+  if (spmm_win_ok(A)) return spmm_win_launch(A, k, X->d, Y->d, nullptr, nullptr, nullptr);
   if (A->pk) {
     static const int chunk = [] { const char *e = getenv("MI355OPT_SPMM_PK_CHUNK"); return e ? atoi(e) : 24; }();
     for (int c0 = 0; c0 < k;) {

@@ -192,10 +192,16 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
     X = Snext->leftCols(nx);
     P = Snext->middleCols(2 * nx, nx);
     ritz_update_into(Sns, C, nx, X, P);
-    AX = A(X);                       // operators re-applied, not AS C               :281-282
-    if (B) BX = (*B)(X);             // B absent: BX is X itself, no copy
     R = Snext->middleCols(nx, nx);   // residuals into its second block
-    residual_and_norms_into(R, AX, B ? BX : X, X, Theta.head(nx), r, xnorm);  // :285,293
+    const auto *fused_op = B ? nullptr : A.template target<MI355::DeviceCsrPanelOperator>();
+    if (fused_op) {
+      // B absent and A a tagged sparse operator: A(X) (:281), the residual (:285) and the norms (:293,302) in one pass
+      AX = apply_with_residual_into(*fused_op, X, Theta.head(nx), R, r, xnorm);
+    } else {
+      AX = A(X);                       // operators re-applied, not AS C               :281-282
+      if (B) BX = (*B)(X);             // B absent: BX is X itself, no copy
+      residual_and_norms_into(R, AX, B ? BX : X, X, Theta.head(nx), r, xnorm);  // :285,293
+    }
     in_basis = true;
     std::swap(Scur, Snext);
 

@@ -243,6 +243,30 @@ inline void ritz_update_into(const DeviceMatrix &S, const HostMatrix &C, size_t 
   check(mi_lobpcg_update2(S.context(), S.rows(), (int)ns, (int)(2 * nx), S.handle(), C2.data(), (int)ns, X.handle(),
                           (int)nx, P.handle()));
 }
+// The sparse operator of a LOBPCG client as a TAGGED callable (put it into the SymmetricLinearOperator<DeviceMatrix>
+// argument `A`): used as a plain callable it is Y = A X (mi_csr_spmm_colmajor); the device LOBPCG loop recognises it
+// (std::function::target) and, when B is absent, asks it for A(X) of the new Ritz block TOGETHER with the residual
+// and its norms (LOBPCG.h:281,285,293,302; mi_csr_spmm_colmajor_residual: one pass over X instead of two).
+struct DeviceCsrPanelOperator {
+  mi_csr *A = nullptr;
+  DeviceMatrix operator()(const DeviceMatrix &X) const {
+    DeviceMatrix Y(X.context(), X.rows(), X.cols());
+    check(mi_csr_spmm_colmajor(A, (int)X.cols(), X.handle(), Y.handle()));
+    return Y;
+  }
+};
+// AX = A X and R = AX - X diag(theta) with the column norms of R and X, R into a caller-supplied panel
+inline DeviceMatrix apply_with_residual_into(const DeviceCsrPanelOperator &op, const DeviceMatrix &X,
+                                             const HostVectorD &theta, DeviceMatrix &R, HostVectorD &rnorm,
+                                             HostVectorD &xnorm) {
+  const size_t nx = X.cols();
+  rnorm.resize(nx);
+  xnorm.resize(nx);
+  DeviceMatrix AX(X.context(), X.rows(), nx);
+  check(mi_csr_spmm_colmajor_residual(op.A, (int)nx, X.handle(), theta.data(), AX.handle(), R.handle(), rnorm.data(),
+                                      xnorm.data()));
+  return AX;
+}
 // R = AX - BX diag(theta) into a caller-supplied panel (a view of the next basis' second block)
 inline void residual_and_norms_into(DeviceMatrix &R, const DeviceMatrix &AX, const DeviceMatrix &BX,
                                     const DeviceMatrix &X, const HostVectorD &theta, HostVectorD &rnorm,

@@ -5,6 +5,7 @@
 // tests/GradientDescent_unit_test.cpp sphere case) plus the BASELINE cfg2 Stiefel problem.
 // Entry points hd_* are called from pytest (-m gpu) and compared with the oracle / golden fixtures.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <optional>
@@ -577,12 +578,19 @@ extern "C" int hd_lobpcg(size_t m, size_t nx, size_t nev, const double *Adiag, c
   mi_csr *csr = nullptr;
   if (rowptr) {
     MI355::check(mi_csr_create(ctx.get(), m, (size_t)rowptr[m], rowptr, col, val, &csr));
-    mi_ctx *c = ctx.get();
-    A = [csr, c, m](const DeviceMatrix &X) {
-      DeviceMatrix Y(c, m, X.cols());
-      MI355::check(mi_csr_spmm_colmajor(csr, (int)X.cols(), X.handle(), Y.handle()));
-      return Y;
-    };
+    // the tagged sparse operator (MI355/Matrix.h): the loop fuses A(X) with the residual and its norms; with
+    // HD_LOBPCG_PLAIN_OPERATOR=1 the same product hidden in a plain lambda (the reference's statement sequence)
+    const char *plain = getenv("HD_LOBPCG_PLAIN_OPERATOR");
+    if (plain && plain[0] == '1') {
+      mi_ctx *c = ctx.get();
+      A = [csr, c, m](const DeviceMatrix &X) {
+        DeviceMatrix Y(c, m, X.cols());
+        MI355::check(mi_csr_spmm_colmajor(csr, (int)X.cols(), X.handle(), Y.handle()));
+        return Y;
+      };
+    } else {
+      A = MI355::DeviceCsrPanelOperator{csr};
+    }
   } else {
     A = diag_op(Adiag);
   }

@@ -334,3 +334,50 @@ def test_panel_update_two_destinations_matches_one(ctx, m, ks, kc, k1):
         assert np.array_equal(Y2.numpy()[: m * (kc - k1)], Y[m * k1:])
     ref = (np.asarray(S.numpy()).reshape(ks, m).T @ Cm).ravel(order="F")
     assert np.abs(Y - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("grid,nx", [((23, 19, 17), 8), ((23, 19, 17), 11), ((40, 37, 31), 24), ((126, 126, 126), 24)])
+def test_spmm_fused_with_the_residual_has_the_bits_of_the_two_passes(ctx, grid, nx):
+    """mi_csr_spmm_colmajor_residual (LOBPCG.h:281,285,293,302 in one pass over X when the matrix takes the window
+    form) against mi_csr_spmm_colmajor followed by mi_lobpcg_residual: AX and R bit for bit, the norms to the
+    rounding of differently grouped sums; cfg5's full size included."""
+    gx, gy, gz = grid
+    m = gx * gy * gz
+    rowptr, col, val = wl.laplacian_3d(gx, gy, gz)
+    A = ctx.csr(m, rowptr, col, val)
+    rng = np.random.default_rng(m % 1000 + nx)
+    X = ctx.upload(rng.normal(size=m * nx))
+    theta = np.linspace(0.2, 3.0, nx)
+    AX0 = A.spmm_colmajor(nx, X)
+    R0, rn0, xn0 = ctx.lobpcg_residual(m, nx, AX0, X, X, theta)
+    AX1, R1, rn1, xn1 = A.spmm_colmajor_residual(nx, X, theta)
+    assert np.array_equal(AX0.numpy(), AX1.numpy())
+    assert np.array_equal(R0.numpy(), R1.numpy())
+    assert np.allclose(rn0, rn1, rtol=1e-13) and np.allclose(xn0, xn1, rtol=1e-13)
+    # against numpy
+    Xh = X.numpy().reshape(nx, m).T
+    import scipy.sparse as sps
+    Ah = sps.csr_matrix((val, col, rowptr), shape=(m, m))
+    Rh = Ah @ Xh - Xh * theta[None, :]
+    assert np.abs(R1.numpy().reshape(nx, m).T - Rh).max() <= 1e-12 * np.abs(Rh).max()
+    assert np.allclose(rn1, np.linalg.norm(Rh, axis=0), rtol=1e-12)
+
+
+def test_lobpcg_with_the_tagged_operator_equals_the_plain_one(monkeypatch):
+    """The device LOBPCG loop with MI355::DeviceCsrPanelOperator (A(X) fused with the residual) against the same run
+    with the operator hidden in a plain lambda: identical iteration counts and Ritz values bit for bit (the residual
+    panel is the same bits, only the norms' sums are grouped differently)."""
+    import harness_py
+    gx, gy, gz, nx, nev = 30, 28, 26, 8, 5
+    m = gx * gy * gz
+    rowptr, col, val = wl.laplacian_3d(gx, gy, gz)
+    X0 = np.linalg.qr(np.random.default_rng(5).normal(size=(m, nx)))[0]
+    out = {}
+    for plain in ("0", "1"):
+        monkeypatch.setenv("HD_LOBPCG_PLAIN_OPERATOR", plain)
+        hz = harness_py.DeviceHarness()
+        out[plain] = hz.lobpcg(m, nx, nev, csr=(rowptr, col, val), X0=X0, max_iters=60, tau=1e-8)
+    a, b = out["0"], out["1"]
+    assert a["num_iters"] == b["num_iters"] and a["nc"] == b["nc"]
+    assert np.array_equal(a["Theta"], b["Theta"])
+    assert np.array_equal(a["X"], b["X"])
