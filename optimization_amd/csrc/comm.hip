@@ -187,6 +187,18 @@ FoldArgs comm_fold_next(mi_ctx *ctx) {
   f.rank = ctx->rank;
   return f;
 }
+FoldArgs comm_fold_next_always(mi_ctx *ctx) {
+  FoldArgs f;
+  Comm *c = (Comm *)ctx->comm;
+  if (!c || !c->ipc_enabled) return f;
+  f.peers = (char *const *)c->peer_dev;
+  f.err = c->err_dev;
+  f.seq = ++c->seq;
+  f.timeout = c->timeout;
+  f.P = ctx->world_size;
+  f.rank = ctx->rank;
+  return f;
+}
 bool comm_fold_enabled(const mi_ctx *ctx) {
   const Comm *c = (const Comm *)ctx->comm;
   return c && c->ipc_enabled && c->fold;

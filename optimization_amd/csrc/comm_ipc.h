@@ -107,5 +107,8 @@ __device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldArgs &f, do
 // host: arguments of the next folded exchange on this context (comm.hip).  peers == nullptr when the peer-memory
 // layer is not carrying the exchanges or folding is switched off (MI355OPT_NO_FOLD=1): separate exchange kernels.
 FoldArgs comm_fold_next(mi_ctx *ctx);
+// the same whenever the peer-memory layer carries the exchanges, MI355OPT_NO_FOLD or not (solvers that have no
+// separate-kernel variant of their exchanges: the fused LSQR)
+FoldArgs comm_fold_next_always(mi_ctx *ctx);
 
 }  // namespace mi

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <utility>
 
+#include "comm_ipc.h"
 #include "mi_internal.h"
 
 using namespace mi;
@@ -94,16 +95,22 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_init_v(size_t nx, const double 
 }
 // [beta = |u|, alpha = |v|]  u /= beta ;  (one launch over max(nx, ny) elements does both vectors)
 // then v /= alpha, alpha /= beta, w = v ; state initialisation
+// (FOLD: several ranks through the peer-memory layer -- every sum over the ranks completes in the prologue of the kernel
+// that consumes it, comm_ipc.h; NoFold: one rank, or RCCL has already summed the partial rows over the ranks)
+template <class FOLD>
 __global__ __launch_bounds__(kBlock) void k_lsqr_init_scale(size_t nx, size_t ny, LsqrConst c, LsqrState *s0,
                                                             const double *__restrict__ pu, int nu,
                                                             const double *__restrict__ pv, int nv,
                                                             double *__restrict__ u, double *__restrict__ v,
-                                                            double *__restrict__ w, HostStatus *hs) {
+                                                            double *__restrict__ w, HostStatus *hs, FOLD fu,
+                                                            FOLD fv) {
 #pragma clang fp contract(off)
   __shared__ double lds[kWaves + 1];
   double r1[1], r2[1];
   reduce_rows<1>(pu, nu, r1, lds);
+  fold_maybe<1>(r1, fu, lds);
   reduce_rows<1>(pv, nv, r2, lds);
+  fold_maybe<1>(r2, fv, lds);
   const double beta = sqrt(r1[0]);
   double alpha = sqrt(r2[0]);
   const bool bpos = beta > 0, apos = alpha > 0;
@@ -181,10 +188,11 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_u(size_t ny, const LsqrState *_
 }
 
 // [beta = |u| ; |Abar| estimate] u /= beta                                              :708-711
+template <class FOLD>
 __global__ __launch_bounds__(kBlock) void k_lsqr_unorm(size_t ny, LsqrConst c, const LsqrState *__restrict__ s_in,
                                                        LsqrState *__restrict__ s_out,
                                                        const double *__restrict__ partials, int nparts,
-                                                       double *__restrict__ u) {
+                                                       double *__restrict__ u, FOLD fold) {
 #pragma clang fp contract(off)
   __shared__ double lds[kWaves + 1];
   LsqrState s = ld(s_in);
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_unorm(size_t ny, LsqrConst c, c
   }
   double r[1];
   reduce_rows<1>(partials, nparts, r, lds);
+  fold_maybe<1>(r, fold, lds);
   const double beta = sqrt(r[0]);
   s.beta = beta;
   s.beta_pos = beta > 0;
@@ -231,12 +240,13 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_v(size_t nx, const LsqrState *_
 }
 
 // [alpha = |v|] v /= alpha ; partials <w,w>, <x,x>, <w,x>                                :713-714,765,785-786
+template <class FOLD>
 __global__ __launch_bounds__(kBlock) void k_lsqr_vnorm(size_t nx, const LsqrState *__restrict__ s_in,
                                                        LsqrState *__restrict__ s_out,
                                                        const double *__restrict__ partials_v, int nparts,
                                                        double *__restrict__ v, const double *__restrict__ w,
                                                        const double *__restrict__ x,
-                                                       double *__restrict__ partials3) {
+                                                       double *__restrict__ partials3, FOLD fold) {
 #pragma clang fp contract(off)
   __shared__ double lds[3 * (kWaves + 1)];
   LsqrState s = ld(s_in);
@@ -248,6 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_vnorm(size_t nx, const LsqrStat
   if (s.beta_pos) {
     double r[1];
     reduce_rows<1>(partials_v, nparts, r, lds);
+    fold_maybe<1>(r, fold, lds);  // (beta_pos is replicated: every rank takes this branch or none does)
     alpha = sqrt(r[0]);
     s.alpha = alpha;
   }
@@ -266,11 +277,12 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_vnorm(size_t nx, const LsqrStat
 }
 
 // [rotations, norms, step lengths, stopping rules] x += t1 w ; w = v + t2 w               :729-837
+template <class FOLD>
 __global__ __launch_bounds__(kBlock) void k_lsqr_xw(size_t nx, LsqrConst c, const LsqrState *__restrict__ s_in,
                                                     LsqrState *__restrict__ s_out,
                                                     const double *__restrict__ partials3, int nparts,
                                                     const double *__restrict__ v, double *__restrict__ w,
-                                                    double *__restrict__ x, HostStatus *hs) {
+                                                    double *__restrict__ x, HostStatus *hs, FOLD fold) {
 #pragma clang fp contract(off)
   __shared__ double lds[3 * (kWaves + 1)];
   LsqrState s = ld(s_in);
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_xw(size_t nx, LsqrConst c, cons
   }
   double d[3];
   reduce_rows<3>(partials3, nparts, d, lds);
+  fold_maybe<3>(d, fold, lds);
   const double w_sq = d[0], xtx = d[1], wtx = d[2];
   const double alpha = s.alpha, beta = s.beta;
   // rotation removing the damping term                                             :729-735
@@ -398,7 +411,14 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
   const size_t nx = A->n, ny = A->n_out ? A->n_out : A->n;
   MI_REQUIRE(At->n == ny && (At->n_out ? At->n_out : At->n) == nx, "A and A' have inconsistent dimensions");
   MI_REQUIRE(b->n == ny && x_out->n == nx, "b / x have the wrong length");
-  MI_REQUIRE(!(ctx->comm && ctx->world_size > 1), "the fused LSQR is single-GPU (no sharded path yet)");
+  // Several ranks (r03): x, b and every work vector are the rank's ROW SLABS; the operators do their own exchange (a
+  // callback's business; the built-in CSR operators of a row-sharded SYMMETRIC matrix exchange halos themselves, and
+  // A' is then the same operator); the five reductions of a pass complete across the ranks either inside the
+  // consumer's prologue (peer-memory layer, comm_ipc.h) or by an in-stream RCCL all-reduce of the partial rows.
+  const bool multi = ctx->comm != nullptr && ctx->world_size > 1;
+  const bool folded = multi && comm_ipc_enabled(ctx);
+  const bool rows = multi && !folded;
+  MI_REQUIRE(!ctx->force_slot_path, "the fused LSQR has no forced slot path (MI355OPT_FORCE_SLOT_PATH)");
   static_assert(sizeof(LsqrState) <= 256, "state slots are 256 bytes apart");
 
   mi_vec *u = nullptr, *v = nullptr, *w = nullptr, *ty = nullptr, *tx = nullptr;
@@ -440,8 +460,18 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
   LQ_CHECK(At->apply(At, u, tx));
   ++applies;
   hipLaunchKernelGGL(k_lsqr_init_v, dim3(gx), dim3(kBlock), 0, stq, nx, (const double *)tx->d, v->d, x_out->d, pb);
-  hipLaunchKernelGGL(k_lsqr_init_scale, dim3(gmax), dim3(kBlock), 0, stq, nx, ny, c, sa, (const double *)pa, gy,
-                     (const double *)pb, gx, u->d, v->d, w->d, ctx->status_dev);
+  if (folded) {
+    const FoldArgs fu = comm_fold_next_always(ctx), fv = comm_fold_next_always(ctx);
+    hipLaunchKernelGGL(k_lsqr_init_scale<FoldArgs>, dim3(gmax), dim3(kBlock), 0, stq, nx, ny, c, sa, (const double *)pa,
+                       gy, (const double *)pb, gx, u->d, v->d, w->d, ctx->status_dev, fu, fv);
+  } else {
+    if (rows) {
+      LQ_CHECK(comm_allreduce_rows(ctx, pa, 1));
+      LQ_CHECK(comm_allreduce_rows(ctx, pb, 1));
+    }
+    hipLaunchKernelGGL(k_lsqr_init_scale<NoFold>, dim3(gmax), dim3(kBlock), 0, stq, nx, ny, c, sa, (const double *)pa,
+                       gy, (const double *)pb, gx, u->d, v->d, w->d, ctx->status_dev, NoFold{}, NoFold{});
+  }
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) LQ_CHECK(hip_fail(e, "lsqr init launch", __FILE__, __LINE__));
@@ -454,7 +484,9 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
       cpu_relax();
       wd = ctx->status->word;
     }
-    if (wd & 1) break;
+    // (several ranks: every enqueued pass carries exchanges, so all ranks enqueue the SAME number -- launches at the
+    // exit + run_ahead, a function of the replicated device state only; cf. mi_stpcg)
+    if ((wd & 1) && (!multi || k >= (wd >> 1) + (uint64_t)run_ahead)) break;
     // operators that can fold `out = Op(in) - scale out` and |out|^2 into their own pass (built-in CSR) save a
     // kernel and a round trip of the product through memory per application
     int nu = gy, nv = gx;
@@ -465,8 +497,14 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
       hipLaunchKernelGGL(k_lsqr_u, dim3(gy), dim3(kBlock), 0, stq, ny, (const LsqrState *)sa, (const double *)ty->d,
                          u->d, pa);
     }
-    hipLaunchKernelGGL(k_lsqr_unorm, dim3(gy), dim3(kBlock), 0, stq, ny, c, (const LsqrState *)sa, sb,
-                       (const double *)pa, nu, u->d);
+    if (folded) {
+      hipLaunchKernelGGL(k_lsqr_unorm<FoldArgs>, dim3(gy), dim3(kBlock), 0, stq, ny, c, (const LsqrState *)sa, sb,
+                         (const double *)pa, nu, u->d, comm_fold_next_always(ctx));
+    } else {
+      if (rows) LQ_CHECK(comm_allreduce_rows(ctx, pa, 1));
+      hipLaunchKernelGGL(k_lsqr_unorm<NoFold>, dim3(gy), dim3(kBlock), 0, stq, ny, c, (const LsqrState *)sa, sb,
+                         (const double *)pa, nu, u->d, NoFold{});
+    }
     if (At->apply_sub_scaled) {
       LQ_CHECK(At->apply_sub_scaled(At, u, &sb->beta, &sb->mode, &sb->beta_pos, v, pb, &nv));
     } else {
@@ -475,10 +513,21 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
                          v->d, pb);
     }
     applies += 2;
-    hipLaunchKernelGGL(k_lsqr_vnorm, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, sa,
-                       (const double *)pb, nv, v->d, (const double *)w->d, (const double *)x_out->d, p3);
-    hipLaunchKernelGGL(k_lsqr_xw, dim3(gx), dim3(kBlock), 0, stq, nx, c, (const LsqrState *)sa, sb,
-                       (const double *)p3, gx, (const double *)v->d, w->d, x_out->d, ctx->status_dev);
+    if (folded) {
+      hipLaunchKernelGGL(k_lsqr_vnorm<FoldArgs>, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, sa,
+                         (const double *)pb, nv, v->d, (const double *)w->d, (const double *)x_out->d, p3,
+                         comm_fold_next_always(ctx));
+      hipLaunchKernelGGL(k_lsqr_xw<FoldArgs>, dim3(gx), dim3(kBlock), 0, stq, nx, c, (const LsqrState *)sa, sb,
+                         (const double *)p3, gx, (const double *)v->d, w->d, x_out->d, ctx->status_dev,
+                         comm_fold_next_always(ctx));
+    } else {
+      if (rows) LQ_CHECK(comm_allreduce_rows(ctx, pb, 1));
+      hipLaunchKernelGGL(k_lsqr_vnorm<NoFold>, dim3(gx), dim3(kBlock), 0, stq, nx, (const LsqrState *)sb, sa,
+                         (const double *)pb, nv, v->d, (const double *)w->d, (const double *)x_out->d, p3, NoFold{});
+      if (rows) LQ_CHECK(comm_allreduce_rows(ctx, p3, 3));
+      hipLaunchKernelGGL(k_lsqr_xw<NoFold>, dim3(gx), dim3(kBlock), 0, stq, nx, c, (const LsqrState *)sa, sb,
+                         (const double *)p3, gx, (const double *)v->d, w->d, x_out->d, ctx->status_dev, NoFold{});
+    }
     std::swap(sa, sb);
   }
   {
@@ -487,6 +536,15 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
     if (e == hipSuccess) e = hipStreamSynchronize(stq);
     ctx->host_syncs++;
     if (e != hipSuccess) LQ_CHECK(hip_fail(e, "lsqr read-back", __FILE__, __LINE__));
+    {
+      int ipc_err = 0;
+      (void)mi_comm_ipc_error(ctx, &ipc_err);
+      if (ipc_err) {
+        set_error("a wait in the peer-memory exchange layer timed out: the result of this solve is invalid");
+        ret = MI_ERR_COMM;
+        goto cleanup;
+      }
+    }
     result->xnorm = h.xnorm;
     result->num_iterations = (size_t)h.k;
     result->exit_reason = h.exit_reason;

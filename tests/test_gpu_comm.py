@@ -355,3 +355,47 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world):
     es = float(np.linalg.norm(s_sh - s1) / np.linalg.norm(s1))
     print(f"cfg4 on one GPU, {world} ranks: s {es:.2e}, alpha {ea:.2e}, beta {eb:.2e}, |s|_M {abs(M - one['M_norm']) / M:.2e}")
     assert es <= 1e-10 and ea <= 1e-9 and eb <= 1e-8
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
+    """mi_lsqr on a communicator (r03: it used to refuse one): a row-sharded symmetric sparse operator (built-in CSR
+    operator with its halo exchange, and the same product behind a callback), x and b as row slabs, the five
+    reductions of a pass completed across the ranks inside their consumers' prologues -- against the single-context
+    solve: same iteration count and exit, x to 1e-10, replicated scalars bit-identical on all ranks.  Plain, damped
+    and trust-region-bounded solves."""
+    import tempfile
+    from optimization_amd import capi, workloads as wl
+    grid = (24, 20, 6 * world + 1)
+    nx, ny, nz = grid
+    n = nx * ny * nz
+    b = np.random.default_rng(17).normal(size=n)
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    c = capi.Context(0)
+    try:
+        A1 = c.csr(n, rowptr, col, val)
+        op1 = c.op_csr(A1, 1)
+        for kw in (dict(btol=1e-11, Atol=1e-11, max_iterations=400), dict(lam=0.3, btol=1e-11, Atol=1e-11),
+                   dict(Delta=2.0, btol=1e-12, Atol=1e-12), dict(max_iterations=7)):
+            one = c.lsqr(op1, op1, c.upload(b), **kw)
+            x1 = one["x"].numpy()
+            with tempfile.TemporaryDirectory() as tmp:
+                np.save(os.path.join(tmp, "b.npy"), b)
+                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                       "--master-addr", "127.0.0.1", "--master-port", str(29620 + world),
+                       os.path.join(ROOT, "tests", "lsqr_worker.py")]
+                env = dict(os.environ, LSQR_WORKER_OUT=tmp, LSQR_GRID=f"{nx},{ny},{nz}", LSQR_KW=json.dumps(kw))
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+                outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
+                xs = {m: np.concatenate([np.load(os.path.join(tmp, f"x_{m}_rank{k}.npy")) for k in range(world)])
+                      for m in ("fused_sub_scaled", "plain_apply")}
+            assert all(o["enabled"] and o["ipc_error"] == 0 for o in outs), outs
+            for m in ("fused_sub_scaled", "plain_apply"):
+                assert all(o[m] == outs[0][m] for o in outs), (kw, m)          # replicated scalars: same bits
+                assert (outs[0][m]["iters"], outs[0][m]["exit"]) == (one["iterations"], one["exit_reason"]), (kw, m)
+                err = np.abs(xs[m] - x1).max() / max(np.abs(x1).max(), 1e-300)
+                assert err <= 1e-10, (kw, m, err)
+                assert abs(float.fromhex(outs[0][m]["xnorm"]) - one["xnorm"]) <= 1e-11 * max(one["xnorm"], 1e-300)
+    finally:
+        c.close()
