@@ -375,7 +375,7 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
     try:
         A1 = c.csr(n, rowptr, col, val)
         op1 = c.op_csr(A1, 1)
-        for kw in (dict(btol=1e-11, Atol=1e-11, max_iterations=400), dict(lam=0.3, btol=1e-11, Atol=1e-11),
+        for kw in (dict(btol=1e-7, Atol=1e-7, max_iterations=400), dict(lam=0.3, btol=1e-11, Atol=1e-11),
                    dict(Delta=2.0, btol=1e-12, Atol=1e-12), dict(max_iterations=7)):
             one = c.lsqr(op1, op1, c.upload(b), **kw)
             x1 = one["x"].numpy()
@@ -395,19 +395,11 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
                 assert all(o[m] == outs[0][m] for o in outs), (kw, m)          # replicated scalars: same bits
                 assert (outs[0][m]["iters"], outs[0][m]["exit"]) == (one["iterations"], one["exit_reason"]), (kw, m)
                 err = np.abs(xs[m] - x1).max() / max(np.abs(x1).max(), 1e-300)
-                # 1e-9, the tolerance of the single-GPU LSQR tests, for solves of up to 60 passes.  The tight solve
-                # runs into its 400-pass limit: LSQR is CG on A'A (condition number squared, 1.4e4 here) and two runs that group their
-                # sums differently drift apart by ~1e-8 while taking the SAME passes, the same exit and reaching the same
-                # residual -- which is what is asserted for it
+                # 1e-9, the tolerance of the single-GPU LSQR tests (LSQR is CG on A'A: condition number squared, 1.4e4
+                # here; a solve pushed into stagnation -- tolerances of 1e-11, 400 passes -- lets two runs that group
+                # their sums differently drift apart by 1e-8 while taking the same passes: not a useful comparison)
                 print(f"sharded lsqr x{world} {kw} {m}: {one['iterations']} passes, x error {err:.2e}")
-                if one["iterations"] <= 60:
-                    assert err <= 1e-9, (kw, m, err)
-                else:
-                    assert err <= 1e-7, (kw, m, err)
-                    import scipy.sparse as sps
-                    Ah = sps.csr_matrix((val, col, rowptr), shape=(n, n))
-                    ra, rb = np.linalg.norm(Ah @ xs[m] - b), np.linalg.norm(Ah @ x1 - b)
-                    assert abs(ra - rb) <= 1e-3 * rb, (ra, rb)
+                assert err <= 1e-9, (kw, m, err)
                 assert abs(float.fromhex(outs[0][m]["xnorm"]) - one["xnorm"]) <= 1e-11 * max(one["xnorm"], 1e-300)
     finally:
         c.close()
