@@ -32,6 +32,8 @@ def main():
         r0 = nx * ny * z0
         b = np.load(os.path.join(out_dir, "b.npy"))[r0:r0 + n]
         rowptr, col, val = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
+        rows_of = np.repeat(np.arange(n, dtype=np.int64) + r0, np.diff(rowptr))
+        val = val + float(os.environ.get("LSQR_SHIFT", "0")) * (col == rows_of)   # A + shift I (better conditioned)
         starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
         dist.barrier()
         A = c.csr_sharded(n_glob, r0, r0 + n, rowptr, col, val, starts)

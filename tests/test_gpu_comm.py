@@ -362,7 +362,7 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
     """mi_lsqr on a communicator (r03: it used to refuse one): a row-sharded symmetric sparse operator (built-in CSR
     operator with its halo exchange, and the same product behind a callback), x and b as row slabs, the five
     reductions of a pass completed across the ranks inside their consumers' prologues -- against the single-context
-    solve: same iteration count and exit, x to 1e-9, replicated scalars bit-identical on all ranks.  Plain, damped
+    solve: same iteration count and exit, x to 1e-10, replicated scalars bit-identical on all ranks.  Plain, damped
     and trust-region-bounded solves."""
     import tempfile
     from optimization_amd import capi, workloads as wl
@@ -371,11 +371,16 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
     n = nx * ny * nz
     b = np.random.default_rng(17).normal(size=n)
     rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    # A = Laplacian + 3.1 I: condition number 5, so that LSQR (CG on A'A) converges in a few dozen passes -- a Lanczos
+    # process that runs for hundreds of passes loses orthogonality and two runs with differently grouped sums then
+    # agree only to the accuracy of the solution, not to rounding
+    shift = 3.0
+    val = val + shift * (col == np.repeat(np.arange(n), np.diff(rowptr)))
     c = capi.Context(0)
     try:
         A1 = c.csr(n, rowptr, col, val)
         op1 = c.op_csr(A1, 1)
-        for kw in (dict(btol=1e-7, Atol=1e-7, max_iterations=400), dict(lam=0.3, btol=1e-11, Atol=1e-11),
+        for kw in (dict(btol=1e-11, Atol=1e-11, max_iterations=400), dict(lam=0.3, btol=1e-11, Atol=1e-11),
                    dict(Delta=2.0, btol=1e-12, Atol=1e-12), dict(max_iterations=7)):
             one = c.lsqr(op1, op1, c.upload(b), **kw)
             x1 = one["x"].numpy()
@@ -384,7 +389,8 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
                 cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                        "--master-addr", "127.0.0.1", "--master-port", str(29620 + world),
                        os.path.join(ROOT, "tests", "lsqr_worker.py")]
-                env = dict(os.environ, LSQR_WORKER_OUT=tmp, LSQR_GRID=f"{nx},{ny},{nz}", LSQR_KW=json.dumps(kw))
+                env = dict(os.environ, LSQR_WORKER_OUT=tmp, LSQR_GRID=f"{nx},{ny},{nz}", LSQR_KW=json.dumps(kw),
+                           LSQR_SHIFT=str(shift))
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
                 assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
                 outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
@@ -395,11 +401,8 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
                 assert all(o[m] == outs[0][m] for o in outs), (kw, m)          # replicated scalars: same bits
                 assert (outs[0][m]["iters"], outs[0][m]["exit"]) == (one["iterations"], one["exit_reason"]), (kw, m)
                 err = np.abs(xs[m] - x1).max() / max(np.abs(x1).max(), 1e-300)
-                # 1e-9, the tolerance of the single-GPU LSQR tests (LSQR is CG on A'A: condition number squared, 1.4e4
-                # here; a solve pushed into stagnation -- tolerances of 1e-11, 400 passes -- lets two runs that group
-                # their sums differently drift apart by 1e-8 while taking the same passes: not a useful comparison)
                 print(f"sharded lsqr x{world} {kw} {m}: {one['iterations']} passes, x error {err:.2e}")
-                assert err <= 1e-9, (kw, m, err)
+                assert err <= 1e-10, (kw, m, err)
                 assert abs(float.fromhex(outs[0][m]["xnorm"]) - one["xnorm"]) <= 1e-11 * max(one["xnorm"], 1e-300)
     finally:
         c.close()
