@@ -415,10 +415,11 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
   // callback's business; the built-in CSR operators of a row-sharded SYMMETRIC matrix exchange halos themselves, and
   // A' is then the same operator); the five reductions of a pass complete across the ranks either inside the
   // consumer's prologue (peer-memory layer, comm_ipc.h) or by an in-stream RCCL all-reduce of the partial rows.
-  const bool multi = ctx->comm != nullptr && ctx->world_size > 1;
-  const bool folded = multi && comm_ipc_enabled(ctx);
-  const bool rows = multi && !folded;
-  MI_REQUIRE(!ctx->force_slot_path, "the fused LSQR has no forced slot path (MI355OPT_FORCE_SLOT_PATH)");
+  // (the predicates of mi_stpcg: a size-1 communicator takes the same code path as 8 ranks -- that is how a 1-GPU
+  // box exercises the RCCL calls, tests/test_gpu_comm.py)
+  const bool multi = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
+  const bool folded = comm_ipc_enabled(ctx);
+  const bool rows = rows_mode(ctx);
   static_assert(sizeof(LsqrState) <= 256, "state slots are 256 bytes apart");
 
   mi_vec *u = nullptr, *v = nullptr, *w = nullptr, *ty = nullptr, *tx = nullptr;
