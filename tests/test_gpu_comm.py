@@ -189,7 +189,8 @@ r2 = c.stpcg(c.upload(gg), c.op_diag(c.upload(D)), c.precon_diag(c.upload(1.0 / 
              kappa_fgr=1e-10, theta=1.0)
 assert np.abs(r2["s"].numpy() + gg / D).max() < 1e-9
 # the fused LSQR through the same RCCL rows path (all-reduce of the partial rows in front of every consumer):
-# the sharded symmetric operator is its own transpose; against the plain-context solve, bit for bit
+# the sharded symmetric operator is its own transpose; against the plain-context solve (whose reductions group their
+# sums over other workgroup counts: same passes and exit, x to the amplification of 60 passes at condition 120^2)
 opA = c.op_csr(A, 1)
 bb = np.sin(np.arange(n) * 0.37)
 l1 = c.lsqr(opA, opA, c.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
@@ -198,7 +199,7 @@ A2 = c2.csr(n, rowptr, col, val)
 opA2 = c2.op_csr(A2, 1)
 l2 = c2.lsqr(opA2, opA2, c2.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
 assert (l1["iterations"], l1["exit_reason"]) == (l2["iterations"], l2["exit_reason"]), (l1["iterations"], l2["iterations"])
-assert np.abs(l1["x"].numpy() - l2["x"].numpy()).max() <= 1e-12 * np.abs(l2["x"].numpy()).max()
+assert np.abs(l1["x"].numpy() - l2["x"].numpy()).max() <= 1e-8 * np.abs(l2["x"].numpy()).max()
 c2.close()
 c.comm_finalize(); c.close()
 print("ok")
