@@ -189,17 +189,24 @@ r2 = c.stpcg(c.upload(gg), c.op_diag(c.upload(D)), c.precon_diag(c.upload(1.0 / 
              kappa_fgr=1e-10, theta=1.0)
 assert np.abs(r2["s"].numpy() + gg / D).max() < 1e-9
 # the fused LSQR through the same RCCL rows path (all-reduce of the partial rows in front of every consumer):
-# the sharded symmetric operator is its own transpose; against the plain-context solve (whose reductions group their
-# sums over other workgroup counts: same passes and exit, x to the amplification of 60 passes at condition 120^2)
+# the sharded symmetric operator is its own transpose; against the plain-context solve.  20 passes: the two SpMV
+# variants (with / without a halo view) round differently in the last bit, and past convergence (~25 passes here) a
+# Lanczos process amplifies that to 1e-7 by pass 60; with callback operators the two contexts agree bit for bit
 opA = c.op_csr(A, 1)
 bb = np.sin(np.arange(n) * 0.37)
-l1 = c.lsqr(opA, opA, c.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
+l1 = c.lsqr(opA, opA, c.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=20)
 c2 = capi.Context(0)
 A2 = c2.csr(n, rowptr, col, val)
 opA2 = c2.op_csr(A2, 1)
-l2 = c2.lsqr(opA2, opA2, c2.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
+l2 = c2.lsqr(opA2, opA2, c2.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=20)
 assert (l1["iterations"], l1["exit_reason"]) == (l2["iterations"], l2["exit_reason"]), (l1["iterations"], l2["iterations"])
-assert np.abs(l1["x"].numpy() - l2["x"].numpy()).max() <= 1e-8 * np.abs(l2["x"].numpy()).max()
+assert np.abs(l1["x"].numpy() - l2["x"].numpy()).max() <= 1e-13 * np.abs(l2["x"].numpy()).max()
+o1, o2 = opA, opA2
+cb1 = c.op_callback(n, lambda i, o: o1.apply(i, o))
+cb2 = c2.op_callback(n, lambda i, o: o2.apply(i, o))
+l1 = c.lsqr(cb1, cb1, c.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
+l2 = c2.lsqr(cb2, cb2, c2.upload(bb), btol=1e-10, Atol=1e-10, max_iterations=60)
+assert l1["iterations"] == l2["iterations"] and np.array_equal(l1["x"].numpy(), l2["x"].numpy())
 c2.close()
 c.comm_finalize(); c.close()
 print("ok")
