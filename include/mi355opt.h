@@ -382,6 +382,10 @@ MI_API int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank,
 MI_API int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok);      /* collective, sync */
 MI_API int mi_comm_ipc_enable(mi_ctx *ctx, int on);
 MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounded wait timed out */
+/* Kernels the peer-memory layer launched on its own so far: out[0] scalar-exchange kernels, out[1] halo-push kernels,
+ * out[2] halo pushes that rode in the kernel producing the vector instead (no launch).  With folding on (the default)
+ * a sharded fused STPCG iteration adds nothing to out[0] and out[1]: it is the three kernels of the single-GPU step. */
+MI_API int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[3]);
 /* Verification hooks (used by tests/test_gpu_comm.py on a ONE-GPU box): pretend to be `rank` of
  * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
  * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in

@@ -44,6 +44,11 @@ struct Comm {
   unsigned int *err_host = nullptr, *err_dev = nullptr;  // pinned, device-visible error word
   double *vals_dev = nullptr;            // staging for value exchanges (kIpcMaxRanks * kIpcVals)
   uint64_t timeout = kIpcTimeoutTicks;   // bound of every device-side wait, in 100 MHz ticks
+  // a halo push folded into the kernel that wrote the vector (comm_halo_fold_next), not yet consumed
+  struct { const mi_csr *A = nullptr; const double *V = nullptr; int p = 0; uint64_t seq = 0; } pushed;
+  // kernels this layer launched itself: [0] scalar exchanges, [1] halo pushes, and [2] halo pushes that rode in the
+  // producer kernel instead (mi_comm_kernel_launches)
+  unsigned long long launched[3] = {0, 0, 0};
 };
 
 int nccl_fail(ncclResult_t r, const char *what) {
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
 int ipc_exchange(mi_ctx *ctx, Comm *c, const double *partials, int count, const double *in_vals, int k, bool sum,
                  double *out) {
   const uint64_t seq = ++c->seq;
+  ++c->launched[0];
 #define IX(K)                                                                                              \
   if (sum)                                                                                                 \
     hipLaunchKernelGGL((k_ipc_exchange<K, true>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count,  \
@@ -258,10 +264,58 @@ int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k,
   return comm_allreduce(ctx, slots, k);
 }
 
+bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloPush *push) {
+  *push = HaloPush{};
+  if (ctx->world_size <= 1 || !ctx->comm || !A) return false;
+  Comm *c = (Comm *)ctx->comm;
+  if (!(c->ipc_enabled && c->fold && A->halo_in_arena)) return false;
+  if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return false;
+  const int rk = ctx->rank, ws = ctx->world_size;
+  const size_t lo = rk > 0 ? A->send_lo * p : 0, hi = rk + 1 < ws ? A->send_hi * p : 0, nd = A->n * (size_t)p;
+  // the pushing kernel stores double2: every boundary of the exchange must fall on one
+  if ((lo | hi | nd | (A->peer_lo_rows * p) | A->halo_stride) & 1) return false;
+  c->pushed = {};  // (an unconsumed one: its counters stay advanced, like an exchange nobody read)
+  const size_t buf_off = A->halo_off + (++A->halo_exchanges & 1) * A->halo_stride * sizeof(double);
+  const bool act_lo = rk > 0 && A->halo_lo + A->send_lo > 0, act_hi = rk + 1 < ws && A->halo_hi + A->send_hi > 0;
+  push->seq = ++c->halo_seq;
+  push->mine = reinterpret_cast<IpcMailbox *>(c->peer[rk]);
+  if (lo) push->dst_lo = reinterpret_cast<double2 *>(c->peer[rk - 1] + buf_off + A->peer_lo_rows * p * sizeof(double));
+  if (hi) push->dst_hi = reinterpret_cast<double2 *>(c->peer[rk + 1] + buf_off);
+  push->lo2 = lo / 2;
+  push->hi_from = (nd - hi) / 2;
+  if (act_lo) push->mb_lo = reinterpret_cast<IpcMailbox *>(c->peer[rk - 1]);
+  if (act_hi) push->mb_hi = reinterpret_cast<IpcMailbox *>(c->peer[rk + 1]);
+  c->pushed.A = A; c->pushed.V = V; c->pushed.p = p; c->pushed.seq = push->seq;
+  ++c->launched[2];
+  return true;
+}
+
+void comm_halo_fold_drop(mi_ctx *ctx) {
+  if (ctx->comm) ((Comm *)ctx->comm)->pushed = {};
+}
+
+int comm_halo_exchange_or_wait(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloWait *w) {
+  *w = HaloWait{};
+  Comm *c = (Comm *)ctx->comm;
+  if (c && c->pushed.seq && c->pushed.A == A && c->pushed.V == V && c->pushed.p == p) {
+    const int rk = ctx->rank, ws = ctx->world_size;
+    w->mine = reinterpret_cast<const IpcMailbox *>(c->peer[rk]);
+    w->err = c->err_dev;
+    w->seq = c->pushed.seq;
+    w->timeout = c->timeout;
+    w->expect_lo = rk > 0 && A->halo_lo + A->send_lo > 0;
+    w->expect_hi = rk + 1 < ws && A->halo_hi + A->send_hi > 0;
+    c->pushed = {};
+    return MI_OK;
+  }
+  return comm_halo_exchange(ctx, A, p, V);
+}
+
 int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
   if (ctx->world_size <= 1 || !ctx->comm) return MI_OK;
   if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
+  c->pushed = {};
   const int rk = ctx->rank, ws = ctx->world_size;
   if (c->ipc_enabled && A->halo_in_arena) {
     // this exchange's buffer (mi_csr::halo_stride); every rank counts the exchanges of a matrix identically
@@ -276,6 +330,7 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
                        (int)(rk > 0 && A->halo_lo + A->send_lo > 0), (int)(rk + 1 < ws && A->halo_hi + A->send_hi > 0),
                        ++c->halo_seq,
                        c->err_dev, c->timeout);
+    ++c->launched[1];
     MI_HIP(hipGetLastError());
     return MI_OK;
   }
@@ -498,6 +553,13 @@ int mi_comm_ipc_error(mi_ctx *ctx, int *err) {
   MI_REQUIRE(ctx && err, "null argument");
   Comm *c = (Comm *)ctx->comm;
   *err = (c && c->ipc_enabled && c->err_host) ? (int)*c->err_host : 0;
+  return MI_OK;
+}
+
+int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[3]) {
+  MI_REQUIRE(ctx && out, "null argument");
+  Comm *c = (Comm *)ctx->comm;
+  for (int i = 0; i < 3; ++i) out[i] = c ? c->launched[i] : 0ull;
   return MI_OK;
 }
 

@@ -103,6 +103,88 @@ template <int K>
 __device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldArgs &f, double *lds) {
   if (f.peers) fold_exchange_sum<K>(d, f, lds);
 }
+struct FoldPush;
+template <int K>
+__device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldPush &fp, double *lds);
+
+// The HALO exchange folded the same way (STPCG's recurrence form over a sharded Stiefel problem): the PUSH half rides
+// in the kernel that writes the next direction -- k_cg_pupdate stores every element a neighbour needs a second time,
+// into that neighbour's halo buffer, and the last workgroup to finish raises the neighbours' flags -- and the WAIT half
+// sits in the prologue of the Hessian pass that reads the halo.  Same flags, sequence numbers and double buffering as
+// k_ipc_halo_push (comm.hip), so a rank whose matrix does not qualify keeps the separate kernel next to ranks that
+// fold.  Buffer reuse: between two pushes every rank passes a folded scalar exchange (k_cg_update), which no rank leaves
+// before every rank has entered it, i.e. has finished the Hessian pass that read the buffer written two pushes ago.
+struct HaloPush {
+  double2 *dst_lo = nullptr, *dst_hi = nullptr;  // rank-1's / rank+1's halo buffer of this exchange (null: no rows)
+  size_t lo2 = 0, hi_from = 0;                   // double2 [0, lo2) go to dst_lo, [hi_from, n2) to dst_hi
+  IpcMailbox *mine = nullptr, *mb_lo = nullptr, *mb_hi = nullptr;  // flags to raise (null: pair not active)
+  uint64_t seq = 0;                              // 0: nothing folded into this launch
+};
+struct FoldPush {  // a folded scalar exchange in the prologue AND a folded halo push in the body (k_cg_pupdate)
+  FoldArgs f;
+  HaloPush h;
+};
+struct HaloWait {
+  const IpcMailbox *mine = nullptr;
+  unsigned int *err = nullptr;
+  uint64_t seq = 0, timeout = 0;  // seq 0: the halo is already in (separate exchange kernel, or not sharded)
+  int expect_lo = 0, expect_hi = 0;
+};
+template <bool HALO>
+struct HaloWaitArg {};  // kernels without a halo carry no argument for it
+template <>
+struct HaloWaitArg<true> {
+  HaloWait w;
+};
+
+__device__ __forceinline__ bool halo_push_store(const NoFold &, size_t, const double2 &) { return false; }
+__device__ __forceinline__ bool halo_push_store(const FoldArgs &, size_t, const double2 &) { return false; }
+__device__ __forceinline__ bool halo_push_store(const FoldPush &fp, size_t i, const double2 &v) {
+  const HaloPush &h = fp.h;
+  bool any = false;
+  if (i < h.lo2) { h.dst_lo[i] = v; any = true; }
+  if (h.dst_hi && i >= h.hi_from) { h.dst_hi[i - h.hi_from] = v; any = true; }
+  return any;
+}
+// every workgroup, once, behind its last halo_push_store (pushed: this thread stored something).  Contains a barrier.
+__device__ __forceinline__ void halo_push_finish(const NoFold &, bool) {}
+__device__ __forceinline__ void halo_push_finish(const FoldArgs &, bool) {}
+__device__ __forceinline__ void halo_push_finish(const FoldPush &fp, bool pushed) {
+  const HaloPush &h = fp.h;
+  if (!h.seq) return;
+  if (pushed) __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const unsigned int done = __hip_atomic_fetch_add(&h.mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (done != gridDim.x - 1) return;
+  __hip_atomic_store(&h.mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (h.mb_lo) __hip_atomic_store(&h.mb_lo->halo_flag[1], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (h.mb_hi) __hip_atomic_store(&h.mb_hi->halo_flag[0], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// prologue of the kernel that reads the halo.  Contains a barrier.
+__device__ __forceinline__ void halo_wait(const HaloWait &w) {
+  if (!w.seq) return;
+  if (threadIdx.x == 0) {
+    if (w.expect_lo) ipc_wait(&w.mine->halo_flag[0], w.seq, w.err, w.timeout);
+    if (w.expect_hi) ipc_wait(&w.mine->halo_flag[1], w.seq, w.err, w.timeout);
+  }
+  __syncthreads();
+}
+
+template <int K>
+__device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldPush &fp, double *lds) {
+  if (fp.f.peers) fold_exchange_sum<K>(d, fp.f, lds);
+}
+
+// host (comm.hip): fold the NEXT halo exchange of the n x p field `V` over A's pattern.  True: `push` goes to the
+// kernel that writes V (launched next on the stream), and the next comm_halo_exchange_or_wait(ctx, A, p, V, &w)
+// launches nothing and hands out the wait instead.  False: nothing changed; the exchange stays a kernel.
+bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloPush *push);
+// comm_halo_exchange for a kernel that can wait in its own prologue: *w is the wait of a folded push of exactly this
+// (A, p, V), or seq 0 after launching the separate exchange kernel (or when nothing is exchanged at all)
+int comm_halo_exchange_or_wait(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloWait *w);
+// forget a folded push nobody consumed (the solve ended behind it; the next exchange is a whole one again)
+void comm_halo_fold_drop(mi_ctx *ctx);
 
 // host: arguments of the next folded exchange on this context (comm.hip).  peers == nullptr when the peer-memory
 // layer is not carrying the exchanges or folding is switched off (MI355OPT_NO_FOLD=1): separate exchange kernels.

@@ -490,6 +490,9 @@ struct mi_dirgram {
   const double *X = nullptr;  // n x p, row-major
   const double *Y = nullptr;  // A X
   const double *S = nullptr;  // device, p x p
+  // the matrix whose halo exchange precedes every apply_dir (null: none).  STPCG may fold the push half of the NEXT
+  // exchange into its direction kernel (comm_ipc.h comm_halo_fold_next); apply_dir then only waits.
+  const struct mi_csr *halo_A = nullptr;
 };
 
 struct mi_precon {

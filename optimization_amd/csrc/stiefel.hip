@@ -14,6 +14,7 @@
 //                   body: Hp = Z - X sym(X'Z); partial rows of <V,Hp>, <Hp,Hp>, <V,V>      [8 (4N)]
 // so the three curvature inner products of STPCG (IterativeSolvers.h:300,305-306) cost no extra pass
 // and no scalar kernel sits between the passes.
+#include "comm_ipc.h"
 #include "spmm_core.h"
 #include "stiefel_core.h"
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
                                                           const double *__restrict__ slots,
                                                           const double *__restrict__ gdir,
                                                           double *__restrict__ out,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
   constexpr bool WIN = HW > 0 && P <= 3;  // (P = 4: ring + parked rows would need > 160 KB of LDS; never dispatched)
   constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
   constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
@@ -213,6 +214,8 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
   __shared__ double vt[PK ? 256 : 1];  // PK: the matrix's value table
   __shared__ double ring[WIN ? kWinLdsRows * P : 1];  // WIN: ring, zero row, far slots
   if (st && st->mode != CG_RUN) return;
+  // sharded: the neighbours' rows of V were pushed by the kernel that wrote V (comm_ipc.h HaloPush); wait for them here
+  if constexpr (HALO) halo_wait(hwait.w);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #ifdef MI_WIN_STAMPS  // both forms: each wave's entry and exit on the constant 100 MHz clock (slots 56, 57)
   const unsigned long long t_entry = wall_clock64();
@@ -695,12 +698,17 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
     const int occ = std::min(window_occupancy(p, halo, A->win_head <= 7 ? 7 : 8), kWaves / kWinWaves);
     int wgs = std::min(cap * occ, kMaxRows);
     if (win_wgs > 0) wgs = std::min(win_wgs, kMaxRows);
+    // (one-GPU rehearsals of several ranks: the pass waits for its neighbours in its prologue, so -- like the CG
+    // kernels -- it must leave room for their kernels while it does; mi_internal.h mi_ctx::max_grid)
+    if (ctx->max_grid < kMaxGrid) wgs = std::min(wgs, ctx->max_grid);  // (lowered explicitly: MI355OPT_MAX_GRID)
     const int *bounds = nullptr;
     MI_TRY(window_bounds(ctx, A, wgs, ntiles, &grid, &bounds));
     wv.bounds = bounds;
   }
   const int block = win ? kWinBlock : kBlock;
-  MI_TRY(comm_halo_exchange(ctx, A, p, in->d));
+  HaloWaitArg<true> hw_halo;   // a push folded into the kernel that wrote `in`: the pass waits in its prologue
+  HaloWaitArg<false> hw_none;
+  MI_TRY(comm_halo_exchange_or_wait(ctx, A, p, in->d, &hw_halo.w));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   if (!recur) {
     if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
@@ -713,7 +721,9 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,  \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),        \
-                                   out->d, ctx->partials))
+                                   out->d, ctx->partials, HW_ARG_##HL))
+#define HW_ARG_true hw_halo
+#define HW_ARG_false hw_none
 #define HF(F, HL, RC)                                                          \
   if (A->pk) { HF3(F, HL, RC, true, 0); }                                      \
   else { HF3(F, HL, RC, false, 0); }
@@ -723,7 +733,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
-                                   out->d, ctx->partials))
+                                   out->d, ctx->partials, hw_none))
   if (win && w16) {  // the window form with computed far columns and 16-bit words
     if (A->win_head <= 7) { HF3D(7, 2); } else { HF3D(8, 2); }
   } else if (win && fard) {  // ... with computed far columns
@@ -744,6 +754,8 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
 #undef HF3D
 #undef HF3
 #undef HF
+#undef HW_ARG_true
+#undef HW_ARG_false
   *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -910,6 +922,7 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   q->dg.X = X->d;
   q->dg.Y = q->Y->d;
   q->dg.S = q->S_dev;
+  q->dg.halo_A = q->A->halo ? q->A : nullptr;
   // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator -- and so does
   // a matrix that is not symmetric (checked at creation): the one-pass form replaces X'(A p) by (A X)'p
   q->hess.dirgram = (sell_stream_ok(q->A, q->p) && q->A->symmetric) ? &q->dg : nullptr;

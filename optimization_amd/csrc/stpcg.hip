@@ -571,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       return;
     }
     double2 vv = vv0, pv = pv0, sv = sv0;
+    bool pushed = false;  // (FoldPush: this thread stored rows of the new direction into a neighbour's halo)
     for (size_t i = i0; i < n2;) {
       const size_t inext = i + stride;
       double2 vn = vv, pn = pv, sn = sv;
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       if (dir) {
         pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
         reinterpret_cast<double2 *>(p)[i] = pv;
+        pushed |= halo_push_store(fold, i, pv);
       }
       i = inext; vv = vn; pv = pn; sv = sn;
     }
@@ -591,6 +593,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, con
       s[n - 1] = s[n - 1] + alpha * p[n - 1];
       if (dir) p[n - 1] = -v[n - 1] + beta * p[n - 1];
     }
+    // the halo exchange of the next Hessian pass, folded in (comm_ipc.h); `dir` is the same in every workgroup of
+    // every rank, so either all of them push or none does -- and the pass that would wait is skipped with them
+    if (dir) halo_push_finish(fold, pushed);
   }
 }
 
@@ -935,8 +940,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
       if (sharded && folded) {
         const FoldArgs fold_b = comm_fold_next(ctx);  // (folded <=> recurrence form <=> sp == 0)
+        // ... and the halo exchange of the NEXT Hessian pass rides in this kernel's stores of the new direction
+        FoldPush fp{fold_b, HaloPush{}};
+        const bool push = dgp && dgp->halo_A && k + 1 < prm->max_iterations &&
+                          comm_halo_fold_next(ctx, dgp->halo_A, dgp->p, p->d, &fp.h);
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
+        if (push)
+          hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldPush>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fp);
+        else
+          hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
       } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
@@ -951,6 +963,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 #undef PUPD_ARGS
     }
     result->hvp_calls = hvp;
+    comm_halo_fold_drop(ctx);  // (a push behind the last enqueued iteration has no reader)
   }
 
   // --- read back the final state ----------------------------------------------------------------

@@ -46,8 +46,11 @@ def main():
         out["f"] = prob.objective(X)
         g, H = prob.model(X)
         c.ktime_enable("stiefel_hess_fused", True)
+        k0 = c.comm_kernel_launches()
         r = c.stpcg(g, H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
         out["one_pass_launches"] = c.ktime_read("stiefel_hess_fused")[0]
+        # kernels the exchange layer launched during the solve: (scalar exchanges, halo pushes, halo pushes folded in)
+        out["comm_kernels"] = [b - a for a, b in zip(k0, c.comm_kernel_launches())]
         np.save(os.path.join(out_dir, f"s_rank{rank}.npy"), r["s"].numpy())
         np.save(os.path.join(out_dir, f"g_rank{rank}.npy"), g.numpy())
         out.update(rows=[r0, r0 + n], iters=r["iterations"], exit=r["exit_reason"], M=float(r["M_norm"]).hex(),

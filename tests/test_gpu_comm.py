@@ -318,7 +318,8 @@ def _run_cfg4_workers(world, grid, Xb, extra_env=None, port=29580):
 
 def test_folded_exchanges_give_the_bits_of_the_exchange_kernels():
     """The scalar exchanges of a sharded STPCG iteration folded into the prologues of their consumer kernels
-    (comm_ipc.h fold_exchange_sum: 4 launches per iteration instead of 6) against the separate one-workgroup
+    (comm_ipc.h fold_exchange_sum) and the halo push folded into the direction kernel (HaloPush): the 3 launches
+    per iteration of the single-GPU step instead of 6, against the separate one-workgroup
     exchange kernels (MI355OPT_NO_FOLD=1): the same local reduction, the same rank-order sum -- bit-identical
     scalars and steps, with 3 real peers on one GPU."""
     from optimization_amd import workloads as wl
@@ -330,6 +331,13 @@ def test_folded_exchanges_give_the_bits_of_the_exchange_kernels():
     for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):
         assert a[0][k] == b[0][k], k
     assert np.array_equal(sa, sb)
+    # launches of the exchange layer's own kernels during the solve: (scalar exchanges, halo pushes, pushes folded in)
+    it = a[0]["iters"]
+    print("comm kernels per solve, folded:", [o["comm_kernels"] for o in a], " separate:", [o["comm_kernels"] for o in b])
+    for o in a:   # folded: the set-up's exchanges and the FIRST pass's halo push only; every later push rides along
+        assert o["comm_kernels"][0] <= 3 and o["comm_kernels"][1] == 1 and o["comm_kernels"][2] >= it - 1, o
+    for o in b:   # separate kernels: two scalar exchanges and one halo push per iteration
+        assert o["comm_kernels"][0] >= 2 * it and o["comm_kernels"][1] >= it and o["comm_kernels"][2] == 0, o
 
 
 @pytest.mark.parametrize("world", [2, 4])
