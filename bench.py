@@ -172,7 +172,7 @@ def run_steps(ctx, g, H, s_out, steps):
     return solves
 
 
-def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank):
+def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, peer_memory=False):
     """Cheap end-to-end checks of the N-rank data path before anything is timed (the 8-GPU node is the first
     place the cross-device exchanges ever run).  Returns a list of failure strings (empty = all good), the same
     on every rank."""
@@ -199,6 +199,17 @@ def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank):
     g, H = prob.model(X)
     r = ctx.stpcg(g, H, Delta=1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0)
     mine = (r["iterations"], r["exit_reason"], float(r["M_norm"]).hex(), r["hvp_calls"], ctx.comm_ipc_error())
+    if peer_memory and os.environ.get("MI355OPT_NO_FOLD") != "1":
+        # the exchanges folded into the CG / Hessian kernels (scalars in the prologues, halo rows in the direction
+        # kernel's stores) against the separate exchange kernels: bit-identical by construction, so any difference
+        # is a cross-device ordering problem of the folded form
+        s_fold = r["s"].numpy()
+        ctx.comm_ipc_fold(False)
+        r2 = ctx.stpcg(g, H, Delta=1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0)
+        ctx.comm_ipc_fold(True)
+        sep = (r2["iterations"], r2["exit_reason"], float(r2["M_norm"]).hex(), r2["hvp_calls"], ctx.comm_ipc_error())
+        if sep != mine or not np.array_equal(s_fold, r2["s"].numpy()):
+            fails.append(f"rank {rank}: folded exchanges {mine} != separate exchange kernels {sep} (or the steps differ)")
     every = [None] * world
     dist.all_gather_object(every, (mine, fails))
     if len({e[0] for e in every}) != 1:
@@ -357,7 +368,7 @@ def main():
     nnz = int(rowptr[-1])
     prob = ctx.stiefel_rq(A, n, p)
     if use_comm:
-        fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank)
+        fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, peer_memory)
         if peer_memory and os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1":
             fails = fails + ["injected failure (test of the fallback path)"]
         if fails and peer_memory and not one_gpu:

@@ -382,6 +382,9 @@ MI_API int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank,
 MI_API int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok);      /* collective, sync */
 MI_API int mi_comm_ipc_enable(mi_ctx *ctx, int on);
 MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounded wait timed out */
+/* exchanges folded into their producer / consumer kernels (default on; env MI355OPT_NO_FOLD=1: off) switched at run
+ * time -- every rank must make the same call between the same two solves.  Results are bit-identical either way. */
+MI_API int mi_comm_ipc_fold(mi_ctx *ctx, int on);
 /* Kernels the peer-memory layer launched on its own so far: out[0] scalar-exchange kernels, out[1] halo-push kernels,
  * out[2] halo pushes that rode in the kernel producing the vector instead (no launch).  With folding on (the default)
  * a sharded fused STPCG iteration adds nothing to out[0] and out[1]: it is the three kernels of the single-GPU step. */

@@ -180,6 +180,7 @@ def load():
         "mi_comm_ipc_enable": [vp, C.c_int],
         "mi_comm_ipc_error": [vp, C.POINTER(C.c_int)],
         "mi_comm_kernel_launches": [vp, C.POINTER(C.c_ulonglong)],
+        "mi_comm_ipc_fold": [vp, C.c_int],
         "mi_debug_time_fused_apply": [vp, vp, vp, C.c_int, c_double_p],
         "mi_debug_set_rank": [vp, C.c_int, C.c_int],
         "mi_debug_csr_set_halo": [vp, C.c_int, c_double_p],
@@ -552,6 +553,9 @@ class Context:
         e = C.c_int(0)
         check(self.L.mi_comm_ipc_error(self.h, C.byref(e)))
         return e.value
+
+    def comm_ipc_fold(self, on):
+        check(self.L.mi_comm_ipc_fold(self.h, int(on)))
 
     def comm_kernel_launches(self):
         """(scalar-exchange kernels, halo-push kernels, halo pushes folded into the producer kernel) so far"""

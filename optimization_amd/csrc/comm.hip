@@ -548,6 +548,16 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
   return MI_OK;
 }
 
+// Exchanges folded into their producer / consumer kernels (comm_ipc.h) on or off at run time; the same on every rank.
+int mi_comm_ipc_fold(mi_ctx *ctx, int on) {
+  MI_REQUIRE(ctx, "ctx is null");
+  Comm *c = (Comm *)ctx->comm;
+  MI_REQUIRE(c, "no communicator");
+  c->fold = on != 0;
+  c->pushed = {};
+  return MI_OK;
+}
+
 // 0: no error; nonzero: a wait inside the peer-memory layer timed out (results since then are invalid)
 int mi_comm_ipc_error(mi_ctx *ctx, int *err) {
   MI_REQUIRE(ctx && err, "null argument");
