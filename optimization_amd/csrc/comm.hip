@@ -191,6 +191,9 @@ FoldArgs comm_fold_next(mi_ctx *ctx) {
   f.timeout = c->timeout;
   f.P = ctx->world_size;
   f.rank = ctx->rank;
+#ifdef MI_FOLD_STAMPS  // experiment: the folded instantiation without its exchange (right only for one rank)
+  if (getenv("MI355OPT_DEBUG_FOLD_NULL")) f.peers = nullptr;
+#endif
   return f;
 }
 FoldArgs comm_fold_next_always(mi_ctx *ctx) {

@@ -66,12 +66,21 @@ __device__ __forceinline__ bool ipc_wait_relaxed(const uint64_t *flag, uint64_t 
 // the sequence-numbered flag with release); every workgroup waits for the P flags in ITS OWN rank's mailbox and sums
 // the P contributions in rank order -- identical code on identical data on every workgroup of every rank: identical
 // bits everywhere, no separate exchange kernel.  lds: >= kIpcVals doubles.  Contains barriers.
+#ifdef MI_FOLD_STAMPS  // experiment builds: where the folded exchange spends its time (8 stamps per workgroup)
+static __device__ unsigned long long *g_fold_stamps = nullptr;
+#define FOLD_STAMP(i) do { if (g_fold_stamps && threadIdx.x == 0) g_fold_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define FOLD_STAMP_K(i) do { if (K > 1) FOLD_STAMP(i); } while (0)  // (k_cg_update's exchange only)
+#else
+#define FOLD_STAMP_K(i) do { } while (0)
+#define FOLD_STAMP(i) do { } while (0)
+#endif
 template <int K>
 __device__ __forceinline__ void fold_exchange_sum(double (&d)[K], const FoldArgs &f, double *lds) {
   static_assert(K <= kIpcVals, "exchange width");
   const int q = (int)(f.seq % kIpcRing);
   const int t = threadIdx.x;
   IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(f.peers[f.rank]);
+  FOLD_STAMP_K(1);
   if (blockIdx.x == 0 && t < f.P) {
     IpcMailbox *mb = reinterpret_cast<IpcMailbox *>(f.peers[t]);
 #pragma unroll
@@ -79,8 +88,11 @@ __device__ __forceinline__ void fold_exchange_sum(double (&d)[K], const FoldArgs
       __hip_atomic_store(&mb->val[q][f.rank][k], d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mb->flag[q][f.rank], f.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  FOLD_STAMP_K(2);
   if (t < f.P) ipc_wait_relaxed(&mine->flag[q][t], f.seq, f.err, f.timeout);
+  FOLD_STAMP_K(3);
   __syncthreads();
+  FOLD_STAMP_K(4);
   if (t < K) {
     double s = 0;
     for (int r = 0; r < f.P; ++r)
@@ -91,6 +103,7 @@ __device__ __forceinline__ void fold_exchange_sum(double (&d)[K], const FoldArgs
 #pragma unroll
   for (int k = 0; k < K; ++k) d[k] = lds[k];
   __syncthreads();
+  FOLD_STAMP_K(5);
 }
 
 // The kernels that can fold an exchange are instantiated twice: with FoldArgs (several ranks, peer-memory layer) and

@@ -277,8 +277,10 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_vnorm(size_t nx, const LsqrStat
 }
 
 // [rotations, norms, step lengths, stopping rules] x += t1 w ; w = v + t2 w               :729-837
+// (at most 80 scalar registers: with the 82..96 it would take, a 1024-thread workgroup gets the CU to itself instead
+// of sharing it with a second one -- stpcg.hip, k_cg_update_s80)
 template <class FOLD>
-__global__ __launch_bounds__(kBlock) void k_lsqr_xw(size_t nx, LsqrConst c, const LsqrState *__restrict__ s_in,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_lsqr_xw(size_t nx, LsqrConst c, const LsqrState *__restrict__ s_in,
                                                     LsqrState *__restrict__ s_out,
                                                     const double *__restrict__ partials3, int nparts,
                                                     const double *__restrict__ v, double *__restrict__ w,

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_so3_objective(size_t E, const int *_
 }
 
 // Y_i = R_i exp(hat(xi_i))  (Rodrigues; same series switch as oracle/problems.c: orc_so3_exp)
-__global__ __launch_bounds__(kBlock) void k_so3_retract(size_t N, const double *__restrict__ R,
+// (80 scalar registers: see stpcg.hip, k_cg_update_s80)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_so3_retract(size_t N, const double *__restrict__ R,
                                                         const double *__restrict__ xi, double *__restrict__ Y) {
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {

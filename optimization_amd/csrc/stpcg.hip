@@ -28,6 +28,7 @@
 #include "stiefel_core.h"
 
 #include <cmath>
+#include <type_traits>
 
 using namespace mi;
 
@@ -294,135 +295,14 @@ struct DirGramArgs {
 //   CG_RUN:            r += alpha Hp (:377); v = P r (:383/386); partial <r,v> (:408)   [s += alpha p: see k_cg_pupdate]
 //   CG_APPLY_SIGMA:    s += sigma p (:360)
 //   CG_KERNEL_PENDING: partial <p,r> (:320)
-template <int PRE, bool FROM_SLOTS, int KC = 3, class FOLD = NoFold>
-__global__ __launch_bounds__(kBlock) void k_cg_update(size_t n, CgConst cc, const CgState *__restrict__ st_in,
-                                                      CgState *__restrict__ st_out,
-                                                      const double *__restrict__ partials_a, int nparts_a,
-                                                      const double *__restrict__ slots,
-                                                      const double *__restrict__ p,
-                                                      const double *__restrict__ Hp,
-                                                      const double *__restrict__ pre,
-                                                      double *__restrict__ s, double *__restrict__ r,
-                                                      double *__restrict__ v,
-                                                      double *__restrict__ partials_b, DirGramArgs dg,
-                                                      FOLD fold) {
-  __shared__ double lds[3 * (kWaves + 1)];
-  static_assert(KC >= 3 && KC <= kWaves, "3 curvature dots + at most 13 Gram components");
-  CgState cs = load_state(st_in);
-  if (cs.mode == CG_DONE) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) store_state(st_out, cs);
-    return;
-  }
-  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
-  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  // software prefetch of the first grid-stride step: its HBM latency overlaps the prologue's
-  // reduction (tools/microbench/prologue.hip: hides the ~2.2 us prologue completely)
-  // (issued BEHIND the prologue's row loads: loads return in order, so the reduction is not held up by them)
-  double2 hv0 = make_double2(0, 0), rv0 = hv0;
-  auto prefetch = [&] {
-    if (PRE != PRE_BLOCK3 && i0 < n2) {
-      hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
-      rv0 = reinterpret_cast<double2 *>(r)[i0];
-    }
-  };
-  double d[KC];
-  if (FROM_SLOTS) {
-    prefetch();
-#pragma unroll
-    for (int i = 0; i < KC; ++i) d[i] = slots[i];
-  } else {
-    reduce_rows<KC>(partials_a, nparts_a, d, lds, prefetch);
-    // several ranks, peer-memory layer: the sum over the ranks completes HERE instead of in an exchange kernel of its
-    // own in front of this one (comm_ipc.h; every rank runs this kernel with the same replicated state)
-    fold_maybe<KC>(d, fold, lds);
-  }
-  step_a(cs, cc, d[0], d[1], d[2]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    store_state(st_out, cs);
-    if (KC > 3 && cs.mode == CG_RUN) {  // G(r) += alpha G(Hp)  (r += alpha Hp, :377)
-#pragma unroll
-      for (int i = 0; i < KC - 3; ++i)
-        if (i < dg.ns) dg.gdir[i] = dg.gdir[i] + cs.alpha * d[3 + i];
-    }
-  }
-
-  const int mode = cs.mode;
-  double acc[1] = {0};
-  if (mode == CG_APPLY_SIGMA) {
-    const double sigma = cs.sigma;
-    for (size_t i = i0; i < n2; i += stride) {
-      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
-      double2 sv = reinterpret_cast<double2 *>(s)[i];
-      sv.x += sigma * pv.x; sv.y += sigma * pv.y;
-      reinterpret_cast<double2 *>(s)[i] = sv;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] += sigma * p[n - 1];
-    return;
-  }
-  if (mode == CG_KERNEL_PENDING) {
-    for (size_t i = i0; i < n2; i += stride) {
-      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
-      const double2 rv = reinterpret_cast<const double2 *>(r)[i];
-      acc[0] += pv.x * rv.x; acc[0] += pv.y * rv.y;
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc[0] += p[n - 1] * r[n - 1];
-  } else {  // CG_RUN
-    const double alpha = cs.alpha;
-    if (PRE == PRE_BLOCK3) {
-      const size_t nb = n / 3;
-      for (size_t b = i0; b < nb; b += stride) {
-        double rr[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const size_t i = 3 * b + c;
-          rr[c] = r[i] + alpha * Hp[i];
-          r[i] = rr[c];
-        }
-        const double *M = pre + 9 * b;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double vv = M[3 * c] * rr[0] + M[3 * c + 1] * rr[1] + M[3 * c + 2] * rr[2];
-          v[3 * b + c] = vv;
-          acc[0] += rr[c] * vv;
-        }
-      }
-    } else {
-      double2 hv = hv0, rv = rv0;
-      for (size_t i = i0; i < n2;) {
-        const size_t inext = i + stride;
-        double2 hn = hv, rn = rv;
-        if (inext < n2) {  // next step's operands are in flight while this one is computed
-          hn = reinterpret_cast<const double2 *>(Hp)[inext];
-          rn = reinterpret_cast<double2 *>(r)[inext];
-        }
-        rv.x += alpha * hv.x; rv.y += alpha * hv.y;
-        reinterpret_cast<double2 *>(r)[i] = rv;
-        if (PRE != PRE_EXTERNAL) {
-          double2 vv = rv;
-          if (PRE == PRE_DIAG) {
-            const double2 dd = reinterpret_cast<const double2 *>(pre)[i];
-            vv.x = dd.x * rv.x; vv.y = dd.y * rv.y;
-            reinterpret_cast<double2 *>(v)[i] = vv;
-          }
-          acc[0] += rv.x * vv.x; acc[0] += rv.y * vv.y;
-        }
-        i = inext; hv = hn; rv = rn;
-      }
-      if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const size_t i = n - 1;
-        const double rv = r[i] + alpha * Hp[i];
-        r[i] = rv;
-        if (PRE != PRE_EXTERNAL) {
-          double vv = rv;
-          if (PRE == PRE_DIAG) { vv = pre[i] * rv; v[i] = vv; }
-          acc[0] += rv * vv;
-        }
-      }
-    }
-    if (PRE == PRE_EXTERNAL) return;  // v = P(r) and <r,v> follow (k_cg_dot_rv)
-  }
-  block_partials_store<1>(acc, lds, partials_b);
+// (the kernels follow the DirGramLds helper below: stpcg_kernels.inc)
+#ifdef MI_FOLD_STAMPS
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int mi_debug_fold_stamp_buffer(void *dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mi::g_fold_stamps), &dev_ptr, sizeof(dev_ptr));
 }
+namespace {
+#endif
 
 // B-step prologue + body:  CG_RUN: s = s + alpha p (:374), p = -v + beta p (:420);  kernel exit: s += sigma p (:336)
 //   SP > 0 (mi_op::dirgram): the fields are rows of SP doubles and the kernel also leaves the partial rows of
@@ -437,167 +317,26 @@ struct DirGramLds<0> {
 };
 static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 
-template <bool FROM_SLOTS, int SP, class FOLD = NoFold>
-__global__ __launch_bounds__(kBlock) void k_cg_pupdate(size_t n, CgConst cc, const CgState *__restrict__ st_in,
-                                                       CgState *__restrict__ st_out,
-                                                       const double *__restrict__ partials_b, int nparts_b,
-                                                       const double *__restrict__ slots,
-                                                       const double *__restrict__ v,
-                                                       double *__restrict__ p, double *__restrict__ s,
-                                                       HostStatus *hs, double *__restrict__ trace,
-                                                       size_t trace_cap, DirGramArgs dg, FOLD fold) {
-  __shared__ double lds[DirGramLds<SP>::value];
-  CgState cs = load_state(st_in);
-  const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-  if (cs.mode == CG_DONE) {
-    if (leader) store_state(st_out, cs);
-    return;
-  }
-  const int mode_in = cs.mode;
-  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock;
-  const size_t i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  // prefetch of the first grid-stride step: overlaps the prologue's reduction, and is issued BEHIND the
-  // prologue's row loads (loads return in order, so the reduction is not held up by it)
-  double2 vv0 = make_double2(0, 0), pv0 = vv0, sv0 = vv0;
-  constexpr int SPN = SP > 0 ? SP : 1;
-  double rv0[SPN], rp0[SPN], rs0[SPN], rx0[SPN], ry0[SPN];  // SP > 0: the same prefetch, one row per lane
-#pragma unroll
-  for (int c = 0; c < SPN; ++c) { rv0[c] = 0; rp0[c] = 0; rs0[c] = 0; rx0[c] = 0; ry0[c] = 0; }
-  auto prefetch = [&] {
-    if (SP > 0) {
-      if (mode_in == CG_RUN && i0 < n / SPN) {
-#pragma unroll
-        for (int c = 0; c < SPN; ++c) {
-          rv0[c] = v[i0 * SPN + c];
-          rp0[c] = p[i0 * SPN + c];
-          rs0[c] = s[i0 * SPN + c];
-          rx0[c] = dg.X[i0 * SPN + c];
-          ry0[c] = dg.Y[i0 * SPN + c];
-        }
-      }
-    } else if (i0 < n2) {
-      vv0 = reinterpret_cast<const double2 *>(v)[i0];
-      pv0 = reinterpret_cast<double2 *>(p)[i0];
-      sv0 = reinterpret_cast<double2 *>(s)[i0];
-    }
-  };
-  double red[1] = {0};
-  if (mode_in != CG_APPLY_SIGMA && !FROM_SLOTS) {
-    reduce_rows<1>(partials_b, nparts_b, red, lds, prefetch);
-    fold_maybe<1>(red, fold, lds);  // (as in k_cg_update)
-  } else {
-    prefetch();
-    if (mode_in != CG_APPLY_SIGMA) red[0] = slots[0];
-  }
-  step_b(cs, cc, red[0]);
-  cs.launches = cs.launches + 1;
-  if (leader) {
-    store_state(st_out, cs);
-    if (mode_in == CG_RUN && trace && cs.k - 1 < trace_cap) {
-      const size_t k = (size_t)(cs.k - 1);
-      trace[k] = cs.alpha;
-      trace[trace_cap + k] = cs.beta;
-      trace[2 * trace_cap + k] = cs.kappa;
-      trace[3 * trace_cap + k] = cs.rv;
-    }
-    publish(hs, cs.launches, cs.mode == CG_DONE);
-    if (SP == 0 && dg.gdir && mode_in == CG_RUN && cs.mode == CG_RUN) {  // G(p) = -G(r) + beta G(p)  (:420)
-      for (int i = 0; i < dg.ns; ++i) dg.gdir[SLOT_GDIR_P + i] = -dg.gdir[i] + cs.beta * dg.gdir[SLOT_GDIR_P + i];
-    }
-  }
-  if (mode_in == CG_KERNEL_PENDING) {
-    const double sigma = cs.sigma;
-    for (size_t i = i0; i < n2; i += stride) {
-      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
-      double2 sv = reinterpret_cast<double2 *>(s)[i];
-      sv.x += sigma * pv.x; sv.y += sigma * pv.y;
-      reinterpret_cast<double2 *>(s)[i] = sv;
-    }
-    if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
-  } else if (mode_in == CG_RUN) {
-    // s = s + alpha p (:374) is applied HERE, next to the direction update, not in k_cg_update: both need
-    // p, so p is read once per iteration instead of twice (8 N bytes saved; same arithmetic, same bits).
-    // It is applied whatever the B-step decided; p = -v + beta p (:420) only if the solve goes on.
-    const double alpha = cs.alpha, beta = cs.beta;
-    const bool dir = cs.mode == CG_RUN;
-    if (SP > 0) {
-      const size_t nrows = n / SPN;
-      double Sm[SPN * SPN], G[SPN * SPN];
-#pragma unroll
-      for (int i = 0; i < SPN * SPN; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
-      double rv[SPN], rp[SPN], rs[SPN], x[SPN], y[SPN];
-#pragma unroll
-      for (int c = 0; c < SPN; ++c) { rv[c] = rv0[c]; rp[c] = rp0[c]; rs[c] = rs0[c]; x[c] = rx0[c]; y[c] = ry0[c]; }
-      for (size_t row = i0; row < nrows;) {
-        const size_t rnext = row + stride;
-        double vn[SPN], pn[SPN], sn[SPN], xn[SPN], yn[SPN];
-#pragma unroll
-        for (int c = 0; c < SPN; ++c) { vn[c] = rv[c]; pn[c] = rp[c]; sn[c] = rs[c]; xn[c] = x[c]; yn[c] = y[c]; }
-        if (rnext < nrows) {
-#pragma unroll
-          for (int c = 0; c < SPN; ++c) {
-            vn[c] = v[rnext * SPN + c];
-            pn[c] = p[rnext * SPN + c];
-            sn[c] = s[rnext * SPN + c];
-            xn[c] = dg.X[rnext * SPN + c];
-            yn[c] = dg.Y[rnext * SPN + c];
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < SPN; ++c) {
-          rs[c] = rs[c] + alpha * rp[c];
-          s[row * SPN + c] = rs[c];
-        }
-        if (dir) {
-#pragma unroll
-          for (int c = 0; c < SPN; ++c) {
-            rp[c] = -rv[c] + beta * rp[c];
-            p[row * SPN + c] = rp[c];
-          }
-#pragma unroll
-          for (int b = 0; b < SPN; ++b) {
-            double t = 0;
-#pragma unroll
-            for (int a = 0; a < SPN; ++a) t += rp[a] * Sm[a * SPN + b];  // (p S)_b, as the Hessian pass forms it
-#pragma unroll
-            for (int a = 0; a < SPN; ++a) G[a * SPN + b] += y[a] * rp[b] - x[a] * t;
-          }
-        }
-        row = rnext;
-#pragma unroll
-        for (int c = 0; c < SPN; ++c) { rv[c] = vn[c]; rp[c] = pn[c]; rs[c] = sn[c]; x[c] = xn[c]; y[c] = yn[c]; }
-      }
-      if (dir) store_sym_partials<SPN>(G, lds, dg.gpartials);
-      return;
-    }
-    double2 vv = vv0, pv = pv0, sv = sv0;
-    bool pushed = false;  // (FoldPush: this thread stored rows of the new direction into a neighbour's halo)
-    for (size_t i = i0; i < n2;) {
-      const size_t inext = i + stride;
-      double2 vn = vv, pn = pv, sn = sv;
-      if (inext < n2) {
-        vn = reinterpret_cast<const double2 *>(v)[inext];
-        pn = reinterpret_cast<double2 *>(p)[inext];
-        sn = reinterpret_cast<double2 *>(s)[inext];
-      }
-      sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
-      reinterpret_cast<double2 *>(s)[i] = sv;
-      if (dir) {
-        pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
-        reinterpret_cast<double2 *>(p)[i] = pv;
-        pushed |= halo_push_store(fold, i, pv);
-      }
-      i = inext; vv = vn; pv = pn; sv = sn;
-    }
-    if ((n & 1) && leader) {
-      s[n - 1] = s[n - 1] + alpha * p[n - 1];
-      if (dir) p[n - 1] = -v[n - 1] + beta * p[n - 1];
-    }
-    // the halo exchange of the next Hessian pass, folded in (comm_ipc.h); `dir` is the same in every workgroup of
-    // every rank, so either all of them push or none does -- and the pass that would wait is skipped with them
-    if (dir) halo_push_finish(fold, pushed);
-  }
-}
+#define CG_KERNEL_ATTR
+#define CG_UPDATE_NAME k_cg_update
+#define CG_PUPDATE_NAME k_cg_pupdate
+#include "stpcg_kernels.inc"
+#undef CG_KERNEL_ATTR
+#undef CG_UPDATE_NAME
+#undef CG_PUPDATE_NAME
+// The same two kernels with at most 80 scalar registers.  Measured on gfx950 (tools/fold_stamps.py, in-kernel clock
+// stamps): a kernel that is allocated 96 SGPRs gets 7 waves per SIMD, not the 8 the compiler reports -- and these
+// kernels run 1024-thread workgroups, two per CU, which needs all 8: with 81..96 SGPRs the second half of the grid only
+// starts when the first half has finished (k_cg_update: +3.7 us of 15).  The single-GPU instantiations of the hot loop
+// sit at exactly 80; the ones that carry the exchange arguments (FoldArgs, FoldPush), read reduced slots, or keep 16
+// components need 82..100 and are launched from this pair instead: a few scalar spills to vector lanes.
+#define CG_KERNEL_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#define CG_UPDATE_NAME k_cg_update_s80
+#define CG_PUPDATE_NAME k_cg_pupdate_s80
+#include "stpcg_kernels.inc"
+#undef CG_KERNEL_ATTR
+#undef CG_UPDATE_NAME
+#undef CG_PUPDATE_NAME
 
 // partial rows of sym(Y'p - (X'p) S) for the FIRST direction (p = -v, :256); later ones come from k_cg_pupdate
 template <int SP>
@@ -887,26 +626,27 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       s_out->d, r->d, vd, ctx->partials_b, dga
       if (recur) {
         // 3 dots + the Gram rows of Hp in one reduction (and one exchange across ranks)
-#define UPD_RECUR(FS, FT, FV)                                                                                      \
+        // KN: k_cg_update, or its 80-SGPR twin for the instantiations that need more (see above; 16 components always do)
+#define UPD_RECUR(KN, FS, FT, FV)                                                                                  \
   switch (kc) {                                                                                                    \
-    case 4: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 4, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
-    case 6: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 6, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
-    case 9: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 9, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;  \
-    default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    case 4: hipLaunchKernelGGL((KN<PRE_NONE, FS, 4, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
+    case 6: hipLaunchKernelGGL((KN<PRE_NONE, FS, 6, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
+    case 9: hipLaunchKernelGGL((KN<PRE_NONE, FS, 9, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
+    default: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
   }
         if (sharded && folded) {
           // the sum over the ranks completes in the kernel's own prologue (comm_ipc.h): no exchange kernel
           const FoldArgs fold_a = comm_fold_next(ctx);
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(false, FoldArgs, fold_a);
+          UPD_RECUR(k_cg_update_s80, false, FoldArgs, fold_a);
         } else if (sharded) {
           CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, kc, slots_g));
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(true, NoFold, NoFold{});
+          UPD_RECUR(k_cg_update_s80, true, NoFold, NoFold{});
         } else {
           if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials, kc));
           KScope ks(ctx, MI_K_CG_UPDATE);
-          UPD_RECUR(false, NoFold, NoFold{});
+          UPD_RECUR(k_cg_update, false, NoFold, NoFold{});
         }
 #undef UPD_RECUR
       } else if (sharded) {
@@ -928,15 +668,17 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 #define PUPD_ARGS                                                                                          \
   n, cc, (const CgState *)st1, st0, (const double *)ctx->partials_b, grid, (const double *)slots_b,        \
       (const double *)vd, p->d, s_out->d, ctx->status_dev, tr, tcap, dga
-#define PUPD(FS, SPV) \
-  hipLaunchKernelGGL((k_cg_pupdate<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, NoFold{})
-#define LAUNCH_PUPD(FS)                 \
-  switch (sp) {                         \
-    case 0: PUPD(FS, 0); break;         \
-    case 1: PUPD(FS, 1); break;         \
-    case 2: PUPD(FS, 2); break;         \
-    case 3: PUPD(FS, 3); break;         \
-    default: PUPD(FS, 4); break;        \
+#define PUPD(KN, FS, SPV) \
+  hipLaunchKernelGGL((KN<FS, SPV>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, NoFold{})
+  // (KN0 / KN1: the kernel for rows of 0 / 1 doubles, the two forms that count on 8 waves per SIMD; wider rows are
+  // bound by their vector registers)
+#define LAUNCH_PUPD(KN0, KN1, FS)               \
+  switch (sp) {                                 \
+    case 0: PUPD(KN0, FS, 0); break;            \
+    case 1: PUPD(KN1, FS, 1); break;            \
+    case 2: PUPD(k_cg_pupdate, FS, 2); break;   \
+    case 3: PUPD(k_cg_pupdate, FS, 3); break;   \
+    default: PUPD(k_cg_pupdate, FS, 4); break;  \
   }
       if (sharded && folded) {
         const FoldArgs fold_b = comm_fold_next(ctx);  // (folded <=> recurrence form <=> sp == 0)
@@ -946,17 +688,17 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
                           comm_halo_fold_next(ctx, dgp->halo_A, dgp->p, p->d, &fp.h);
         KScope ks(ctx, MI_K_CG_PUPDATE);
         if (push)
-          hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldPush>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fp);
+          hipLaunchKernelGGL((k_cg_pupdate_s80<false, 0, FoldPush>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fp);
         else
-          hipLaunchKernelGGL((k_cg_pupdate<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
+          hipLaunchKernelGGL((k_cg_pupdate_s80<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
       } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        LAUNCH_PUPD(true);
+        LAUNCH_PUPD(k_cg_pupdate_s80, k_cg_pupdate_s80, true);
       } else {
         if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        LAUNCH_PUPD(false);
+        LAUNCH_PUPD(k_cg_pupdate, k_cg_pupdate_s80, false);
       }
 #undef LAUNCH_PUPD
 #undef PUPD
