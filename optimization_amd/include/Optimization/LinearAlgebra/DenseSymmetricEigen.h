@@ -192,6 +192,12 @@ inline void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, doub
         p = d[mm];
         double c = 1, c2 = 1, c3 = 1, s = 0, s2 = 0;
         const double el1 = e[l + 1];
+        // The rotations' scalar recurrence (a chain of a square root and two divisions per step) does not depend on V,
+        // so rotation i is applied to V one step LATE, next to the scalar work of rotation i - 1: the two are then
+        // independent inside one loop body and overlap in the core, instead of the vector update waiting for its own
+        // c and s.  Same operations on every element in the same order: same bits.
+        double ca = 0, sa = 0;  // the rotation waiting to be applied (to columns ia, ia + 1)
+        int ia = -1;
         for (int i = mm - 1; i >= l; --i) {
           c3 = c2;
           c2 = c;
@@ -204,10 +210,24 @@ inline void sym_eigh(int n, std::vector<double> &M, std::vector<double> &V, doub
           c = p / r;
           p = c * d[i] - s * g;
           d[i + 1] = h + s * (c * g + s * d[i]);
+          if (ia >= 0) {
+            double *va = &VV(0, ia), *vb = &VV(0, ia + 1);
+            for (int k = 0; k < n; ++k) {
+              const double hk = vb[k];
+              vb[k] = sa * va[k] + ca * hk;
+              va[k] = ca * va[k] - sa * hk;
+            }
+          }
+          ca = c;
+          sa = s;
+          ia = i;
+        }
+        if (ia >= 0) {
+          double *va = &VV(0, ia), *vb = &VV(0, ia + 1);
           for (int k = 0; k < n; ++k) {
-            h = VV(k, i + 1);
-            VV(k, i + 1) = s * VV(k, i) + c * h;
-            VV(k, i) = c * VV(k, i) - s * h;
+            const double hk = vb[k];
+            vb[k] = sa * va[k] + ca * hk;
+            va[k] = ca * va[k] - sa * hk;
           }
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
