@@ -237,18 +237,46 @@ __global__ __launch_bounds__(kBlock) void k_cg_dot3(size_t n, const CgState *__r
   block_partials_store<3>(a, lds, partials);
 }
 
+// G(p0) (packed symmetric, gns <= kWaves components, wave w sums component w's `count` partial rows in fixed order)
+// into gdir[SLOT_GDIR_P..), and G(r0) = -G(p0) (p0 = -r0) into gdir[0..)
+__device__ __forceinline__ void gdir_from_rows(const double *__restrict__ partials, int count, int gns,
+                                               double *__restrict__ gdir) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (w >= gns) return;
+  const double *src = partials + (size_t)w * kMaxRows;
+  double t[kMaxRows / 64];
+#pragma unroll
+  for (int j = 0; j < kMaxRows / 64; ++j) {
+    const int r = lane + 64 * j;
+    t[j] = (r < count) ? src[r] : 0.0;
+  }
+  double v = 0;
+#pragma unroll
+  for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+  v = wave_reduce_sum(v);
+  if (lane == 0) {
+    gdir[SLOT_GDIR_P + w] = v;
+    gdir[w] = -v;
+  }
+}
+
 struct CgSetup {
   double Delta, kappa_fgr, theta, epsilon;
   unsigned long long max_iterations;
 };
 
 // one workgroup, once per solve: :259-279 and the first pass of :285-290
+// gdir != nullptr: k_cg_gdir_init's work rides along (one rank, recurrence form: its kernel has nothing to wait for):
+// G(p0) from the `gcount` Gram rows k_cg_init_dirgram left, G(r0) = -G(p0)
 template <bool FROM_SLOTS>
 __global__ __launch_bounds__(kBlock) void k_cg_scalar_init(CgState *st, CgSetup cfg,
                                                            const double *partials, int nparts,
-                                                           const double *slots, HostStatus *hs) {
+                                                           const double *slots, HostStatus *hs,
+                                                           const double *__restrict__ gpartials, int gcount, int gns,
+                                                           double *__restrict__ gdir) {
 #pragma clang fp contract(off)
   __shared__ double lds[kWaves + 1];
+  if (gdir) gdir_from_rows(gpartials, gcount, gns, gdir);
   double red[1];
   if (FROM_SLOTS) red[0] = slots[0];
   else reduce_rows<1>(partials, nparts, red, lds);
@@ -362,28 +390,58 @@ __global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const doubl
   store_sym_partials<SP>(G, lds, dg.gpartials);
 }
 
+// k_cg_init<PRE_NONE> and k_cg_dirgram in one pass for the unpreconditioned solve over rows of SP doubles (the cfg2 /
+// cfg4 hot path: v = r, p = -g): g is read once, p is not read back, one launch fewer per solve (16.4 + 14.3 us as two
+// kernels at cfg2).  Row r of every field belongs to the thread k_cg_dirgram gives it, so the Gram rows have its bits;
+// the partial rows of <r,v> group their terms by rows instead of by pairs of elements.
+template <int SP>
+__global__ __launch_bounds__(kBlock) void k_cg_init_dirgram(size_t nrows, const double *__restrict__ g,
+                                                            double *__restrict__ r, double *__restrict__ p,
+                                                            double *__restrict__ s, double *__restrict__ partials,
+                                                            DirGramArgs dg) {
+  __shared__ double lds[SymIdx<SP>::NS * kWaves];
+  double Sm[SP * SP], G[SP * SP];
+#pragma unroll
+  for (int i = 0; i < SP * SP; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
+  double acc[1] = {0};
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    double x[SP], y[SP], gv[SP], pv[SP];
+#pragma unroll
+    for (int c = 0; c < SP; ++c) { x[c] = dg.X[row * SP + c]; y[c] = dg.Y[row * SP + c]; gv[c] = g[row * SP + c]; }
+#pragma unroll
+    for (int c = 0; c < SP; ++c) {
+      pv[c] = -gv[c];                      // p = -v, v = r = g  (:211,231,256)
+      r[row * SP + c] = gv[c];
+      s[row * SP + c] = 0 * gv[c];         // :214
+      p[row * SP + c] = pv[c];
+      acc[0] += gv[c] * gv[c];             // <r,v>  (:266)
+    }
+#pragma unroll
+    for (int b = 0; b < SP; ++b) {
+      double t = 0;
+#pragma unroll
+      for (int a = 0; a < SP; ++a) t += pv[a] * Sm[a * SP + b];
+#pragma unroll
+      for (int a = 0; a < SP; ++a) G[a * SP + b] += y[a] * pv[b] - x[a] * t;
+    }
+  }
+  store_sym_partials<SP>(G, lds, dg.gpartials);
+  __syncthreads();
+  block_partials_store<1>(acc, lds, partials);
+}
+
 // recurrence form: G(p0) from the rows k_cg_dirgram left (or the all-reduced slots); G(r0) = -G(p0) (p0 = -r0)
 __global__ __launch_bounds__(kBlock) void k_cg_gdir_init(const double *__restrict__ partials, int count, int ns,
                                                          const double *__restrict__ slots, int from_slots,
                                                          double *__restrict__ gdir) {
+  if (!from_slots) {
+    gdir_from_rows(partials, count, ns, gdir);
+    return;
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (w >= ns) return;
-  double v;
-  if (from_slots) {
-    v = slots[w];
-  } else {
-    const double *src = partials + (size_t)w * kMaxRows;
-    double t[kMaxRows / 64];
-#pragma unroll
-    for (int j = 0; j < kMaxRows / 64; ++j) {
-      const int r = lane + 64 * j;
-      t[j] = (r < count) ? src[r] : 0.0;
-    }
-    v = 0;
-#pragma unroll
-    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
-    v = wave_reduce_sum(v);
-  }
+  const double v = slots[w];
   if (lane == 0) {
     gdir[SLOT_GDIR_P + w] = v;
     gdir[w] = -v;
@@ -524,6 +582,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // scalar exchanges of an iteration are folded into the prologues of their consumers (no exchange kernels).  Every
   // other combination keeps the separate exchange kernels.
   const bool folded = sharded && recur && comm_fold_enabled(ctx) && !ctx->force_slot_path;
+  // unpreconditioned recurrence form: initialisation and the first direction's Gram rows in one pass
+  // (k_cg_init_dirgram); one rank, nothing to exchange: G(p0), G(r0) set by k_cg_scalar_init itself
+  const bool init_fused = recur && n == dgp->n * (size_t)dgp->p;
+  const bool gdir_in_scalar_init = recur && !sharded && !rows;
   double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
   ctx->cg_live = st0;
@@ -552,7 +614,20 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
 
   // --- initialisation -----------------------------------------------------------------------
-  {
+  if (init_fused) {
+    KScope ks(ctx, MI_K_CG_INIT);
+    const size_t nrows = dgp->n;
+#define INIT_DG(SPV)                                                                                       \
+  hipLaunchKernelGGL(k_cg_init_dirgram<SPV>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)g->d, \
+                     r->d, p->d, s_out->d, ctx->partials_b, dga)
+    switch (dgp->p) {
+      case 1: INIT_DG(1); break;
+      case 2: INIT_DG(2); break;
+      case 3: INIT_DG(3); break;
+      default: INIT_DG(4); break;
+    }
+#undef INIT_DG
+  } else {
     KScope ks(ctx, MI_K_CG_INIT);
     LAUNCH_PRE(k_cg_init, n, (const double *)g->d, pred, r->d, vd, p->d, s_out->d, ctx->partials_b);
   }
@@ -564,13 +639,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
   if (dgp) {
     const size_t nrows = dgp->n;
-    switch (dgp->p) {
-      case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-      case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-      case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-      default: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+    if (!init_fused) {
+      switch (dgp->p) {
+        case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        default: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+      }
     }
-    if (recur) {
+    if (recur && !gdir_in_scalar_init) {
       if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, gns, slots_g));
       else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, gns));
       hipLaunchKernelGGL(k_cg_gdir_init, dim3(1), dim3(kBlock), 0, st, (const double *)ctx->partials2, grid, gns,
@@ -580,11 +657,13 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   if (sharded) {
     CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
     hipLaunchKernelGGL(k_cg_scalar_init<true>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
-                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
+                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev,
+                       (const double *)nullptr, 0, 0, (double *)nullptr);
   } else {
     if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
     hipLaunchKernelGGL(k_cg_scalar_init<false>, dim3(1), dim3(kBlock), 0, st, st0, cfg,
-                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev);
+                       (const double *)ctx->partials_b, grid, (const double *)slots_b, ctx->status_dev,
+                       (const double *)ctx->partials2, grid, gns, gdir_in_scalar_init ? dga.gdir : (double *)nullptr);
   }
   {
     hipError_t e = hipGetLastError();
