@@ -64,7 +64,11 @@ static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
 }
 
 static double g_last_tnt_seconds = 0.0;
+static double g_last_tnt_wall_seconds = 0.0;
 static size_t g_last_tnt_syncs = 0;
+// wall time of the last TNT call itself on a microsecond clock (TNTResult::elapsed_time has the reference
+// Stopwatch's millisecond resolution)
+extern "C" double hd_last_tnt_wall_seconds() { return g_last_tnt_wall_seconds; }
 // host<->device synchronisations the library made during the last hd_tnt_stiefel run (mi_ctx_sync_count)
 extern "C" size_t hd_last_tnt_syncs() { return g_last_tnt_syncs; }
 static double g_last_solve_seconds = 0.0;
@@ -311,9 +315,11 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
   }
   size_t s0 = 0, s1 = 0;
   MI355::check(mi_ctx_sync_count(ctx.get(), &s0));
+  const auto wall0 = std::chrono::steady_clock::now();
   RM::TNTResult<DeviceVector, double> r =
       RM::TNT<DeviceVector, DeviceVector>(f, QM, metric, retract, x0,
                                           std::optional<RM::LinearOperator<DeviceVector, DeviceVector>>(), tp, uf);
+  g_last_tnt_wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   MI355::check(mi_ctx_sync_count(ctx.get(), &s1));
   g_last_tnt_syncs = s1 - s0;
   export_result(r, accepted, res);
@@ -347,8 +353,10 @@ extern "C" int hd_tnt_so3n(size_t N, size_t E, const int32_t *ei, const int32_t 
   if (with_precon & 2) retract = prob.plain_retraction();
   size_t s0 = 0, s1 = 0;
   MI355::check(mi_ctx_sync_count(ctx.get(), &s0));
+  const auto wall0 = std::chrono::steady_clock::now();
   RM::TNTResult<DeviceVector, double> r = RM::TNT<DeviceVector, DeviceVector>(
       prob.objective(), prob.quadratic_model(), prob.metric(), retract, x0, pc, tp, uf);
+  g_last_tnt_wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
   MI355::check(mi_ctx_sync_count(ctx.get(), &s1));
   g_last_tnt_syncs = s1 - s0;
   export_result(r, accepted, res);
