@@ -36,7 +36,7 @@ def record(tag, r):
 
 if which in ("cfg3", "both"):
     N = 500_000
-    ei, ej, Rt, w, Rtrue, Rinit = wl.pose_graph(N, seed=7)
+    ei, ej, Rt, w, Rtrue, Rinit = wl.pose_graph(N, seed=7, init_sigma=0.02)  # near the optimum: PSD Hessians, full inner solves
     for tag, kw, flags in (("cfg3_warmup", dict(max_iterations=2), 1), ("cfg3_run", dict(max_iterations=12), 1),
                            ("cfg3_run_without_fused_trial_step", dict(max_iterations=12), 3)):
         prm = O.default_params(max_TPCG_iterations=50, gradient_tolerance=1e-12, relative_decrease_tolerance=0.0,
