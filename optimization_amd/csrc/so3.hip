@@ -66,8 +66,12 @@ __device__ __forceinline__ void q_hat_basis(const double *Q, int m, double *M) {
 }
 
 // One thread per node: gradient, C_i, D_i, D_i^-1, and the off-diagonal blocks w B_ij of the Hessian.
+// Sinc / winc: the measurement of every incidence as ITS node uses it (Rt_e at the head, Rt_e' at the tail) and its
+// weight, in the incidences' own component-major slot order -- static, built once by mi_so3n_create.  Gathered from
+// the edge arrays they were 72 bytes at a random place per incidence (1.56 cache lines on average, each edge fetched
+// from both ends: ~600 MB per assembly at N = 5e5); as a stream they are 216 MB.
 __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
-                                                   const double *__restrict__ Rt, const double *__restrict__ w,
+                                                   const double *__restrict__ Sinc, const double *__restrict__ winc,
                                                    double *__restrict__ grad, double *__restrict__ Dblk,
                                                    double *__restrict__ Dinv, double *__restrict__ Bblk,
                                                    double *__restrict__ Dsl) {
@@ -89,19 +93,13 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
     double Bk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (live && eid >= 0) {
       const size_t j = (size_t)inc.nbr[e0];
-      const double we = w[eid];
+      const double we = winc[e0];
       double S[9], Rj[9];
 #pragma unroll
       for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
-      if (inc.dir[e0] > 0) {  // this node is the head: term R_i - R_j Rt  (j = tail)
+      // head: term R_i - R_j Rt (j = tail); tail: R_i - R_j Rt'  (the transposition is in Sinc)
 #pragma unroll
-        for (int c = 0; c < 9; ++c) S[c] = Rt[9 * (size_t)eid + c];
-      } else {                // this node is the tail: term R_i - R_j Rt'
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) S[r * 3 + c] = Rt[9 * (size_t)eid + c * 3 + r];
-      }
+      for (int c = 0; c < 9; ++c) S[c] = Sinc[((size_t)k * 9 + c) * 64 + lane];
       double RjS[9];
       mat3_mul(Rj, S, RjS);
 #pragma unroll
@@ -284,6 +282,7 @@ struct mi_so3n {
   signed char *dir = nullptr;
   mi_vec *Dblk = nullptr, *Dinv = nullptr;  // 9N each (node order: preconditioner, diagnostics)
   double *Bblk = nullptr;                   // padded * 9
+  double *Sinc = nullptr, *winc = nullptr;  // padded * 9, padded: per-incidence measurement and weight (k_so3_model)
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
   mi_op hess;
   mi_precon bj;
@@ -402,6 +401,19 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
         }
       }
     }
+  // the measurement and weight of every incidence in slot order (k_so3_model streams them)
+  std::vector<double> sinc(std::max<size_t>(1, padded * 9), 0.0), winc(std::max<size_t>(1, padded), 0.0);
+  for (size_t s = 0; s < nslices; ++s)
+    for (long long k = sp[s]; k < sp[s + 1]; ++k)
+      for (int lane = 0; lane < 64; ++lane) {
+        const size_t e0 = (size_t)k * 64 + lane;
+        const int e = edge[e0];
+        if (e < 0) continue;
+        winc[e0] = w[e];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c)
+            sinc[((size_t)k * 9 + r * 3 + c) * 64 + lane] = dir[e0] > 0 ? Rt[9 * (size_t)e + r * 3 + c] : Rt[9 * (size_t)e + c * 3 + r];
+      }
   mi_so3n *q = new mi_so3n();
   q->ctx = ctx;
   q->N = N;
@@ -420,6 +432,8 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
   MI_TRY(upload((void **)&q->edge, edge.data(), padded * sizeof(int)));
   MI_TRY(upload((void **)&q->dir, dir.data(), padded * sizeof(signed char)));
   MI_HIP(hipMalloc((void **)&q->Bblk, std::max<size_t>(1, padded * 9) * sizeof(double)));
+  MI_TRY(upload((void **)&q->Sinc, sinc.data(), sinc.size() * sizeof(double)));
+  MI_TRY(upload((void **)&q->winc, winc.data(), winc.size() * sizeof(double)));
   MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dblk));
   MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dinv));
   q->hess.ctx = ctx;
@@ -445,6 +459,7 @@ int mi_so3n_destroy(mi_so3n *q) {
   (void)hipFree(q->ei); (void)hipFree(q->ej); (void)hipFree(q->Rt); (void)hipFree(q->w);
   (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr); (void)hipFree(q->edge); (void)hipFree(q->dir);
   (void)hipFree(q->Bblk); (void)hipFree(q->perm); (void)hipFree(q->Dsl);
+  (void)hipFree(q->Sinc); (void)hipFree(q->winc);
   (void)hipFree(q->Bblk_next); (void)hipFree(q->Dsl_next);
   mi_vec_destroy(q->Dblk);
   mi_vec_destroy(q->Dinv);
@@ -490,7 +505,7 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
   } else {
     const int grid = (int)((q->nslices + 3) / 4);
     hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
-                       (const double *)q->Rt, (const double *)q->w, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk,
+                       (const double *)q->Sinc, (const double *)q->winc, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk,
                        q->Dsl);
     MI_HIP(hipGetLastError());
   }
@@ -557,7 +572,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   {
     const int grid = (int)((q->nslices + 3) / 4);
     hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
-                       (const double *)q->Rt, (const double *)q->w, q->grad_next->d, q->Dblk_next->d,
+                       (const double *)q->Sinc, (const double *)q->winc, q->grad_next->d, q->Dblk_next->d,
                        q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
     MI_HIP(hipGetLastError());
   }

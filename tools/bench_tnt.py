@@ -21,6 +21,7 @@ hz.L.hd_last_tnt_seconds.restype = ctypes.c_double
 hz.L.hd_last_tnt_wall_seconds.restype = ctypes.c_double
 hz.L.hd_last_tnt_syncs.restype = ctypes.c_size_t
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
+hz.L.hd_set_tnt_repeats(2)   # every run twice in its context, the second one timed (pool filled, kernels loaded)
 out = {}
 
 
