@@ -386,9 +386,11 @@ MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounde
  * time -- every rank must make the same call between the same two solves.  Results are bit-identical either way. */
 MI_API int mi_comm_ipc_fold(mi_ctx *ctx, int on);
 /* Kernels the peer-memory layer launched on its own so far: out[0] scalar-exchange kernels, out[1] halo-push kernels,
- * out[2] halo pushes that rode in the kernel producing the vector instead (no launch).  With folding on (the default)
- * a sharded fused STPCG iteration adds nothing to out[0] and out[1]: it is the three kernels of the single-GPU step. */
-MI_API int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[3]);
+ * out[2] halo pushes that rode in the kernel producing the vector instead (no launch), out[3] those of out[2] in the
+ * EARLY form (the producer walks its vector starting at the neighbours' rows and signals after its first step).
+ * With folding on (the default) a sharded fused STPCG iteration adds nothing to out[0] and out[1]: it is the three
+ * kernels of the single-GPU step. */
+MI_API int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[4]);
 /* Verification hooks (used by tests/test_gpu_comm.py on a ONE-GPU box): pretend to be `rank` of
  * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
  * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in

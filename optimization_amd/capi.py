@@ -558,8 +558,9 @@ class Context:
         check(self.L.mi_comm_ipc_fold(self.h, int(on)))
 
     def comm_kernel_launches(self):
-        """(scalar-exchange kernels, halo-push kernels, halo pushes folded into the producer kernel) so far"""
-        out = (C.c_ulonglong * 3)()
+        """(scalar-exchange kernels, halo-push kernels, halo pushes folded into the producer kernel, of those: in the
+        early form) so far"""
+        out = (C.c_ulonglong * 4)()
         check(self.L.mi_comm_kernel_launches(self.h, out))
         return tuple(int(v) for v in out)
 

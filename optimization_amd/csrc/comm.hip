@@ -48,7 +48,7 @@ struct Comm {
   struct { const mi_csr *A = nullptr; const double *V = nullptr; int p = 0; uint64_t seq = 0; } pushed;
   // kernels this layer launched itself: [0] scalar exchanges, [1] halo pushes, and [2] halo pushes that rode in the
   // producer kernel instead (mi_comm_kernel_launches)
-  unsigned long long launched[3] = {0, 0, 0};
+  unsigned long long launched[4] = {0, 0, 0, 0};  // ([3]: of the folded pushes, those in the early form)
 };
 
 int nccl_fail(ncclResult_t r, const char *what) {
@@ -288,8 +288,17 @@ bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, H
   push->hi_from = (nd - hi) / 2;
   if (act_lo) push->mb_lo = reinterpret_cast<IpcMailbox *>(c->peer[rk - 1]);
   if (act_hi) push->mb_hi = reinterpret_cast<IpcMailbox *>(c->peer[rk + 1]);
+  // the early form (comm_ipc.h): both boundary regions inside the pushing kernel's FIRST grid-stride step
+  push->n2 = nd / 2;
+  push->rot = push->hi_from;
+  {
+    const size_t first = (hi + lo) / 2, step = (size_t)grid_for(ctx, nd, 4) * kBlock;
+    static const bool late = [] { const char *e = getenv("MI355OPT_HALO_PUSH_LATE"); return e && e[0] == '1'; }();
+    push->early_waves = (!late && first > 0 && first <= step && first <= push->n2) ? (unsigned int)((first + 63) / 64) : 0u;
+  }
   c->pushed.A = A; c->pushed.V = V; c->pushed.p = p; c->pushed.seq = push->seq;
   ++c->launched[2];
+  if (push->early_waves) ++c->launched[3];
   return true;
 }
 
@@ -569,10 +578,10 @@ int mi_comm_ipc_error(mi_ctx *ctx, int *err) {
   return MI_OK;
 }
 
-int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[3]) {
+int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[4]) {
   MI_REQUIRE(ctx && out, "null argument");
   Comm *c = (Comm *)ctx->comm;
-  for (int i = 0; i < 3; ++i) out[i] = c ? c->launched[i] : 0ull;
+  for (int i = 0; i < 4; ++i) out[i] = c ? c->launched[i] : 0ull;
   return MI_OK;
 }
 

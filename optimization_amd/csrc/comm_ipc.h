@@ -132,6 +132,13 @@ struct HaloPush {
   size_t lo2 = 0, hi_from = 0;                   // double2 [0, lo2) go to dst_lo, [hi_from, n2) to dst_hi
   IpcMailbox *mine = nullptr, *mb_lo = nullptr, *mb_hi = nullptr;  // flags to raise (null: pair not active)
   uint64_t seq = 0;                              // 0: nothing folded into this launch
+  // EARLY form (early_waves > 0): the pushing kernel walks its vector rotated by `rot` double2 (logical element L is
+  // physical element (L + rot) mod n2, rot = hi_from), so that the rows the neighbours need -- the LAST hi rows, then
+  // the FIRST lo rows -- are the first thing its first grid-stride step touches; the `early_waves` waves that hold
+  // them signal as soon as their step is stored and fenced, two thirds of the kernel before its end, and the xGMI
+  // transfer hides behind the rest of the kernel instead of standing between it and the neighbour's Hessian pass.
+  size_t rot = 0, n2 = 0;
+  unsigned int early_waves = 0;
 };
 struct FoldPush {  // a folded scalar exchange in the prologue AND a folded halo push in the body (k_cg_pupdate)
   FoldArgs f;
@@ -159,12 +166,41 @@ __device__ __forceinline__ bool halo_push_store(const FoldPush &fp, size_t i, co
   if (h.dst_hi && i >= h.hi_from) { h.dst_hi[i - h.hi_from] = v; any = true; }
   return any;
 }
+// the rotation of the pushing kernel's walk (0 for every kernel but the early form)
+__device__ __forceinline__ size_t halo_rot(const NoFold &) { return 0; }
+__device__ __forceinline__ size_t halo_rot(const FoldArgs &) { return 0; }
+__device__ __forceinline__ size_t halo_rot(const FoldPush &fp) { return fp.h.early_waves ? fp.h.rot : 0; }
+__device__ __forceinline__ size_t halo_phys(const NoFold &, size_t L) { return L; }
+__device__ __forceinline__ size_t halo_phys(const FoldArgs &, size_t L) { return L; }
+__device__ __forceinline__ size_t halo_phys(const FoldPush &fp, size_t L) {
+  if (!fp.h.early_waves) return L;
+  const size_t q = L + fp.h.rot;
+  return q >= fp.h.n2 ? q - fp.h.n2 : q;
+}
+// early form: every wave, once, right behind the stores of its FIRST grid-stride step (wave-uniform control flow, no
+// barrier): the waves that hold the neighbours' rows fence and count themselves, the last of them raises the flags
+__device__ __forceinline__ void halo_push_first_step_done(const NoFold &) {}
+__device__ __forceinline__ void halo_push_first_step_done(const FoldArgs &) {}
+__device__ __forceinline__ void halo_push_first_step_done(const FoldPush &fp) {
+  const HaloPush &h = fp.h;
+  if (!h.seq || !h.early_waves) return;
+  const unsigned int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // this wave's first logical element / 64
+  if (gw >= h.early_waves) return;
+  __threadfence_system();
+  if ((threadIdx.x & 63) != 0) return;
+  const unsigned int done = __hip_atomic_fetch_add(&h.mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (done != h.early_waves - 1) return;
+  __hip_atomic_store(&h.mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (h.mb_lo) __hip_atomic_store(&h.mb_lo->halo_flag[1], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (h.mb_hi) __hip_atomic_store(&h.mb_hi->halo_flag[0], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // every workgroup, once, behind its last halo_push_store (pushed: this thread stored something).  Contains a barrier.
+// (Nothing in the early form: its waves have signalled already.)
 __device__ __forceinline__ void halo_push_finish(const NoFold &, bool) {}
 __device__ __forceinline__ void halo_push_finish(const FoldArgs &, bool) {}
 __device__ __forceinline__ void halo_push_finish(const FoldPush &fp, bool pushed) {
   const HaloPush &h = fp.h;
-  if (!h.seq) return;
+  if (!h.seq || h.early_waves) return;
   if (pushed) __threadfence_system();
   __syncthreads();
   if (threadIdx.x != 0) return;

@@ -331,11 +331,17 @@ def test_folded_exchanges_give_the_bits_of_the_exchange_kernels():
     for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):
         assert a[0][k] == b[0][k], k
     assert np.array_equal(sa, sb)
+    # the late form of the folded push (signal at the end of the direction kernel): the same bits again
+    c_, sc, _ = _run_cfg4_workers(3, grid, Xb, extra_env={"MI355OPT_HALO_PUSH_LATE": "1"}, port=29598)
+    assert all(o["enabled"] and o["ipc_error"] == 0 and o["comm_kernels"][3] == 0 for o in c_)
+    assert np.array_equal(sa, sc) and all(a[0][k] == c_[0][k] for k in ("iters", "exit", "M", "rv", "alpha", "beta"))
     # launches of the exchange layer's own kernels during the solve: (scalar exchanges, halo pushes, pushes folded in)
     it = a[0]["iters"]
     print("comm kernels per solve, folded:", [o["comm_kernels"] for o in a], " separate:", [o["comm_kernels"] for o in b])
-    for o in a:   # folded: the set-up's exchanges and the FIRST pass's halo push only; every later push rides along
+    for o in a:   # folded: the set-up's exchanges and the FIRST pass's halo push only; every later push rides along ...
         assert o["comm_kernels"][0] <= 3 and o["comm_kernels"][1] == 1 and o["comm_kernels"][2] >= it - 1, o
+        # ... in the early form (the direction kernel starts at the neighbours' rows and signals after its first step)
+        assert o["comm_kernels"][3] == o["comm_kernels"][2], o
     for o in b:   # separate kernels: two scalar exchanges and one halo push per iteration
         assert o["comm_kernels"][0] >= 2 * it and o["comm_kernels"][1] >= it and o["comm_kernels"][2] == 0, o
 
