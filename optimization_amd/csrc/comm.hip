@@ -294,7 +294,8 @@ bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, H
   {
     const size_t first = (hi + lo) / 2, step = (size_t)grid_for(ctx, nd, 4) * kBlock;
     static const bool late = [] { const char *e = getenv("MI355OPT_HALO_PUSH_LATE"); return e && e[0] == '1'; }();
-    push->early_waves = (!late && first > 0 && first <= step && first <= push->n2) ? (unsigned int)((first + 63) / 64) : 0u;
+    // (step <= n2: the kernel's first step is a whole grid-stride step)
+    push->early_waves = (!late && first > 0 && first <= step && step <= push->n2) ? (unsigned int)((first + 63) / 64) : 0u;
   }
   c->pushed.A = A; c->pushed.V = V; c->pushed.p = p; c->pushed.seq = push->seq;
   ++c->launched[2];
