@@ -85,6 +85,9 @@ static_assert(sizeof(CgState) <= 128, "the CG state is meant to fit one 128-byte
 struct CgConst {
   double Delta, Delta_2, epsilon;  // :171,271,179
   unsigned long long max_iterations;
+  // the walk of the two streaming kernels over their n/2 double2 elements (stpcg_kernels.inc): whole grid-stride steps
+  // up to rag0, then the ragged rest in one contiguous piece of rag_per elements per workgroup
+  unsigned long long rag0, rag_per;
 };
 enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_DONE = 3 };
 

@@ -564,9 +564,14 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
   CgSetup cfg{prm->Delta, prm->kappa_fgr, prm->theta, prm->epsilon,
               (unsigned long long)prm->max_iterations};
-  const CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations};
+  CgConst cc{prm->Delta, prm->Delta * prm->Delta, prm->epsilon, (unsigned long long)prm->max_iterations, 0ull, 0ull};
   hipStream_t st = ctx->stream;
   const int grid = (pre == PRE_BLOCK3) ? grid_for(ctx, n / 3, 2) : grid_for(ctx, n, 4);
+  {
+    const size_t n2 = n >> 1, step = (size_t)grid * kBlock;
+    cc.rag0 = (n2 / step) * step;
+    cc.rag_per = (n2 - cc.rag0 + (size_t)grid - 1) / (size_t)grid;
+  }
   // recurrence form of the direction Gram: needs v == r (no preconditioner)
   const bool recur = dgp && pre == PRE_NONE && !ctx->dirgram_direct;
   const int gns = dgp ? dgp->p * (dgp->p + 1) / 2 : 0;
