@@ -395,6 +395,10 @@ MI_API int mi_comm_kernel_launches(mi_ctx *ctx, unsigned long long out[4]);
  * `world_size` WITHOUT a communicator, and fill a sharded matrix's halo rows by hand, so that the halo
  * addressing of the sparse kernels can be checked against the global product.  Not part of the drop-in
  * surface; with a communicator the halo is filled by the in-stream ncclSend/ncclRecv exchange. */
+/* which form of the sparse kernels a matrix got: out = {window half-width in 64-row chunks (0: none), widest slice, far
+ * stride D when every entry outside the window is at row +- D (the kernels then compute those columns, halo columns
+ * of a row shard included) else 0, halo rows} */
+MI_API int mi_debug_csr_window_info(const mi_csr *A, size_t out[4]);
 /* host-only: the run plan of the LDS-window kernels (first tile of every run + the end) for `ntiles` tiles of 256 rows,
  * a workgroup budget, a CU count and the matrix's far stride in rows (0: none); needs no GPU */
 MI_API int mi_debug_window_runs(int ntiles, int max_wgs, int num_cu, size_t far_stride, int *bounds_out, int cap,

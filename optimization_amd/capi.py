@@ -181,6 +181,7 @@ def load():
         "mi_comm_ipc_error": [vp, C.POINTER(C.c_int)],
         "mi_comm_kernel_launches": [vp, C.POINTER(C.c_ulonglong)],
         "mi_comm_ipc_fold": [vp, C.c_int],
+        "mi_debug_csr_window_info": [vp, c_size_p],
         "mi_debug_time_fused_apply": [vp, vp, vp, C.c_int, c_double_p],
         "mi_debug_set_rank": [vp, C.c_int, C.c_int],
         "mi_debug_csr_set_halo": [vp, C.c_int, c_double_p],
@@ -694,6 +695,12 @@ class Csr:
         W = W if W is not None else Vec(self.ctx, self.n * p)
         check(self.L.mi_csr_spmm(self.h, p, V.h, W.h))
         return W
+
+    def window_info(self):
+        """(window half-width in chunks, widest slice, far stride D if the far columns are computed else 0, halo rows)"""
+        out = (C.c_size_t * 4)()
+        check(self.L.mi_debug_csr_window_info(self.h, out))
+        return tuple(int(v) for v in out)
 
     def debug_set_halo(self, p, rows):
         rows = np.ascontiguousarray(rows, dtype=np.float64)

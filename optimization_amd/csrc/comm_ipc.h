@@ -155,6 +155,7 @@ struct HaloWaitArg {};  // kernels without a halo carry no argument for it
 template <>
 struct HaloWaitArg<true> {
   HaloWait w;
+  unsigned int halo_lo = 0, halo_hi = 0;  // the matrix's halo extents (computed far columns: spmm_core.h load_far)
 };
 
 __device__ __forceinline__ bool halo_push_store(const NoFold &, size_t, const double2 &) { return false; }

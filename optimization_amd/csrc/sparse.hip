@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled_stream(SellView A, c
 // value table.  MI355OPT_WIN_CHUNKS=k forces k (0 switches the window form off).
 int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col,
                  const std::vector<long long> &sp, const std::vector<uint32_t> &pk, std::vector<double> &table,
-                 int ntable) {
+                 int ntable, size_t halo_lo, size_t halo_hi) {
   if (n == 0 || nnz == 0) return MI_OK;
   const int ncand = 3, cand[ncand] = {1, 2, 4};
   static_assert(kMaxWinChunks <= 4, "candidates");
@@ -251,19 +251,27 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   std::unordered_map<unsigned long long, size_t> far_strides;  // |column - row| of the far entries
   size_t far_total = 0;
   // "Pure" far structure: EVERY entry outside the window lies exactly D rows above or below its row (the two plane
-  // neighbours of a 3-D stencil) and none is a halo column.  The far slots are then assigned by direction -- slot 0
-  // = row + D, slot 1 = row - D -- and the kernels compute the far columns instead of loading them (mi_csr::
-  // win_far_pure; 8 bytes per row less to read).
+  // neighbours of a 3-D stencil).  The far slots are then assigned by direction -- slot 0 = row + D, slot 1 = row - D
+  // -- and the kernels compute the far columns instead of loading them (mi_csr::win_far_pure; 8 bytes per row less to
+  // read).  A HALO column counts as the row it stands for in the neighbour's slab: column n + h is row h - halo_lo
+  // (h < halo_lo: the LAST rows of rank - 1, i.e. negative local rows) or row n + (h - halo_lo) (the first rows of
+  // rank + 1), so a z-slab of a stencil is pure too and its halo columns are computed as well (spmm_core.h load_far).
+  auto virtual_row = [&](long long c) -> long long {
+    if ((size_t)c < n) return c;
+    const long long h = c - (long long)n;
+    return h < (long long)halo_lo ? h - (long long)halo_lo : (long long)n + (h - (long long)halo_lo);
+  };
   size_t pure_D = 0;
   bool pure = true;
   for (size_t r = 0; r < n && pure; ++r)
     for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-      const long long c = col[k], d = c - (long long)r;
+      const long long c = col[k], d = virtual_row(c) - (long long)r;
       const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
       if ((size_t)c < n && ad <= 64ull * wc) continue;  // in the window
-      if ((size_t)c >= n) { pure = false; break; }
       if (pure_D == 0) pure_D = (size_t)ad;
       if ((size_t)ad != pure_D) { pure = false; break; }
+      // (a computed halo column must exist: row - D >= -halo_lo, row + D < n + halo_hi)
+      if (d < 0 ? (long long)r - (long long)pure_D < -(long long)halo_lo : r + pure_D >= n + halo_hi) { pure = false; break; }
     }
   if (pure_D == 0) pure = false;
   for (size_t sl = 0; sl < nslices; ++sl) {
@@ -285,7 +293,7 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
           rowidx = (uint32_t)(((size_t)c >> 6) % (size_t)nc) * 64u + (uint32_t)(c & 63);
         } else {
           if (nfar == kFarCap) return MI_OK;  // a row with a third far entry: not eligible
-          const int slot = pure ? (d > 0 ? 0 : 1) : nfar;
+          const int slot = pure ? (virtual_row(c) > (long long)r ? 0 : 1) : nfar;
           rowidx = zrow + 1u + (uint32_t)(sl % kWinWaves) * (uint32_t)(kFarCap * 64) + (uint32_t)slot * 64u +
                    (uint32_t)lane;
           wfar[(sl * kFarCap + slot) * 64 + lane] = (int32_t)c;
@@ -338,8 +346,9 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
 }
 
 // Build the sliced-ELL image on the host from CSR with LOCAL column indices.
+// halo_lo: of the ncols - n halo columns behind the local ones, how many belong to rank - 1 (they come first)
 int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *rowptr,
-               const int32_t *col, const double *val, mi_csr **out) {
+               const int32_t *col, const double *val, mi_csr **out, size_t halo_lo = 0) {
   const size_t nslices = (n + 63) / 64;
   std::vector<long long> sp(nslices + 1, 0);
   for (size_t s = 0; s < nslices; ++s) {
@@ -422,7 +431,7 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
       MI_TRY(upload((void **)&A->vtab, table.data(), 256 * sizeof(double)));
       A->nvtab = (int)index.size();
       // the window form of the same matrix, when it qualifies (local columns only: col, not pcol)
-      MI_TRY(build_window(A, n, nnz, rowptr, col, sp, pk, table, ntable));
+      MI_TRY(build_window(A, n, nnz, rowptr, col, sp, pk, table, ntable, halo_lo, ncols - n - halo_lo));
     }
   }
   *out = A;
@@ -758,7 +767,7 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
   MI_TRY(mi_csr_shard_plan(n_global, ws, rk, row_starts, nnz_local, col_global, lcol.data(), &need_lo,
                            &need_hi));
   mi_csr *A = nullptr;
-  MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A));
+  MI_TRY(build_sell(ctx, n, n + need_lo + need_hi, nnz_local, rowptr, lcol.data(), val, &A, need_lo));
   A->symmetric = csr_is_symmetric(n, rowptr, lcol.data(), val);  // the diagonal block (the couplings are the caller's word)
   A->halo_lo = need_lo;
   A->halo_hi = need_hi;
@@ -780,6 +789,17 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
     return st;
   }
   *out = A;
+  return MI_OK;
+}
+
+// Verification hook: which form of the sparse kernels a matrix got (tests): out = {window half-width in chunks (0: no
+// window form), widest slice, far stride D when the far structure is pure (computed far columns) else 0, halo rows}
+int mi_debug_csr_window_info(const mi_csr *A, size_t out[4]) {
+  MI_REQUIRE(A && out, "null argument");
+  out[0] = (size_t)A->win_chunks;
+  out[1] = (size_t)A->win_head;
+  out[2] = A->win_far_pure;
+  out[3] = A->halo_lo + A->halo_hi;
   return MI_OK;
 }
 

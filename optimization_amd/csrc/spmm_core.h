@@ -306,13 +306,16 @@ struct WinView {
 
 // Tiles [t0, t1) of kWinWaves slices for this workgroup; `lds_rows` = kWinLdsRows x P doubles (ring, zero row, far slots).
 // FARD: the matrix's far structure is pure (mi_csr::win_far_pure): the far columns of a row are row + D and row - D
-// (slot 0, slot 1) and are computed, not loaded (never with HALO: a far column could then be a halo column)
+// (slot 0, slot 1) and are computed, not loaded (with HALO: possibly a halo column, see halo_lo / halo_hi)
 // W16: the words come in the 16-bit form (mi_csr::wk16: eight entries per row in four dwords, indexed by slice; a
 // non-entry is the zero word, so no slice bounds are consulted)
+// halo_lo / halo_hi (HALO && FARD): rows of rank - 1 / rank + 1 in the halo buffer; a computed far column that leaves
+// the local rows is the halo column of that row (mi_csr: column n + h, h < halo_lo: row h - halo_lo of the slab below,
+// else row h - halo_lo of the slab above)
 template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi>
 __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
                                             const double *__restrict__ V, const double *vt, double *lds_rows,
-                                            Epi &epi) {
+                                            Epi &epi, unsigned halo_lo = 0, unsigned halo_hi = 0) {
   static_assert(HW <= kWinHead, "head width");
   constexpr int NW = kWinWaves;
   const int nchunks = (int)A.nslices;
@@ -374,10 +377,18 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   };
   auto load_far = [&](unsigned (&f)[kFarCap], int sl) {
     if constexpr (FARD) {
-      static_assert(!FARD || (!HALO && kFarCap == 2), "computed far columns: local rows only, two slots");
-      const unsigned r = (unsigned)sl * 64u + (unsigned)lane, rr = r < nloc ? r : nloc - 1u;
-      f[0] = rr + W.far_d < nloc ? rr + W.far_d : rr;  // (a row without that neighbour has no word for the slot)
-      f[1] = rr >= W.far_d ? rr - W.far_d : rr;
+      static_assert(!FARD || kFarCap == 2, "computed far columns: two slots");
+      const unsigned r = (unsigned)sl * 64u + (unsigned)lane, rr = r < nloc ? r : nloc - 1u, D = W.far_d;
+      // (a row without that neighbour has no word for the slot: any valid column will do -- its own)
+      if constexpr (HALO) {
+        const unsigned up = rr + D;  // local row, or row up - nloc of the slab above = halo column nloc + halo_lo + that
+        f[0] = up < nloc ? up : (up - nloc < halo_hi ? up + halo_lo : rr);
+        // row rr - D, or row -(D - rr) of the slab below = halo column nloc + halo_lo - (D - rr)
+        f[1] = rr >= D ? rr - D : (D - rr <= halo_lo ? nloc + halo_lo - (D - rr) : rr);
+      } else {
+        f[0] = rr + D < nloc ? rr + D : rr;
+        f[1] = rr >= D ? rr - D : rr;
+      }
     } else {
       const char *fb = reinterpret_cast<const char *>(W.wfar) + (unsigned)sl * (unsigned)(kFarCap * 256) + lane4;
 #pragma unroll

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
       t0 = scalar_int(Wv.bounds, lb);
       t1 = scalar_int(Wv.bounds, lb + 1);
     }
-    sell_window<P, HW, HALO, (FAR >= 1) && !HALO, (FAR == 2) && !HALO>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
+    if constexpr (HALO)
+      sell_window<P, HW, true, (FAR >= 1), false>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi, hwait.halo_lo, hwait.halo_hi);
+    else
+      sell_window<P, HW, false, (FAR >= 1), (FAR == 2)>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
   } else {
     sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   }
@@ -638,20 +641,23 @@ int rq_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
 
 // resident workgroups per CU of the window instantiation that will run (registers + LDS), asked of the runtime once
 // per instantiation: the launch plan must fit one round
-int window_occupancy(int p, bool halo, int hw) {
-  static int cache[4][2][2] = {};
-  int &slot = cache[p][halo ? 1 : 0][hw == 7 ? 0 : 1];
+int window_occupancy(int p, bool halo, int hw, bool fard) {
+  static int cache[4][2][2][2] = {};
+  int &slot = cache[p][halo ? 1 : 0][hw == 7 ? 0 : 1][fard ? 1 : 0];
   if (slot == 0) {
     int nb = 0;
     hipError_t e = hipErrorUnknown;
-#define OCC(PV, HL, HWV)                                                                                  \
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_st_hess_fused<PV, false, HL, true, true, HWV>,  \
+#define OCC(PV, HL, HWV, FV)                                                                                   \
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_st_hess_fused<PV, false, HL, true, true, HWV, FV>,  \
                                                    kWinBlock, 0)
+#define OCC_F(PV, HL, HWV) \
+  if (fard) OCC(PV, HL, HWV, 1); else OCC(PV, HL, HWV, 0)
 #define OCC_P(PV)                                                \
-  if (halo) { if (hw == 7) OCC(PV, true, 7); else OCC(PV, true, 8); } \
-  else { if (hw == 7) OCC(PV, false, 7); else OCC(PV, false, 8); }
+  if (halo) { if (hw == 7) { OCC_F(PV, true, 7); } else { OCC_F(PV, true, 8); } } \
+  else { if (hw == 7) { OCC_F(PV, false, 7); } else { OCC_F(PV, false, 8); } }
     if (p == 1) { OCC_P(1) } else if (p == 2) { OCC_P(2) } else { OCC_P(3) }
 #undef OCC_P
+#undef OCC_F
 #undef OCC
     slot = (e == hipSuccess && nb > 0) ? nb : 1;
     (void)hipGetLastError();
@@ -679,12 +685,12 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
   // (computed far columns: matrices whose far entries are all at row +- D, not sharded, D in 32 bits)
   const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
-  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !A->halo &&
+  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
                     !(no_fard_env && no_fard_env[0] == '1');
   // 16-bit words: opt-in (MI355OPT_WORDS16=1).  On cfg2 they shorten the pass by ~1 us (25.9 -> 24.9 us) by halving
   // the matrix stream (28 -> 16 MB of 132 MB); the pass then runs at the same ~5.5 TB/s of a smaller total.
   const char *w16_env = getenv("MI355OPT_WORDS16");
-  const bool w16 = fard && A->wk16 && w16_env && w16_env[0] == '1';
+  const bool w16 = fard && !A->halo && A->wk16 && w16_env && w16_env[0] == '1';
   WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr, fard ? (unsigned)A->win_far_pure : 0u,
              A->wk16};
 #ifdef MI_WIN_DEBUG
@@ -695,7 +701,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
     static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
     // the workgroup budget: what is resident at once (one round), at most kMaxRows partial rows
-    const int occ = std::min(window_occupancy(p, halo, A->win_head <= 7 ? 7 : 8), kWaves / kWinWaves);
+    const int occ = std::min(window_occupancy(p, halo, A->win_head <= 7 ? 7 : 8, fard), kWaves / kWinWaves);
     int wgs = std::min(cap * occ, kMaxRows);
     if (win_wgs > 0) wgs = std::min(win_wgs, kMaxRows);
     // (one-GPU rehearsals of several ranks: the pass waits for its neighbours in its prologue, so -- like the CG
@@ -709,6 +715,8 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   HaloWaitArg<true> hw_halo;   // a push folded into the kernel that wrote `in`: the pass waits in its prologue
   HaloWaitArg<false> hw_none;
   MI_TRY(comm_halo_exchange_or_wait(ctx, A, p, in->d, &hw_halo.w));
+  hw_halo.halo_lo = (unsigned)A->halo_lo;  // (computed far columns of a row shard: spmm_core.h load_far)
+  hw_halo.halo_hi = (unsigned)A->halo_hi;
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   if (!recur) {
     if (rows_mode(ctx)) MI_TRY(comm_allreduce_rows(ctx, ctx->partials2, nsym(p)));
@@ -734,8 +742,17 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
                                    out->d, ctx->partials, hw_none))
+#define HF3DH(HWV)                                                                                            \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, true, true, true, HWV, 1>), dim3(grid),         \
+                                   dim3(block), 0, ctx->stream, view, wv, (const CgState *)ctx->cg_live,      \
+                                   (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
+                                   (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
+                                   (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
+                                   out->d, ctx->partials, hw_halo))
   if (win && w16) {  // the window form with computed far columns and 16-bit words
     if (A->win_head <= 7) { HF3D(7, 2); } else { HF3D(8, 2); }
+  } else if (win && fard && halo) {  // ... with computed far columns, some of them halo columns
+    if (A->win_head <= 7) { HF3DH(7); } else { HF3DH(8); }
   } else if (win && fard) {  // ... with computed far columns
     if (A->win_head <= 7) { HF3D(7, 1); } else { HF3D(8, 1); }
   } else if (win) {  // the window form (recurrence form only: the unpreconditioned solve)
@@ -751,6 +768,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   } else {
     if (sharded) { HF(true, false, false); } else { HF(false, false, false); }
   }
+#undef HF3DH
 #undef HF3D
 #undef HF3
 #undef HF

@@ -41,6 +41,7 @@ def main():
         starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
         dist.barrier()
         A = c.csr_sharded(n_glob, r0, r0 + n, rowptr, col, val, starts)
+        out["window_info"] = list(A.window_info())
         prob = c.stiefel_rq(A, n, p)
         X = c.upload(np.ascontiguousarray(Xb))
         out["f"] = prob.objective(X)

@@ -363,6 +363,9 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world):
     for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):  # replicated: the same bits on every rank
         assert all(o[k] == outs[0][k] for o in outs), k
     assert all(o["one_pass_launches"] >= 50 for o in outs)
+    # every slab has the window form with COMPUTED far columns (stride = one z-plane), its halo columns included
+    for o in outs:
+        assert o["window_info"][0] > 0 and o["window_info"][2] == nx * ny and o["window_info"][3] > 0, o["window_info"]
     # the single-context solve
     c = capi.Context(0)
     try:
