@@ -189,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_u(size_t ny, const LsqrState *_
 
 // [beta = |u| ; |Abar| estimate] u /= beta                                              :708-711
 template <class FOLD>
-__global__ __launch_bounds__(kBlock) void k_lsqr_unorm(size_t ny, LsqrConst c, const LsqrState *__restrict__ s_in,
+// (80 scalar registers: the FoldArgs instantiation would take 84; see k_lsqr_xw)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_lsqr_unorm(size_t ny, LsqrConst c, const LsqrState *__restrict__ s_in,
                                                        LsqrState *__restrict__ s_out,
                                                        const double *__restrict__ partials, int nparts,
                                                        double *__restrict__ u, FOLD fold) {
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(kBlock) void k_lsqr_v(size_t nx, const LsqrState *_
 
 // [alpha = |v|] v /= alpha ; partials <w,w>, <x,x>, <w,x>                                :713-714,765,785-786
 template <class FOLD>
-__global__ __launch_bounds__(kBlock) void k_lsqr_vnorm(size_t nx, const LsqrState *__restrict__ s_in,
+// (80 scalar registers: the FoldArgs instantiation would take 82; see k_lsqr_xw)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_lsqr_vnorm(size_t nx, const LsqrState *__restrict__ s_in,
                                                        LsqrState *__restrict__ s_out,
                                                        const double *__restrict__ partials_v, int nparts,
                                                        double *__restrict__ v, const double *__restrict__ w,
