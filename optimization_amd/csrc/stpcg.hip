@@ -358,7 +358,7 @@ static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 // starts when the first half has finished (k_cg_update: +3.7 us of 15).  The single-GPU instantiations of the hot loop
 // sit at exactly 80; the ones that carry the exchange arguments (FoldArgs, FoldPush), read reduced slots, or keep 16
 // components need 82..100 and are launched from this pair instead: a few scalar spills to vector lanes.
-#define CG_KERNEL_ATTR __attribute__((amdgpu_num_sgpr(80)))
+#define CG_KERNEL_ATTR __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8)))
 #define CG_UPDATE_NAME k_cg_update_s80
 #define CG_PUPDATE_NAME k_cg_pupdate_s80
 #include "stpcg_kernels.inc"
