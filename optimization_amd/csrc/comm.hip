@@ -473,6 +473,9 @@ int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTE
   MI_HIP(hipSetDevice(ctx->device));
   MI_HIP(hipExtMallocWithFlags((void **)&c->arena, kIpcArenaBytes, hipDeviceMallocFinegrained));
   MI_HIP(hipMemset(c->arena, 0, kIpcArenaBytes));
+  // (the zeros must be there before any peer can write: hipMemset may return early, and the context's stream does not
+  // order itself behind the null stream)
+  MI_HIP(hipDeviceSynchronize());
   hipIpcMemHandle_t h;
   MI_HIP(hipIpcGetMemHandle(&h, c->arena));
   memset(handle, 0, MI_COMM_IPC_HANDLE_BYTES);
