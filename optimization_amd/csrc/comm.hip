@@ -407,7 +407,10 @@ int comm_halo_alloc(mi_ctx *ctx, size_t bytes, double **ptr, bool *in_arena, siz
     *arena_off = c->arena_top;
     *in_arena = true;
     c->arena_top += bytes;  // never reclaimed: a context holds a handful of sharded matrices
-    MI_HIP(hipMemsetAsync(*ptr, 0, bytes, ctx->stream));
+    // NOT zeroed here: the whole arena was zeroed before its handle was exported and a region is handed out once --
+    // and a neighbour that is ahead may ALREADY have pushed its rows of the first exchange into this region (it needs
+    // nothing from this rank to do so: the offset is the same everywhere), which a memset enqueued now would wipe
+    // (seen once in ~100 runs of the 2-process test under CPU contention: a slab product with a zero halo).
     return MI_OK;
   }
   MI_HIP(hipMalloc((void **)ptr, bytes));
