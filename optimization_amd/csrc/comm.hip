@@ -414,7 +414,7 @@ int comm_halo_alloc(mi_ctx *ctx, size_t bytes, double **ptr, bool *in_arena, siz
     return MI_OK;
   }
   MI_HIP(hipMalloc((void **)ptr, bytes));
-  MI_HIP(hipMemset(*ptr, 0, bytes));
+  MI_HIP(hipMemsetAsync(*ptr, 0, bytes, ctx->stream));
   return MI_OK;
 }
 

@@ -170,7 +170,8 @@ static int ctx_init(mi_ctx *ctx, int device) {
   const size_t pbytes = sizeof(double) * kMaxComps * kMaxRows;
   const size_t slab_bytes = 2u << 20;
   MI_HIP(hipMalloc((void **)&ctx->control_slab, slab_bytes));
-  MI_HIP(hipMemset(ctx->control_slab, 0, slab_bytes));
+  // (on the context's own stream: it is a non-blocking stream, which does not order itself behind the null stream)
+  MI_HIP(hipMemsetAsync(ctx->control_slab, 0, slab_bytes, ctx->stream));
   {
     char *top = (char *)ctx->control_slab;
     auto carve = [&](size_t bytes) {

@@ -866,7 +866,7 @@ int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stief
   q->p = p;
   q->X = nullptr;
   MI_HIP(hipMalloc((void **)&q->S_dev, 16 * sizeof(double)));
-  MI_HIP(hipMemset(q->S_dev, 0, 16 * sizeof(double)));
+  MI_HIP(hipMemsetAsync(q->S_dev, 0, 16 * sizeof(double), ctx->stream));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Z));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Y));
   q->hess.ctx = ctx;
