@@ -178,19 +178,26 @@ __device__ __forceinline__ size_t halo_phys(const FoldPush &fp, size_t L) {
   const size_t q = L + fp.h.rot;
   return q >= fp.h.n2 ? q - fp.h.n2 : q;
 }
-// early form: every wave, once, right behind the stores of its FIRST grid-stride step (wave-uniform control flow, no
-// barrier): the waves that hold the neighbours' rows fence and count themselves, the last of them raises the flags
+// early form: every WORKGROUP, once, right behind the stores of its first grid-stride step (all of its threads are in
+// that step: the host takes the early form only when the vector is at least one step long).  The workgroups that hold
+// the neighbours' rows count themselves and the last of them raises the flags.  One system-scope release per workgroup,
+// behind a barrier (the other waves' stores happen before it), not one per wave: such a release writes the whole L2
+// back, in the middle of a kernel that dirties 48 MB -- per wave (~470 of them) it cost the 2-rank rehearsal 6 % and
+// the 4-rank one 10 % per step.  Contains a barrier (uniform: every thread of the workgroup calls it or none does).
 __device__ __forceinline__ void halo_push_first_step_done(const NoFold &) {}
 __device__ __forceinline__ void halo_push_first_step_done(const FoldArgs &) {}
 __device__ __forceinline__ void halo_push_first_step_done(const FoldPush &fp) {
   const HaloPush &h = fp.h;
   if (!h.seq || !h.early_waves) return;
-  const unsigned int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // this wave's first logical element / 64
-  if (gw >= h.early_waves) return;
-  __threadfence_system();
-  if ((threadIdx.x & 63) != 0) return;
+  // (early_waves counts 64-element chunks: this workgroup holds some of them iff its first chunk is one)
+  const unsigned int wpb = blockDim.x >> 6, first_chunk = blockIdx.x * wpb;
+  if (first_chunk >= h.early_waves) return;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  __threadfence_system();  // (replaced by a plain wait for the stores -- they are uncached peer stores -- nothing changes)
+  const unsigned int nblocks = (h.early_waves + wpb - 1) / wpb;
   const unsigned int done = __hip_atomic_fetch_add(&h.mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (done != h.early_waves - 1) return;
+  if (done != nblocks - 1) return;
   __hip_atomic_store(&h.mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (h.mb_lo) __hip_atomic_store(&h.mb_lo->halo_flag[1], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (h.mb_hi) __hip_atomic_store(&h.mb_hi->halo_flag[0], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
