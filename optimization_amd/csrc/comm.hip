@@ -122,11 +122,13 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
     const double *src = V + (n_doubles - hi_doubles);
     for (size_t i = i0; i < hi_doubles; i += stride) dst[i] = src[i];
   }
-  __threadfence_system();
+  // one system-scope release per workgroup, behind the barrier that orders the other waves' stores before it (a
+  // release per thread writes the whole L2 back once per wave: comm_ipc.h halo_push_first_step_done)
   __syncthreads();
   __shared__ bool last;
   IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(peers[rank]);
   if (threadIdx.x == 0) {
+    __threadfence_system();
     const unsigned int done = __hip_atomic_fetch_add(&mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     last = (done == gridDim.x - 1);
   }

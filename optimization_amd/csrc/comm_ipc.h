@@ -209,9 +209,10 @@ __device__ __forceinline__ void halo_push_finish(const FoldArgs &, bool) {}
 __device__ __forceinline__ void halo_push_finish(const FoldPush &fp, bool pushed) {
   const HaloPush &h = fp.h;
   if (!h.seq || h.early_waves) return;
-  if (pushed) __threadfence_system();
+  (void)pushed;
   __syncthreads();
   if (threadIdx.x != 0) return;
+  __threadfence_system();  // (one release per workgroup behind the barrier, as in halo_push_first_step_done)
   const unsigned int done = __hip_atomic_fetch_add(&h.mine->halo_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   if (done != gridDim.x - 1) return;
   __hip_atomic_store(&h.mine->halo_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
