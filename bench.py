@@ -159,6 +159,33 @@ def extra_leg(ctx, nx, p, steps, warmup, packed, label):
     return out
 
 
+def generic_leg_in_its_own_process(n, p, packed, label):
+    """The cfg2 workload through the OTHER matrix format in a process of its own (`python bench.py --no-legs` with
+    MI355OPT_NO_PACKED flipped): the gather-based Hessian kernel of the generic CSR path depends on where the vectors
+    happen to lie -- inside this process, behind the main workload's allocations, the same leg measured
+    68 ... 74.5 us/step from run to run; a fresh process, which is what a user of that path has, gives 66.9-67.6."""
+    import subprocess
+    env = dict(os.environ, MI355OPT_NO_PACKED="1" if packed else "0")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "200", "--warmup", "20", "--no-legs",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("generic leg subprocess failed: " + r.stderr[-500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    moved = d["config"]["moved_bytes_per_step_per_gpu"]
+    rf = d["roofline"] or {}
+    return {"workload": label, "rows": n, "nnz": d["config"]["nnz_per_gpu"], "packed_matrix": d["config"]["packed_matrix"],
+            "steps": d["steps"], "us_per_step": 1e3 * d["ms_per_step"], "moved_bytes_per_step": moved,
+            "value": d["value"], "unit": "GB/s", "hbm_roofline_frac_whole_step": d["value"] / HBM_PEAK_GBS,
+            "process": "its own (python bench.py --no-legs --no-cpu-baseline, MI355OPT_NO_PACKED flipped)",
+            # the dominant kernel of THIS leg on its own compulsory bytes: event pairs net of their own cost, as in the
+            # main line's roofline block (raw figure next to it)
+            "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                "algorithmic_bytes_per_launch", "avg_launch_us",
+                                                "avg_launch_us_event_pairs", "frac_event_pairs_uncorrected", "timing")},
+            "sum_kernel_us_over_step_us": rf.get("sum_kernel_us_over_step_us"),
+            "kernels": {k: v for k, v in (rf.get("kernels") or {}).items() if v.get("launches")}}
+
+
 def run_steps(ctx, g, H, s_out, steps):
     """Execute exactly `steps` completed STPCG inner iterations; returns number of solves."""
     done, solves = 0, 0
@@ -484,10 +511,14 @@ def main():
     if rank == 0 and world == 1 and not use_comm:
         if not args.no_legs:
             try:
-                plain_leg = extra_leg(ctx, nx, p, min(args.steps, 200), 20, packed=not packed,
-                                      label=f"cfg2 St({n},{p}), generic CSR path: the matrix in " +
-                                            ("plain 12-byte entries (what any sparse SPD matrix gets)" if packed
-                                             else "4-byte value-indexed entries"))
+                plain_label = (f"cfg2 St({n},{p}), generic CSR path: the matrix in " +
+                               ("plain 12-byte entries (what any sparse SPD matrix gets)" if packed
+                                else "4-byte value-indexed entries"))
+                try:
+                    plain_leg = generic_leg_in_its_own_process(n, p, packed, plain_label)
+                except Exception as e:  # noqa: BLE001  (fall back to the in-process leg)
+                    print("bench.py: %s; running the generic leg in this process" % e, file=sys.stderr)
+                    plain_leg = extra_leg(ctx, nx, p, min(args.steps, 200), 20, packed=not packed, label=plain_label)
                 big_leg = extra_leg(ctx, 200, p, 50, 10, packed=packed,
                                     label=f"St(8000000,{p}), 200^3 grid, one GPU: beyond the Infinity Cache")
             except capi.MiError as e:  # an extra leg must never take the headline down with it
