@@ -472,7 +472,7 @@ void mi_stpcg_default_params(mi_stpcg_params *p) {
   p->kappa_fgr = .1;
   p->theta = .5;
   p->epsilon = 1e-8;  // :179
-  p->run_ahead = 3;
+  p->run_ahead = 0;  // 0: the library default (3, or MI355OPT_RUN_AHEAD)
   p->constraint_At = 0;
   p->defer_result = 0;
 }
@@ -536,7 +536,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const mi_dirgram *dgp = (!ctx->no_dirgram && H->dirgram && H->apply_dir) ? H->dirgram : nullptr;
   MI_REQUIRE(!dgp || (dgp->p >= 1 && dgp->p <= 4 && dgp->n * (size_t)dgp->p == g->n),
              "operator's direction-Gram description does not match the problem dimension");
-  const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
+  // (default depth: MI355OPT_RUN_AHEAD, else 3)
+  static const int run_ahead_default = [] { const char *e = getenv("MI355OPT_RUN_AHEAD"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
+  const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : run_ahead_default;
   const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
 
   mi_vec *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr;
