@@ -134,9 +134,10 @@ struct HaloPush {
   uint64_t seq = 0;                              // 0: nothing folded into this launch
   // EARLY form (early_waves > 0): the pushing kernel walks its vector rotated by `rot` double2 (logical element L is
   // physical element (L + rot) mod n2, rot = hi_from), so that the rows the neighbours need -- the LAST hi rows, then
-  // the FIRST lo rows -- are the first thing its first grid-stride step touches; the `early_waves` waves that hold
-  // them signal as soon as their step is stored and fenced, two thirds of the kernel before its end, and the xGMI
-  // transfer hides behind the rest of the kernel instead of standing between it and the neighbour's Hessian pass.
+  // the FIRST lo rows -- are the first thing its first grid-stride step touches (in `early_waves` 64-element chunks);
+  // the workgroups that hold them signal as soon as that step is stored and fenced, two thirds of the kernel before
+  // its end, and the xGMI transfer hides behind the rest of the kernel instead of standing between it and the
+  // neighbour's Hessian pass.
   size_t rot = 0, n2 = 0;
   unsigned int early_waves = 0;
 };
@@ -167,10 +168,7 @@ __device__ __forceinline__ bool halo_push_store(const FoldPush &fp, size_t i, co
   if (h.dst_hi && i >= h.hi_from) { h.dst_hi[i - h.hi_from] = v; any = true; }
   return any;
 }
-// the rotation of the pushing kernel's walk (0 for every kernel but the early form)
-__device__ __forceinline__ size_t halo_rot(const NoFold &) { return 0; }
-__device__ __forceinline__ size_t halo_rot(const FoldArgs &) { return 0; }
-__device__ __forceinline__ size_t halo_rot(const FoldPush &fp) { return fp.h.early_waves ? fp.h.rot : 0; }
+// where logical element L of the pushing kernel's walk lives (L itself for every kernel but the early form)
 __device__ __forceinline__ size_t halo_phys(const NoFold &, size_t L) { return L; }
 __device__ __forceinline__ size_t halo_phys(const FoldArgs &, size_t L) { return L; }
 __device__ __forceinline__ size_t halo_phys(const FoldPush &fp, size_t L) {
@@ -203,7 +201,7 @@ __device__ __forceinline__ void halo_push_first_step_done(const FoldPush &fp) {
   if (h.mb_hi) __hip_atomic_store(&h.mb_hi->halo_flag[0], h.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // every workgroup, once, behind its last halo_push_store (pushed: this thread stored something).  Contains a barrier.
-// (Nothing in the early form: its waves have signalled already.)
+// (Nothing in the early form: its workgroups have signalled already.)
 __device__ __forceinline__ void halo_push_finish(const NoFold &, bool) {}
 __device__ __forceinline__ void halo_push_finish(const FoldArgs &, bool) {}
 __device__ __forceinline__ void halo_push_finish(const FoldPush &fp, bool pushed) {
