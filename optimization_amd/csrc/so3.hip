@@ -72,7 +72,7 @@ __device__ __forceinline__ void q_hat_basis(const double *Q, int m, double *M) {
 // from both ends: ~600 MB per assembly at N = 5e5); as a stream they are 216 MB.
 __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
                                                    const double *__restrict__ Sinc, const double *__restrict__ winc,
-                                                   double *__restrict__ grad, double *__restrict__ Dblk,
+                                                   double *__restrict__ grad,
                                                    double *__restrict__ Dinv, double *__restrict__ Bblk,
                                                    double *__restrict__ Dsl) {
   const int lane = threadIdx.x & 63;
@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
     for (int b = 0; b < 3; ++b) C[a * 3 + b] = .5 * (Q[a * 3 + b] + Q[b * 3 + a]);
   const double tr = C[0] + C[4] + C[8], d = 2 * degw - tr;
   const double a = d + C[0], b = C[1], c = C[2], e = d + C[4], f = C[5], g = d + C[8];
-  double *D = Dblk + 9 * i;
-  D[0] = a; D[1] = b; D[2] = c; D[3] = b; D[4] = e; D[5] = f; D[6] = c; D[7] = f; D[8] = g;
-  {  // the same block, component-major per slice, for the coalesced SpMV stream
+  // (the block is kept component-major per slice only, for the coalesced SpMV stream: a second, node-ordered copy --
+  // nine scattered 8-byte stores per node, read by nobody -- was written here until late r03)
+  {
     const double dd[9] = {a, b, c, b, e, f, c, f, g};
 #pragma unroll
     for (int q = 0; q < 9; ++q) Dsl[(slice * 9 + q) * 64 + lane] = dd[q];
@@ -280,7 +280,7 @@ struct mi_so3n {
   long long *slice_ptr = nullptr;
   int *perm = nullptr, *nbr = nullptr, *edge = nullptr;
   signed char *dir = nullptr;
-  mi_vec *Dblk = nullptr, *Dinv = nullptr;  // 9N each (node order: preconditioner, diagnostics)
+  mi_vec *Dinv = nullptr;  // 9N (node order): the inverse diagonal blocks, the block-Jacobi preconditioner
   double *Bblk = nullptr;                   // padded * 9
   double *Sinc = nullptr, *winc = nullptr;  // padded * 9, padded: per-incidence measurement and weight (k_so3_model)
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
@@ -291,7 +291,7 @@ struct mi_so3n {
   // mi_so3n_trial: the model assembled speculatively at the trial point (a second set of the arrays above plus the
   // gradient), swapped in by the next mi_so3n_model call if that call is for the same vector -- keyed on the
   // handle AND the identity of its contents (mi_vec::serial / gen), as in stiefel.hip
-  mi_vec *Dblk_next = nullptr, *Dinv_next = nullptr, *grad_next = nullptr, *Hh = nullptr, *Pg = nullptr;
+  mi_vec *Dinv_next = nullptr, *grad_next = nullptr, *Hh = nullptr, *Pg = nullptr;
   double *Bblk_next = nullptr, *Dsl_next = nullptr;
   const mi_vec *trial_R = nullptr;
   const double *trial_d = nullptr;
@@ -434,7 +434,6 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
   MI_HIP(hipMalloc((void **)&q->Bblk, std::max<size_t>(1, padded * 9) * sizeof(double)));
   MI_TRY(upload((void **)&q->Sinc, sinc.data(), sinc.size() * sizeof(double)));
   MI_TRY(upload((void **)&q->winc, winc.data(), winc.size() * sizeof(double)));
-  MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dblk));
   MI_TRY(mi_vec_create(ctx, 9 * N, &q->Dinv));
   q->hess.ctx = ctx;
   q->hess.n = 3 * N;
@@ -461,9 +460,7 @@ int mi_so3n_destroy(mi_so3n *q) {
   (void)hipFree(q->Bblk); (void)hipFree(q->perm); (void)hipFree(q->Dsl);
   (void)hipFree(q->Sinc); (void)hipFree(q->winc);
   (void)hipFree(q->Bblk_next); (void)hipFree(q->Dsl_next);
-  mi_vec_destroy(q->Dblk);
   mi_vec_destroy(q->Dinv);
-  mi_vec_destroy(q->Dblk_next);
   mi_vec_destroy(q->Dinv_next);
   mi_vec_destroy(q->grad_next);
   mi_vec_destroy(q->Hh);
@@ -496,7 +493,6 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
   mi_ctx *ctx = q->ctx;
   if (q->is_trial(R)) {
     // R is the point mi_so3n_trial just evaluated: its model exists already
-    std::swap(q->Dblk, q->Dblk_next);
     std::swap(q->Dinv, q->Dinv_next);
     std::swap(q->Bblk, q->Bblk_next);
     std::swap(q->Dsl, q->Dsl_next);
@@ -505,7 +501,7 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
   } else {
     const int grid = (int)((q->nslices + 3) / 4);
     hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
-                       (const double *)q->Sinc, (const double *)q->winc, grad->d, q->Dblk->d, q->Dinv->d, q->Bblk,
+                       (const double *)q->Sinc, (const double *)q->winc, grad->d, q->Dinv->d, q->Bblk,
                        q->Dsl);
     MI_HIP(hipGetLastError());
   }
@@ -543,7 +539,6 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   mi_ctx *ctx = q->ctx;
   const size_t N3 = 3 * q->N;
   if (!q->grad_next) {
-    MI_TRY(mi_vec_create(ctx, 9 * q->N, &q->Dblk_next));
     MI_TRY(mi_vec_create(ctx, 9 * q->N, &q->Dinv_next));
     MI_TRY(mi_vec_create(ctx, N3, &q->grad_next));
     MI_TRY(mi_vec_create(ctx, N3, &q->Hh));
@@ -572,7 +567,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   {
     const int grid = (int)((q->nslices + 3) / 4);
     hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
-                       (const double *)q->Sinc, (const double *)q->winc, q->grad_next->d, q->Dblk_next->d,
+                       (const double *)q->Sinc, (const double *)q->winc, q->grad_next->d,
                        q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
     MI_HIP(hipGetLastError());
   }
