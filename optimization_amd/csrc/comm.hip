@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
     for (size_t i = i0; i < hi_doubles; i += stride) dst[i] = src[i];
   }
   // one system-scope release per workgroup, behind the barrier that orders the other waves' stores before it (a
-  // release per thread writes the whole L2 back once per wave: comm_ipc.h halo_push_first_step_done)
+  // release per thread writes the whole L2 back once per wave: comm_ipc.h halo_push_first_step_done); every wave has
+  // waited for its own stores first (wave_stores_done)
+  wave_stores_done();
   __syncthreads();
   __shared__ bool last;
   IpcMailbox *mine = reinterpret_cast<IpcMailbox *>(peers[rank]);

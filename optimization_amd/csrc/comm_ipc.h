@@ -48,17 +48,32 @@ __device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, un
   }
   return true;
 }
-// The same without the acquire's cache invalidation, for waits inside a streaming kernel: what is read afterwards
-// (the mailbox values) is read with system-scope atomic loads, which do not come out of a cache, and loads issue and
-// return in program order behind the flag load.
+// The same for waits inside a streaming kernel: the POLL is relaxed (no cache invalidation per look) and ONE
+// system-scope acquire fence follows the successful look, so that whatever is read afterwards -- by this thread or,
+// behind a workgroup barrier, by any other thread of the workgroup -- happens after the peer's release in the formal
+// model too, not only because the mailbox values are read with system-scope atomic loads that bypass the caches
+// (r04, ADVICE: the relaxed form had no acquire at all).  Measured on one rank: no change of the sharded step.
 __device__ __forceinline__ bool ipc_wait_relaxed(const uint64_t *flag, uint64_t want, unsigned int *err,
                                                  uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
+  bool ok = true;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (ipc_give_up(wall_clock64() - t0, err, timeout)) return false;
+    if (ipc_give_up(wall_clock64() - t0, err, timeout)) { ok = false; break; }
     __builtin_amdgcn_s_sleep(1);
   }
-  return true;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
+  return ok;
+}
+// Every wave, behind its last peer store and in front of the workgroup barrier that precedes the ONE system-scope
+// release of its workgroup: wait until this wave's own vector-memory operations have completed.  A workgroup barrier
+// does not do that (one CU per workgroup: the compiler puts `s_waitcnt lgkmcnt(0)` only in front of s_barrier), and the
+// release thread 0 issues behind the barrier drains wave 0's queue, nobody else's -- on a real xGMI link the other
+// waves' rows could still be in flight when the flag goes up (r04, ADVICE).  No cache write-back involved (that is what
+// made one release PER WAVE expensive): once every wave's stores have reached the L2 the single write-back of thread 0,
+// which runs on the same XCD, covers them all.
+__device__ __forceinline__ void wave_stores_done() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // compiler: no store sinks below this point
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
 }
 
 // Folded all-reduce: every thread of every workgroup holds the SAME local sums d[0..K) (the prologue re-reduction of
@@ -190,6 +205,7 @@ __device__ __forceinline__ void halo_push_first_step_done(const FoldPush &fp) {
   // (early_waves counts 64-element chunks: this workgroup holds some of them iff its first chunk is one)
   const unsigned int wpb = blockDim.x >> 6, first_chunk = blockIdx.x * wpb;
   if (first_chunk >= h.early_waves) return;
+  wave_stores_done();
   __syncthreads();
   if (threadIdx.x != 0) return;
   __threadfence_system();  // (replaced by a plain wait for the stores -- they are uncached peer stores -- nothing changes)
@@ -208,6 +224,7 @@ __device__ __forceinline__ void halo_push_finish(const FoldPush &fp, bool pushed
   const HaloPush &h = fp.h;
   if (!h.seq || h.early_waves) return;
   (void)pushed;
+  wave_stores_done();
   __syncthreads();
   if (threadIdx.x != 0) return;
   __threadfence_system();  // (one release per workgroup behind the barrier, as in halo_push_first_step_done)
