@@ -20,9 +20,17 @@ matrix in plain 12-byte entries instead of the 4-byte value-indexed copy (`gener
 one GPU -- beyond the 256 MiB Infinity Cache -- (`beyond_cache_leg`), and the CPU baselines: the reference's
 own single-threaded path and the oracle's OpenMP build on all host cores this process may use.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--no-roofline] [--no-legs]
-       (N > 1: launched by torch.distributed.run, one rank per GPU; RCCL for the data path,
-        torch.distributed/gloo only for rendezvous, barriers and the max-over-ranks time.)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--wakeup-steps S] [--no-cpu-baseline] [--no-roofline]
+                       [--no-legs] [--comm auto|peer|peer-separate|rccl] [--ab-steps A]
+       N > 1: one rank per GPU.  Either launched by torch.distributed.run (the driver's way: RANK / LOCAL_RANK /
+       WORLD_SIZE / MASTER_* in the environment) or BARE -- `python bench.py --gpus N` re-launches itself under
+       torch.distributed.run on 127.0.0.1 (on a box with fewer than N GPUs as a functional rehearsal with all ranks on
+       GPU 0, flagged `rehearsal_one_gpu` in the JSON line: its timings mean nothing).  torch.distributed/gloo is the
+       control plane only (rendezvous, barriers, max-over-ranks time); the data path's exchanges go through the
+       peer-memory layer (hipIpc arenas over xGMI) or RCCL.  Before the timed region an N > 1 run times every exchange
+       layer that verifies (`comm_ab_legs`: peer-memory with the exchanges folded into the solver's kernels, the same
+       with separate exchange kernels, RCCL; --ab-steps each) and the headline runs on the fastest one (--comm /
+       MI355OPT_COMM force one), so that ONE run on an 8-GPU node yields the curve and says why.
 """
 import argparse
 import json
@@ -116,16 +124,12 @@ def wall_steps(ctx, g, H, s_out, steps, warmup):
 def extra_leg(ctx, nx, p, steps, warmup, packed, label):
     """One more single-GPU leg: St(nx^3, p), matrix packed or plain, its own moved-bytes bandwidth."""
     n = nx ** 3
-    prev = os.environ.get("MI355OPT_NO_PACKED")
-    os.environ["MI355OPT_NO_PACKED"] = "0" if packed else "1"
+    ctx.set_option("NO_PACKED", 0 if packed else 1)   # (acts at matrix creation)
     try:
         rowptr, col, val = wl.laplacian_3d(nx, nx, nx)
         A = ctx.csr(n, rowptr, col, val)
     finally:
-        if prev is None:
-            os.environ.pop("MI355OPT_NO_PACKED", None)
-        else:
-            os.environ["MI355OPT_NO_PACKED"] = prev
+        ctx.set_option("NO_PACKED", 1 if os.environ.get("MI355OPT_NO_PACKED", "0") == "1" else 0)
     nnz = int(rowptr[-1])
     del rowptr, col, val
     prob = ctx.stiefel_rq(A, n, p)
@@ -328,22 +332,120 @@ def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
     return out[0], out[1]
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU on
+    127.0.0.1 (free port), stdout (= the one JSON line of rank 0) passed through."""
+    import socket
+    import subprocess
+    ndev = capi.device_count()
+    env = dict(os.environ)
+    if ndev < args.gpus:
+        if ndev < 1:
+            raise SystemExit("bench.py: no GPU visible")
+        # fewer GPUs than ranks: a FUNCTIONAL rehearsal of the N-rank flow with all ranks on GPU 0 (peer-memory layer
+        # only: RCCL refuses duplicate devices); the JSON line says so
+        print(f"bench.py: {ndev} GPU(s) visible for --gpus {args.gpus}: rehearsal with all ranks on GPU 0 "
+              "(timings are meaningless)", file=sys.stderr)
+        env["MI355OPT_BENCH_ONE_GPU"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=_RESULT_FD)
+    raise SystemExit(r.returncode)
+
+
+def comm_set_layer(ctx, layer, peer_up=True):
+    """switch the exchange layer of a context (the same call on every rank); peer_up: the peer-memory layer is mapped"""
+    if layer == "rccl":
+        if peer_up:
+            ctx.comm_ipc_enable(False)
+    else:
+        ctx.comm_ipc_enable(True)
+        ctx.comm_ipc_fold(layer == "peer")
+
+
+LAYER_TEXT = {"peer": "peer-memory layer (hipIpc-mapped arenas over xGMI), scalar exchanges folded into the CG kernels' "
+                      "prologues and the halo push into the direction kernel: 3 launches per iteration",
+              "peer-separate": "peer-memory layer with separate one-workgroup exchange kernels and a halo-push kernel: "
+                               "6 launches per iteration",
+              "rccl": "RCCL: in-stream ncclAllReduce of the partial rows (2 per iteration, each one group = one launch) "
+                      "and an ncclSend/ncclRecv group for the halo rows"}
+
+
+def comm_ab_leg(ctx, dist, prob, X, s_out, layer, steps, world, rank, verify, peer_up):
+    """One exchange layer: verify (replicated 10-iteration solve, bounded waits clean), then `steps` timed steps (max over
+    ranks) and a second, event-paired pass for the per-launch cost of the exchanges that are launches of their own."""
+    import torch
+    comm_set_layer(ctx, layer, peer_up)
+    dist.barrier()
+    fails = verify()
+    leg = {"layer": layer, "what": LAYER_TEXT[layer], "verified": not fails}
+    if fails:
+        leg["failures"] = fails[:4]
+        return leg
+    g, H = prob.model(X)
+    run_steps(ctx, g, H, s_out, 100)
+    ctx.sync()
+    dist.barrier()
+    k0 = ctx.comm_kernel_launches()
+    t0 = time.perf_counter()
+    run_steps(ctx, g, H, s_out, steps)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    k1 = ctx.comm_kernel_launches()
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    leg["steps"] = steps
+    leg["us_per_step"] = 1e6 * float(t[0]) / steps
+    leg["own_launches_per_step"] = {"scalar_exchange_kernels": (k1[0] - k0[0]) / steps,
+                                    "halo_push_kernels": (k1[1] - k0[1]) / steps,
+                                    "halo_pushes_folded": (k1[2] - k0[2]) / steps,
+                                    "of_those_early_form": (k1[3] - k0[3]) / steps}
+    # per-collective microseconds (raw HIP event pairs on the launch stream, ~1.7 us of their own each): every rank
+    # runs these steps (they contain the exchanges), rank 0's figures are reported
+    names = ["comm_allreduce", "comm_halo"] + HOT
+    for k in names:
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    run_steps(ctx, g, H, s_out, 100)
+    per = {}
+    for k in names:
+        cnt, ms = ctx.ktime_read(k)
+        ctx.ktime_enable(k, False)
+        if cnt:
+            per[k] = {"launches_per_step": cnt / 100, "avg_us_event_pairs": 1e3 * ms / cnt}
+    leg["per_launch"] = per
+    leg["ipc_error"] = ctx.comm_ipc_error()
+    dist.barrier()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--wakeup-steps", type=int, default=int(os.environ.get("MI355OPT_BENCH_WAKEUP_STEPS", "1000")),
+                    help="untimed steps of the same solve AHEAD of --warmup that bring an idle device to its steady "
+                         "state (reported as device_wakeup_steps; 0 switches it off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the plain-matrix and beyond-cache legs")
+    ap.add_argument("--comm", default=os.environ.get("MI355OPT_COMM", "auto"),
+                    choices=["auto", "peer", "peer-separate", "rccl"],
+                    help="exchange layer of the headline at N > 1 (auto: the fastest layer that verifies)")
+    ap.add_argument("--ab-steps", type=int, default=300, help="timed steps of each exchange-layer A/B leg at N > 1")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     # MI355OPT_BENCH_FORCE_COMM=1: run the multi-GPU code path (rendezvous, communicator, sharded matrix,
     # slot-path kernels) even with one rank -- the dress rehearsal tests/test_gpu_comm.py runs on a 1-GPU box
     use_comm = world > 1 or os.environ.get("MI355OPT_BENCH_FORCE_COMM") == "1"
@@ -362,16 +464,19 @@ def main():
         os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
     ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
+    rccl_nranks = 0
     if use_comm:
         if not one_gpu:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(world, rank, uid[0])
-        # The peer-memory layer (scalar all-reduces and halo rows by xGMI peer stores) carries the small exchanges
-        # whenever every rank's bring-up + self-test succeeds AND the sharded data path verifies through it below;
-        # otherwise -- or with MI355OPT_COMM=rccl -- RCCL does.  The one-GPU rehearsal needs it (RCCL refuses
-        # duplicate devices).
-        peer_memory = ctx.enable_peer_memory(world, rank, dist, force=one_gpu)
+            rccl_nranks = ctx.comm_rccl_count()
+        # The peer-memory layer (scalar all-reduces and halo rows by xGMI peer stores) is brought up whenever every
+        # rank's export / map / self-test succeeds (the self-test includes the folded exchange and all three forms of
+        # the halo push between the real peers); which layer the headline uses is decided below.  The one-GPU rehearsal
+        # needs it (RCCL refuses duplicate devices).
+        if args.comm != "rccl" or one_gpu:
+            peer_memory = ctx.enable_peer_memory(world, rank, dist, force=True)
         if one_gpu and not peer_memory:
             raise SystemExit("one-GPU rehearsal needs the peer-memory layer")
         dist.barrier()
@@ -394,22 +499,44 @@ def main():
         A = ctx.csr_sharded(n_glob, nx * ny * z0, nx * ny * z1, rowptr, col, val, starts)
     nnz = int(rowptr[-1])
     prob = ctx.stiefel_rq(A, n, p)
-    if use_comm:
-        fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, peer_memory)
-        if peer_memory and os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1":
-            fails = fails + ["injected failure (test of the fallback path)"]
-        if fails and peer_memory and not one_gpu:
-            if rank == 0:
-                print("bench.py: peer-memory layer failed verification, falling back to RCCL:\n  " +
-                      "\n  ".join(fails), file=sys.stderr)
-            ctx.comm_ipc_enable(False)
-            peer_memory = False
-            fails = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank)
-        if fails:
-            raise SystemExit("bench.py: distributed data path failed verification:\n  " + "\n  ".join(fails))
     X = ctx.upload(Xb)
-    g, H = prob.model(X)
     s_out = ctx.vec(n * p)
+    # ---- N > 1: every exchange layer that is up is verified and timed; the headline takes the fastest --------------
+    comm_layer, comm_legs, comm_choice = None, None, None
+    if use_comm:
+        layers = (["peer", "peer-separate"] if peer_memory else []) + ([] if one_gpu else ["rccl"])
+        inject = os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1"  # (test of the fallback path)
+
+        def verifier(layer):
+            def verify():
+                f = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank,
+                                       peer_memory=(layer == "peer"))
+                if inject and layer != "rccl":
+                    f = f + ["injected failure (test of the fallback path)"]
+                return f
+            return verify
+        peer_up = peer_memory
+        comm_legs = [comm_ab_leg(ctx, dist, prob, X, s_out, L, args.ab_steps, world, rank, verifier(L), peer_up)
+                     for L in layers]
+        good = [leg for leg in comm_legs if leg["verified"] and not leg.get("ipc_error")]
+        for leg in comm_legs:
+            if not leg["verified"] and rank == 0:
+                print(f"bench.py: exchange layer '{leg['layer']}' failed verification" +
+                      (", falling back to RCCL" if leg["layer"] != "rccl" else "") + ":\n  " +
+                      "\n  ".join(leg.get("failures", [])), file=sys.stderr)
+        if not good:
+            raise SystemExit("bench.py: distributed data path failed verification on every exchange layer")
+        forced = [leg for leg in good if leg["layer"] == args.comm]
+        if args.comm != "auto" and forced:
+            comm_layer, comm_choice = args.comm, "forced (--comm / MI355OPT_COMM)"
+        else:
+            comm_layer = min(good, key=lambda leg: leg["us_per_step"])["layer"]
+            comm_choice = "fastest verified layer of comm_ab_legs" + \
+                ("" if args.comm == "auto" else f" ('{args.comm}' asked for but not available / not verified)")
+        comm_set_layer(ctx, comm_layer, peer_up)
+        peer_memory = comm_layer != "rccl"
+        dist.barrier()
+    g, H = prob.model(X)
     N = n * p
     bytes_per_step = wl.cg_bytes_per_iter(N) + wl.stiefel_hvp_bytes(n, nnz, p)  # per GPU
 
@@ -423,9 +550,9 @@ def main():
     # state; W warmup steps of 57 us are over long before that (measured, 20 timed steps: W = 5 -> 58.8 us/step,
     # W = 500 -> 57.7, W = 2000 -> 57.4; 500 timed steps: 56.5).  So the device is woken up with a FIXED number of
     # steps of the same solve (the same on every rank: they contain the exchanges) before the W warmup steps the
-    # command line asks for; the count is reported in the JSON line (`device_wakeup_steps`; MI355OPT_BENCH_WAKEUP_STEPS=0
-    # switches it off).  The timed region is unchanged: exactly K steps between two barrier + synchronise pairs.
-    wakeup_steps = int(os.environ.get("MI355OPT_BENCH_WAKEUP_STEPS", "1000"))
+    # command line asks for; the count is reported in the JSON line (`device_wakeup_steps`; --wakeup-steps 0 switches it
+    # off).  The timed region is unchanged: exactly K steps between two barrier + synchronise pairs.
+    wakeup_steps = args.wakeup_steps
     if wakeup_steps > 0:
         run_steps(ctx, g, H, s_out, wakeup_steps)
     if args.warmup > 0:
@@ -539,10 +666,7 @@ def main():
                        "moved_bytes_per_step_per_gpu": moved_bytes,
                        "reference_schedule_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
                        "packed_matrix": packed,
-                       "parallelism": (f"row-sharded z-slabs x{world}, comm: " +
-                                       ("peer-memory layer (hipIpc-mapped arenas over xGMI: scalar all-reduce and "
-                                        "halo rows by peer stores), RCCL for bring-up" if peer_memory else
-                                        "RCCL (all-reduce of partial rows, halo send/recv)")) if use_comm
+                       "parallelism": (f"row-sharded z-slabs x{world}, comm: " + LAYER_TEXT[comm_layer]) if use_comm
                        else "single GPU",
                        "device": ctx.device_name()},
             # `value` = compulsory HBM bytes of the kernels that ran / time: comparable with the 8 TB/s peak.
@@ -556,6 +680,9 @@ def main():
             # (88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration); the fused kernels never move those bytes
             "reference_schedule_bytes_per_second_not_a_bandwidth": world * args.steps * bytes_per_step / dt,
             "roofline": roofline,
+            # N > 1: which exchange layer the headline ran on and why; every layer's own figure next to it
+            "comm_layer": comm_layer, "comm_layer_choice": comm_choice, "rccl_nranks": rccl_nranks if use_comm else None,
+            "comm_ab_legs": comm_legs, "rehearsal_one_gpu": bool(one_gpu) if use_comm else None,
             # the second first-class number: the SAME workload through the generic path any CSR matrix takes
             # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
             "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,

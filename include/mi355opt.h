@@ -77,8 +77,20 @@ enum {
   MI_K_CG_INIT, MI_K_CG_DOT3, MI_K_CG_SCALAR_A, MI_K_CG_UPDATE, MI_K_CG_SCALAR_B, MI_K_CG_PUPDATE,
   MI_K_SPMM, MI_K_STIEFEL_SPMM_GRAM, MI_K_STIEFEL_GRAM_REDUCE, MI_K_STIEFEL_FINISH_DOTS,
   MI_K_STIEFEL_RETRACT, MI_K_BSR3_SPMV_DOTS, MI_K_BLAS1, MI_K_LOBPCG_GRAM, MI_K_LOBPCG_UPDATE,
-  MI_K_LOBPCG_RESIDUAL, MI_K_STIEFEL_HESS_FUSED, MI_K_COUNT
+  MI_K_LOBPCG_RESIDUAL, MI_K_STIEFEL_HESS_FUSED,
+  MI_K_COMM_ALLREDUCE, /* a scalar exchange across ranks that is a launch of its own: one RCCL all-reduce (group) or
+                          one exchange kernel of the peer-memory layer; folded exchanges have none */
+  MI_K_COMM_HALO,      /* a halo exchange that is a launch of its own: ncclSend/ncclRecv group or push kernel */
+  MI_K_COUNT
 };
+/* The library's switches (A/B forms of its kernels, verification hooks of the multi-rank path) are read from the
+ * environment ONCE per context, in mi_ctx_create: MI355OPT_<NAME>=<integer> for NAME in FORCE_SLOT_PATH,
+ * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
+ * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA (DESIGN.md
+ * says what each selects).  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
+ * prefix); format switches (NO_PACKED) act when a matrix is created, the communication ones before the layer they
+ * concern is brought up.  Nothing else in the library reads the environment. */
+MI_API int mi_ctx_set_option(mi_ctx *ctx, const char *name, long value);
 MI_API int mi_ktime_enable(mi_ctx *ctx, int kernel_id, int on);
 MI_API int mi_ktime_reset(mi_ctx *ctx);
 /* sync: resolves recorded event pairs; returns launches and total milliseconds for kernel_id */
@@ -103,6 +115,11 @@ MI_API int mi_vec_destroy(mi_vec *v);                           /* returns stora
 MI_API int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out);
 MI_API int mi_vec_len(const mi_vec *v, size_t *n);
 MI_API int mi_vec_data(const mi_vec *v, void **device_ptr);
+/* Announce a write made OUTSIDE the library through the pointer of mi_vec_data (torch interop, a user kernel): problem
+ * objects cache speculative results keyed on a vector's contents (the trial point of mi_stiefel_rq_trial /
+ * mi_so3n_trial), and every library entry point that writes a vector advances its generation stamp itself -- a view
+ * shares the stamp of the vector that owns the storage -- but a raw-pointer write is invisible to it. */
+MI_API int mi_vec_touch(mi_vec *v);
 MI_API int mi_vec_upload(mi_vec *v, const double *host, size_t n);         /* sync */
 MI_API int mi_vec_download(const mi_vec *v, double *host, size_t n);       /* sync */
 MI_API int mi_vec_copy(mi_vec *dst, const mi_vec *src);   /* `r_k = g;` IterativeSolvers.h:214,231,383 */
@@ -369,6 +386,8 @@ MI_API int mi_comm_init(mi_ctx *ctx, int world_size, int rank,
                         const unsigned char uid[MI_COMM_UID_BYTES]); /* sync */
 MI_API int mi_comm_finalize(mi_ctx *ctx);
 MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
+/* ranks of the RCCL communicator as RCCL itself reports them (ncclCommCount); 0: no RCCL communicator attached */
+MI_API int mi_comm_rccl_count(mi_ctx *ctx, int *nranks);
 /* Peer-memory layer for the tiny, latency-bound exchanges of the STPCG path (scalar all-reduces, halo
  * rows): every rank exports one fine-grained device arena (hipIpcGetMemHandle), the launcher gathers
  * the handles, every rank maps all of them (hipIpcOpenMemHandle: plain xGMI peer stores), runs the
@@ -379,7 +398,12 @@ MI_API int mi_comm_info(mi_ctx *ctx, int *world_size, int *rank);
 MI_API int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTES]);
 MI_API int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank,
                               const unsigned char *handles /* world_size x MI_COMM_IPC_HANDLE_BYTES */);
-MI_API int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok);      /* collective, sync */
+/* Collective, sync.  Known-value all-reduces and all-gathers through the exchange kernel, then (world_size > 1) the
+ * FOLDED forms between the real peers: the scalar exchange inside a streaming kernel's prologue and all three forms of
+ * the halo push (early fold, late fold, separate kernel) over 24 rounds with a consumer that checks every halo double.
+ * The caller must combine the ranks' verdicts (a collective: no rank may go on before every rank is through) and pass
+ * the result to mi_comm_ipc_enable on every rank. */
+MI_API int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok);
 MI_API int mi_comm_ipc_enable(mi_ctx *ctx, int on);
 MI_API int mi_comm_ipc_error(mi_ctx *ctx, int *err);        /* nonzero: a bounded wait timed out */
 /* exchanges folded into their producer / consumer kernels (default on; env MI355OPT_NO_FOLD=1: off) switched at run

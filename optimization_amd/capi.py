@@ -18,7 +18,7 @@ STATUS = {0: "MI_OK", 1: "MI_ERR_INVALID_ARGUMENT", 2: "MI_ERR_HIP", 3: "MI_ERR_
 KERNELS = ["none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
            "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
            "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
-           "lobpcg_residual", "stiefel_hess_fused"]
+           "lobpcg_residual", "stiefel_hess_fused", "comm_allreduce", "comm_halo"]
 KID = {k: i for i, k in enumerate(KERNELS)}
 STPCG_EXIT = ["RESIDUAL", "MAXIT", "KERNEL", "BOUNDARY"]
 
@@ -91,6 +91,7 @@ def load():
         "mi_ctx_create": [C.c_int, C.POINTER(vp)],
         "mi_ctx_destroy": [vp],
         "mi_ctx_sync": [vp],
+        "mi_ctx_set_option": [vp, C.c_char_p, C.c_long],
         "mi_ctx_sync_count": [vp, c_size_p],
         "mi_ctx_stream": [vp, C.POINTER(vp)],
         "mi_ctx_device_name": [vp, C.c_char_p, C.c_size_t],
@@ -106,6 +107,7 @@ def load():
         "mi_vec_destroy": [vp],
         "mi_vec_len": [vp, c_size_p],
         "mi_vec_data": [vp, C.POINTER(vp)],
+        "mi_vec_touch": [vp],
         "mi_vec_upload": [vp, c_double_p, C.c_size_t],
         "mi_vec_download": [vp, c_double_p, C.c_size_t],
         "mi_vec_copy": [vp, vp],
@@ -174,6 +176,7 @@ def load():
         "mi_comm_init": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
         "mi_comm_finalize": [vp],
         "mi_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mi_comm_rccl_count": [vp, C.POINTER(C.c_int)],
         "mi_comm_ipc_export": [vp, C.POINTER(C.c_ubyte)],
         "mi_comm_ipc_attach": [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)],
         "mi_comm_ipc_selftest": [vp, C.POINTER(C.c_int)],
@@ -259,6 +262,11 @@ class Context:
 
     def sync(self):
         check(self.L.mi_ctx_sync(self.h))
+
+    def set_option(self, name, value):
+        """mi_ctx_set_option: one of the library's MI355OPT_<NAME> switches on this live context"""
+        check(self.L.mi_ctx_set_option(self.h, name.encode(), int(value)))
+        return self
 
     def sync_count(self):
         n = C.c_size_t(0)
@@ -611,6 +619,12 @@ class Context:
     def comm_finalize(self):
         check(self.L.mi_comm_finalize(self.h))
 
+    def comm_rccl_count(self):
+        """ranks of the RCCL communicator as RCCL reports them (ncclCommCount); 0 without one"""
+        n = C.c_int(0)
+        check(self.L.mi_comm_rccl_count(self.h, C.byref(n)))
+        return n.value
+
 
 class Vec:
     def __init__(self, ctx, n, handle=None):
@@ -651,6 +665,24 @@ class Vec:
 
     def fill(self, a):
         check(self.L.mi_vec_fill(self.h, a))
+        return self
+
+    def view(self, offset, n):
+        """non-owning window [offset, offset + n) (mi_vec_view); this vector must outlive it"""
+        h = vp()
+        check(self.L.mi_vec_view(self.h, offset, n, C.byref(h)))
+        v = Vec(self.ctx, 0, handle=h)
+        v.owned, v.base = True, self      # the VIEW object is ours to destroy (not the storage)
+        return v
+
+    def data_ptr(self):
+        p = vp()
+        check(self.L.mi_vec_data(self.h, C.byref(p)))
+        return p.value
+
+    def touch(self):
+        """announce a write made through data_ptr() outside the library (mi_vec_touch)"""
+        check(self.L.mi_vec_touch(self.h))
         return self
 
     def scale(self, a):

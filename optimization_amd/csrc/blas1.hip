@@ -146,7 +146,7 @@ int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out) {
   MI_REQUIRE(ctx && out, "null argument");
   void *p = nullptr;
   MI_TRY(pool_alloc(ctx, n * sizeof(double), &p));
-  mi_vec *v = new mi_vec{ctx, n, (double *)p, true, ++ctx->vec_serial, 0};
+  mi_vec *v = new mi_vec{ctx, n, (double *)p, true, ++ctx->vec_serial, 0, nullptr};
   *out = v;
   return MI_OK;
 }
@@ -162,7 +162,14 @@ int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out) {
   MI_REQUIRE(base && out, "null argument");
   MI_REQUIRE(offset + n <= base->n, "view [%zu, %zu) exceeds the base vector (%zu)", offset, offset + n, base->n);
   // an odd offset only costs alignment: gfx950 global 16-byte accesses need 4-byte alignment
-  *out = new mi_vec{base->ctx, n, base->d + offset, false, ++base->ctx->vec_serial, 0};
+  mi_vec *root = base->root ? base->root : const_cast<mi_vec *>(base);
+  *out = new mi_vec{base->ctx, n, base->d + offset, false, ++base->ctx->vec_serial, 0, root};
+  return MI_OK;
+}
+
+int mi_vec_touch(mi_vec *v) {
+  MI_REQUIRE(v, "null argument");
+  touch(v);
   return MI_OK;
 }
 

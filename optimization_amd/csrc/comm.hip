@@ -153,10 +153,55 @@ __global__ __launch_bounds__(256) void k_ipc_halo_push(const double *__restrict_
   }
 }
 
+
+// ---- self-test of the FOLDED forms (r04, ADVICE: the check bench.py made must be the library's own) ---------------
+// Stand-ins for k_cg_pupdate<FoldPush> and for the Hessian pass that consumes its halo, built from the SAME helpers in
+// the same places: a folded scalar exchange in the prologue, halo_push_store next to the stores of a (rotated)
+// grid-stride walk, the first-step signal of the early form, halo_push_finish of the late one; the consumer waits in
+// its prologue and checks every halo double.  Values are exact functions of (rank, round, index), so a row that
+// arrives late, never, or from the wrong exchange is counted.
+__device__ __forceinline__ double selftest_val(int rank, int round, size_t idx) {
+  return (double)(rank + 1) * 1099511627776.0 /* 2^40 */ + (double)round * 16777216.0 /* 2^24 */ + (double)idx;
+}
+template <class FOLD>
+__global__ __launch_bounds__(kBlock) void k_ipc_selftest_producer(size_t n2, double2 *__restrict__ vec, int rank,
+                                                                  int round, FOLD fold, double *__restrict__ sums) {
+  __shared__ double lds[kIpcVals];
+  double d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = (double)((rank + 1) * (k + 1)) + (double)round;
+  fold_maybe<3>(d, fold, lds);
+  if (blockIdx.x == 0 && threadIdx.x < 3) sums[threadIdx.x] = d[threadIdx.x];
+  const size_t stride = (size_t)gridDim.x * kBlock, i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  bool pushed = false;
+  for (size_t L = i0; L < n2; L += stride) {
+    const size_t q = halo_phys(fold, L);
+    const double2 v = make_double2(selftest_val(rank, round, 2 * q), selftest_val(rank, round, 2 * q + 1));
+    vec[q] = v;
+    pushed |= halo_push_store(fold, q, v);
+    if (L == i0) halo_push_first_step_done(fold);
+  }
+  halo_push_finish(fold, pushed);
+}
+__global__ __launch_bounds__(256) void k_ipc_selftest_consumer(HaloWait w, const double *halo, size_t lo,
+                                                                size_t hi, size_t n, int rank, int round,
+                                                                unsigned int *__restrict__ bad) {
+  halo_wait(w);
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int mine = 0;
+  // [0, lo): the LAST lo doubles of rank-1; [lo, lo + hi): the FIRST hi doubles of rank+1.  PLAIN loads on purpose:
+  // that is how the Hessian pass reads its halo, and the buffer was read two rounds ago -- a line that survived in a
+  // cache through the wait's acquire would show up here
+  for (size_t i = i0; i < lo; i += stride) mine += halo[i] != selftest_val(rank - 1, round, n - lo + i);
+  for (size_t i = i0; i < hi; i += stride) mine += halo[lo + i] != selftest_val(rank + 1, round, i);
+  if (mine) atomicAdd(bad, mine);
+}
+
 int ipc_exchange(mi_ctx *ctx, Comm *c, const double *partials, int count, const double *in_vals, int k, bool sum,
                  double *out) {
   const uint64_t seq = ++c->seq;
   ++c->launched[0];
+  KScope ks(ctx, MI_K_COMM_ALLREDUCE);
 #define IX(K)                                                                                              \
   if (sum)                                                                                                 \
     hipLaunchKernelGGL((k_ipc_exchange<K, true>), dim3(1), dim3(kBlock), 0, ctx->stream, partials, count,  \
@@ -195,9 +240,6 @@ FoldArgs comm_fold_next(mi_ctx *ctx) {
   f.timeout = c->timeout;
   f.P = ctx->world_size;
   f.rank = ctx->rank;
-#ifdef MI_FOLD_STAMPS  // experiment: the folded instantiation without its exchange (right only for one rank)
-  if (getenv("MI355OPT_DEBUG_FOLD_NULL")) f.peers = nullptr;
-#endif
   return f;
 }
 FoldArgs comm_fold_next_always(mi_ctx *ctx) {
@@ -223,6 +265,7 @@ int comm_allreduce(mi_ctx *ctx, double *buf, int count) {
   if (!ctx->comm) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   if (c->nccl) {
+    KScope ks(ctx, MI_K_COMM_ALLREDUCE);
     MI_NCCL(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->nccl, ctx->stream));
     return MI_OK;
   }
@@ -248,6 +291,7 @@ int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k) {
   Comm *c = (Comm *)ctx->comm;
   if (c && c->nccl && ctx->uniform_grid && k > 0) {
     if (k == 1) return comm_allreduce(ctx, partials, kMaxGrid);
+    KScope ks(ctx, MI_K_COMM_ALLREDUCE);
     MI_NCCL(ncclGroupStart());
     for (int j = 0; j < k; ++j) {
       double *seg = partials + (size_t)j * kMaxRows;
@@ -297,7 +341,7 @@ bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, H
   push->rot = push->hi_from;
   {
     const size_t first = (hi + lo) / 2, step = (size_t)grid_for(ctx, nd, 4) * kBlock;
-    static const bool late = [] { const char *e = getenv("MI355OPT_HALO_PUSH_LATE"); return e && e[0] == '1'; }();
+    const bool late = ctx->cfg.halo_push_late;
     // (step <= n2: the kernel's first step is a whole grid-stride step)
     push->early_waves = (!late && first > 0 && first <= step && step <= push->n2) ? (unsigned int)((first + 63) / 64) : 0u;
   }
@@ -340,6 +384,7 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
     const size_t lo = A->send_lo * p, hi = A->send_hi * p;
     const size_t work = std::max(lo, hi);
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((work + 255) / 256, 64));
+    KScope ks(ctx, MI_K_COMM_HALO);
     hipLaunchKernelGGL(k_ipc_halo_push, dim3(grid), dim3(256), 0, ctx->stream, V, A->n * (size_t)p, lo, hi,
                        (char *const *)c->peer_dev, ws, rk,
                        buf_off + A->peer_lo_rows * p * sizeof(double),  // behind rank-1's lower halo
@@ -352,6 +397,7 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
     return MI_OK;
   }
   MI_REQUIRE(c->nccl, "halo exchange needs RCCL or the enabled peer-memory layer");
+  KScope ks(ctx, MI_K_COMM_HALO);
   MI_NCCL(ncclGroupStart());
   if (rk > 0) {
     if (A->send_lo) MI_NCCL(ncclSend(V, A->send_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream));
@@ -457,7 +503,7 @@ int mi_comm_init(mi_ctx *ctx, int world_size, int rank, const unsigned char uid[
   ctx->comm = c;
   ctx->world_size = world_size;
   ctx->rank = rank;
-  ctx->uniform_grid = world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr;
+  ctx->uniform_grid = world_size > 1 || ctx->cfg.force_uniform_grid;
   // warm the communicator (first collective builds the rings) with one tiny all-reduce
   MI_HIP(hipMemsetAsync(ctx->scalars + SLOT_MISC, 0, sizeof(double), ctx->stream));
   MI_TRY(comm_allreduce(ctx, ctx->scalars + SLOT_MISC, 1));
@@ -475,8 +521,8 @@ int mi_comm_ipc_export(mi_ctx *ctx, unsigned char handle[MI_COMM_IPC_HANDLE_BYTE
     ctx->comm = c;
   }
   MI_REQUIRE(!c->arena, "arena already exported");
-  if (const char *e = getenv("MI355OPT_IPC_TIMEOUT_MS")) c->timeout = (uint64_t)std::max(1L, atol(e)) * 100000ull;
-  if (const char *e = getenv("MI355OPT_NO_FOLD")) c->fold = !(e[0] == '1');
+  if (ctx->cfg.ipc_timeout_ms > 0) c->timeout = (uint64_t)ctx->cfg.ipc_timeout_ms * 100000ull;
+  c->fold = !ctx->cfg.no_fold;
   MI_HIP(hipSetDevice(ctx->device));
   MI_HIP(hipExtMallocWithFlags((void **)&c->arena, kIpcArenaBytes, hipDeviceMallocFinegrained));
   MI_HIP(hipMemset(c->arena, 0, kIpcArenaBytes));
@@ -523,6 +569,118 @@ int mi_comm_ipc_attach(mi_ctx *ctx, int world_size, int rank, const unsigned cha
   return MI_OK;
 }
 
+// The folded exchange and the three forms of the halo push (early fold, late fold, separate kernel) between real
+// peers, the form changing from round to round the way a solve mixes them: 12 rounds on a boundary that fits the
+// producer's first grid-stride step (the early form's condition) and 12 on a boundary the size of cfg4's (one 200 x 200
+// plane of a 3-column field per neighbour: late form and separate kernel).  The producer runs 32 workgroups whatever
+// the context's grid cap is: every workgroup waits for its peers in its prologue, so with all ranks on ONE GPU (the
+// rehearsals) (ranks - 1) x grid + 1 workgroups must be resident together.  Collective.  *good stays true only if every
+// halo double and every folded sum of every round was right on THIS rank and no wait timed out.
+static int ipc_selftest_folded_b(mi_ctx *ctx, Comm *c, size_t b, int rounds, int round0, bool *good) {
+  const int P = ctx->world_size, rk = ctx->rank;
+  const size_t n = (size_t)3 << 20;  // doubles per rank
+  mi_csr A;                          // only the halo description of a sharded matrix (p = 1: rows = doubles)
+  A.ctx = ctx;
+  A.n = n;
+  A.halo_lo = rk > 0 ? b : 0;
+  A.halo_hi = rk + 1 < P ? b : 0;
+  A.send_lo = A.halo_lo;
+  A.send_hi = A.halo_hi;
+  A.peer_lo_rows = rk > 1 ? b : 0;  // halo_lo of rank-1
+  A.halo_stride = 2 * b;
+  bool in_arena = false;
+  size_t off = 0;
+  double *halo = nullptr;
+  MI_TRY(comm_halo_alloc(ctx, 2 * A.halo_stride * sizeof(double), &halo, &in_arena, &off));
+  if (!in_arena) {  // (the arena is exhausted: nothing to test with, and nothing would fold either)
+    comm_halo_free(ctx, halo, in_arena);
+    return MI_OK;
+  }
+  A.halo = halo;
+  A.halo_in_arena = true;
+  A.halo_off = off;
+  double2 *vec = nullptr;
+  double *sums = nullptr;
+  MI_TRY(pool_alloc(ctx, n * sizeof(double), (void **)&vec));
+  int rc = pool_alloc(ctx, 256, (void **)&sums);
+  if (rc != MI_OK) {
+    pool_free(ctx, vec);
+    return rc;
+  }
+  unsigned int *bad = reinterpret_cast<unsigned int *>(sums + 3);
+  const bool was_enabled = c->ipc_enabled, was_fold = c->fold;
+  c->ipc_enabled = true;
+  const int grid = std::min(grid_for(ctx, n, 4), 32);
+  bool ok = hipMemsetAsync(sums, 0, 256, ctx->stream) == hipSuccess;
+  for (int i = 0; i < rounds && rc == MI_OK && ok; ++i) {
+    const int round = round0 + i;
+    const int form = was_fold ? i % 3 : 2;  // 0: folded, early where the geometry allows; 1: folded, late; 2: separate
+    FoldPush fp{};
+    HaloWait w{};
+    double want[3];
+    for (int k = 0; k < 3; ++k) {
+      want[k] = 0;
+      for (int r = 0; r < P; ++r) want[k] += (double)((r + 1) * (k + 1)) + (double)round;
+    }
+    if (form < 2) {
+      c->fold = true;
+      fp.f = comm_fold_next(ctx);
+      const bool folded = comm_halo_fold_next(ctx, &A, 1, reinterpret_cast<const double *>(vec), &fp.h);
+      // (the early form's condition for THIS kernel's grid: both boundary regions inside its first grid-stride step)
+      const size_t first = (A.send_lo + A.send_hi) / 2, step = (size_t)grid * kBlock;
+      fp.h.early_waves = (form == 0 && first > 0 && first <= step && step <= fp.h.n2) ? (unsigned int)((first + 63) / 64) : 0u;
+      hipLaunchKernelGGL((k_ipc_selftest_producer<FoldPush>), dim3(grid), dim3(kBlock), 0, ctx->stream, n / 2, vec, rk,
+                         round, fp, sums);
+      if (!folded) ok = false;  // (b and n are even and in the arena: it must fold)
+      rc = comm_halo_exchange_or_wait(ctx, &A, 1, reinterpret_cast<const double *>(vec), &w);
+    } else {
+      FoldArgs fa = comm_fold_next_always(ctx);
+      hipLaunchKernelGGL((k_ipc_selftest_producer<FoldArgs>), dim3(grid), dim3(kBlock), 0, ctx->stream, n / 2, vec, rk,
+                         round, fa, sums);
+      rc = comm_halo_exchange(ctx, &A, 1, reinterpret_cast<const double *>(vec));
+    }
+    if (rc != MI_OK) break;
+    hipLaunchKernelGGL(k_ipc_selftest_consumer, dim3(64), dim3(256), 0, ctx->stream, w, A.halo_cur(), A.halo_lo, A.halo_hi,
+                       n, rk, round, bad);
+    double got[4];
+    if (hipMemcpyAsync(got, sums, sizeof(got), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      rc = MI_ERR_HIP;
+      set_error("peer-memory self-test: HIP error in round %d", round);
+      break;
+    }
+    unsigned int nbad = 0;
+    memcpy(&nbad, &got[3], sizeof(nbad));  // (`bad` lives right behind sums[0..3): one copy)
+    if (nbad || *c->err_host) ok = false;
+    for (int k = 0; k < 3; ++k)
+      if (got[k] != want[k]) ok = false;
+  }
+  c->fold = was_fold;
+  c->ipc_enabled = was_enabled;
+  c->pushed = {};
+  (void)hipStreamSynchronize(ctx->stream);
+  pool_free(ctx, vec);
+  pool_free(ctx, sums);
+  if (rc != MI_OK) return rc;
+  if (!ok) *good = false;
+  return MI_OK;
+}
+static int ipc_selftest_folded(mi_ctx *ctx, Comm *c, bool *good) {
+  const size_t top0 = c->arena_top;
+  int rc = ipc_selftest_folded_b(ctx, c, 16384, 12, 0, good);   // early / late / separate
+  if (rc == MI_OK && *good) rc = ipc_selftest_folded_b(ctx, c, 120000, 12, 12, good);  // cfg4's boundary: late / separate
+  // The test's halo regions go back to the arena, zeroed as they were handed out.  Safe: every rank has consumed its
+  // last round (so every push into this rank's regions has landed), and no rank can start pushing rows of a real
+  // matrix before the caller has combined the ranks' verdicts -- a collective, i.e. after every rank is through here.
+  if (c->arena_top > top0) {
+    hipError_t e = hipMemsetAsync(c->arena + top0, 0, c->arena_top - top0, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess && rc == MI_OK) rc = hip_fail(e, "peer-memory self-test: arena reset", __FILE__, __LINE__);
+    c->arena_top = top0;
+  }
+  return rc;
+}
+
 // Collective: a few exchanges with known per-rank values; *ok = 1 iff every sum / gather came back
 // right and no wait timed out on THIS rank.  The caller combines the ranks' verdicts (min) and passes
 // the result to mi_comm_ipc_enable on every rank.
@@ -555,6 +713,7 @@ int mi_comm_ipc_selftest(mi_ctx *ctx, int *ok) {
           if (out[r * 4 + k] != (r + 1) * 1000.0 + round * 16 + k) good = false;
     }
   }
+  if (good && P > 1) MI_TRY(ipc_selftest_folded(ctx, c, &good));
   *ok = good ? 1 : 0;
   return MI_OK;
 }
@@ -567,7 +726,7 @@ int mi_comm_ipc_enable(mi_ctx *ctx, int on) {
   c->ipc_enabled = on != 0;
   if (!c->ipc_enabled && c->err_host) *c->err_host = 0;  // a failed layer must not poison the RCCL path
   // slot path (peer-memory): rows never cross ranks; RCCL rows mode needs the same row count everywhere
-  ctx->uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || getenv("MI355OPT_FORCE_UNIFORM_GRID") != nullptr);
+  ctx->uniform_grid = !c->ipc_enabled && (ctx->world_size > 1 || ctx->cfg.force_uniform_grid);
   return MI_OK;
 }
 
@@ -631,6 +790,14 @@ int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host) {
   const size_t rows = A->halo_lo + A->halo_hi;
   if (rows)
     MI_HIP(hipMemcpy(const_cast<double *>(A->halo_cur()), halo_rows_host, rows * (size_t)p * sizeof(double), hipMemcpyHostToDevice));
+  return MI_OK;
+}
+
+int mi_comm_rccl_count(mi_ctx *ctx, int *nranks) {
+  MI_REQUIRE(ctx && nranks, "null argument");
+  *nranks = 0;
+  Comm *c = (Comm *)ctx->comm;
+  if (c && c->nccl) MI_NCCL(ncclCommCount(c->nccl, nranks));
   return MI_OK;
 }
 

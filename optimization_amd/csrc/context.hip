@@ -117,6 +117,57 @@ KScope::~KScope() {
 
 using namespace mi;
 
+// The one place the library reads its environment: every MI355OPT_<NAME> switch, once per context.
+namespace {
+struct OptionDesc {
+  const char *name;
+  int (*set)(mi_ctx *, long);
+};
+// (plain functions, not lambdas: a captureless lambda does not convert to a function pointer in hipcc's device pass)
+#define OPT_BOOL(FN, FIELD) \
+  int FN(mi_ctx *c, long v) { c->FIELD = v != 0; return MI_OK; }
+OPT_BOOL(opt_force_slot_path, force_slot_path)
+OPT_BOOL(opt_force_lockstep, force_lockstep)
+OPT_BOOL(opt_no_dirgram, no_dirgram)
+OPT_BOOL(opt_dirgram_direct, dirgram_direct)
+OPT_BOOL(opt_force_uniform_grid, cfg.force_uniform_grid)
+OPT_BOOL(opt_no_fold, cfg.no_fold)
+OPT_BOOL(opt_halo_push_late, cfg.halo_push_late)
+OPT_BOOL(opt_no_packed, cfg.no_packed)
+OPT_BOOL(opt_no_window, cfg.no_window)
+OPT_BOOL(opt_no_win_bounds, cfg.no_win_bounds)
+OPT_BOOL(opt_no_far_computed, cfg.no_far_computed)
+OPT_BOOL(opt_words16, cfg.words16)
+OPT_BOOL(opt_no_spmm_stream, cfg.no_spmm_stream)
+OPT_BOOL(opt_no_spmm_win, cfg.no_spmm_win)
+OPT_BOOL(opt_no_update_mfma, cfg.no_update_mfma)
+#undef OPT_BOOL
+int opt_max_grid(mi_ctx *c, long v) {
+  c->max_grid = (int)std::min<long>(kMaxGrid, std::max<long>(1, v));
+  return MI_OK;
+}
+int opt_ipc_timeout_ms(mi_ctx *c, long v) {
+  c->cfg.ipc_timeout_ms = std::max<long>(0, v);
+  return MI_OK;
+}
+const OptionDesc kOptions[] = {
+    {"FORCE_SLOT_PATH", opt_force_slot_path}, {"FORCE_LOCKSTEP", opt_force_lockstep},
+    {"NO_DIRGRAM", opt_no_dirgram}, {"DIRGRAM_DIRECT", opt_dirgram_direct}, {"MAX_GRID", opt_max_grid},
+    {"FORCE_UNIFORM_GRID", opt_force_uniform_grid}, {"IPC_TIMEOUT_MS", opt_ipc_timeout_ms},
+    {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
+    {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
+    {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
+    {"NO_UPDATE_MFMA", opt_no_update_mfma},
+};
+void config_from_env(mi_ctx *ctx) {
+  for (const OptionDesc &o : kOptions) {
+    char name[64];
+    snprintf(name, sizeof(name), "MI355OPT_%s", o.name);
+    if (const char *e = getenv(name)) (void)o.set(ctx, atol(e));
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char *mi_version(void) { return "mi355opt 0.1.0 (gfx950)"; }
@@ -138,10 +189,19 @@ static const char *kKernelNames[MI_K_COUNT] = {
     "none", "cg_init", "cg_dot3", "cg_scalar_a", "cg_update", "cg_scalar_b", "cg_pupdate",
     "csr_spmm", "stiefel_spmm_gram", "stiefel_gram_reduce", "stiefel_finish_dots",
     "stiefel_retract", "bsr3_spmv_dots", "blas1", "lobpcg_gram", "lobpcg_update",
-    "lobpcg_residual", "stiefel_hess_fused"};
+    "lobpcg_residual", "stiefel_hess_fused", "comm_allreduce", "comm_halo"};
 const char *mi_kernel_name(int id) {
   if (id < 0 || id >= MI_K_COUNT) return "?";
   return kKernelNames[id];
+}
+
+int mi_ctx_set_option(mi_ctx *ctx, const char *name, long value) {
+  MI_REQUIRE(ctx && name, "null argument");
+  if (strncmp(name, "MI355OPT_", 9) == 0) name += 9;
+  for (const OptionDesc &o : kOptions)
+    if (strcmp(o.name, name) == 0) return o.set(ctx, value);
+  set_error("unknown option '%s'", name);
+  return MI_ERR_INVALID_ARGUMENT;
 }
 
 int mi_device_count(int *count) {
@@ -197,11 +257,7 @@ static int ctx_init(mi_ctx *ctx, int device) {
                        hipHostMallocMapped | hipHostMallocCoherent));
   memset((void *)ctx->status, 0, sizeof(HostStatus));
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
-  { const char *e = getenv("MI355OPT_FORCE_SLOT_PATH"); ctx->force_slot_path = e && e[0] == '1'; }
-  if (const char *e = getenv("MI355OPT_MAX_GRID")) ctx->max_grid = std::min(kMaxGrid, std::max(1, atoi(e)));
-  { const char *e = getenv("MI355OPT_FORCE_LOCKSTEP"); ctx->force_lockstep = e && e[0] == '1'; }
-  { const char *e = getenv("MI355OPT_NO_DIRGRAM"); ctx->no_dirgram = e && e[0] == '1'; }
-  { const char *e = getenv("MI355OPT_DIRGRAM_DIRECT"); ctx->dirgram_direct = e && e[0] == '1'; }
+  config_from_env(ctx);
   MI_HIP(hipEventCreate(&ctx->t_start));
   MI_HIP(hipEventCreate(&ctx->t_stop));
   return MI_OK;

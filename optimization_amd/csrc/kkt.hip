@@ -202,6 +202,10 @@ int mi_precon_create_constraint(mi_ctx *ctx, size_t n, size_t m, const mi_vec *A
   MI_REQUIRE(A->ctx == ctx && Minv->ctx == ctx, "vector belongs to another context");
   MI_REQUIRE(m >= 1 && m <= (size_t)kKktMaxM, "number of constraints must be in [1,%d], got %zu", kKktMaxM, m);
   MI_REQUIRE(n >= m && A->n == n * m && Minv->n == n, "constraint matrix must be m x n row-major (m <= n), M^-1 of length n");
+  // S = A M^-1 A' and b = A M^-1 r are sums over ALL columns: on a row-sharded context they would be rank-local partial
+  // sums nobody reduces (a wrong, rank-dependent lambda; the replicated CG scalars would part ways)
+  MI_REQUIRE(ctx->world_size <= 1, "the constraint preconditioner is single-rank (context has %d ranks): its Schur "
+             "complement and right-hand sides are not reduced across ranks", ctx->world_size);
   MI_TRY(ensure_device());
   KktImpl *k = new KktImpl();
   k->n = n;

@@ -929,7 +929,7 @@ static int gram_impl(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, con
   const int kapad = (ka + 15) / 16 * 16, kbpad = (kb + 15) / 16 * 16;
   // square panels of up to 80 columns on 32-byte-aligned columns: the LDS-free one-wave-per-row-range kernel
   const bool direct = ka == kb && ka <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T->d % 32 == 0 &&
-                      (!T2 || (uintptr_t)T2 % 32 == 0) && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+                      (!T2 || (uintptr_t)T2 % 32 == 0) && m >= 16 * kGdH;
   MI_REQUIRE(!T2 || direct, "split panels need the direct Gram kernel");
   size_t nb, nwaves = 0;
   const size_t mfull = m - m % (16 * kGdH);  // rows k_gram_direct covers in whole pipeline steps
@@ -1034,7 +1034,7 @@ static int assemble_panel(mi_ctx *ctx, size_t m, int k, int k1, const mi_vec *T1
 }
 static bool split_direct_ok(size_t m, int k, const mi_vec *S, const mi_vec *T1, const mi_vec *T2) {
   return k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T1->d % 32 == 0 &&
-         (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+         (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH;
 }
 
 // The two Grams of a Rayleigh-Ritz step with ONE synchronisation: both are enqueued back to back (the device goes
@@ -1091,7 +1091,7 @@ int mi_lobpcg_gram_split(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1, 
   MI_TRY(check_panel(ctx, m, k - k1, T2, "T2"));
   // the kernel that takes the two pieces as they lie (square panels of <= 80 columns, 32-byte aligned) ...
   const bool direct = k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)T1->d % 32 == 0 &&
-                      (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH && !getenv("MI355OPT_GRAM_LDS");
+                      (uintptr_t)T2->d % 32 == 0 && m >= 16 * kGdH;
   if (direct) return gram_impl(ctx, m, k, k, S, T1, T2, k1, G_host);
   // ... else T = [T1 | T2] assembled once
   mi_vec *T = nullptr;
@@ -1164,9 +1164,7 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
                      (const double *)Cdev + ch.off, ch.c0, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr, r_begin)
     size_t r_begin = 0;
     // the whole-iteration update (48 columns from <= 72) on the matrix pipe, leftover rows through the VALU kernel
-    const char *no_mfma_env = getenv("MI355OPT_NO_UPDATE_MFMA");
-    if (ch.width == 48 && ch.c0 == 0 && (ks == 48 || ks == 72) && m >= 16 &&
-        !(no_mfma_env && no_mfma_env[0] == '1')) {
+    if (ch.width == 48 && ch.c0 == 0 && (ks == 48 || ks == 72) && m >= 16 && !ctx->cfg.no_update_mfma) {
       const size_t nblocks = m / 16;
       const int mgrid = (int)std::min<size_t>((nblocks + 3) / 4, (size_t)2 * ctx->num_cu);
       if (ks == 48)
@@ -1267,8 +1265,7 @@ int mi_panel_rowscale(mi_ctx *ctx, size_t m, int k, const mi_vec *d, const mi_ve
 namespace {
 // the window form of the panel product applies (matrices that qualify, sparse.hip build_window; one context, no halo)
 bool spmm_win_ok(const mi_csr *A) {
-  const char *no_win_env = getenv("MI355OPT_NO_SPMM_WIN");  // (read per call: the tests compare both forms in one process)
-  const bool no_win = no_win_env && no_win_env[0] == '1';
+  const bool no_win = A->ctx->cfg.no_spmm_win;
   return A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !no_win && !A->ctx->uniform_grid &&
          A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n * 8 < ((size_t)1 << 32);
 }
@@ -1285,9 +1282,7 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
   const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
   const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1, res = theta_dev != nullptr;
   const void *fn = nullptr;
-  const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
-  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
-                    !(no_fard_env && no_fard_env[0] == '1');
+  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
 #define PICK3(HWV, WCV, FV, RV) fn = (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, FV, RV>
 #define PICK(HWV, WCV)                                                        \
   if (res) { if (fard) PICK3(HWV, WCV, true, true); else PICK3(HWV, WCV, false, true); } \
@@ -1307,8 +1302,7 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
   const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
   int wgrid = 0;
   const int *bounds = nullptr;
-  static const int wgs_env = [] { const char *e = getenv("MI355OPT_SPMM_WIN_WGS"); return e ? atoi(e) : 0; }();
-  MI_TRY(window_bounds(ctx, A, wgs_env > 0 ? wgs_env : std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
+  MI_TRY(window_bounds(ctx, A, std::min(occ, 4) * ctx->num_cu, ntiles, &wgrid, &bounds));
   SellView view = sell_view(A);
   WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
              nullptr};
@@ -1344,11 +1338,16 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
   const int nchunks = (nx + 7) / 8;
   void *thdev = nullptr, *sums = nullptr;
   MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
-  MI_TRY(pool_alloc(ctx, (size_t)nchunks * 16 * sizeof(double), &sums));
-  MI_TRY(stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev));  // (no host wait)
-  {
+  int st = pool_alloc(ctx, (size_t)nchunks * 16 * sizeof(double), &sums);
+  if (st == MI_OK) st = stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev);  // (no host wait)
+  if (st == MI_OK) {
     KScope ks(ctx, MI_K_SPMM);
-    MI_TRY(spmm_win_launch(A, nx, X->d, AX->d, (const double *)thdev, R->d, (double *)sums));
+    st = spmm_win_launch(A, nx, X->d, AX->d, (const double *)thdev, R->d, (double *)sums);
+  }
+  if (st != MI_OK) {  // (the pool buffers go back on every path)
+    if (sums) pool_free(ctx, sums);
+    pool_free(ctx, thdev);
+    return st;
   }
   std::vector<double> out((size_t)nchunks * 16);
   hipError_t e = hipMemcpyAsync(out.data(), sums, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -1399,7 +1398,7 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   KScope ks(ctx, MI_K_SPMM);
   if (spmm_win_ok(A)) return spmm_win_launch(A, k, X->d, Y->d, nullptr, nullptr, nullptr);
   if (A->pk) {
-    static const int chunk = [] { const char *e = getenv("MI355OPT_SPMM_PK_CHUNK"); return e ? atoi(e) : 24; }();
+    constexpr int chunk = 24;  // (narrower column chunks measured slower: DESIGN 7.5)
     for (int c0 = 0; c0 < k;) {
       const int left = k - c0;
 #define SPMMPK(KC)                                                                                            \

@@ -424,6 +424,11 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
   const bool multi = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
   const bool folded = comm_ipc_enabled(ctx);
   const bool rows = rows_mode(ctx);
+  // a communicator of several ranks whose reductions would stay rank-local (RCCL with the slot path forced: neither
+  // folded nor rows) must not run: every norm would be a partial sum, the ranks would leave the loop at different passes
+  MI_REQUIRE(!(ctx->comm != nullptr && ctx->world_size > 1) || folded || rows,
+             "mi_lsqr on %d ranks needs the peer-memory layer or the RCCL rows mode (MI355OPT_FORCE_SLOT_PATH is set?)",
+             ctx->world_size);
   static_assert(sizeof(LsqrState) <= 256, "state slots are 256 bytes apart");
 
   mi_vec *u = nullptr, *v = nullptr, *w = nullptr, *ty = nullptr, *tx = nullptr;

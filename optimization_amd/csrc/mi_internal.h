@@ -91,6 +91,25 @@ struct CgConst {
 };
 enum CgMode { CG_RUN = 0, CG_KERNEL_PENDING = 1, CG_APPLY_SIGMA = 2, CG_DONE = 3 };
 
+// Every MI355OPT_* switch of the library.  Parsed ONCE per context, in mi_ctx_create (context.hip config_from_env):
+// nothing on an enqueue path reads the environment.  mi_ctx_set_option changes one of them on a live context (the A/B
+// tests that compare two forms of a kernel inside one process); matrix-format switches (no_packed) act when a
+// matrix is created.
+struct Config {
+  bool force_uniform_grid = false;  // FORCE_UNIFORM_GRID: kMaxGrid workgroups in every reduction-producing kernel
+  long ipc_timeout_ms = 0;          // IPC_TIMEOUT_MS: bound of the peer-memory layer's waits (0: the default, 20 s)
+  bool no_fold = false;             // NO_FOLD: separate exchange kernels instead of the folded forms (comm_ipc.h)
+  bool halo_push_late = false;      // HALO_PUSH_LATE: the folded halo push signals at the END of the direction kernel
+  bool no_packed = false;           // NO_PACKED: no value-indexed 4-byte copy of a matrix (generic 12-byte path)
+  bool no_window = false;           // NO_WINDOW: the one-pass Hessian in streaming form
+  bool no_win_bounds = false;       // NO_WIN_BOUNDS: equal runs instead of the planned ones (window kernels)
+  bool no_far_computed = false;     // NO_FAR_COMPUTED: far columns loaded from wfar
+  bool words16 = false;             // WORDS16: 16-bit window words (opt-in)
+  bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
+  bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
+  bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
+};
+
 struct KTimer {
   bool enabled = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -154,6 +173,7 @@ struct mi_ctx {
   bool force_lockstep = false;   // env MI355OPT_FORCE_LOCKSTEP=1: multi-rank enqueue rule of mi_stpcg on one GPU
   bool no_dirgram = false;       // env MI355OPT_NO_DIRGRAM=1: STPCG ignores mi_op::dirgram (two-pass Stiefel Hessian)
   bool dirgram_direct = false;   // env MI355OPT_DIRGRAM_DIRECT=1: direction-kernel Gram rows even without a preconditioner
+  mi::Config cfg;                // the other switches (parsed with the five above at creation; mi_ctx_set_option)
 };
 
 struct mi_vec {
@@ -164,13 +184,19 @@ struct mi_vec {
   // Identity of the CONTENTS, for caches keyed on "this vector as it was when I looked" (the speculative trial point
   // of mi_stiefel_rq_trial): `serial` is unique per mi_vec_create/mi_vec_view on a context (handles and pooled
   // device pointers are both recycled), `gen` is bumped by every entry point that writes the vector (mi::touch).
+  // A VIEW (mi_vec_view) shares the generation counter of the vector that owns the storage (`root`; null for an owning
+  // vector, the owner itself for a view of a view): a write through the base, through a sibling view or through the
+  // view itself invalidates whatever was cached on any of them (r04, ADVICE).  Writes through the raw pointer of
+  // mi_vec_data are invisible to the library: the caller announces them with mi_vec_touch.
   uint64_t serial = 0;
   uint64_t gen = 0;
+  mi_vec *root = nullptr;
 };
 namespace mi {
 inline void touch(mi_vec *v) {
-  if (v) ++v->gen;
+  if (v) ++(v->root ? v->root : v)->gen;
 }
+inline uint64_t gen_of(const mi_vec *v) { return (v->root ? v->root : v)->gen; }
 }  // namespace mi
 
 namespace mi {

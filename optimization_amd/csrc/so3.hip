@@ -297,7 +297,7 @@ struct mi_so3n {
   const double *trial_d = nullptr;
   uint64_t trial_serial = 0, trial_gen = 0;
   bool is_trial(const mi_vec *X) const {
-    return trial_R == X && trial_d == X->d && trial_serial == X->serial && trial_gen == X->gen;
+    return trial_R == X && trial_d == X->d && trial_serial == X->serial && trial_gen == gen_of(X);
   }
 };
 
@@ -313,8 +313,7 @@ int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int 
   const size_t ngroups = (q->nslices + kWaves - 1) / kWaves;
   const int grid = uniform_grid(ctx, ngroups);
   KScope ks(ctx, MI_K_BSR3_SPMV_DOTS);
-  const char *nt_env = getenv("MI355OPT_BSR3_NT");  // (per call: A/B runs in one process)
-  const bool nt = nt_env ? nt_env[0] == '1' : kBsr3NtDefault;
+  constexpr bool nt = kBsr3NtDefault;
 #define BSR3(DV, NTV, STATE, PART)                                                                               \
   hipLaunchKernelGGL((k_bsr3_spmv<DV, NTV>), dim3(grid), dim3(kBlock), 0, ctx->stream, view(q), STATE,          \
                      (const double *)q->Dsl, (const double *)q->Bblk, (const double *)in->d, out->d, PART)
@@ -597,7 +596,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   q->trial_R = R_trial;
   q->trial_d = R_trial->d;
   q->trial_serial = R_trial->serial;
-  q->trial_gen = R_trial->gen;
+  q->trial_gen = gen_of(R_trial);
   return MI_OK;
 }
 

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_sub_scaled_stream(SellView A, c
 // 90 % of the entries the widest would -- provided that is at least one off-diagonal entry per row on average (a
 // matrix without such a band, e.g. a random graph, keeps the plain gather kernels), every slice is at most kWinHead
 // entries wide, every row has at most kFarCap entries outside the window, and 0.0 has (or can get) a place in the
-// value table.  MI355OPT_WIN_CHUNKS=k forces k (0 switches the window form off).
+// value table.
 int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const int32_t *col,
                  const std::vector<long long> &sp, const std::vector<uint32_t> &pk, std::vector<double> &table,
                  int ntable, size_t halo_lo, size_t halo_hi) {
@@ -205,11 +205,7 @@ int build_window(mi_csr *A, size_t n, size_t nnz, const int32_t *rowptr, const i
   const int ncand = 3, cand[ncand] = {1, 2, 4};
   static_assert(kMaxWinChunks <= 4, "candidates");
   int wc = 0;
-  if (const char *e = getenv("MI355OPT_WIN_CHUNKS")) {
-    wc = atoi(e);
-    if (wc <= 0) return MI_OK;
-    if (wc > kMaxWinChunks) wc = kMaxWinChunks;
-  } else {
+  {
     size_t near[ncand] = {0, 0, 0};
     for (size_t r = 0; r < n; ++r)
       for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
@@ -391,9 +387,9 @@ int build_sell(mi_ctx *ctx, size_t n, size_t ncols, size_t nnz, const int32_t *r
   MI_TRY(upload((void **)&A->val, pval.data(), stored * sizeof(double)));
   // value-indexed packed copy (mi_csr::pk): distinct stored values by BIT PATTERN (so -0.0, NaN payloads
   // and denormals survive), column as a signed 24-bit offset from the row
-  // (read at every creation, not once: bench.py builds the same matrix both ways in one process)
-  const char *no_pack_env = getenv("MI355OPT_NO_PACKED");
-  const bool no_pack = no_pack_env && no_pack_env[0] == '1';
+  // (the context's switch as it stands at THIS creation: mi_ctx_set_option("NO_PACKED") between two creations builds
+  // the same matrix both ways in one process)
+  const bool no_pack = A->ctx->cfg.no_packed;
   if (!no_pack) {
     std::unordered_map<uint64_t, int> index;
     std::vector<double> table;
@@ -527,8 +523,7 @@ std::vector<int> window_runs(int ntiles, int max_wgs, int num_cu, size_t far_str
 // workgroup -> first tile table on the device
 int window_bounds(mi_ctx *ctx, const mi_csr *A, int wgs, int ntiles, int *grid, const int **bounds_out) {
   *bounds_out = nullptr;
-  const char *off_env = getenv("MI355OPT_NO_WIN_BOUNDS");  // (per call: tests compare the plans in one process)
-  const bool off = off_env && off_env[0] == '1';
+  const bool off = ctx->cfg.no_win_bounds;
   const int key = off ? -wgs : wgs;
   auto it = A->win_plans.find(key);
   if (it == A->win_plans.end()) {
@@ -554,7 +549,7 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
   const int grid = (int)std::min<size_t>(ngroups, kMaxGrid);
   SellView view = sell_view(A);
   KScope ks(ctx, MI_K_SPMM);
-  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  const bool no_stream = ctx->cfg.no_spmm_stream;
   if (!no_stream && p >= 1 && p <= 4 && sell_stream_ok(A, p)) {
     const int sgrid = (int)std::min<size_t>(ngroups, 256);  // one workgroup per CU, one round
 #define SS(PV, HL, PKV) \
@@ -621,7 +616,7 @@ int csr_spmv_sub_scaled(const mi_csr *A, const mi_vec *V, const double *scale, c
   MI_TRY(comm_halo_exchange(ctx, A, 1, V->d));
   int grid = uniform_grid(ctx, sell_groups(A));
   KScope ks(ctx, MI_K_SPMM);
-  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  const bool no_stream = ctx->cfg.no_spmm_stream;
   if (!no_stream && sell_stream_ok(A, 1)) {
     if (!ctx->uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
 #define SV(HL, PKV)                                                                                          \

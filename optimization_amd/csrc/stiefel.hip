@@ -529,7 +529,7 @@ int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, con
   MI_TRY(comm_halo_exchange(ctx, A, p, V));
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
-  static const bool no_stream = [] { const char *e = getenv("MI355OPT_NO_SPMM_STREAM"); return e && e[0] == '1'; }();
+  const bool no_stream = ctx->cfg.no_spmm_stream;
   if (!no_stream && sell_stream_ok(A, p)) {
     if (!ctx->uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
 #define SG(HL, PKV)                                                                                            \
@@ -613,10 +613,10 @@ struct mi_stiefel_rq {
     trial_X = Xt;
     trial_d = Xt->d;
     trial_serial = Xt->serial;
-    trial_gen = Xt->gen;
+    trial_gen = gen_of(Xt);
   }
   bool is_trial(const mi_vec *X) const {
-    return trial_X == X && trial_d == X->d && trial_serial == X->serial && trial_gen == X->gen;
+    return trial_X == X && trial_d == X->d && trial_serial == X->serial && trial_gen == gen_of(X);
   }
 };
 
@@ -672,7 +672,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const int p = q->p;
   // one workgroup per CU and one round (the kernel needs > 64 VGPRs: a second round would only repeat the
   // prologue); the rows mode of several ranks needs the uniform 512-row partial layout instead
-  static const int cap = [] { const char *e = getenv("MI355OPT_HESS_GRID"); return e ? atoi(e) : 256; }();
+  constexpr int cap = 256;
   int grid = uniform_grid(ctx, sell_groups(A));
   if (!ctx->uniform_grid && grid > cap) grid = cap;
   double *slots = ctx->scalars + SLOT_GRAM;
@@ -680,30 +680,21 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   const bool sharded = slot_mode(ctx) && !recur;
   const bool halo = A->halo != nullptr;
   // the window form when the matrix qualifies (decided at creation, sparse.hip build_window); p = 4 does not fit
-  const char *no_win_env = getenv("MI355OPT_NO_WINDOW");  // (per call: the tests compare both forms in one process)
-  const bool no_win = no_win_env && no_win_env[0] == '1';
+  const bool no_win = ctx->cfg.no_window;
   const int wc = (no_win || p > 3 || !A->wk) ? 0 : A->win_chunks;
   // (computed far columns: matrices whose far entries are all at row +- D, not sharded, D in 32 bits)
-  const char *no_fard_env = getenv("MI355OPT_NO_FAR_COMPUTED");
-  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) &&
-                    !(no_fard_env && no_fard_env[0] == '1');
+  const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
   // 16-bit words: opt-in (MI355OPT_WORDS16=1).  On cfg2 they shorten the pass by ~1 us (25.9 -> 24.9 us) by halving
   // the matrix stream (28 -> 16 MB of 132 MB); the pass then runs at the same ~5.5 TB/s of a smaller total.
-  const char *w16_env = getenv("MI355OPT_WORDS16");
-  const bool w16 = fard && !A->halo && A->wk16 && w16_env && w16_env[0] == '1';
+  const bool w16 = fard && !A->halo && A->wk16 && ctx->cfg.words16;
   WinView wv{A->wk, A->wfar, wc, 2 * kWinWaves + 2 * wc, A->win_zero, nullptr, fard ? (unsigned)A->win_far_pure : 0u,
              A->wk16};
-#ifdef MI_WIN_DEBUG
-  if (const char *e = getenv("MI355OPT_WIN_DEBUG")) wv.wc |= atoi(e) << 8;
-#endif
   const bool win = recur && wc > 0;
   if (win && !ctx->uniform_grid) {  // planned runs of whole tiles (sparse.hip window_bounds)
-    static const int win_wgs = [] { const char *e = getenv("MI355OPT_WIN_WGS"); return e ? atoi(e) : 0; }();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
     // the workgroup budget: what is resident at once (one round), at most kMaxRows partial rows
     const int occ = std::min(window_occupancy(p, halo, A->win_head <= 7 ? 7 : 8, fard), kWaves / kWinWaves);
     int wgs = std::min(cap * occ, kMaxRows);
-    if (win_wgs > 0) wgs = std::min(win_wgs, kMaxRows);
     // (one-GPU rehearsals of several ranks: the pass waits for its neighbours in its prologue, so -- like the CG
     // kernels -- it must leave room for their kernels while it does; mi_internal.h mi_ctx::max_grid)
     if (ctx->max_grid < kMaxGrid) wgs = std::min(wgs, ctx->max_grid);  // (lowered explicitly: MI355OPT_MAX_GRID)

@@ -280,7 +280,8 @@ def test_bench_falls_back_to_rccl_when_the_peer_memory_layer_fails_verification(
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "falling back to RCCL" in r.stderr
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "RCCL (all-reduce of partial rows" in d["config"]["parallelism"] and d["value"] > 500
+    assert d["comm_layer"] == "rccl" and "RCCL" in d["config"]["parallelism"] and d["value"] > 500
+    assert [leg["verified"] for leg in d["comm_ab_legs"]] == [False, False, True]
 
 
 def test_peer_memory_wait_is_bounded_and_fails_loudly():
@@ -443,3 +444,70 @@ def test_fused_lsqr_row_sharded_matches_the_single_context_solve(world):
                 assert abs(float.fromhex(outs[0][m]["xnorm"]) - one["xnorm"]) <= 1e-11 * max(one["xnorm"], 1e-300)
     finally:
         c.close()
+
+
+# ---- cross-device: these run the first time the suite meets a box with >= 2 GPUs (r04) -----------------------------
+def _ngpus():
+    try:
+        from optimization_amd import capi
+        return capi.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs (cross-device RCCL / xGMI peer memory)")
+@pytest.mark.parametrize("layer", ["rccl", "peer", "peer-separate"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cross_device_exchange_layers(world, layer):
+    """Rank r on GPU r: RCCL with more than one rank (ncclAllReduce of the partial rows, ncclSend / ncclRecv halo) and the
+    peer-memory layer over real xGMI links (folded and with separate exchange kernels), each against the
+    single-context solve: sharded products bit-identical to the global one over three exchanges in a row, the fused
+    STPCG with the same exits and counts, the step to 1e-10, every replicated scalar bit-identical on all ranks."""
+    if _ngpus() < world:
+        pytest.skip(f"needs {world} GPUs")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "xdev_worker.py")]
+        env = dict(os.environ, XDEV_WORKER_OUT=tmp, XDEV_LAYER=layer)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
+    assert len({o["device"] for o in outs}) >= 1 and all(o["rccl_nranks"] == world for o in outs)
+    if layer != "rccl":
+        assert all(o["enabled"] for o in outs), "peer-memory layer did not come up (self-test incl. the folded forms)"
+    for o in outs:
+        assert o["ipc_error"] == 0
+        assert o["dot_err"] < 1e-13 and o["spmm0_equal"] and o["spmm1_equal"] and o["spmm2_equal"], o
+        assert o["f_err"] < 1e-12 and o["g_err"] < 1e-12 and o["s_err"] < 1e-10, o
+        assert (o["iters"], o["exit"]) == (o["iters_ref"], o["exit_ref"])
+        assert (o["b_iters"], o["b_exit"]) == (o["b_iters_ref"], o["b_exit_ref"])
+        assert abs(float.fromhex(o["M"]) - o["M_ref"]) <= 1e-10 * abs(o["M_ref"]) and o["same_s"]
+    for k in ("dot", "f", "M", "b_M", "iters", "hvp1", "hvp5", "alpha"):   # replicated: the same bits on every rank
+        assert all(o[k] == outs[0][k] for o in outs), k
+    if layer == "peer":      # folded: the layer launches nothing of its own per iteration
+        assert all(o["comm_kernels"][2] >= o["iters"] - 1 for o in outs), [o["comm_kernels"] for o in outs]
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bare_bench_command_self_launches_its_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it (r04): re-executes itself under torch.distributed.run, one
+    rank per GPU -- on this box, with fewer GPUs than ranks, as the one-GPU functional rehearsal -- and prints exactly
+    one JSON line with the exchange-layer A/B legs of the N-rank run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "60", "--warmup", "5",
+           "--wakeup-steps", "100", "--ab-steps", "60"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 60 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["rehearsal_one_gpu"] == (_ngpus() < n)
+    legs = {leg["layer"]: leg for leg in d["comm_ab_legs"]}
+    assert "peer" in legs and "peer-separate" in legs and (d["rehearsal_one_gpu"] or "rccl" in legs)
+    assert all(leg["verified"] and leg["ipc_error"] == 0 and leg["us_per_step"] > 0 for leg in legs.values()), legs
+    assert d["comm_layer"] in legs and d["comm_layer_choice"].startswith("fastest")
+    assert legs["peer"]["own_launches_per_step"]["scalar_exchange_kernels"] < 0.2            # folded: none per step
+    assert legs["peer-separate"]["own_launches_per_step"]["scalar_exchange_kernels"] >= 2    # two per iteration
+    if not d["rehearsal_one_gpu"]:
+        assert d["rccl_nranks"] == n

@@ -71,13 +71,15 @@ def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, mo
     A = ctx.csr(n, rowptr, col, val)
     X = np.random.default_rng(n + k).normal(size=(n, k))
     Xd = ctx.upload(np.asfortranarray(X).ravel(order="F"))
-    monkeypatch.delenv("MI355OPT_NO_SPMM_WIN", raising=False)
-    Yw = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
-    monkeypatch.setenv("MI355OPT_NO_FAR_COMPUTED", "1")  # far columns loaded from wfar instead of computed
-    Yl = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
-    monkeypatch.delenv("MI355OPT_NO_FAR_COMPUTED")
-    monkeypatch.setenv("MI355OPT_NO_SPMM_WIN", "1")
-    Yg = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    try:
+        ctx.set_option("NO_SPMM_WIN", 0)
+        Yw = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+        ctx.set_option("NO_FAR_COMPUTED", 1)  # far columns loaded from wfar instead of computed
+        Yl = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+        ctx.set_option("NO_FAR_COMPUTED", 0).set_option("NO_SPMM_WIN", 1)
+        Yg = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+    finally:
+        ctx.set_option("NO_FAR_COMPUTED", 0).set_option("NO_SPMM_WIN", 0)
     assert np.array_equal(Yw, Yg) and np.array_equal(Yw, Yl)
     ref = sps.csr_matrix((val, col, rowptr), shape=(n, n)) @ X
     assert np.abs(Yw - ref).max() <= 1e-14 * np.abs(ref).max()
@@ -93,15 +95,16 @@ def test_panel_update_on_the_matrix_pipe_has_the_bits_of_the_vector_kernel(ctx, 
     S = rng.normal(size=(m, ks))
     Cm = rng.normal(size=(ks, 48))
     Sd = ctx.upload(np.asfortranarray(S).ravel(order="F"))
-    monkeypatch.delenv("MI355OPT_NO_UPDATE_MFMA", raising=False)
     Y1 = ctx.lobpcg_update(m, Sd, ks, Cm).numpy().reshape(48, m).T
-    monkeypatch.setenv("MI355OPT_NO_UPDATE_MFMA", "1")
-    Y0 = ctx.lobpcg_update(m, Sd, ks, Cm).numpy().reshape(48, m).T
+    try:
+        ctx.set_option("NO_UPDATE_MFMA", 1)
+        Y0 = ctx.lobpcg_update(m, Sd, ks, Cm).numpy().reshape(48, m).T
+    finally:
+        ctx.set_option("NO_UPDATE_MFMA", 0)
     assert np.array_equal(Y0, Y1)
     ref = S @ Cm
     assert np.abs(Y1 - ref).max() <= 1e-13 * np.abs(ref).max()
     # two destinations (X and P of an iteration) through the same kernels
-    monkeypatch.delenv("MI355OPT_NO_UPDATE_MFMA", raising=False)
     Ya, Yb = ctx.lobpcg_update2(m, Sd, ks, Cm, 24)
     assert np.array_equal(Ya.numpy().reshape(24, m).T, Y1[:, :24])
     assert np.array_equal(Yb.numpy()[:m * 24].reshape(24, m).T, Y1[:, 24:])

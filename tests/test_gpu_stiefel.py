@@ -534,6 +534,44 @@ def test_speculative_trial_model_is_keyed_on_the_vector_contents(ctx):
         del Y, g3
 
 
+def test_trial_cache_sees_writes_through_views_and_announced_raw_writes(ctx):
+    """a view shares the generation stamp of the vector that owns the storage, so a write through a view (or
+    through the base, for a cache keyed on a view) invalidates the speculative trial model; a write through the raw
+    pointer of mi_vec_data is invisible to the library and must be announced with mi_vec_touch."""
+    import ctypes
+    nx, ny, nz, p = 12, 10, 9, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    X = ctx.upload(wl.random_stiefel(n, p, seed=3))
+    h = ctx.stiefel_project(n, p, X, ctx.upload(np.random.default_rng(4).normal(size=(n, p)) * 1e-2))
+    other = wl.random_stiefel(n, p, seed=99)
+    g_ref = ctx.stiefel_rq(A, n, p).model(ctx.upload(other))[0].numpy()
+    # (i) write through a view of the trial vector
+    g, H = prob.model(X)
+    Xt, _ = prob.trial(X, h, g)
+    Xt.view(0, n * p).set(other)
+    assert np.array_equal(prob.model(Xt)[0].numpy(), g_ref)
+    # (ii) the cache keyed on a VIEW, the write through its base
+    g, H = prob.model(X)
+    base = ctx.vec(n * p + 8)
+    Xv = base.view(8, n * p)
+    ctx.L.mi_vec_copy(Xv.h, X.h)
+    gv, Hv = prob.model(Xv)
+    assert np.array_equal(gv.numpy(), g.numpy())
+    # (iii) a raw-pointer write, announced
+    g, H = prob.model(X)
+    Xt, _ = prob.trial(X, h, g)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    ctx.sync()
+    o = np.ascontiguousarray(other, dtype=np.float64)
+    assert hip.hipMemcpy(Xt.data_ptr(), o.ctypes.data, o.nbytes, 1) == 0
+    Xt.touch()
+    assert np.array_equal(prob.model(Xt)[0].numpy(), g_ref)
+
+
 def test_deferred_stpcg_result(ctx):
     """mi_stpcg with defer_result: no wait at the exit, s valid in stream order, scalars through mi_stpcg_collect --
     identical to the blocking call; collect after another read-back does not wait again."""

@@ -1,0 +1,96 @@
+"""One rank of the CROSS-DEVICE tests (tests/test_gpu_comm.py, skipped on a box with fewer GPUs than ranks): rank r on
+GPU r, a real RCCL communicator (ncclCommInitRank with world > 1: ncclAllReduce of the partial rows, ncclSend/ncclRecv
+halo) and the peer-memory layer over real xGMI links, one exchange layer per run (XDEV_LAYER = rccl | peer |
+peer-separate).  Every rank also solves the global problem on a plain context of its own GPU as the reference."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from optimization_amd import capi, workloads as wl  # noqa: E402  (ROCm before torch)
+
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    layer = os.environ.get("XDEV_LAYER", "rccl")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = capi.Context(int(os.environ.get("LOCAL_RANK", rank)))
+    uid = [c.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    c.comm_init(world, rank, uid[0])
+    out = {"rank": rank, "layer": layer, "rccl_nranks": c.comm_rccl_count(), "device": c.device_name()}
+    if layer != "rccl":
+        out["enabled"] = c.enable_peer_memory(world, rank, dist, force=True)   # incl. the folded-form self-test
+        if out["enabled"]:
+            c.comm_ipc_fold(layer == "peer")
+    nx, ny, nz, p = 40, 36, 8 * world + 3, 3          # uneven slabs, halo = one 40 x 36 plane
+    n = nx * ny * nz
+    slabs = wl.shard_rows(nz, world)
+    starts = [nx * ny * a for a, _ in slabs] + [n]
+    r0, r1 = starts[rank], starts[rank + 1]
+    rng = np.random.default_rng(23)
+    V = rng.normal(size=(n, p))
+    W = rng.normal(size=(n, p))
+    # scalar all-reduce
+    d = c.upload(V[r0:r1]).dot(c.upload(W[r0:r1]))
+    out["dot"] = float(d).hex()
+    out["dot_err"] = abs(d - float(np.sum(V * W))) / abs(float(np.sum(V * W)))
+    # halo exchange: the sharded product has the bits of the global one (entry-by-entry rounding in storage order)
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    rp, colg, vl = wl.laplacian_3d(nx, ny, nz, z_range=slabs[rank])
+    dist.barrier()
+    A = c.csr_sharded(n, r0, r1, rp, colg, vl, starts)
+    c1 = capi.Context(int(os.environ.get("LOCAL_RANK", rank)))
+    A1 = c1.csr(n, rowptr, col, val)
+    for k, F in enumerate((V, W, V + W)):   # three exchanges in a row: flags / double buffering must advance
+        Y = A.spmm(p, c.upload(F[r0:r1])).numpy()
+        Y1 = A1.spmm(p, c1.upload(F)).numpy().reshape(n, p)[r0:r1].ravel()
+        out[f"spmm{k}_equal"] = bool(np.array_equal(Y, Y1))
+    # sharded Stiefel model + fused STPCG (residual exit with run-ahead 1 and 5, boundary exit)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
+    prob = c.stiefel_rq(A, r1 - r0, p)
+    X = c.upload(Xb[r0:r1])
+    out["f"] = float(prob.objective(X)).hex()
+    g, H = prob.model(X)
+    k0 = c.comm_kernel_launches()
+    res = {ra: c.stpcg(g, H, Delta=1e3, max_iterations=40, kappa_fgr=1e-9, theta=1.0, run_ahead=ra, trace_cap=64)
+           for ra in (1, 5)}
+    k1 = c.comm_kernel_launches()
+    r = res[1]
+    rb = c.stpcg(g, H, Delta=1e-3, max_iterations=25)
+    out.update(iters=r["iterations"], exit=r["exit_reason"], M=float(r["M_norm"]).hex(), hvp1=res[1]["hvp_calls"],
+               hvp5=res[5]["hvp_calls"], same_s=bool(np.array_equal(res[1]["s"].numpy(), res[5]["s"].numpy())),
+               alpha=[float(a).hex() for a in r["trace"]["alpha"]], b_iters=rb["iterations"], b_exit=rb["exit_reason"],
+               b_M=float(rb["M_norm"]).hex(), comm_kernels=[b - a for a, b in zip(k0, k1)],
+               ipc_error=c.comm_ipc_error())
+    # reference on this rank's own GPU
+    prob1 = c1.stiefel_rq(A1, n, p)
+    X1 = c1.upload(Xb)
+    f1 = prob1.objective(X1)
+    g1, H1 = prob1.model(X1)
+    r1s = c1.stpcg(g1, H1, Delta=1e3, max_iterations=40, kappa_fgr=1e-9, theta=1.0)
+    r1b = c1.stpcg(g1, H1, Delta=1e-3, max_iterations=25)
+    sref = r1s["s"].numpy().reshape(n, p)
+    out.update(f_err=abs(float.fromhex(out["f"]) - f1) / abs(f1),
+               g_err=float(np.abs(g.numpy().reshape(-1, p) - g1.numpy().reshape(n, p)[r0:r1]).max() / np.abs(g1.numpy()).max()),
+               s_err=float(np.abs(r["s"].numpy().reshape(-1, p) - sref[r0:r1]).max() / np.abs(sref).max()),
+               iters_ref=r1s["iterations"], exit_ref=r1s["exit_reason"], M_ref=r1s["M_norm"],
+               b_iters_ref=r1b["iterations"], b_exit_ref=r1b["exit_reason"])
+    c1.close()
+    dist.barrier()
+    c.comm_finalize()
+    c.close()
+    with open(os.path.join(os.environ["XDEV_WORKER_OUT"], f"rank{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
