@@ -162,6 +162,30 @@ MI_API int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *us
 /* rectangular operator (n_in -> n_out), e.g. a Jacobian and its adjoint for LSQR / TNLS */
 MI_API int mi_op_create_callback_rect(mi_ctx *ctx, size_t n_in, size_t n_out, mi_apply_fn fn, void *user,
                                       mi_op **out);
+/* A USER operator with the solver's reductions inside its own pass (r04).  The whole point of the reference is the
+ * user-supplied Hessian (`H(p)` at IterativeSolvers.h:294, bound from the caller's QuadraticModel at TNT.h:400-426); a
+ * plain callback operator pays a separate 2N-byte pass for the three curvature inner products of :300,305-306.  A
+ * fused callback leaves them behind itself, like the built-in operators do: next to out = Op(in) the user's kernel
+ * writes, for each of its workgroups b in [0, rows), the workgroup's partial sums of
+ *     component 0: <in, out>     component 1: <out, out>     component 2: <in, in>
+ * at args->partials[c * args->partial_stride + b] (fp64, EVERY row in [0, rows) written, zeros for idle workgroups) and
+ * reports `rows`.  Contract: 1 <= rows <= args->max_rows; if args->required_rows > 0 (several ranks with RCCL: every
+ * rank must leave the same number of rows) rows must equal it; the partial sums must be deterministic (fixed-order
+ * reduction inside the workgroup, no atomics) because every workgroup of the consuming kernel re-reduces the rows in a
+ * fixed order and all of them must obtain the same bits.  Everything is enqueued on args->stream (the context's
+ * stream), nothing may synchronise.  With such an operator a fused STPCG iteration is three launches for ANY HIP
+ * operator: the user's pass, k_cg_update, k_cg_pupdate.  `fn` is the same product without the sums (mi_op_apply, the
+ * `dm` product of TNT.h:512).  examples/stpcg_user_stencil.hip is a complete client. */
+typedef struct mi_fused_args {
+  double *partials;      /* device; component-major partial rows */
+  size_t partial_stride; /* doubles between components */
+  int max_rows;          /* at most this many workgroups may leave a row */
+  int required_rows;     /* > 0: exactly this many rows */
+  void *stream;          /* hipStream_t of the context */
+} mi_fused_args;
+typedef int (*mi_apply_fused_fn)(void *user, const mi_vec *in, mi_vec *out, const mi_fused_args *args, int *rows);
+MI_API int mi_op_create_callback_fused(mi_ctx *ctx, size_t n, mi_apply_fn fn, mi_apply_fused_fn fused, void *user,
+                                       mi_op **out);
 MI_API int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out);           /* Hp = d .* p */
 MI_API int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out);     /* Hp = A p    */
 MI_API int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out);
@@ -349,6 +373,12 @@ MI_API int mi_lobpcg_gram_split(mi_ctx *ctx, size_t m, int k, const mi_vec *S, i
 MI_API int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
                                const mi_vec *Ta2, int k1b, const mi_vec *Tb1, const mi_vec *Tb2, double *Ga_host,
                                double *Gb_host);
+/* The same for the case every LOBPCG iteration without a B operator is in: G_a = S' [Ta1 | Ta2] with T = A S for a
+ * SYMMETRIC operator A (the reference's SymmetricLinearOperator, LOBPCG.h:131-134) and G_b = S' S, LOBPCG.h:271-272.
+ * Both are symmetric; only the upper block triangle of each is formed (16 x 16 tiles; the lower block triangle is its
+ * mirror image, which is also all the reference's eigensolver reads), from ONE pass over S and T.  Ta2 may be null. */
+MI_API int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
+                                   const mi_vec *Ta2, double *Ga_host, double *Gb_host);
 /* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
 MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
                             const double *C_host, int ldc, mi_vec *Y);
@@ -363,6 +393,11 @@ MI_API int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, c
                               double *xnorm);
 /* Rayleigh-Ritz on the host (ns <= 96): LOBPCG.h:53-62.  Theta ascending, C'AC = Theta, C'BC = I */
 MI_API int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, double *C);
+/* The k LOWEST Ritz pairs only: Theta[k] ascending, C n x k column-major with C'AC = diag(Theta), C'BC = I.  An LOBPCG
+ * iteration reads nx of the ns <= 3 nx pairs (LOBPCG.h:278,288,293-318); same reduction, same QL recurrence (the Ritz
+ * values have the bits of mi_rayleigh_ritz), the vectors from the recorded rotations applied to k columns instead of n
+ * (they agree with the full solver's columns to rounding).  Host, like mi_rayleigh_ritz. */
+MI_API int mi_rayleigh_ritz_lowest(int n, int k, const double *A, const double *B, double *Theta, double *C);
 /* Y (n x k column-major) = A X : the sparse operator of LOBPCG clients (called at LOBPCG.h:213,218,267,281) */
 MI_API int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y);
 /* AX (n x nx) = A X (LOBPCG.h:281) together with R = AX - X diag(theta) (:285, B absent so BX = X) and the column norms

@@ -165,10 +165,56 @@ def build_harness(force=False):
             if r.returncode != 0:
                 raise RuntimeError(f"example build failed ({src}):\n" + r.stderr[-6000:])
         out.append(exe)
+    # examples/*.hip: clients that bring HIP kernels of their own (a user-written Hessian-vector product): hipcc
+    for src in sorted(glob.glob(os.path.join(exdir, "*.hip"))):
+        exe = os.path.join(exdir, "bin", os.path.splitext(os.path.basename(src))[0])
+        if force or _newer(src, exe, hdrs + [LIB]):
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-std=c++17", "-O2", "-Wall"] + inc + \
+                  ["-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", HERE, "-lmi355opt",
+                   "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"example build failed ({src}):\n" + r.stderr[-6000:])
+        out.append(exe)
     return out
+
+
+def build_sanitize(force=False, run=True):
+    """tests/cpp/sanitize_host: the template layer on a host vector (the host harness's translation unit + a main that
+    drives TNT, GradientDescent, LSQR, TNLS, LOBPCG once) under -fsanitize=address,undefined; run here, any report is a
+    build failure (the sanitizer / host-hardening target)."""
+    tdir = os.path.join(ROOT, "tests", "cpp")
+    odir = os.path.join(ROOT, "oracle")
+    exe = os.path.join(tdir, "sanitize_host")
+    src = os.path.join(tdir, "sanitize_host.cpp")
+    deps = glob.glob(os.path.join(HERE, "include", "Optimization", "*", "*.h")) + glob.glob(os.path.join(odir, "*.inc")) + \
+        glob.glob(os.path.join(odir, "*.[ch]")) + [os.path.join(tdir, "harness_host.cpp")]
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1",
+           "-ffp-contract=off"]
+    if force or _newer(src, exe, deps):
+        objs = []
+        for c in ("oracle.c", "problems.c"):
+            o = os.path.join(tdir, "san_" + c + ".o")
+            r = subprocess.run(["gcc"] + san + ["-I", odir, "-c", os.path.join(odir, c), "-o", o],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("sanitizer build failed:\n" + r.stderr[-4000:])
+            objs.append(o)
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wno-type-limits"] + san +
+                           ["-I", os.path.join(HERE, "include"), "-I", odir, "-I", tdir, src] + objs + ["-lm", "-o", exe],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("sanitizer build failed:\n" + r.stderr[-6000:])
+    if run:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+        if r.returncode != 0 or "sanitize_host: ok" not in r.stdout:
+            raise RuntimeError("the template layer failed under ASan/UBSan:\n" + r.stdout[-2000:] + r.stderr[-6000:])
+    return exe
 
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build(force=force, verbose=True))
     print(build_harness(force=force))
+    print(build_sanitize(force=force))

@@ -165,11 +165,13 @@ def load():
         "mi_lobpcg_residual": [vp, C.c_size_t, C.c_int, vp, vp, vp, c_double_p, vp, c_double_p,
                                c_double_p],
         "mi_rayleigh_ritz": [C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
+        "mi_rayleigh_ritz_lowest": [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p],
         "mi_csr_spmm_colmajor": [vp, C.c_int, vp, vp],
         "mi_csr_spmm_colmajor_residual": [vp, C.c_int, vp, c_double_p, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_split": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p],
         "mi_debug_window_runs": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)],
         "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
+        "mi_lobpcg_gram_pair_sym": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
         "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
         "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
@@ -490,6 +492,13 @@ class Context:
                                          Tb1.h, Tb2.h if Tb2 is not None else None, _dp(Ga), _dp(Gb)))
         return Ga, Gb
 
+    def lobpcg_gram_pair_sym(self, m, S, k, Ta1, k1a, Ta2):
+        """(S'[Ta1|Ta2] for a symmetric product, S'S) from one pass (mi_lobpcg_gram_pair_sym); Ta2 may be None"""
+        Ga, Gb = np.zeros((k, k), order="F"), np.zeros((k, k), order="F")
+        check(self.L.mi_lobpcg_gram_pair_sym(self.h, m, k, S.h, k1a, Ta1.h, Ta2.h if Ta2 is not None else None,
+                                             _dp(Ga), _dp(Gb)))
+        return Ga, Gb
+
     def lobpcg_update(self, m, S, ks, Cmat):
         Cmat = np.asfortranarray(Cmat, dtype=np.float64)
         kc = Cmat.shape[1]
@@ -520,6 +529,15 @@ class Context:
         th = np.zeros(n)
         Cm = np.zeros((n, n), order="F")
         check(self.L.mi_rayleigh_ritz(n, _dp(A), _dp(B), _dp(th), _dp(Cm)))
+        return th, Cm
+
+    def rayleigh_ritz_lowest(self, A, B, k):
+        A = np.asfortranarray(A, dtype=np.float64)
+        B = np.asfortranarray(B, dtype=np.float64)
+        n = A.shape[0]
+        th = np.zeros(k)
+        Cm = np.zeros((n, k), order="F")
+        check(self.L.mi_rayleigh_ritz_lowest(n, k, _dp(A), _dp(B), _dp(th), _dp(Cm)))
         return th, Cm
 
     def panel_rowscale(self, m, k, d, X):

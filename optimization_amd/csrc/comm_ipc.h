@@ -48,21 +48,23 @@ __device__ __forceinline__ bool ipc_wait(const uint64_t *flag, uint64_t want, un
   }
   return true;
 }
-// The same for waits inside a streaming kernel: the POLL is relaxed (no cache invalidation per look) and ONE
-// system-scope acquire fence follows the successful look, so that whatever is read afterwards -- by this thread or,
-// behind a workgroup barrier, by any other thread of the workgroup -- happens after the peer's release in the formal
-// model too, not only because the mailbox values are read with system-scope atomic loads that bypass the caches
-// (r04, ADVICE: the relaxed form had no acquire at all).  Measured on one rank: no change of the sharded step.
+// The same without the acquire's cache invalidation, for waits inside a streaming kernel.  What is read afterwards are
+// the mailbox VALUES, and only with system-scope atomic loads (fold_exchange_sum): those are issued behind this loop
+// (program order; from the other threads behind the workgroup barrier that follows it) and are served by memory, not
+// by a cache, so there is no stale line an acquire would have to invalidate -- the peer wrote the values before its
+// release of the flag.  A formal acquire was tried (r04, ADVICE: one system-scope acquire fence per workgroup behind
+// the successful poll = `buffer_inv sc0 sc1`): it invalidates the XCD's L2 under the streaming kernel that is running,
+// measured on the sharded step at one rank k_cg_update 17.3 -> 20.1 us and k_cg_pupdate 21.9 -> 25.4 us, the step
+// 60.8 -> 66.1 us, more than the separate exchange kernels cost (63.9).  Not kept; the cross-device behaviour of this
+// form is what the self-test of mi_comm_ipc_selftest checks between the real peers before the layer is enabled.
 __device__ __forceinline__ bool ipc_wait_relaxed(const uint64_t *flag, uint64_t want, unsigned int *err,
                                                  uint64_t timeout) {
   const uint64_t t0 = wall_clock64();
-  bool ok = true;
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-    if (ipc_give_up(wall_clock64() - t0, err, timeout)) { ok = false; break; }
+    if (ipc_give_up(wall_clock64() - t0, err, timeout)) return false;
     __builtin_amdgcn_s_sleep(1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
-  return ok;
+  return true;
 }
 // Every wave, behind its last peer store and in front of the workgroup barrier that precedes the ONE system-scope
 // release of its workgroup: wait until this wave's own vector-memory operations have completed.  A workgroup barrier

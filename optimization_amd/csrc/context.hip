@@ -146,6 +146,10 @@ int opt_max_grid(mi_ctx *c, long v) {
   c->max_grid = (int)std::min<long>(kMaxGrid, std::max<long>(1, v));
   return MI_OK;
 }
+int opt_so3_sort_nbr(mi_ctx *c, long v) {
+  c->cfg.so3_sort_nbr = (int)v;
+  return MI_OK;
+}
 int opt_ipc_timeout_ms(mi_ctx *c, long v) {
   c->cfg.ipc_timeout_ms = std::max<long>(0, v);
   return MI_OK;
@@ -157,7 +161,7 @@ const OptionDesc kOptions[] = {
     {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
-    {"NO_UPDATE_MFMA", opt_no_update_mfma},
+    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
 };
 void config_from_env(mi_ctx *ctx) {
   for (const OptionDesc &o : kOptions) {

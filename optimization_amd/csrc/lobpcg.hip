@@ -28,6 +28,7 @@
 
 namespace mi {
 int rr_host(int n, const double *A, const double *B, double *Theta, double *C);  // rr_host.cpp (g++, AVX2, no FMA)
+int rr_host_lowest(int n, int k, const double *A, const double *B, double *Theta, double *C);
 }
 
 using namespace mi;
@@ -330,6 +331,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   gram_direct_body<T, SAME, 0, NT>(mfull, m, k, S, Tm, T2, k1, wave, (size_t)gridDim.x * 4,
                                    partial + wave * (size_t)k * k);
+}
+
+// ---- both Grams of a Rayleigh-Ritz step in ONE pass over S (r04) ---------------------------------------------------
+// G_A = S' [T1 | T2] (T = A S, the operator is SYMMETRIC: LinearAlgebra/Concepts.h SymmetricLinearOperator, so G_A is
+// too) and G_B = S' S (B absent), reference LOBPCG.h:271-272, from one read of S and one of T.  The two separate
+// launches are bound by the matrix pipe on PADDED tiles, not by memory (ns = 72 -> 5 x 5 tiles of 16: S'AS 25 tiles at
+// 80 % of the measured 71.5 TF/s, S'S 15): here only the upper block triangle of BOTH is formed -- 30 tiles instead of
+// 40, the mirror image is filled by the reduction as it always was for S'S -- and S is read once instead of twice
+// (2.30 GB instead of 3.45 at ns = 72).  Upper triangle only is also what the reference's eigensolver looks at (Eigen's
+// self-adjoint solvers read one triangle of their arguments).  Per wave: 30 x 4 accumulator doubles (240 registers, the
+// compiler keeps them in the accumulation half of the 512-entry file) + two operand sets of 2 x T double4 (160): one
+// wave per SIMD (amdgpu_waves_per_eu(1, 1)); the overlap of loads and MFMAs is the software pipeline of
+// gram_direct_body (the loads of step s + 1 are issued before the 120 MFMAs of step s).
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ? 1 : 2))) void k_gram_pair_sym(
+    size_t mfull, size_t m, int k, const double *__restrict__ S, const double *__restrict__ Tm,
+    const double *__restrict__ T2, int k1, double *__restrict__ partialA, double *__restrict__ partialB) {
+  const size_t rowwave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nrow = (size_t)gridDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const size_t lane_off = 4 * (size_t)(lane >> 4);
+  const double *ps[T], *pt[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int c = std::min(16 * t + (lane & 15), k - 1);  // (clamped: products of padding columns are never stored)
+    ps[t] = S + (size_t)c * m + lane_off;
+    pt[t] = (T2 && c >= k1 ? T2 + (size_t)(c - k1) * m : Tm + (size_t)c * m) + lane_off;
+  }
+  double4v accA[T][T], accB[T][T];  // (only a <= b is used)
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      accA[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
+      accB[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
+    }
+  const size_t band = 16 * nrow;
+  double4l sa[T], sb[T], na[T], nb[T];
+  size_t r0 = rowwave * 16;
+  if (r0 < mfull) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      na[t] = *reinterpret_cast<const double4l *>(ps[t] + r0);
+      nb[t] = *reinterpret_cast<const double4l *>(pt[t] + r0);
+    }
+  }
+  for (; r0 < mfull; r0 += band) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {  // the one wait of the step
+      sa[t] = na[t];
+      sb[t] = nb[t];
+    }
+    if (r0 + band < mfull) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        na[t] = *reinterpret_cast<const double4l *>(ps[t] + r0 + band);
+        nb[t] = *reinterpret_cast<const double4l *>(pt[t] + r0 + band);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int b = a; b < T; ++b) {
+          accA[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a][j], sb[b][j], accA[a][b], 0, 0, 0);
+          accB[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a][j], sa[b][j], accB[a][b], 0, 0, 0);
+        }
+  }
+  double *outA = partialA + rowwave * (size_t)k * k, *outB = partialB + rowwave * (size_t)k * k;
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = a; b < T; ++b) {
+      const int col = b * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = a * 16 + (lane >> 4) + 4 * j;
+        if (row < k && col < k) {
+          outA[(size_t)col * k + row] = accA[a][b][j];
+          outB[(size_t)col * k + row] = accB[a][b][j];
+        }
+      }
+    }
 }
 
 // rows [r_begin, m) (fewer than 16) of S'T as one more partial Gram: one thread per output element
@@ -1074,6 +1158,81 @@ int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, 
   return st != MI_OK ? st : fin;
 }
 
+// G_A = S' [Ta1 | Ta2] for a SYMMETRIC product (T = A S with a symmetric operator: G_A is symmetric and only its upper
+// block triangle is formed, the mirror image filled in) and G_B = S' S, both from ONE pass over S and T
+// (k_gram_pair_sym); one synchronisation.  Ta2 may be null (one panel of k columns).  Shapes the fused kernel does not
+// take (k > 80, unaligned panels, fewer than 16 rows) go through mi_lobpcg_gram_pair, which forms all of G_A.
+int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
+                            const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
+  MI_REQUIRE(ctx && S && Ta1 && Ga_host && Gb_host, "null argument");
+  MI_REQUIRE(k >= 1 && k <= kGramMaxK, "panel width must be in [1,%d]", kGramMaxK);
+  MI_TRY(check_panel(ctx, m, k, S, "S"));
+  if (Ta2) {
+    MI_REQUIRE(k1a >= 1 && k1a < k, "need 1 <= k1 < k");
+    MI_TRY(check_panel(ctx, m, k1a, Ta1, "T1"));
+    MI_TRY(check_panel(ctx, m, k - k1a, Ta2, "T2"));
+  } else {
+    MI_TRY(check_panel(ctx, m, k, Ta1, "T"));
+    k1a = k;
+  }
+  const bool direct = k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)Ta1->d % 32 == 0 &&
+                      (!Ta2 || (uintptr_t)Ta2->d % 32 == 0) && m >= 16;
+  if (!direct) return mi_lobpcg_gram_pair(ctx, m, k, S, k1a, Ta1, Ta2, k, S, nullptr, Ga_host, Gb_host);
+  const int nelem = k * k, kpad = (k + 15) / 16 * 16;
+  const size_t mfull = m - m % 16;
+  const int occ = kpad <= 32 ? 2 : 1;  // (resident waves per SIMD: 62+16 / 132+48 registers at 1 / 2 tiles, then > 256)
+  const size_t nwaves = (std::min<size_t>(4 * (size_t)occ * ctx->num_cu, mfull / 16) + 3) / 4 * 4;
+  const size_t nb = nwaves + (mfull < m ? 1 : 0);
+  GramJob jobs[2] = {{nullptr, nullptr, nelem}, {nullptr, nullptr, nelem}};
+  int st = MI_OK;
+  for (int i = 0; i < 2 && st == MI_OK; ++i) {
+    st = pool_alloc(ctx, nb * (size_t)nelem * sizeof(double), &jobs[i].partial);
+    if (st == MI_OK) st = pool_alloc(ctx, (size_t)nelem * sizeof(double), &jobs[i].Gdev);
+  }
+  if (st != MI_OK) {
+    for (int i = 0; i < 2; ++i) {
+      if (jobs[i].partial) pool_free(ctx, jobs[i].partial);
+      if (jobs[i].Gdev) pool_free(ctx, jobs[i].Gdev);
+    }
+    return st;
+  }
+  const double *T2 = Ta2 ? Ta2->d : nullptr;
+  {
+    KScope ks(ctx, MI_K_LOBPCG_GRAM);
+    if (mfull < m) {  // the < 16 leftover rows: one more partial Gram each
+      hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, k, k,
+                         (const double *)S->d, (const double *)Ta1->d, T2, k1a,
+                         (double *)jobs[0].partial + (nb - 1) * (size_t)nelem);
+      hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, k, k,
+                         (const double *)S->d, (const double *)S->d, (const double *)nullptr, k,
+                         (double *)jobs[1].partial + (nb - 1) * (size_t)nelem);
+    }
+#define GPS(TT)                                                                                                     \
+  hipLaunchKernelGGL((k_gram_pair_sym<TT>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, m, k,     \
+                     (const double *)S->d, (const double *)Ta1->d, T2, k1a, (double *)jobs[0].partial,              \
+                     (double *)jobs[1].partial)
+    switch (kpad / 16) {
+      case 1: GPS(1); break;
+      case 2: GPS(2); break;
+      case 3: GPS(3); break;
+      case 4: GPS(4); break;
+      default: GPS(5); break;
+    }
+#undef GPS
+  }
+  for (int i = 0; i < 2; ++i) {
+    hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + kRedElems - 1) / kRedElems), dim3(kRedElems * kRedGroups), 0,
+                       ctx->stream, (int)nb, k, nelem, 1, (const double *)jobs[i].partial, (double *)jobs[i].Gdev);
+    if (ctx->comm)
+      for (int off = 0; off < nelem && st == MI_OK; off += 4096)
+        st = comm_allreduce(ctx, (double *)jobs[i].Gdev + off, std::min(4096, nelem - off));
+  }
+  double *dst[2] = {Ga_host, Gb_host};
+  const int fin = gram_finish(ctx, jobs, 2, dst);
+  if (st == MI_OK) st = hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+  return st != MI_OK ? st : fin;
+}
+
 int mi_lobpcg_gram(mi_ctx *ctx, size_t m, int ka, int kb, const mi_vec *S, const mi_vec *T, double *G_host) {
   MI_REQUIRE(ctx && G_host, "null argument");
   MI_REQUIRE(ka >= 1 && ka <= kGramMaxK && kb >= 1 && kb <= kGramMaxK, "panel widths must be in [1,%d]", kGramMaxK);
@@ -1238,6 +1397,20 @@ int mi_rayleigh_ritz(int n, const double *A, const double *B, double *Theta, dou
   MI_REQUIRE(n >= 1 && A && B && Theta && C, "bad argument");
   // the header-only host solver of the template's generic path, compiled in its own host-only unit
   const int rc = mi::rr_host(n, A, B, Theta, C);
+  if (rc == 1) {
+    set_error("Rayleigh-Ritz: B has a non-positive diagonal entry");
+    return MI_ERR_INVALID_ARGUMENT;
+  }
+  if (rc == 2) {
+    set_error("Rayleigh-Ritz: equilibrated B is not positive definite");
+    return MI_ERR_INVALID_ARGUMENT;
+  }
+  return MI_OK;
+}
+
+int mi_rayleigh_ritz_lowest(int n, int k, const double *A, const double *B, double *Theta, double *C) {
+  MI_REQUIRE(n >= 1 && k >= 1 && k <= n && A && B && Theta && C, "bad argument");
+  const int rc = mi::rr_host_lowest(n, k, A, B, Theta, C);
   if (rc == 1) {
     set_error("Rayleigh-Ritz: B has a non-positive diagonal entry");
     return MI_ERR_INVALID_ARGUMENT;

@@ -108,6 +108,7 @@ struct Config {
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
+  int so3_sort_nbr = 0;             // SO3_SORT_NBR: mi_so3n_create orders a node's incidences by neighbour (experiment)
 };
 
 struct KTimer {

@@ -90,6 +90,38 @@ int op_csr_apply_sub_scaled(mi_op *self, const mi_vec *in, const double *scale, 
 }
 void op_csr_destroy(mi_op *self) { delete (CsrOpImpl *)self->impl; }
 
+struct FusedCallbackImpl {
+  mi_apply_fn fn;
+  mi_apply_fused_fn fused;
+  void *user;
+};
+int op_fused_callback_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  FusedCallbackImpl *c = (FusedCallbackImpl *)self->impl;
+  int s = c->fn(c->user, in, out);
+  if (s != MI_OK) set_error("operator callback returned status %d", s);
+  return s;
+}
+// out = Op(in) with the three curvature partials left by the USER's kernel (mi355opt.h mi_apply_fused_fn)
+int op_fused_callback_apply_dots(mi_op *self, const mi_vec *in, mi_vec *out, int *nparts) {
+  FusedCallbackImpl *c = (FusedCallbackImpl *)self->impl;
+  mi_ctx *ctx = self->ctx;
+  const mi_fused_args a{ctx->partials, (size_t)kMaxRows, ctx->uniform_grid ? kMaxGrid : kMaxRows,
+                        ctx->uniform_grid ? kMaxGrid : 0, (void *)ctx->stream};
+  int rows = 0;
+  int s = c->fused(c->user, in, out, &a, &rows);
+  if (s != MI_OK) {
+    set_error("fused operator callback returned status %d", s);
+    return s;
+  }
+  MI_REQUIRE(rows >= 1 && rows <= a.max_rows, "fused operator callback reported %d partial rows (allowed: 1..%d)", rows,
+             a.max_rows);
+  MI_REQUIRE(a.required_rows == 0 || rows == a.required_rows,
+             "fused operator callback reported %d partial rows, this context needs exactly %d", rows, a.required_rows);
+  *nparts = rows;
+  return MI_OK;
+}
+void op_fused_callback_destroy(mi_op *self) { delete (FusedCallbackImpl *)self->impl; }
+
 int precon_callback_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
   CallbackImpl *c = (CallbackImpl *)self->impl;
   int s = c->fn(c->user, r, v);
@@ -135,6 +167,20 @@ int mi_op_create_callback(mi_ctx *ctx, size_t n, mi_apply_fn fn, void *user, mi_
   op->apply = op_callback_apply;
   op->destroy = op_callback_destroy;
   op->impl = new CallbackImpl{fn, user};
+  *out = op;
+  return MI_OK;
+}
+
+int mi_op_create_callback_fused(mi_ctx *ctx, size_t n, mi_apply_fn fn, mi_apply_fused_fn fused, void *user,
+                                mi_op **out) {
+  MI_REQUIRE(ctx && fn && fused && out, "null argument");
+  mi_op *op = new mi_op();
+  op->ctx = ctx;
+  op->n = n;
+  op->apply = op_fused_callback_apply;
+  op->apply_dots = op_fused_callback_apply_dots;
+  op->destroy = op_fused_callback_destroy;
+  op->impl = new FusedCallbackImpl{fn, fused, user};
   *out = op;
   return MI_OK;
 }

@@ -13,4 +13,9 @@ __attribute__((target_clones("avx2", "default"), flatten))
 int rr_host(int n, const double *A, const double *B, double *Theta, double *C) {
   return Optimization::LinearAlgebra::dense::generalized_symmetric_eig(n, A, B, Theta, C);
 }
+// the nx lowest Ritz pairs only (what an LOBPCG iteration reads; DenseSymmetricEigen.h generalized_symmetric_eig_lowest)
+__attribute__((target_clones("avx2", "default"), flatten))
+int rr_host_lowest(int n, int k, const double *A, const double *B, double *Theta, double *C) {
+  return Optimization::LinearAlgebra::dense::generalized_symmetric_eig_lowest(n, k, A, B, Theta, C);
+}
 }  // namespace mi

@@ -301,6 +301,213 @@ inline int generalized_symmetric_eig(int n, const double *A, const double *B, do
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The k LOWEST eigenpairs only (r04).  An LOBPCG iteration uses nx of the ns <= 3 nx Ritz pairs of its projected
+// pencil (reference LOBPCG.h:278,288 read C(:, :nx), :293-318 Theta(:nx)); the full solver above spends two thirds of
+// its time on eigenvector columns nobody reads.  Same mathematics, same reflectors, same rotations:
+//   * Householder reduction as in sym_eigh, but the reflectors are KEPT (not accumulated into an n x n matrix);
+//   * implicit QL on (d, e) with the SAME scalar recurrence -- so the eigenvalues have the bits of the full solver --
+//     while every plane rotation (c, s, position) is recorded instead of being applied to n rows;
+//   * the wanted eigenvectors of the tridiagonal matrix are the wanted columns of the rotations' product, obtained by
+//     applying the recorded rotations in REVERSE to unit vectors (a rotation touches two entries of a vector: 6 k flops
+//     instead of 6 n), then the reflectors, then L^-T and D, all on an n x k block.
+// No inverse iteration, no re-orthogonalisation: the vectors are as orthogonal as tql2's, clusters or not (the converged
+// Ritz values of LOBPCG ARE clusters).  They agree with the full solver's columns to rounding, not to the bit.
+// 72 x 72, k = 24: 2.4 instead of 5 Mflop.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlaneRotation {
+  double c, s;
+  int i;  // acts on entries (i, i + 1)
+};
+
+inline int generalized_symmetric_eig_lowest(int n, int k, const double *A, const double *B, double *Theta, double *C) {
+  if (k > n) k = n;
+  std::vector<double> D(n), L((size_t)n * n), M((size_t)n * n), T((size_t)n * n);
+  for (int i = 0; i < n; ++i) {
+    if (!(B[i + (size_t)i * n] > 0)) return 1;
+    D[i] = 1.0 / std::sqrt(B[i + (size_t)i * n]);
+  }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      L[i + (size_t)j * n] = D[i] * B[i + (size_t)j * n] * D[j];
+      M[i + (size_t)j * n] = D[i] * A[i + (size_t)j * n] * D[j];
+    }
+  if (cholesky_lower(n, L)) return 2;
+  lower_solve_inplace(n, L, M);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) T[i + (size_t)j * n] = M[j + (size_t)i * n];
+  lower_solve_inplace(n, L, T);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) M[i + (size_t)j * n] = T[j + (size_t)i * n];
+  for (int j = 0; j < n; ++j)
+    for (int i = j + 1; i < n; ++i) {
+      const double a = .5 * (M[i + (size_t)j * n] + M[j + (size_t)i * n]);
+      M[i + (size_t)j * n] = a;
+      M[j + (size_t)i * n] = a;
+    }
+  // --- Householder tridiagonalisation, last row first: the statements of sym_eigh; reflector i stays in column i of V
+  // (rows 0 .. i-1) with its h in hs[i]
+  std::vector<double> &V = M;
+  std::vector<double> dv((size_t)n, 0.0), ev((size_t)n, 0.0), hs((size_t)n, 0.0);
+  double *d = dv.data(), *e = ev.data();
+#define VV(i, j) V[(size_t)(i) + (size_t)(j) * n]
+  for (int j = 0; j < n; ++j) d[j] = VV(n - 1, j);
+  for (int i = n - 1; i > 0; --i) {
+    double scale = 0, h = 0;
+    for (int kk = 0; kk < i; ++kk) scale += std::fabs(d[kk]);
+    if (scale == 0) {
+      e[i] = d[i - 1];
+      for (int j = 0; j < i; ++j) {
+        d[j] = VV(i - 1, j);
+        VV(i, j) = 0;
+        VV(j, i) = 0;
+      }
+    } else {
+      for (int kk = 0; kk < i; ++kk) {
+        d[kk] /= scale;
+        h += d[kk] * d[kk];
+      }
+      double f = d[i - 1];
+      double g = f > 0 ? -std::sqrt(h) : std::sqrt(h);
+      e[i] = scale * g;
+      h -= f * g;
+      d[i - 1] = f - g;
+      for (int j = 0; j < i; ++j) e[j] = 0;
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        VV(j, i) = f;
+        g = e[j] + VV(j, j) * f;
+        for (int kk = j + 1; kk < i; ++kk) {
+          g += VV(kk, j) * d[kk];
+          e[kk] += VV(kk, j) * f;
+        }
+        e[j] = g;
+      }
+      f = 0;
+      for (int j = 0; j < i; ++j) {
+        e[j] /= h;
+        f += e[j] * d[j];
+      }
+      const double hh = f / (h + h);
+      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+      for (int j = 0; j < i; ++j) {
+        f = d[j];
+        g = e[j];
+        for (int kk = j; kk < i; ++kk) VV(kk, j) -= f * e[kk] + g * d[kk];
+        d[j] = VV(i - 1, j);
+        VV(i, j) = 0;
+      }
+    }
+    hs[i] = h;
+  }
+  // diagonal of the tridiagonal matrix (what sym_eigh parks in row n-1 while it accumulates)
+  for (int i = 0; i < n; ++i) d[i] = VV(i, i);
+  // --- implicit QL on (d, e): the scalar recurrence of sym_eigh, rotations recorded
+  std::vector<PlaneRotation> rot;
+  rot.reserve((size_t)n * n);
+  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+  e[n - 1] = 0;
+  double shift = 0, tst = 0;
+  const double eps = 2.220446049250313e-16;
+  for (int l = 0; l < n; ++l) {
+    tst = std::max(tst, std::fabs(d[l]) + std::fabs(e[l]));
+    int mm = l;
+    while (mm < n - 1 && std::fabs(e[mm]) > eps * tst) ++mm;
+    if (mm > l) {
+      int guard = 0;
+      do {
+        double g = d[l];
+        double p = (d[l + 1] - g) / (2 * e[l]);
+        double r = fast_hypot(p, 1.0);
+        if (p < 0) r = -r;
+        d[l] = e[l] / (p + r);
+        d[l + 1] = e[l] * (p + r);
+        const double dl1 = d[l + 1];
+        double h = g - d[l];
+        for (int i = l + 2; i < n; ++i) d[i] -= h;
+        shift += h;
+        p = d[mm];
+        double c = 1, c2 = 1, c3 = 1, s = 0, s2 = 0;
+        const double el1 = e[l + 1];
+        for (int i = mm - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          g = c * e[i];
+          h = c * p;
+          r = fast_hypot(p, e[i]);
+          e[i + 1] = s * r;
+          s = e[i] / r;
+          c = p / r;
+          p = c * d[i] - s * g;
+          d[i + 1] = h + s * (c * g + s * d[i]);
+          rot.push_back(PlaneRotation{c, s, i});  // V(:, i), V(:, i+1) <- V(:, i) c - V(:, i+1) s,  V(:, i) s + V(:, i+1) c
+        }
+        p = -s * s2 * c3 * el1 * e[l] / dl1;
+        e[l] = s * p;
+        d[l] = c * p;
+      } while (std::fabs(e[l]) > eps * tst && ++guard < 200);
+    }
+    d[l] += shift;
+    e[l] = 0;
+  }
+  // --- the k smallest, ascending (ties by position)
+  std::vector<int> order((size_t)n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+  // W (row-major n x k: a rotation then updates two contiguous rows): column j = e_{order[j]}, rotations in reverse.
+  // With V_final = G_1 G_2 ... G_K (each G acting on two columns from the right), V_final e_p = G_1 ( ... (G_K e_p)).
+  std::vector<double> W((size_t)n * k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    Theta[j] = d[order[j]];
+    W[(size_t)order[j] * k + j] = 1.0;
+  }
+  for (size_t q = rot.size(); q-- > 0;) {
+    const double c = rot[q].c, s = rot[q].s;
+    double *wa = &W[(size_t)rot[q].i * k], *wb = wa + k;
+    for (int j = 0; j < k; ++j) {
+      const double a = wa[j], b = wb[j];
+      wa[j] = c * a + s * b;
+      wb[j] = c * b - s * a;
+    }
+  }
+  // --- the reflectors: Z = P_{n-1} ... P_1 with P_i = I - u_i u_i' / h_i on the leading i entries (the order in which
+  // sym_eigh accumulates them), so Z W = P_{n-1}( ... (P_1 W))
+  std::vector<double> gj((size_t)k);
+  for (int i = 1; i < n; ++i) {
+    const double h = hs[i];
+    if (h == 0) continue;
+    const double *u = &VV(0, i);
+    for (int j = 0; j < k; ++j) gj[j] = 0;
+    for (int r = 0; r < i; ++r) {
+      const double ur = u[r];
+      const double *wr = &W[(size_t)r * k];
+      for (int j = 0; j < k; ++j) gj[j] += ur * wr[j];
+    }
+    for (int r = 0; r < i; ++r) {
+      const double ur = u[r] / h;
+      double *wr = &W[(size_t)r * k];
+      for (int j = 0; j < k; ++j) wr[j] -= gj[j] * ur;
+    }
+  }
+#undef VV
+  // --- x = L^-T y (backward substitution, row-major block: row r -= L(i, r) * row i), C = D x
+  for (int i = n; i-- > 0;) {
+    double *wi = &W[(size_t)i * k];
+    const double lii = L[i + (size_t)i * n];
+    for (int j = 0; j < k; ++j) wi[j] /= lii;
+    for (int r = 0; r < i; ++r) {
+      const double lir = L[i + (size_t)r * n];  // L(i, r)
+      double *wr = &W[(size_t)r * k];
+      for (int j = 0; j < k; ++j) wr[j] -= lir * wi[j];
+    }
+  }
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < n; ++i) C[i + (size_t)j * n] = D[i] * W[(size_t)i * k + j];
+  return 0;
+}
+
 }  // namespace dense
 }  // namespace LinearAlgebra
 }  // namespace Optimization

@@ -181,9 +181,12 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
     const Matrix BS = !B ? Matrix() : (reuse_x ? (*B)(Srest) : (*B)(Sns));  // :268 (B absent: S'BS = S'S, no copy)
     // both Grams enqueued back to back, one read-back (:271-275)
     const Matrix none;
-    auto gg = reuse_x ? (B ? gram_pair(Sns, AX, AS, BX, BS) : gram_pair(Sns, AX, AS, Sns, none))
-                      : (B ? gram_pair(Sns, AS, none, BS, none) : gram_pair(Sns, AS, none, Sns, none));
-    auto tc = rayleigh_ritz(gg.first, gg.second);
+    // (B absent: S'A(S) and S'S from ONE pass over S, the upper block triangle of each -- A is a
+    // SymmetricLinearOperator, so both are symmetric, and one triangle is all the reference's eigensolver reads)
+    auto gg = reuse_x ? (B ? gram_pair(Sns, AX, AS, BX, BS) : gram_pair_sym(Sns, AX, AS))
+                      : (B ? gram_pair(Sns, AS, none, BS, none) : gram_pair_sym(Sns, AS, none));
+    // only the nx lowest Ritz pairs are read below (:278,288,293-318): the solver that forms just those columns
+    auto tc = rayleigh_ritz_lowest(gg.first, gg.second, nx);
     Theta = Vector(std::move(tc.first));
     const auto &C = tc.second;
 

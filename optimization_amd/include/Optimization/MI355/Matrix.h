@@ -206,6 +206,15 @@ inline std::pair<HostMatrix, HostMatrix> gram_pair(const DeviceMatrix &S, const 
                             GA.data(), GB.data()));
   return {std::move(GA), std::move(GB)};
 }
+// (S' [A1 | A2], S' S) for a SYMMETRIC product A1|A2 = A(S) (LOBPCG.h:271-272 without a B operator): one pass over S and
+// A(S), the upper block triangle of both formed and mirrored (mi_lobpcg_gram_pair_sym); A2 may be empty
+inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const DeviceMatrix &S, const DeviceMatrix &A1,
+                                                       const DeviceMatrix &A2) {
+  HostMatrix GA(S.cols(), S.cols()), GB(S.cols(), S.cols());
+  check(mi_lobpcg_gram_pair_sym(S.context(), S.rows(), (int)S.cols(), S.handle(), (int)A1.cols(), A1.handle(),
+                                A2.cols() > 0 ? A2.handle() : nullptr, GA.data(), GB.data()));
+  return {std::move(GA), std::move(GB)};
+}
 // Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
 inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size_t row0, size_t kc) {
   DeviceMatrix Y(S.context(), S.rows(), kc);
@@ -310,6 +319,17 @@ inline std::pair<HostVectorD, HostMatrix> rayleigh_ritz(const HostMatrix &A, con
   HostVectorD theta(n);
   HostMatrix C(n, n);
   check(mi_rayleigh_ritz((int)n, A.data(), B.data(), theta.data(), C.data()));
+  return std::make_pair(std::move(theta), std::move(C));
+}
+
+// the k lowest Ritz pairs only (what an LOBPCG iteration reads: LOBPCG.h:278,288,293-318); Theta has k entries, C is
+// n x k.  Same reduction and QL recurrence as rayleigh_ritz: the Ritz values have its bits, the vectors agree to rounding.
+inline std::pair<HostVectorD, HostMatrix> rayleigh_ritz_lowest(const HostMatrix &A, const HostMatrix &B, size_t k) {
+  const size_t n = A.rows();
+  if (k > n) k = n;
+  HostVectorD theta(k);
+  HostMatrix C(n, k);
+  check(mi_rayleigh_ritz_lowest((int)n, (int)k, A.data(), B.data(), theta.data(), C.data()));
   return std::make_pair(std::move(theta), std::move(C));
 }
 

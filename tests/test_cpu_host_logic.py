@@ -80,3 +80,14 @@ def test_library_rayleigh_ritz_unit_has_the_bits_of_the_header_compiled_elsewher
     scale = np.abs(th1).max()
     assert np.abs(C1.T @ A @ C1 - np.diag(th1)).max() <= 1e-10 * scale
     assert np.abs(C1.T @ B @ C1 - np.eye(n)).max() <= 1e-10
+
+
+def test_template_layer_is_clean_under_asan_and_ubsan():
+    """SURVEY.md 5 (sanitizer / host-hardening target): the drop-in headers instantiated on a host vector -- TNT with and
+    without preconditioner, GradientDescent, LSQR, TNLS with and without preconditioner, the generic LOBPCG path and its
+    Rayleigh-Ritz -- built with g++ -fsanitize=address,undefined -fno-sanitize-recover=all and run; any report (heap
+    error, leak, signed overflow, misaligned or out-of-bounds access ...) fails."""
+    from optimization_amd import build as b
+    exe = b.build_sanitize(run=True)   # raises with the sanitizer's report on any finding
+    import os
+    assert os.path.exists(exe)

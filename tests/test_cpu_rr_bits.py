@@ -40,3 +40,43 @@ def test_rayleigh_ritz_identities_on_the_integer_pencils(n):
     assert np.all(np.diff(th) >= 0)
     assert np.abs(Cm.T @ B @ Cm - np.eye(n)).max() < 1e-12
     assert np.abs(Cm.T @ A @ Cm - np.diag(th)).max() < 1e-10 * np.abs(th).max()
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 1), (5, 2), (24, 24), (48, 16), (72, 24), (96, 32), (72, 72), (60, 20)])
+def test_lowest_pairs_solver_against_the_full_one(n, k):
+    """mi_rayleigh_ritz_lowest (r04: the nx lowest Ritz pairs of the ns <= 3 nx an LOBPCG iteration reads; same
+    reduction, same QL recurrence, the recorded plane rotations applied in reverse to k unit columns instead of forward
+    to n rows): Ritz values BIT-identical to the full solver's first k, vectors equal to rounding -- also inside
+    clusters (a triple and a sextuple that differs in the 12th digit: the converged Ritz values of cfg5 are such
+    clusters), where an inverse-iteration scheme would need re-orthogonalisation -- and the reference's identities."""
+    import ctypes as C
+    from optimization_amd import capi
+    L = capi.load()
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(100 + n)
+    G = rng.normal(size=(n + 5, n))
+    B = G.T @ G + 0.1 * np.eye(n)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.sort(rng.uniform(0.1, 3.0, size=n))
+    if n >= 24:
+        lam[3:6] = lam[3]
+        lam[10:16] = lam[10] * (1 + 1e-12 * np.arange(6))
+    Lc = np.linalg.cholesky(B)
+    A = Lc @ (Q * lam) @ Q.T @ Lc.T
+    A = np.asfortranarray(.5 * (A + A.T))
+    B = np.asfortranarray(B)
+    th, Cm = np.zeros(n), np.zeros((n, n), order="F")
+    assert L.mi_rayleigh_ritz(n, A.ctypes.data_as(dp), B.ctypes.data_as(dp), th.ctypes.data_as(dp), Cm.ctypes.data_as(dp)) == 0
+    L.mi_rayleigh_ritz_lowest.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
+    tl, Cl = np.zeros(k), np.zeros((n, k), order="F")
+    assert L.mi_rayleigh_ritz_lowest(n, k, A.ctypes.data_as(dp), B.ctypes.data_as(dp), tl.ctypes.data_as(dp),
+                                     Cl.ctypes.data_as(dp)) == 0
+    assert np.array_equal(tl, th[:k])
+    assert np.abs(Cl - Cm[:, :k]).max() <= 1e-13 * np.abs(Cm).max()
+    assert np.abs(Cl.T @ B @ Cl - np.eye(k)).max() < 1e-12
+    assert np.abs(Cl.T @ A @ Cl - np.diag(tl)).max() < 1e-11 * np.abs(th).max()
+    # the reference's argument behaviour: a B that is not positive definite is an error, not a wrong answer
+    Bbad = B.copy()
+    Bbad[0, 0] = -1.0
+    assert L.mi_rayleigh_ritz_lowest(n, k, A.ctypes.data_as(dp), Bbad.ctypes.data_as(dp), tl.ctypes.data_as(dp),
+                                     Cl.ctypes.data_as(dp)) != 0

@@ -131,6 +131,40 @@ def test_gram_pair_with_one_synchronisation_has_the_bits_of_the_separate_grams(c
     assert np.abs(Ga - ref).max() <= 1e-12 * np.abs(ref).max() * max(1, np.sqrt(m) / 10)
 
 
+@pytest.mark.parametrize("m,k,k1", [(100_004, 48, 24), (200_012, 72, 24), (65_540, 72, 24), (40_000, 66, 22),
+                                    (30_008, 24, 0), (5_000, 16, 0), (1001, 10, 3), (126 ** 3, 72, 24)])
+def test_fused_symmetric_gram_pair(ctx, m, k, k1):
+    """mi_lobpcg_gram_pair_sym (r04): S'[A(S)] for a symmetric A and S'S from ONE pass over S and A(S), the upper block
+    triangle of each formed and mirrored -- against numpy with the operator of the test's own making (a diagonal one, so
+    S'A S is symmetric), against the separate full Grams, and for exact symmetry across the 16 x 16 tile blocks.  The
+    shapes: the direct kernel at 2, 3 and 5 tiles, a width that is no multiple of 16, leftover rows (m % 16 != 0), one
+    piece and two pieces, cfg5's full size, and the fallback for shapes the fused kernel does not take (m odd)."""
+    rng = np.random.default_rng(m % 9973 + k)
+    S = rng.normal(size=(m, k))
+    d = rng.uniform(0.5, 3.0, size=m)
+    AS = d[:, None] * S
+    Sd = ctx.upload(np.asfortranarray(S).ravel(order="F"))
+    if k1:
+        A1, A2 = ctx.upload(np.asfortranarray(AS[:, :k1]).ravel(order="F")), ctx.upload(np.asfortranarray(AS[:, k1:]).ravel(order="F"))
+    else:
+        A1, A2 = ctx.upload(np.asfortranarray(AS).ravel(order="F")), None
+    s0 = ctx.sync_count()
+    Ga, Gb = ctx.lobpcg_gram_pair_sym(m, Sd, k, A1, k1 or k, A2)
+    assert ctx.sync_count() - s0 == 1
+    ra, rb = S.T @ AS, S.T @ S
+    tol = 1e-13 * max(1.0, np.sqrt(m) / 30)
+    assert np.abs(Ga - ra).max() <= tol * np.abs(ra).max() and np.abs(Gb - rb).max() <= tol * np.abs(rb).max()
+    # against the separate launches (all of S'A(S) formed there): rounding of differently partitioned row sums
+    Fa, Fb = ctx.lobpcg_gram_pair(m, Sd, k, A1, k1 or k, A2, Sd, k, None)
+    assert np.abs(Ga - Fa).max() <= tol * np.abs(ra).max() and np.abs(Gb - Fb).max() <= tol * np.abs(rb).max()
+    if m % 4 == 0:   # the fused kernel ran: blocks below the block diagonal are the mirror image, bit for bit
+        for G in (Ga, Gb):
+            for i in range(k):
+                for j in range(k):
+                    if i // 16 > j // 16:
+                        assert G[i, j] == G[j, i]
+
+
 def test_gram_identity_operand(ctx):
     """A = I check: S = first 16 unit vectors => S'T = top 16 rows of T."""
     m, k = 64, 16

@@ -350,6 +350,9 @@ def _nonsym_sparse(n, seed):
     return sps.csr_matrix(A)
 
 
+LSQR_TOL = 1e-10   # BASELINE.json's iterate tolerance (r03 asserted 1e-9 here; measured errors are printed)
+
+
 @pytest.mark.parametrize("mode", [0, 1], ids=["fused", "generic"])
 @pytest.mark.parametrize("kw", [dict(), dict(lam=0.3), dict(Delta=0.5), dict(max_iterations=7),
                                 dict(btol=1e-12, Atol=1e-12, Acond_limit=50.0)])
@@ -367,12 +370,14 @@ def test_lsqr_device_matches_host_template(harness, golden, kw, mode):
     assert abs(float(A.sum()) - fx["A_checksum"]) < 1e-9
     assert d["rc"] == 0, d["err"]
     assert d["iterations"] == fx["iterations"]
-    assert np.abs(d["x"] - np.array(fx["x"])).max() <= 1e-9 * max(1.0, np.abs(fx["x"]).max())
-    assert abs(d["xnorm"] - fx["xnorm"]) <= 1e-9 * max(1.0, fx["xnorm"])
+    ex = np.abs(d["x"] - np.array(fx["x"])).max() / max(1.0, np.abs(fx["x"]).max())
+    en = abs(d["xnorm"] - fx["xnorm"]) / max(1.0, fx["xnorm"])
     h = hz.lsqr_dense(A.toarray(), b, **kw)
+    eh = np.abs(d["x"] - h["x"]).max() / max(1.0, np.abs(h["x"]).max())
+    print(f"lsqr {kw} mode {mode}: x vs reference fixture {ex:.2e}, |x| {en:.2e}, x vs host template {eh:.2e}")
+    assert ex <= LSQR_TOL and en <= LSQR_TOL
     assert d["iterations"] == h["iterations"]
-    assert np.abs(d["x"] - h["x"]).max() <= 1e-9 * max(1.0, np.abs(h["x"]).max())
-    assert abs(d["xnorm"] - h["xnorm"]) <= 1e-9 * max(1.0, h["xnorm"])
+    assert eh <= LSQR_TOL and abs(d["xnorm"] - h["xnorm"]) <= LSQR_TOL * max(1.0, h["xnorm"])
 
 
 def test_lsqr_device_large(harness):
@@ -409,8 +414,10 @@ def test_tnls_device_matches_host_template(harness, golden, kw, mode):
     assert d["status"] == fx["status"]
     if kw.get("root_tolerance", 1.0) > 0:
         assert (d["outer"], d["inner_total"]) == (fx["outer"], fx["inner_total"])
-    assert np.abs(d["x"] - np.array(fx["x"])).max() <= 1e-9 * max(1.0, np.abs(fx["x"]).max())
-    assert abs(d["f"] - fx["f"]) <= 1e-9 * max(1.0, abs(fx["f"]))
+    ex = np.abs(d["x"] - np.array(fx["x"])).max() / max(1.0, np.abs(fx["x"]).max())
+    ef = abs(d["f"] - fx["f"]) / max(1.0, abs(fx["f"]))
+    print(f"tnls {kw} mode {mode}: x vs reference fixture {ex:.2e}, f {ef:.2e}")
+    assert ex <= LSQR_TOL and ef <= LSQR_TOL
     h = hz.tnls_affine(A.toarray(), b, x0, **kw)
     assert d["status"] == h["status"]
     if kw.get("root_tolerance", 1.0) > 0:
