@@ -206,6 +206,18 @@ MI_API int mi_precon_create_block3(mi_ctx *ctx, const mi_vec *inv_blocks, mi_pre
  * (r -= A' lambda after every preconditioner application, :251,403) inside the same pass.  A and Minv must outlive P. */
 MI_API int mi_precon_create_constraint(mi_ctx *ctx, size_t n, size_t m, const mi_vec *A_rowmajor,
                                        const mi_vec *Minv_diag, mi_precon **out);
+/* The same for SPARSE constraints and any number of them (r04): A (m x n) in CSR on the host (int32), M still diagonal.
+ * A, A' and S = A M^-1 A' (formed once, on the host, as a sparse matrix) live on the device; an application is three
+ * launches and no host round trip: b = A M^-1 r, then S lambda = b by a Jacobi-preconditioned CG iteration running
+ * inside ONE workgroup (fixed-order reductions: deterministic) to a relative residual of inner_tol (0: 1e-14 -- the
+ * projection must be accurate to rounding or the outer iterates drift out of the null space of A) or
+ * inner_max_iterations (0: 10 m + 100), then v = M^-1 (r - A' lambda) and, with constraint_At, r -= A' lambda.
+ * mi_precon_constraint_info reports what the inner iteration needed and left (sync).  Minv must outlive P. */
+MI_API int mi_precon_create_constraint_csr(mi_ctx *ctx, size_t n, size_t m, const int32_t *rowptr, const int32_t *col,
+                                           const double *val, const mi_vec *Minv, double inner_tol,
+                                           size_t inner_max_iterations, mi_precon **out);
+MI_API int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, double *last_relative_residual,
+                                     double *worst_relative_residual);
 MI_API int mi_precon_constraint_solve(mi_precon *P, const mi_vec *r, mi_vec *v, mi_vec *lambda /*nullable*/);
 MI_API int mi_precon_constraint_At(mi_precon *P, const mi_vec *lambda, mi_vec *out);
 MI_API int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v);

@@ -136,6 +136,9 @@ def load():
         "mi_precon_create_block3": [vp, vp, C.POINTER(vp)],
         "mi_precon_apply": [vp, vp, vp],
         "mi_precon_create_constraint": [vp, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(vp)],
+        "mi_precon_create_constraint_csr": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, vp, C.c_double,
+                                            C.c_size_t, C.POINTER(vp)],
+        "mi_precon_constraint_info": [vp, c_size_p, c_double_p, c_double_p],
         "mi_precon_constraint_solve": [vp, vp, vp, vp],
         "mi_precon_constraint_At": [vp, vp, vp],
         "mi_precon_destroy": [vp],
@@ -389,6 +392,24 @@ class Context:
         h = vp()
         check(self.L.mi_precon_create_constraint(self.h, n, m, Ad.h, Md.h, C.byref(h)))
         P = ConstraintPrecon(self, h, keep=[Ad, Md])
+        P.m, P.n = m, n
+        return P
+
+    def precon_constraint_csr(self, A, Minv, inner_tol=0.0, inner_max_iterations=0):
+        """mi_precon_create_constraint_csr: A scipy.sparse (m x n) or dense numpy (its non-zeros are taken)"""
+        import scipy.sparse as sps
+        A = sps.csr_matrix(A)
+        A.sort_indices()
+        m, n = A.shape
+        Md = self.upload(Minv)
+        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        cl = np.ascontiguousarray(A.indices, dtype=np.int32)
+        vl = np.ascontiguousarray(A.data, dtype=np.float64)
+        h = vp()
+        check(self.L.mi_precon_create_constraint_csr(self.h, n, m, rp.ctypes.data_as(c_int32_p),
+                                                     cl.ctypes.data_as(c_int32_p), _dp(vl), Md.h, inner_tol,
+                                                     inner_max_iterations, C.byref(h)))
+        P = ConstraintPrecon(self, h, keep=[Md])
         P.m, P.n = m, n
         return P
 
@@ -830,6 +851,12 @@ class ConstraintPrecon(Precon):
         out = Vec(self.ctx, self.n)
         check(self.L.mi_precon_constraint_At(self.h, lam.h, out.h))
         return out
+
+    def info(self):
+        """(inner iterations of the last application, its relative residual, the worst one so far): sparse form only"""
+        it, last, worst = C.c_size_t(0), C.c_double(0), C.c_double(0)
+        check(self.L.mi_precon_constraint_info(self.h, C.byref(it), C.byref(last), C.byref(worst)))
+        return it.value, last.value, worst.value
 
 
 class _BorrowedPrecon(Precon):

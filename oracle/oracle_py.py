@@ -327,6 +327,23 @@ def projected_stpcg_problem(case, n=1000, m=100):
                 kappa={"exact": 1e-8, "truncated": .1}[case], theta=.7)
 
 
+def projected_stpcg_sparse_problem(n=2000, m=150, per_row=8, seed=904):
+    """A SPARSE equality-constrained STPCG case (r04; the reference only tests dense constraints): every constraint
+    couples `per_row` random unknowns plus one of its own (unknown 13 a, so the rows are independent), diagonal Hessian
+    and diagonal M as in projected_stpcg_problem.  A is returned dense (the reference driver takes it that way)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = rng.uniform(-1, 1, n)
+    P = 2000 + 1000 * rng.uniform(-1, 1, n)
+    M = 2000 + 1000 * rng.uniform(-1, 1, n)
+    A = np.zeros((m, n))
+    for a in range(m):
+        cols = rng.choice(n, size=per_row, replace=False)
+        A[a, cols] = 1000 * rng.uniform(-1, 1, per_row)
+        A[a, (13 * a) % n] += 3000.0
+    return dict(n=n, m=m, g=g, P=P, M=M, A=np.ascontiguousarray(A), Delta=float(np.finfo(np.float64).max),
+                max_iterations=5 * n, kappa=1e-9, theta=.7)
+
+
 def stpcg_projected(lib, prefix, pr):
     """<prefix>_stpcg_projected of a template-driver library (oracle/template_driver.inc)"""
     fn = getattr(lib, prefix + "_stpcg_projected")

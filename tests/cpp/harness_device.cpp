@@ -211,6 +211,13 @@ extern "C" int hd_stpcg_diag_stop(size_t n, const double *g, const double *D, co
 // (mi_precon_create_constraint: S = A M^-1 A' formed, factored and inverted on the GPU) as tagged P / At callables ->
 // the whole projected solve runs through the fused loop (mi_stpcg with constraint_At);  mode 2: the same device
 // callables hidden in plain lambdas -> generic loop, device KKT algebra.
+static size_t g_last_kkt_inner = 0;
+static double g_last_kkt_worst = 0;
+// inner CG of the sparse constraint preconditioner during the last hd_stpcg_projected call: iterations of its last
+// application, and the largest relative residual any application ended with
+extern "C" size_t hd_last_kkt_inner() { return g_last_kkt_inner; }
+extern "C" double hd_last_kkt_worst_residual() { return g_last_kkt_worst; }
+
 extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const double *Pdiag, const double *Mdiag,
                                   const double *A, double Delta, size_t max_iterations, double kappa_fgr,
                                   double theta, int mode, double *s_out, double *M_norm, size_t *iterations) {
@@ -226,7 +233,22 @@ extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const dou
     for (size_t i = 0; i < n; ++i) mi[i] = 1.0 / Mdiag[i];
     DeviceVector Ad(ctx, A, n * m), Mi(ctx, mi);
     mi_precon *kkt = nullptr;
-    MI355::check(mi_precon_create_constraint(ctx.get(), n, m, Ad.handle(), Mi.handle(), &kkt));
+    if (mode == 3) {  // the SPARSE form of the device KKT object: CSR of A's non-zeros, S l = b by the in-kernel CG
+      std::vector<int32_t> rp(m + 1, 0), cl;
+      std::vector<double> vl;
+      for (size_t a = 0; a < m; ++a) {
+        for (size_t j = 0; j < n; ++j)
+          if (A[a * n + j] != 0.0) {
+            cl.push_back((int32_t)j);
+            vl.push_back(A[a * n + j]);
+          }
+        rp[a + 1] = (int32_t)cl.size();
+      }
+      MI355::check(mi_precon_create_constraint_csr(ctx.get(), n, m, rp.data(), cl.data(), vl.data(), Mi.handle(), 0.0, 0,
+                                                   &kkt));
+    } else {
+      MI355::check(mi_precon_create_constraint(ctx.get(), n, m, Ad.handle(), Mi.handle(), &kkt));
+    }
     const MI355::DeviceConstraintPreconditioner cp{kkt, m};
     const MI355::DeviceConstraintTranspose ct{kkt, n};
     std::optional<LA::STPCGPreconditioner<DeviceVector, DeviceVector>> P = LA::STPCGPreconditioner<DeviceVector, DeviceVector>(cp);
@@ -246,6 +268,9 @@ extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const dou
     std::memcpy(s_out, sh.data(), n * sizeof(double));
     *M_norm = mn;
     *iterations = it;
+    g_last_kkt_inner = 0;
+    g_last_kkt_worst = 0;
+    MI355::check(mi_precon_constraint_info(kkt, &g_last_kkt_inner, nullptr, &g_last_kkt_worst));
     mi_precon_destroy(kkt);
     mi_op_destroy(op);
     return 0;

@@ -106,8 +106,11 @@ class DeviceHarness:
         rc = self.L.hd_stpcg_projected(pr["n"], pr["m"], _dp(pr["g"]), _dp(pr["P"]), _dp(pr["M"]),
                                        _dp(np.ascontiguousarray(pr["A"])), pr["Delta"], pr["max_iterations"],
                                        pr["kappa"], pr["theta"], mode, _dp(s), C.byref(mn), C.byref(it))
+        self.L.hd_last_kkt_inner.restype = C.c_size_t
+        self.L.hd_last_kkt_worst_residual.restype = C.c_double
         return dict(rc=rc, err=self.err() if rc else "", s=s, M_norm=mn.value, iterations=it.value,
-                    syncs=self.L.hd_last_tnt_syncs())
+                    syncs=self.L.hd_last_tnt_syncs(), kkt_inner=self.L.hd_last_kkt_inner(),
+                    kkt_worst_residual=self.L.hd_last_kkt_worst_residual())
 
     def tnt_rosenbrock(self, n, precon_kind, x0, params, mode=0):
         """BASELINE cfg1 through EuclideanTNT<DeviceVector> (hd_tnt_rosenbrock)"""

@@ -116,6 +116,29 @@ def test_projected_stpcg_on_device_vectors(harness, golden, case, mode):
     assert np.linalg.norm(pr["A"] @ r["s"]) < 1e-6
 
 
+def test_projected_stpcg_with_sparse_constraints_vs_the_reference(harness, golden):
+    """The projected STPCG (reference IterativeSolvers.h:229-253,381-405) with SPARSE constraints (n = 2000, 150
+    constraints of 9 non-zeros) through the sparse device KKT object (mi_precon_create_constraint_csr: S lambda = b by a
+    CG iteration inside one workgroup) as ONE fused mi_stpcg call, against the fixture the REAL reference produced with a
+    dense KKT factorisation on the same inputs (tests/golden/stpcg_projected_sparse.json, make_golden_sparse_kkt.py):
+    same iteration count, iterate to 1e-10, |A s| ~ 0, one host synchronisation."""
+    import hashlib
+    import oracle_py
+    pr = oracle_py.projected_stpcg_sparse_problem()
+    fx = golden("stpcg_projected_sparse.json")
+    sha = hashlib.sha256(pr["A"].tobytes() + pr["g"].tobytes() + pr["P"].tobytes() + pr["M"].tobytes()).hexdigest()
+    assert sha == fx["inputs_sha256"]                      # the seeded inputs are the ones the fixture was made from
+    r = harness.stpcg_projected(pr, 3)
+    assert r["rc"] == 0, r["err"]
+    print("sparse projected STPCG:", r["iterations"], "iterations; inner CG", r["kkt_inner"], "iterations in the last "
+          "application, worst relative residual", r["kkt_worst_residual"])
+    assert r["syncs"] == 1 and r["kkt_worst_residual"] <= 1e-13
+    assert r["iterations"] == fx["iterations"]
+    assert rel_err(r["s"], np.array(fx["s"])) < 1e-10
+    assert abs(r["M_norm"] - fx["M_norm"]) < 1e-10 * fx["M_norm"]
+    assert np.linalg.norm(pr["A"] @ r["s"]) < 1e-6
+
+
 @pytest.mark.parametrize("key,pk", [("plain", 0), ("jacobi", 1)])
 @pytest.mark.parametrize("mode", [0, 1], ids=["device-csr-hessian", "host-lambda-hessian"])
 def test_tnt_rosenbrock100_device_golden(harness, oracle, golden, key, pk, mode):
