@@ -356,6 +356,58 @@ def self_launch(args, argv):
     raise SystemExit(r.returncode)
 
 
+def peer_probe_main(args):
+    """`--peer-probe` (a throwaway process per rank, started by peer_probe below): bring the peer-memory layer up and run
+    its self-test -- known-value exchanges, then the folded exchange and all three forms of the halo push between the
+    real peers -- and say through the exit code whether it came up: 0 yes, 3 no."""
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    one_gpu = os.environ.get("MI355OPT_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // max(world, 1))))
+        os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
+    ctx = capi.Context(0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0")))
+    ok = ctx.enable_peer_memory(world, rank, dist, force=True)
+    dist.barrier()
+    ctx.comm_finalize()
+    ctx.close()
+    os._exit(0 if ok else 3)
+
+
+def peer_probe(dist, world, rank):
+    """The first cross-device peer stores of this code base happen on the node the scaling bench runs on.  A layer that
+    merely fails its self-test falls back to RCCL by itself; one that takes the process down (a fault on a peer
+    mapping) would take the bench line with it -- so the bring-up and the whole self-test run in a throwaway process per
+    rank FIRST, and the real processes map peer memory only if every probe came back clean.  Returns (ok, seconds)."""
+    import socket
+    import subprocess
+    t0 = time.perf_counter()
+    port = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    # (under torch.distributed.run the launcher's agent hosts the rendezvous store and the ranks only connect to it
+    # -- TORCHELASTIC_USE_AGENT_STORE; the probe's own rendezvous on a fresh port needs its rank 0 to host one)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_PORT=str(port[0]), MASTER_ADDR="127.0.0.1")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--peer-probe", "--gpus", str(world)], env=env,
+                           capture_output=True, text=True, timeout=240)
+        ok, note = r.returncode == 0, (r.stderr or "")[-300:]
+    except subprocess.TimeoutExpired:
+        ok, note = False, "probe timed out"
+    every = [None] * world
+    dist.all_gather_object(every, (ok, note))
+    if rank == 0 and not all(e[0] for e in every):
+        print("bench.py: the peer-memory probe failed on rank(s) %s: RCCL carries the exchanges\n  %s" %
+              ([i for i, e in enumerate(every) if not e[0]], " | ".join(e[1].strip().splitlines()[-1] if e[1].strip() else "-"
+                                                                        for e in every if not e[0])), file=sys.stderr)
+    return all(e[0] for e in every), time.perf_counter() - t0
+
+
 def comm_set_layer(ctx, layer, peer_up=True):
     """switch the exchange layer of a context (the same call on every rank); peer_up: the peer-memory layer is mapped"""
     if layer == "rccl":
@@ -437,7 +489,12 @@ def main():
                     choices=["auto", "peer", "peer-separate", "rccl"],
                     help="exchange layer of the headline at N > 1 (auto: the fastest layer that verifies)")
     ap.add_argument("--ab-steps", type=int, default=300, help="timed steps of each exchange-layer A/B leg at N > 1")
+    ap.add_argument("--peer-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-peer-probe", action="store_true",
+                    help="N > 1: map peer memory in the bench processes without trying it in throwaway ones first")
     args = ap.parse_args()
+    if args.peer_probe:
+        peer_probe_main(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args, sys.argv[1:])
@@ -465,6 +522,7 @@ def main():
     ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
     rccl_nranks = 0
+    probe = None
     if use_comm:
         if not one_gpu:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
@@ -475,7 +533,9 @@ def main():
         # rank's export / map / self-test succeeds (the self-test includes the folded exchange and all three forms of
         # the halo push between the real peers); which layer the headline uses is decided below.  The one-GPU rehearsal
         # needs it (RCCL refuses duplicate devices).
-        if args.comm != "rccl" or one_gpu:
+        if (args.comm != "rccl" or one_gpu) and world > 1 and not args.no_peer_probe:
+            probe = peer_probe(dist, world, rank)
+        if (args.comm != "rccl" or one_gpu) and (probe is None or probe[0]):
             peer_memory = ctx.enable_peer_memory(world, rank, dist, force=True)
         if one_gpu and not peer_memory:
             raise SystemExit("one-GPU rehearsal needs the peer-memory layer")
@@ -683,6 +743,7 @@ def main():
             # N > 1: which exchange layer the headline ran on and why; every layer's own figure next to it
             "comm_layer": comm_layer, "comm_layer_choice": comm_choice, "rccl_nranks": rccl_nranks if use_comm else None,
             "comm_ab_legs": comm_legs, "rehearsal_one_gpu": bool(one_gpu) if use_comm else None,
+            "peer_memory_probe": ({"passed": probe[0], "seconds": probe[1]} if use_comm and probe is not None else None),
             # the second first-class number: the SAME workload through the generic path any CSR matrix takes
             # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
             "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,

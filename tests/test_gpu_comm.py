@@ -503,6 +503,7 @@ def test_bare_bench_command_self_launches_its_ranks(n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["steps"] == 60 and d["scaling"] == "weak" and d["value"] > 0
     assert d["rehearsal_one_gpu"] == (_ngpus() < n)
+    assert d["peer_memory_probe"]["passed"]          # the throwaway-process probe of the peer-memory layer ran first
     legs = {leg["layer"]: leg for leg in d["comm_ab_legs"]}
     assert "peer" in legs and "peer-separate" in legs and (d["rehearsal_one_gpu"] or "rccl" in legs)
     assert all(leg["verified"] and leg["ipc_error"] == 0 and leg["us_per_step"] > 0 for leg in legs.values()), legs
