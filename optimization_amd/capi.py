@@ -31,6 +31,14 @@ vp = C.c_void_p
 APPLY_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp)
 
 
+class FusedArgs(C.Structure):
+    _fields_ = [("partials", C.POINTER(C.c_double)), ("partial_stride", C.c_size_t), ("max_rows", C.c_int),
+                ("required_rows", C.c_int), ("stream", vp)]
+
+
+APPLY_FUSED_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, C.POINTER(FusedArgs), C.POINTER(C.c_int))
+
+
 class MiError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"{STATUS.get(status, status)}: {msg}")
@@ -124,6 +132,7 @@ def load():
         "mi_csr_spmm": [vp, C.c_int, vp, vp],
         "mi_op_create_callback": [vp, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
         "mi_op_create_callback_rect": [vp, C.c_size_t, C.c_size_t, APPLY_FN, vp, C.POINTER(vp)],
+        "mi_op_create_callback_fused": [vp, C.c_size_t, APPLY_FN, APPLY_FUSED_FN, vp, C.POINTER(vp)],
         "mi_lsqr_default_params": [C.POINTER(LsqrParams)],
         "mi_lsqr": [vp, vp, vp, vp, C.POINTER(LsqrParams), vp, C.POINTER(LsqrResult)],
         "mi_op_create_diag": [vp, vp, C.POINTER(vp)],
@@ -373,6 +382,33 @@ class Context:
         h = vp()
         check(self.L.mi_op_create_callback(self.h, n, cfn, None, C.byref(h)))
         return Op(self, h, keep=[cfn])
+
+    def op_callback_fused(self, n, fn, fused):
+        """mi_op_create_callback_fused.  fn(in_vec, out_vec) enqueues out = Op(in); fused(in_vec, out_vec, args) does the
+        same AND leaves the three curvature partial rows (args: FusedArgs), returning the number of rows written.  (A
+        real client does both in a HIP kernel of its own: examples/stpcg_user_stencil.hip; from Python this serves the
+        contract tests.)"""
+        def cb(_u, pin, pout):
+            try:
+                fn(Vec(self, 0, handle=vp(pin)), Vec(self, 0, handle=vp(pout)))
+                return 0
+            except Exception:  # noqa
+                import traceback
+                traceback.print_exc()
+                return 6
+
+        def cbf(_u, pin, pout, args, rows):
+            try:
+                rows[0] = int(fused(Vec(self, 0, handle=vp(pin)), Vec(self, 0, handle=vp(pout)), args.contents))
+                return 0
+            except Exception:  # noqa
+                import traceback
+                traceback.print_exc()
+                return 6
+        c1, c2 = APPLY_FN(cb), APPLY_FUSED_FN(cbf)
+        h = vp()
+        check(self.L.mi_op_create_callback_fused(self.h, n, c1, c2, None, C.byref(h)))
+        return Op(self, h, keep=[c1, c2])
 
     def precon_diag(self, dinv):
         h = vp()

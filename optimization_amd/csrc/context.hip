@@ -23,6 +23,34 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return MI_ERR_HIP;
 }
 
+int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += (bytes[i] + 63) / 64 * 64;
+  if (total > ctx->readback_bytes) {
+    if (ctx->readback_host) (void)hipHostFree(ctx->readback_host);
+    ctx->readback_host = nullptr;
+    ctx->readback_bytes = 0;
+    const size_t cap = std::max<size_t>(total, 256 * 1024);
+    MI_HIP(hipHostMalloc(&ctx->readback_host, cap, hipHostMallocDefault));
+    ctx->readback_bytes = cap;
+  }
+  size_t off = 0;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < n && e == hipSuccess; ++i) {
+    e = hipMemcpyAsync((char *)ctx->readback_host + off, dev[i], bytes[i], hipMemcpyDeviceToHost, ctx->stream);
+    off += (bytes[i] + 63) / 64 * 64;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ctx->host_syncs++;
+  if (e != hipSuccess) return hip_fail(e, "read-back", __FILE__, __LINE__);
+  off = 0;
+  for (int i = 0; i < n; ++i) {
+    memcpy(host[i], (const char *)ctx->readback_host + off, bytes[i]);
+    off += (bytes[i] + 63) / 64 * 64;
+  }
+  return MI_OK;
+}
+
 int ensure_device() {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -303,6 +331,7 @@ int mi_ctx_destroy(mi_ctx *ctx) {
   (void)hipFree(ctx->control_slab);
   (void)hipFree(ctx->trace_dev);
   (void)hipHostFree(ctx->host_scalars);
+  if (ctx->readback_host) (void)hipHostFree(ctx->readback_host);
   if (ctx->cg_deferred_ev) (void)hipEventDestroy(ctx->cg_deferred_ev);
   (void)hipHostFree(ctx->cg_host);
   (void)hipHostFree((void *)ctx->status);

@@ -988,18 +988,20 @@ struct GramJob {
   int nelem = 0;
 };
 static int gram_finish(mi_ctx *ctx, GramJob *jobs, int njobs, double *const *G_host) {
-  hipError_t e = hipSuccess;
-  for (int i = 0; i < njobs && e == hipSuccess; ++i)
-    e = hipMemcpyAsync(G_host[i], jobs[i].Gdev, (size_t)jobs[i].nelem * sizeof(double), hipMemcpyDeviceToHost,
-                       ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ctx->host_syncs++;
+  const void *dev[4];
+  size_t bytes[4];
+  void *host[4];
+  for (int i = 0; i < njobs && i < 4; ++i) {
+    dev[i] = jobs[i].Gdev;
+    bytes[i] = (size_t)jobs[i].nelem * sizeof(double);
+    host[i] = G_host[i];
+  }
+  const int st = njobs > 0 ? readback_sync(ctx, njobs, dev, bytes, host) : MI_OK;  // (pinned landing area: no blit kernel)
   for (int i = 0; i < njobs; ++i) {
     pool_free(ctx, jobs[i].partial);
     pool_free(ctx, jobs[i].Gdev);
   }
-  if (e != hipSuccess) return hip_fail(e, "gram read-back", __FILE__, __LINE__);
-  return MI_OK;
+  return st;
 }
 
 // T = [T (k1 columns) | T2 (kb - k1 columns)] when T2 != null (square direct shapes only), else T alone.
@@ -1523,12 +1525,13 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
     return st;
   }
   std::vector<double> out((size_t)nchunks * 16);
-  hipError_t e = hipMemcpyAsync(out.data(), sums, out.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ctx->host_syncs++;
+  const void *dv[1] = {sums};
+  const size_t by[1] = {out.size() * sizeof(double)};
+  void *hs[1] = {out.data()};
+  st = readback_sync(ctx, 1, dv, by, hs);
   pool_free(ctx, sums);
   pool_free(ctx, thdev);
-  if (e != hipSuccess) return hip_fail(e, "residual norms read-back", __FILE__, __LINE__);
+  if (st != MI_OK) return st;
   for (int c = 0; c < nx; ++c) {
     rnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + c % 8]);
     xnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + 8 + c % 8]);

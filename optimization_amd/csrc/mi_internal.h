@@ -163,6 +163,10 @@ struct mi_ctx {
   void *stage_host[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   int stage_next = 0;
+  // pinned landing area for small device -> host read-backs (readback_sync, context.hip): a copy into PAGEABLE memory
+  // goes through the runtime's own staging buffers with a blit kernel and an internal wait (15 us per 41 KB Gram)
+  void *readback_host = nullptr;
+  size_t readback_bytes = 0;
   // timing
   mi::KTimer ktime[MI_K_COUNT];
   std::vector<hipEvent_t> event_pool;
@@ -208,6 +212,9 @@ void pool_free(mi_ctx *ctx, void *p);
 // and from there in-stream; the caller's buffer may die at once, the host does not wait for the device (a slot is
 // reused only after the copy that read it has completed).
 int stage_upload(mi_ctx *ctx, const void *src, size_t bytes, void *dst_dev);
+// n device buffers -> n host buffers behind ONE stream synchronisation, through the context's pinned landing area
+// (counted in mi_ctx::host_syncs)
+int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host);
 int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements

@@ -455,25 +455,21 @@ def _ngpus():
         return 0
 
 
-@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs (cross-device RCCL / xGMI peer memory)")
-@pytest.mark.parametrize("layer", ["rccl", "peer", "peer-separate"])
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_cross_device_exchange_layers(world, layer):
-    """Rank r on GPU r: RCCL with more than one rank (ncclAllReduce of the partial rows, ncclSend / ncclRecv halo) and the
-    peer-memory layer over real xGMI links (folded and with separate exchange kernels), each against the
-    single-context solve: sharded products bit-identical to the global one over three exchanges in a row, the fused
-    STPCG with the same exits and counts, the step to 1e-10, every replicated scalar bit-identical on all ranks."""
-    if _ngpus() < world:
-        pytest.skip(f"needs {world} GPUs")
+def _run_xdev(world, layer, one_gpu):
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(29700 + world), os.path.join(ROOT, "tests", "xdev_worker.py")]
         env = dict(os.environ, XDEV_WORKER_OUT=tmp, XDEV_LAYER=layer)
+        if one_gpu:
+            env["XDEV_ONE_GPU"] = "1"
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-        outs = [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
-    assert len({o["device"] for o in outs}) >= 1 and all(o["rccl_nranks"] == world for o in outs)
+        return [json.load(open(os.path.join(tmp, f"rank{k}.json"))) for k in range(world)]
+
+
+def _check_xdev(outs, world, layer, rccl):
+    assert all(o["rccl_nranks"] == (world if rccl else 0) for o in outs)
     if layer != "rccl":
         assert all(o["enabled"] for o in outs), "peer-memory layer did not come up (self-test incl. the folded forms)"
     for o in outs:
@@ -487,6 +483,26 @@ def test_cross_device_exchange_layers(world, layer):
         assert all(o[k] == outs[0][k] for o in outs), k
     if layer == "peer":      # folded: the layer launches nothing of its own per iteration
         assert all(o["comm_kernels"][2] >= o["iters"] - 1 for o in outs), [o["comm_kernels"] for o in outs]
+
+
+@pytest.mark.parametrize("layer", ["peer", "peer-separate"])
+def test_cross_device_worker_on_one_gpu(layer):
+    """The worker of the cross-device tests below with both ranks on GPU 0 and without RCCL: every line of it except
+    the RCCL bring-up runs in the 1-GPU suite, so that the first multi-GPU box meets a script that is known to work."""
+    _check_xdev(_run_xdev(2, layer, one_gpu=True), 2, layer, rccl=False)
+
+
+@pytest.mark.skipif(_ngpus() < 2, reason="needs two GPUs (cross-device RCCL / xGMI peer memory)")
+@pytest.mark.parametrize("layer", ["rccl", "peer", "peer-separate"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cross_device_exchange_layers(world, layer):
+    """Rank r on GPU r: RCCL with more than one rank (ncclAllReduce of the partial rows, ncclSend / ncclRecv halo) and the
+    peer-memory layer over real xGMI links (folded and with separate exchange kernels), each against the
+    single-context solve: sharded products bit-identical to the global one over three exchanges in a row, the fused
+    STPCG with the same exits and counts, the step to 1e-10, every replicated scalar bit-identical on all ranks."""
+    if _ngpus() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _check_xdev(_run_xdev(world, layer, one_gpu=False), world, layer, rccl=True)
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])

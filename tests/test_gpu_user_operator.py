@@ -51,3 +51,33 @@ def test_user_stencil_operator_at_scale_three_launches_per_iteration():
     print(out)
     us = {ln.split()[0]: float(ln.split()[-4]) for ln in out.splitlines() if "us per iteration" in ln}
     assert iters > 20 and us["fused"] < us["plain"]
+
+
+def test_fused_callback_contract_is_enforced(ctx):
+    """mi_op_create_callback_fused: a callback that reports a row count outside [1, max_rows] -- or fails -- stops the
+    solve with an error instead of letting k_cg_update re-reduce rows nobody wrote; the plain product of the same
+    operator (mi_op_apply, TNT's `dm` product) does not touch the partial buffer."""
+    from optimization_amd import capi
+    n = 4096
+    D = ctx.upload(np.full(n, 2.0))
+    Hd = ctx.op_diag(D)
+    seen = {}
+
+    def plain(i, o):
+        Hd.apply(i, o)
+
+    def fused_bad_rows(i, o, a):
+        seen["args"] = (a.partial_stride, a.max_rows, a.required_rows, bool(a.stream))
+        Hd.apply(i, o)
+        return a.max_rows + 1
+
+    def fused_raises(i, o, a):
+        raise RuntimeError("user kernel failed to launch")
+    g = ctx.upload(np.ones(n))
+    for fused in (fused_bad_rows, lambda i, o, a: 0, fused_raises):
+        H = ctx.op_callback_fused(n, plain, fused)
+        with pytest.raises(capi.MiError):
+            ctx.stpcg(g, H, Delta=1e9, max_iterations=5)
+        assert np.array_equal(H.apply(g).numpy(), np.full(n, 2.0))          # the plain product still works
+    assert seen["args"] == (1024, 1024, 0, True)     # the contract a single-rank context hands out
+    ctx.sync()

@@ -20,10 +20,18 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     layer = os.environ.get("XDEV_LAYER", "rccl")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    c = capi.Context(int(os.environ.get("LOCAL_RANK", rank)))
-    uid = [c.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    c.comm_init(world, rank, uid[0])
+    # XDEV_ONE_GPU=1: the same script with every rank on GPU 0 and without RCCL (it refuses duplicate devices) -- so that
+    # the 1-GPU suite executes every line of this worker except the RCCL bring-up before a multi-GPU box ever does
+    one_gpu = os.environ.get("XDEV_ONE_GPU") == "1"
+    dev = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", rank))
+    if one_gpu:
+        os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // world)))
+        os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
+    c = capi.Context(dev)
+    if not one_gpu:
+        uid = [c.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        c.comm_init(world, rank, uid[0])
     out = {"rank": rank, "layer": layer, "rccl_nranks": c.comm_rccl_count(), "device": c.device_name()}
     if layer != "rccl":
         out["enabled"] = c.enable_peer_memory(world, rank, dist, force=True)   # incl. the folded-form self-test
@@ -46,7 +54,7 @@ def main():
     rp, colg, vl = wl.laplacian_3d(nx, ny, nz, z_range=slabs[rank])
     dist.barrier()
     A = c.csr_sharded(n, r0, r1, rp, colg, vl, starts)
-    c1 = capi.Context(int(os.environ.get("LOCAL_RANK", rank)))
+    c1 = capi.Context(dev)
     A1 = c1.csr(n, rowptr, col, val)
     for k, F in enumerate((V, W, V + W)):   # three exchanges in a row: flags / double buffering must advance
         Y = A.spmm(p, c.upload(F[r0:r1])).numpy()
