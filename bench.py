@@ -408,6 +408,54 @@ def peer_probe(dist, world, rank):
     return all(e[0] for e in every), time.perf_counter() - t0
 
 
+class Watchdog:
+    """N > 1 only.  arm(what, seconds) before a phase that may never return (an exchange layer's first collectives on a
+    real node), disarm() behind it.  If a phase overruns: rank 0 prints the line that keep() registered -- the headline
+    already measured on an earlier, verified layer -- with a note naming the phase, and every rank ends the process with
+    exit code 0; with nothing kept the exit code is 3.  A hung collective cannot be cancelled; a clean line can still
+    be delivered."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.deadline, self.what, self.kept = rank, None, "", None
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, what, seconds):
+        with self.lock:
+            self.what, self.deadline = what, time.monotonic() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def keep(self, make):
+        """make(note) -> the JSON dict to print if a later phase does not return (rank 0 only uses it)"""
+        with self.lock:
+            self.kept = make
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                what, kept = self.what, self.kept
+            if not late:
+                continue
+            print(f"bench.py: rank {self.rank}: '{what}' did not return in time" +
+                  ("; printing the line measured before it" if kept else ""), file=sys.stderr, flush=True)
+            if self.rank == 0 and kept is not None:
+                try:
+                    out = kept(f"'{what}' did not return within its time limit afterwards")
+                    out["watchdog"] = f"'{what}' did not return; this line was measured before it"
+                    os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
+                except Exception as e:  # noqa: BLE001
+                    print("bench.py: could not print the kept line: %r" % (e,), file=sys.stderr, flush=True)
+                    os._exit(3)
+            os._exit(0 if (kept is not None or self.rank != 0) else 3)
+
+
 def comm_set_layer(ctx, layer, peer_up=True):
     """switch the exchange layer of a context (the same call on every rank); peer_up: the peer-memory layer is mapped"""
     if layer == "rccl":
@@ -432,6 +480,8 @@ def comm_ab_leg(ctx, dist, prob, X, s_out, layer, steps, world, rank, verify, pe
     import torch
     comm_set_layer(ctx, layer, peer_up)
     dist.barrier()
+    if os.environ.get("MI355OPT_BENCH_INJECT_HANG") == layer:   # (test of the watchdog: a layer that never returns)
+        time.sleep(1e9)
     fails = verify()
     leg = {"layer": layer, "what": LAYER_TEXT[layer], "verified": not fails}
     if fails:
@@ -489,6 +539,9 @@ def main():
                     choices=["auto", "peer", "peer-separate", "rccl"],
                     help="exchange layer of the headline at N > 1 (auto: the fastest layer that verifies)")
     ap.add_argument("--ab-steps", type=int, default=300, help="timed steps of each exchange-layer A/B leg at N > 1")
+    ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MI355OPT_BENCH_LEG_TIMEOUT", "240")),
+                    help="N > 1: seconds an exchange layer's leg (or a headline measurement) may take before the "
+                         "watchdog prints the line already measured on an earlier layer and ends the run")
     ap.add_argument("--peer-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-peer-probe", action="store_true",
                     help="N > 1: map peer memory in the bench processes without trying it in throwaway ones first")
@@ -561,8 +614,161 @@ def main():
     prob = ctx.stiefel_rq(A, n, p)
     X = ctx.upload(Xb)
     s_out = ctx.vec(n * p)
+    N = n * p
+    bytes_per_step = wl.cg_bytes_per_iter(N) + wl.stiefel_hvp_bytes(n, nnz, p)  # per GPU
+    packed = os.environ.get("MI355OPT_NO_PACKED", "0") != "1"
+    peer_up = peer_memory
+
+    def make_line(m, layer, choice, legs, plain_leg=None, big_leg=None, cpu=None, cpu_all=None):
+        """the JSON line for one measurement `m` of measure()"""
+        dt, value, moved_bytes = m["dt"], m["value"], m["moved_bytes"]
+        return {
+            "metric": "TNT Steihaug-CG HVP+inner-product throughput", "value": value, "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "device_wakeup_steps": m["wakeup_steps"],
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2 Stiefel({n_glob},{p}) Rayleigh quotient, 7-pt Laplacian "
+                                   f"{nx}x{ny}x{nz}+0.1I, fused device STPCG in solves of {TPCG} inner "
+                                   f"iterations at a near-optimal iterate (modes {modes})",
+                       "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
+                       "moved_bytes_per_step_per_gpu": moved_bytes,
+                       "reference_schedule_bytes_per_step_per_gpu": bytes_per_step, "solves": m["solves"],
+                       "packed_matrix": packed,
+                       "parallelism": (f"row-sharded z-slabs x{world}, comm: " + LAYER_TEXT[layer]) if use_comm
+                       else "single GPU",
+                       "device": ctx.device_name()},
+            # `value` = compulsory HBM bytes of the kernels that ran / time: comparable with the 8 TB/s peak.
+            "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
+            "value_basis": "compulsory HBM bytes of the three kernels of an iteration (one-pass Hessian: "
+                           "4 nnz + 4 (n+1) + 32 N with the value-indexed matrix, 12 nnz + ... without; "
+                           "cg_update 24 N; cg_pupdate 40 N) per second; working set "
+                           f"{(6 * 8 * N + (4 if packed else 12) * nnz) / 1e6:.0f} MB per GPU (Infinity Cache: 268 MB)",
+            "packed_matrix": packed,
+            # NOT a bandwidth: the same time priced by the bytes SURVEY.md 8(d) attributes to the reference's schedule
+            # (88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration); the fused kernels never move those bytes
+            "reference_schedule_bytes_per_second_not_a_bandwidth": world * args.steps * bytes_per_step / dt,
+            "roofline": m["roofline"],
+            # N > 1: which exchange layer the headline ran on and why; every layer's own figure next to it
+            "comm_layer": layer, "comm_layer_choice": choice, "rccl_nranks": rccl_nranks if use_comm else None,
+            "comm_ab_legs": legs, "rehearsal_one_gpu": bool(one_gpu) if use_comm else None,
+            "peer_memory_probe": ({"passed": probe[0], "seconds": probe[1]} if use_comm and probe is not None else None),
+            # the second first-class number: the SAME workload through the generic path any CSR matrix takes
+            # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
+            "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,
+            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+        }
+
+    def measure(layer):
+        """The headline on one exchange layer (None: no communicator): device wake-up, W warmup steps, EXACTLY K timed
+        steps between barrier + synchronise pairs (max over ranks), then the event-paired roofline pass."""
+        if use_comm:
+            comm_set_layer(ctx, layer, peer_up)
+            dist.barrier()
+        g, H = prob.model(X)
+
+        def barrier():
+            ctx.sync()
+            if dist is not None:
+                dist.barrier()
+
+        # ---- device wake-up, warmup, timed region ---------------------------------------------------
+        # An idle MI355X needs tens of milliseconds of work before its clocks and its memory system are at their steady
+        # state; W warmup steps of 57 us are over long before that (measured, 20 timed steps: W = 5 -> 58.8 us/step,
+        # W = 500 -> 57.7, W = 2000 -> 57.4; 500 timed steps: 56.5).  So the device is woken up with a FIXED number of
+        # steps of the same solve (the same on every rank: they contain the exchanges) before the W warmup steps the
+        # command line asks for; the count is reported in the JSON line (`device_wakeup_steps`; --wakeup-steps 0 switches it
+        # off).  The timed region is unchanged: exactly K steps between two barrier + synchronise pairs.
+        wakeup_steps = args.wakeup_steps
+        if wakeup_steps > 0:
+            run_steps(ctx, g, H, s_out, wakeup_steps)
+        if args.warmup > 0:
+            run_steps(ctx, g, H, s_out, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        solves = run_steps(ctx, g, H, s_out, args.steps)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        packed = os.environ.get("MI355OPT_NO_PACKED", "0") != "1"
+        kb = kernel_bytes(n, nnz, p, packed=packed)
+        # compulsory bytes of the three kernels a completed iteration launches (the per-solve initialisation kernels,
+        # ~2 % of the time at 50 iterations per solve, are inside the timed region but not counted)
+        recur = os.environ.get("MI355OPT_NO_DIRGRAM", "0") != "1"
+        moved_model = (kb["stiefel_hess_fused"] if recur else kb["stiefel_spmm_gram"] + kb["stiefel_finish_dots"]) + \
+            kb["cg_update"] + kb["cg_pupdate"]
+
+        # ---- roofline leg: same steps again with HIP-event pairs around every hot kernel ------------
+        roofline = None
+        moved_bytes = moved_model
+        # EVERY rank runs these steps (they contain the same exchanges as the timed ones: a rank running them alone
+        # would wait for peers that never come); rank 0's own kernel timings are the ones reported.
+        if not args.no_roofline:
+            # (200 steps whatever K is: with K = 20 the averages were over 20 launches, the first of them behind a solve's
+            # set-up kernels)
+            per, moved_measured = timed_kernels(ctx, g, H, s_out, 200, kb)
+            moved_bytes = moved_measured
+            ran = [k for k in HOT if per[k]["launches"]]
+            dom = max(ran, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
+            # An event pair also times its own two records: the instrumented steps are slower than the timed region by
+            # exactly that, the same amount per launch.  Measured live: (time of a step's launches by event pairs - time
+            # of an un-instrumented step) / launches per step, subtracted from every pair average (0 when the step
+            # contains launches that are not timed here, e.g. exchange kernels of a multi-rank run).  The net figures add
+            # up to the un-instrumented step and agree with rocprofv3's kernel durations (profiles/r02_summary.md) to 1 %.
+            tsteps = 200
+            pair_us_per_step = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
+            launches_per_step = sum(per[k]["launches"] for k in ran) / tsteps
+            ev_overhead = max(0.0, (pair_us_per_step - dt / args.steps * 1e6) / max(launches_per_step, 1e-9))
+            if ev_overhead > 0.25 * min(per[k]["avg_us"] for k in ran):  # implausible: keep the raw pairs
+                ev_overhead = 0.0
+            net_us = per[dom]["avg_us"] - ev_overhead
+            achieved = kb[dom] / (net_us * 1e-6) / 1e9
+            # `traffic` is NOT measured in this run: PMC counters need separate rocprofv3 passes (tools/pmc_bytes.sh);
+            # the figure is the last committed measurement of the same kernel on the same workload, labelled as such
+            traffic, traffic_source = None, None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_bytes.sh on this " \
+                                     "workload; not collected in this run)"
+                except Exception:  # noqa
+                    traffic = None
+            sum_kernel_us = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": traffic_source,
+                        "algorithmic_bytes_per_launch": kb[dom],
+                        "avg_launch_us": net_us,
+                        # sum of the kernels' durations over the un-instrumented step: 1.0 = no gaps between kernels
+                        "sum_kernel_us_over_step_us": (sum_kernel_us - ev_overhead * launches_per_step)
+                                                      / (dt / args.steps * 1e6),
+                        "sum_kernel_us_over_step_us_event_pairs": sum_kernel_us / (dt / args.steps * 1e6),
+                        "avg_launch_us_event_pairs": per[dom]["avg_us"],
+                        "event_record_overhead_us_per_launch": ev_overhead,
+                        "timing": "HIP event pair around every launch on the launch stream, minus the pairs' own cost "
+                                  "measured live as (pair-timed step - un-instrumented step) / launches per step",
+                        "frac_event_pairs_uncorrected": kb[dom] / (per[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "kernels": per}
+            barrier()
+            if rank != 0:
+                roofline = None
+        value = world * args.steps * moved_bytes / dt / 1e9
+        return dict(dt=dt, solves=solves, roofline=roofline, moved_bytes=moved_bytes, value=value,
+                    wakeup_steps=wakeup_steps)
+
     # ---- N > 1: every exchange layer that is up is verified and timed; the headline takes the fastest --------------
-    comm_layer, comm_legs, comm_choice = None, None, None
+    # The first cross-device run of this code happens inside the driver's scaling bench, where a layer that HANGS (an
+    # RCCL collective that never returns is not bounded by anything of ours) would cost the whole line.  So the
+    # headline is measured on the FIRST layer that verifies, right away, and kept; the remaining layers are then tried
+    # under a watchdog, and if one of them does not come back the kept line is printed (with a note) and the run ends
+    # cleanly.  If a later layer is faster the headline is measured again on it.
+    comm_layer, comm_legs, comm_choice, m = None, None, None, None
+    wd = Watchdog(rank) if use_comm else None
     if use_comm:
         layers = (["peer", "peer-separate"] if peer_memory else []) + ([] if one_gpu else ["rccl"])
         inject = os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1"  # (test of the fallback path)
@@ -575,15 +781,21 @@ def main():
                     f = f + ["injected failure (test of the fallback path)"]
                 return f
             return verify
-        peer_up = peer_memory
-        comm_legs = [comm_ab_leg(ctx, dist, prob, X, s_out, L, args.ab_steps, world, rank, verifier(L), peer_up)
-                     for L in layers]
-        good = [leg for leg in comm_legs if leg["verified"] and not leg.get("ipc_error")]
-        for leg in comm_legs:
+        comm_legs, kept = [], None
+        for L in layers:
+            wd.arm(f"exchange layer '{L}'", args.leg_timeout)
+            leg = comm_ab_leg(ctx, dist, prob, X, s_out, L, args.ab_steps, world, rank, verifier(L), peer_up)
+            comm_legs.append(leg)
             if not leg["verified"] and rank == 0:
                 print(f"bench.py: exchange layer '{leg['layer']}' failed verification" +
                       (", falling back to RCCL" if leg["layer"] != "rccl" else "") + ":\n  " +
                       "\n  ".join(leg.get("failures", [])), file=sys.stderr)
+            if leg["verified"] and not leg.get("ipc_error") and kept is None:
+                wd.arm(f"headline on '{L}'", args.leg_timeout)
+                kept = (L, measure(L))
+                wd.keep(lambda note, kl=L, km=kept[1], legs=list(comm_legs): make_line(
+                    km, kl, "the first layer that verified; " + note, legs))
+        good = [leg for leg in comm_legs if leg["verified"] and not leg.get("ipc_error")]
         if not good:
             raise SystemExit("bench.py: distributed data path failed verification on every exchange layer")
         forced = [leg for leg in good if leg["layer"] == args.comm]
@@ -593,105 +805,15 @@ def main():
             comm_layer = min(good, key=lambda leg: leg["us_per_step"])["layer"]
             comm_choice = "fastest verified layer of comm_ab_legs" + \
                 ("" if args.comm == "auto" else f" ('{args.comm}' asked for but not available / not verified)")
-        comm_set_layer(ctx, comm_layer, peer_up)
+        wd.arm(f"headline on '{comm_layer}'", args.leg_timeout)
+        m = kept[1] if kept[0] == comm_layer else measure(comm_layer)
+        wd.disarm()
         peer_memory = comm_layer != "rccl"
         dist.barrier()
-    g, H = prob.model(X)
-    N = n * p
-    bytes_per_step = wl.cg_bytes_per_iter(N) + wl.stiefel_hvp_bytes(n, nnz, p)  # per GPU
-
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-
-    # ---- device wake-up, warmup, timed region ---------------------------------------------------
-    # An idle MI355X needs tens of milliseconds of work before its clocks and its memory system are at their steady
-    # state; W warmup steps of 57 us are over long before that (measured, 20 timed steps: W = 5 -> 58.8 us/step,
-    # W = 500 -> 57.7, W = 2000 -> 57.4; 500 timed steps: 56.5).  So the device is woken up with a FIXED number of
-    # steps of the same solve (the same on every rank: they contain the exchanges) before the W warmup steps the
-    # command line asks for; the count is reported in the JSON line (`device_wakeup_steps`; --wakeup-steps 0 switches it
-    # off).  The timed region is unchanged: exactly K steps between two barrier + synchronise pairs.
-    wakeup_steps = args.wakeup_steps
-    if wakeup_steps > 0:
-        run_steps(ctx, g, H, s_out, wakeup_steps)
-    if args.warmup > 0:
-        run_steps(ctx, g, H, s_out, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    solves = run_steps(ctx, g, H, s_out, args.steps)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    barrier()
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    packed = os.environ.get("MI355OPT_NO_PACKED", "0") != "1"
-    kb = kernel_bytes(n, nnz, p, packed=packed)
-    # compulsory bytes of the three kernels a completed iteration launches (the per-solve initialisation kernels,
-    # ~2 % of the time at 50 iterations per solve, are inside the timed region but not counted)
-    recur = os.environ.get("MI355OPT_NO_DIRGRAM", "0") != "1"
-    moved_model = (kb["stiefel_hess_fused"] if recur else kb["stiefel_spmm_gram"] + kb["stiefel_finish_dots"]) + \
-        kb["cg_update"] + kb["cg_pupdate"]
-
-    # ---- roofline leg: same steps again with HIP-event pairs around every hot kernel ------------
-    roofline = None
-    moved_bytes = moved_model
-    # EVERY rank runs these steps (they contain the same exchanges as the timed ones: a rank running them alone
-    # would wait for peers that never come); rank 0's own kernel timings are the ones reported.
-    if not args.no_roofline:
-        # (200 steps whatever K is: with K = 20 the averages were over 20 launches, the first of them behind a solve's
-        # set-up kernels)
-        per, moved_measured = timed_kernels(ctx, g, H, s_out, 200, kb)
-        moved_bytes = moved_measured
-        ran = [k for k in HOT if per[k]["launches"]]
-        dom = max(ran, key=lambda k: per[k]["avg_us"] * per[k]["launches"])
-        # An event pair also times its own two records: the instrumented steps are slower than the timed region by
-        # exactly that, the same amount per launch.  Measured live: (time of a step's launches by event pairs - time
-        # of an un-instrumented step) / launches per step, subtracted from every pair average (0 when the step
-        # contains launches that are not timed here, e.g. exchange kernels of a multi-rank run).  The net figures add
-        # up to the un-instrumented step and agree with rocprofv3's kernel durations (profiles/r02_summary.md) to 1 %.
-        tsteps = 200
-        pair_us_per_step = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
-        launches_per_step = sum(per[k]["launches"] for k in ran) / tsteps
-        ev_overhead = max(0.0, (pair_us_per_step - dt / args.steps * 1e6) / max(launches_per_step, 1e-9))
-        if ev_overhead > 0.25 * min(per[k]["avg_us"] for k in ran):  # implausible: keep the raw pairs
-            ev_overhead = 0.0
-        net_us = per[dom]["avg_us"] - ev_overhead
-        achieved = kb[dom] / (net_us * 1e-6) / 1e9
-        # `traffic` is NOT measured in this run: PMC counters need separate rocprofv3 passes (tools/pmc_bytes.sh);
-        # the figure is the last committed measurement of the same kernel on the same workload, labelled as such
-        traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_bytes.sh on this " \
-                                 "workload; not collected in this run)"
-            except Exception:  # noqa
-                traffic = None
-        sum_kernel_us = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": traffic_source,
-                    "algorithmic_bytes_per_launch": kb[dom],
-                    "avg_launch_us": net_us,
-                    # sum of the kernels' durations over the un-instrumented step: 1.0 = no gaps between kernels
-                    "sum_kernel_us_over_step_us": (sum_kernel_us - ev_overhead * launches_per_step)
-                                                  / (dt / args.steps * 1e6),
-                    "sum_kernel_us_over_step_us_event_pairs": sum_kernel_us / (dt / args.steps * 1e6),
-                    "avg_launch_us_event_pairs": per[dom]["avg_us"],
-                    "event_record_overhead_us_per_launch": ev_overhead,
-                    "timing": "HIP event pair around every launch on the launch stream, minus the pairs' own cost "
-                              "measured live as (pair-timed step - un-instrumented step) / launches per step",
-                    "frac_event_pairs_uncorrected": kb[dom] / (per[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "kernels": per}
-        barrier()
-        if rank != 0:
-            roofline = None
-    value = world * args.steps * moved_bytes / dt / 1e9
+    else:
+        m = measure(None)
+    dt, solves, roofline, moved_bytes, value, wakeup_steps = (m[k] for k in ("dt", "solves", "roofline", "moved_bytes",
+                                                                               "value", "wakeup_steps"))
 
     # ---- extra legs and CPU baselines: rank 0 of a single-GPU run -------------------------------------------
     plain_leg = big_leg = cpu = cpu_all = None
@@ -714,41 +836,7 @@ def main():
             cpu, cpu_all = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, moved_bytes, bytes_per_step)
 
     if rank == 0:
-        out = {
-            "metric": "TNT Steihaug-CG HVP+inner-product throughput", "value": value, "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "device_wakeup_steps": wakeup_steps,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg2 Stiefel({n_glob},{p}) Rayleigh quotient, 7-pt Laplacian "
-                                   f"{nx}x{ny}x{nz}+0.1I, fused device STPCG in solves of {TPCG} inner "
-                                   f"iterations at a near-optimal iterate (modes {modes})",
-                       "rows_per_gpu": n, "nnz_per_gpu": nnz, "N_per_gpu": N,
-                       "moved_bytes_per_step_per_gpu": moved_bytes,
-                       "reference_schedule_bytes_per_step_per_gpu": bytes_per_step, "solves": solves,
-                       "packed_matrix": packed,
-                       "parallelism": (f"row-sharded z-slabs x{world}, comm: " + LAYER_TEXT[comm_layer]) if use_comm
-                       else "single GPU",
-                       "device": ctx.device_name()},
-            # `value` = compulsory HBM bytes of the kernels that ran / time: comparable with the 8 TB/s peak.
-            "hbm_roofline_frac_whole_step": value / world / HBM_PEAK_GBS,
-            "value_basis": "compulsory HBM bytes of the three kernels of an iteration (one-pass Hessian: "
-                           "4 nnz + 4 (n+1) + 32 N with the value-indexed matrix, 12 nnz + ... without; "
-                           "cg_update 24 N; cg_pupdate 40 N) per second; working set "
-                           f"{(6 * 8 * N + (4 if packed else 12) * nnz) / 1e6:.0f} MB per GPU (Infinity Cache: 268 MB)",
-            "packed_matrix": packed,
-            # NOT a bandwidth: the same time priced by the bytes SURVEY.md 8(d) attributes to the reference's schedule
-            # (88 N + 12 nnz + 4 (n+1) + 16 n p + 56 N per iteration); the fused kernels never move those bytes
-            "reference_schedule_bytes_per_second_not_a_bandwidth": world * args.steps * bytes_per_step / dt,
-            "roofline": roofline,
-            # N > 1: which exchange layer the headline ran on and why; every layer's own figure next to it
-            "comm_layer": comm_layer, "comm_layer_choice": comm_choice, "rccl_nranks": rccl_nranks if use_comm else None,
-            "comm_ab_legs": comm_legs, "rehearsal_one_gpu": bool(one_gpu) if use_comm else None,
-            "peer_memory_probe": ({"passed": probe[0], "seconds": probe[1]} if use_comm and probe is not None else None),
-            # the second first-class number: the SAME workload through the generic path any CSR matrix takes
-            # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
-            "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,
-            "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
-        }
+        out = make_line(m, comm_layer, comm_choice, comm_legs, plain_leg, big_leg, cpu, cpu_all)
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

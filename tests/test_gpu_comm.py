@@ -528,3 +528,20 @@ def test_bare_bench_command_self_launches_its_ranks(n):
     assert legs["peer-separate"]["own_launches_per_step"]["scalar_exchange_kernels"] >= 2    # two per iteration
     if not d["rehearsal_one_gpu"]:
         assert d["rccl_nranks"] == n
+
+
+def test_bench_watchdog_delivers_the_kept_line_when_a_later_layer_hangs():
+    """N > 1: the headline is measured on the FIRST exchange layer that verifies and kept; a later layer that never
+    returns (on a real node: an RCCL collective that hangs -- nothing of ours bounds that) must not cost the line: the
+    watchdog prints the kept one with a note and every rank exits 0.  The hang is injected into the second layer of a
+    2-rank one-GPU rehearsal."""
+    env = dict(os.environ, MI355OPT_BENCH_INJECT_HANG="peer-separate")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "5",
+           "--wakeup-steps", "100", "--ab-steps", "60", "--leg-timeout", "15"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert "did not return" in d["watchdog"] and d["comm_layer"] == "peer" and d["value"] > 0 and d["n_gpus"] == 2
+    assert [leg["layer"] for leg in d["comm_ab_legs"]] == ["peer"] and d["comm_ab_legs"][0]["verified"]
