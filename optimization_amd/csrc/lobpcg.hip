@@ -570,8 +570,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       for (int j = 0; j < 4; ++j) {
         const int col = 16 * t + q + 4 * j;
         if (col < kc) {
-          if (col < k1) Y[(size_t)col * m + row] = acc[t][j];
-          else Y2[(size_t)(col - k1) * m + row] = acc[t][j];
+          // non-temporal stores (r04): the 0.77 GB of X and P written here are read by nobody before they have left
+          // the L2s anyway, and as ordinary stores they push the S lines this kernel is streaming out of them --
+          // 449 -> 403 us per call at cfg5 (non-temporal LOADS of S instead: 507 us)
+          if (col < k1) __builtin_nontemporal_store(acc[t][j], Y + (size_t)col * m + row);
+          else __builtin_nontemporal_store(acc[t][j], Y2 + (size_t)(col - k1) * m + row);
         }
       }
   }
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
             if (c0 + c < k) {
               const double xv = own[(unsigned)c * RR];
               const double res = __builtin_fma(-xv, th[c], acc[c]);   // AX - BX theta with BX = X, as k_residual
-              R[(size_t)(c0 + c) * m + row] = res;
+              R[(size_t)(c0 + c) * m + row] = res;  // (non-temporal: no measurable change, r04)
               nr[c] = __builtin_fma(res, res, nr[c]);
               nxs[c] = __builtin_fma(xv, xv, nxs[c]);
             }
