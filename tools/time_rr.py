@@ -23,4 +23,12 @@ for n in (24, 48, 72, 96):
     t0 = time.perf_counter()
     for _ in range(10):
         L.mi_rayleigh_ritz(n, A.ctypes.data_as(dp), B.ctypes.data_as(dp), th.ctypes.data_as(dp), Cm.ctypes.data_as(dp))
-    print("n=%d  %.3f ms" % (n, (time.perf_counter() - t0) / 10 * 1e3), "theta[0] %.17g" % th[0])
+    full = (time.perf_counter() - t0) / 10 * 1e3
+    k = max(1, n // 3)
+    L.mi_rayleigh_ritz_lowest.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp]
+    tl, Cl = np.zeros(k), np.zeros((n, k), order="F")
+    t0 = time.perf_counter()
+    for _ in range(10):
+        L.mi_rayleigh_ritz_lowest(n, k, A.ctypes.data_as(dp), B.ctypes.data_as(dp), tl.ctypes.data_as(dp), Cl.ctypes.data_as(dp))
+    low = (time.perf_counter() - t0) / 10 * 1e3
+    print("n=%d  full %.3f ms   lowest %d pairs %.3f ms" % (n, full, k, low), "theta[0] %.17g" % th[0], tl[0] == th[0])
