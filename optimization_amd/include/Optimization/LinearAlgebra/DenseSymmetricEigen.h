@@ -404,8 +404,10 @@ inline int generalized_symmetric_eig_lowest(int n, int k, const double *A, const
   // diagonal of the tridiagonal matrix (what sym_eigh parks in row n-1 while it accumulates)
   for (int i = 0; i < n; ++i) d[i] = VV(i, i);
   // --- implicit QL on (d, e): the scalar recurrence of sym_eigh, rotations recorded
-  std::vector<PlaneRotation> rot;
-  rot.reserve((size_t)n * n);
+  // (a plain array with a running count: push_back's capacity test sits on the recurrence's critical path otherwise.
+  // tql2 needs ~1.2 n^2 rotations on these pencils; 200 guard iterations of n rotations per eigenvalue is the hard cap)
+  std::vector<PlaneRotation> rot((size_t)4 * n * n + 64);
+  size_t nrot = 0;
   for (int i = 1; i < n; ++i) e[i - 1] = e[i];
   e[n - 1] = 0;
   double shift = 0, tst = 0;
@@ -442,7 +444,11 @@ inline int generalized_symmetric_eig_lowest(int n, int k, const double *A, const
           c = p / r;
           p = c * d[i] - s * g;
           d[i + 1] = h + s * (c * g + s * d[i]);
-          rot.push_back(PlaneRotation{c, s, i});  // V(:, i), V(:, i+1) <- V(:, i) c - V(:, i+1) s,  V(:, i) s + V(:, i+1) c
+          if (nrot == rot.size()) rot.resize(2 * rot.size());
+          rot[nrot].c = c;  // V(:, i), V(:, i+1) <- V(:, i) c - V(:, i+1) s,  V(:, i) s + V(:, i+1) c
+          rot[nrot].s = s;
+          rot[nrot].i = i;
+          ++nrot;
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
         e[l] = s * p;
@@ -463,7 +469,7 @@ inline int generalized_symmetric_eig_lowest(int n, int k, const double *A, const
     Theta[j] = d[order[j]];
     W[(size_t)order[j] * k + j] = 1.0;
   }
-  for (size_t q = rot.size(); q-- > 0;) {
+  for (size_t q = nrot; q-- > 0;) {
     const double c = rot[q].c, s = rot[q].s;
     double *wa = &W[(size_t)rot[q].i * k], *wb = wa + k;
     for (int j = 0; j < k; ++j) {
