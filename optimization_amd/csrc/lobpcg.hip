@@ -1454,7 +1454,8 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
                     double *sums_dev) {
   mi_ctx *ctx = A->ctx;
   // 49 KB of ring at a half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 columns per pass: 313 us
-  // per 24 columns, 8: 251)
+  // per 24 columns, 8: 251 -> 224-236 with the later changes; r04: 12 columns per pass -- 74 KB of ring, 241-244 VGPRs,
+  // still two waves per SIMD -- 234-242 us in the same call: the per-pass costs are not the bound, not kept)
   constexpr int kSpmmWinCols = 8;
   const int nc = 2 * kWinWaves + 2 * A->win_chunks;
   const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);

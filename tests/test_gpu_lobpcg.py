@@ -58,7 +58,7 @@ def test_gram_of_a_panel_held_in_two_pieces_has_the_bits_of_the_assembled_panel(
 
 
 @pytest.mark.parametrize("grid,k", [((20, 20, 20), 3), ((37, 29, 23), 5), ((50, 50, 50), 24), ((64, 64, 16), 9),
-                                    ((126, 30, 30), 24)])
+                                    ((126, 30, 30), 24), ((33, 31, 29), 12), ((40, 40, 40), 48)])
 def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, monkeypatch):
     """mi_csr_spmm_colmajor on matrices that qualify for the LDS-window form (k_spmm_colmajor_win: ring in LDS, far
     rows from registers, per-entry wave-uniform dispatch) against the same call with MI355OPT_NO_SPMM_WIN=1
