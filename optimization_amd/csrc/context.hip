@@ -23,10 +23,9 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   return MI_ERR_HIP;
 }
 
-int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host) {
-  size_t total = 0;
-  for (int i = 0; i < n; ++i) total += (bytes[i] + 63) / 64 * 64;
+static int readback_reserve(mi_ctx *ctx, size_t total) {
   if (total > ctx->readback_bytes) {
+    MI_HIP(hipStreamSynchronize(ctx->stream));  // (nobody may still be writing into the old area)
     if (ctx->readback_host) (void)hipHostFree(ctx->readback_host);
     ctx->readback_host = nullptr;
     ctx->readback_bytes = 0;
@@ -34,6 +33,18 @@ int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *byte
     MI_HIP(hipHostMalloc(&ctx->readback_host, cap, hipHostMallocDefault));
     ctx->readback_bytes = cap;
   }
+  return MI_OK;
+}
+int readback_area(mi_ctx *ctx, size_t bytes, void **host, void **dev) {
+  MI_TRY(readback_reserve(ctx, bytes));
+  *host = ctx->readback_host;
+  MI_HIP(hipHostGetDevicePointer(dev, ctx->readback_host, 0));
+  return MI_OK;
+}
+int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += (bytes[i] + 63) / 64 * 64;
+  MI_TRY(readback_reserve(ctx, total));
   size_t off = 0;
   hipError_t e = hipSuccess;
   for (int i = 0; i < n && e == hipSuccess; ++i) {
@@ -168,6 +179,7 @@ OPT_BOOL(opt_no_far_computed, cfg.no_far_computed)
 OPT_BOOL(opt_words16, cfg.words16)
 OPT_BOOL(opt_no_spmm_stream, cfg.no_spmm_stream)
 OPT_BOOL(opt_no_spmm_win, cfg.no_spmm_win)
+OPT_BOOL(opt_no_zero_copy, cfg.no_zero_copy)
 OPT_BOOL(opt_no_update_mfma, cfg.no_update_mfma)
 #undef OPT_BOOL
 int opt_max_grid(mi_ctx *c, long v) {
@@ -189,6 +201,7 @@ const OptionDesc kOptions[] = {
     {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
+    {"NO_ZERO_COPY", opt_no_zero_copy},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
 };
 void config_from_env(mi_ctx *ctx) {

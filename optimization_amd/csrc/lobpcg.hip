@@ -1190,14 +1190,24 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
   const size_t nb = nwaves + (mfull < m ? 1 : 0);
   GramJob jobs[2] = {{nullptr, nullptr, nelem}, {nullptr, nullptr, nelem}};
   int st = MI_OK;
+  // One rank: the reduction kernel writes the two k x k results STRAIGHT into pinned host memory (82 KB over PCIe at
+  // ns = 72) -- no device buffer, no copy behind the kernel (a blit kernel of ~15 us per Gram even into pinned memory).
+  // Several ranks: the results are all-reduced on the device first.
+  const bool zero_copy = ctx->comm == nullptr && !ctx->cfg.no_zero_copy;
+  const size_t slot = ((size_t)nelem * sizeof(double) + 255) / 256 * 256;
+  char *zc_host = nullptr, *zc_dev = nullptr;
+  if (zero_copy) st = readback_area(ctx, 2 * slot, (void **)&zc_host, (void **)&zc_dev);
   for (int i = 0; i < 2 && st == MI_OK; ++i) {
     st = pool_alloc(ctx, nb * (size_t)nelem * sizeof(double), &jobs[i].partial);
-    if (st == MI_OK) st = pool_alloc(ctx, (size_t)nelem * sizeof(double), &jobs[i].Gdev);
+    if (st == MI_OK) {
+      if (zero_copy) jobs[i].Gdev = zc_dev + (size_t)i * slot;
+      else st = pool_alloc(ctx, (size_t)nelem * sizeof(double), &jobs[i].Gdev);
+    }
   }
   if (st != MI_OK) {
     for (int i = 0; i < 2; ++i) {
       if (jobs[i].partial) pool_free(ctx, jobs[i].partial);
-      if (jobs[i].Gdev) pool_free(ctx, jobs[i].Gdev);
+      if (!zero_copy && jobs[i].Gdev) pool_free(ctx, jobs[i].Gdev);
     }
     return st;
   }
@@ -1233,7 +1243,18 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
         st = comm_allreduce(ctx, (double *)jobs[i].Gdev + off, std::min(4096, nelem - off));
   }
   double *dst[2] = {Ga_host, Gb_host};
-  const int fin = gram_finish(ctx, jobs, 2, dst);
+  int fin = MI_OK;
+  if (zero_copy) {
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->host_syncs++;
+    if (e != hipSuccess) fin = hip_fail(e, "gram read-back", __FILE__, __LINE__);
+    for (int i = 0; i < 2; ++i) {
+      if (fin == MI_OK) memcpy(dst[i], zc_host + (size_t)i * slot, (size_t)nelem * sizeof(double));
+      pool_free(ctx, jobs[i].partial);
+    }
+  } else {
+    fin = gram_finish(ctx, jobs, 2, dst);
+  }
   if (st == MI_OK) st = hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
   return st != MI_OK ? st : fin;
 }
@@ -1517,23 +1538,36 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
   const int nchunks = (nx + 7) / 8;
   void *thdev = nullptr, *sums = nullptr;
   MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
-  int st = pool_alloc(ctx, (size_t)nchunks * 16 * sizeof(double), &sums);
+  // one rank: the 2 nx column sums land straight in pinned host memory (the one-workgroup reduction kernel of each pass
+  // stores them there), no copy behind the last kernel; several ranks: device buffer + read-back
+  const bool zero_copy = ctx->comm == nullptr && !ctx->cfg.no_zero_copy;
+  const size_t nsums = (size_t)nchunks * 16;
+  void *zc_host = nullptr;
+  int st = zero_copy ? readback_area(ctx, nsums * sizeof(double), &zc_host, &sums)
+                     : pool_alloc(ctx, nsums * sizeof(double), &sums);
   if (st == MI_OK) st = stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev);  // (no host wait)
   if (st == MI_OK) {
     KScope ks(ctx, MI_K_SPMM);
     st = spmm_win_launch(A, nx, X->d, AX->d, (const double *)thdev, R->d, (double *)sums);
   }
   if (st != MI_OK) {  // (the pool buffers go back on every path)
-    if (sums) pool_free(ctx, sums);
+    if (sums && !zero_copy) pool_free(ctx, sums);
     pool_free(ctx, thdev);
     return st;
   }
-  std::vector<double> out((size_t)nchunks * 16);
-  const void *dv[1] = {sums};
-  const size_t by[1] = {out.size() * sizeof(double)};
-  void *hs[1] = {out.data()};
-  st = readback_sync(ctx, 1, dv, by, hs);
-  pool_free(ctx, sums);
+  std::vector<double> out(nsums);
+  if (zero_copy) {
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->host_syncs++;
+    if (e != hipSuccess) st = hip_fail(e, "residual norms read-back", __FILE__, __LINE__);
+    else memcpy(out.data(), zc_host, nsums * sizeof(double));
+  } else {
+    const void *dv[1] = {sums};
+    const size_t by[1] = {nsums * sizeof(double)};
+    void *hs[1] = {out.data()};
+    st = readback_sync(ctx, 1, dv, by, hs);
+    pool_free(ctx, sums);
+  }
   pool_free(ctx, thdev);
   if (st != MI_OK) return st;
   for (int c = 0; c < nx; ++c) {

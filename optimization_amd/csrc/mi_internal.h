@@ -107,6 +107,7 @@ struct Config {
   bool words16 = false;             // WORDS16: 16-bit window words (opt-in)
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
+  bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
   int so3_sort_nbr = 0;             // SO3_SORT_NBR: mi_so3n_create orders a node's incidences by neighbour (experiment)
 };
@@ -215,6 +216,10 @@ int stage_upload(mi_ctx *ctx, const void *src, size_t bytes, void *dst_dev);
 // n device buffers -> n host buffers behind ONE stream synchronisation, through the context's pinned landing area
 // (counted in mi_ctx::host_syncs)
 int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host);
+// The landing area itself, for kernels that write their (small) result straight into host memory: at least `bytes`
+// of pinned memory, as a host pointer and as the device pointer of the same memory.  One user at a time: whoever asks
+// next may get the same bytes.
+int readback_area(mi_ctx *ctx, size_t bytes, void **host, void **dev);
 int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements
