@@ -357,9 +357,10 @@ def self_launch(args, argv):
 
 
 def peer_probe_main(args):
-    """`--peer-probe` (a throwaway process per rank, started by peer_probe below): bring the peer-memory layer up and run
-    its self-test -- known-value exchanges, then the folded exchange and all three forms of the halo push between the
-    real peers -- and say through the exit code whether it came up: 0 yes, 3 no."""
+    """`--peer-probe WHAT` (a throwaway process per rank, started by layer_probe below).  WHAT = "peer": bring the
+    peer-memory layer up and run its self-test -- known-value exchanges, then the folded exchange and all three forms
+    of the halo push between the real peers.  WHAT = "rccl": ncclCommInitRank over all ranks and two all-reduces of
+    known values through the library's own reduction path.  The exit code says whether it came up: 0 yes, 3 no."""
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -368,18 +369,30 @@ def peer_probe_main(args):
         os.environ.setdefault("MI355OPT_MAX_GRID", str(max(16, 192 // max(world, 1))))
         os.environ.setdefault("MI355OPT_IPC_TIMEOUT_MS", "5000")
     ctx = capi.Context(0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0")))
-    ok = ctx.enable_peer_memory(world, rank, dist, force=True)
+    if args.peer_probe == "rccl":
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+        ok = ctx.comm_rccl_count() == world
+        v = ctx.upload(np.full(4096, float(rank + 1)))
+        want = 4096.0 * sum((r + 1.0) ** 2 for r in range(world))
+        for _ in range(2):
+            ok = ok and v.dot(v) == want   # (small integers: exact in any summation order)
+    else:
+        ok = ctx.enable_peer_memory(world, rank, dist, force=True)
     dist.barrier()
     ctx.comm_finalize()
     ctx.close()
     os._exit(0 if ok else 3)
 
 
-def peer_probe(dist, world, rank):
-    """The first cross-device peer stores of this code base happen on the node the scaling bench runs on.  A layer that
-    merely fails its self-test falls back to RCCL by itself; one that takes the process down (a fault on a peer
-    mapping) would take the bench line with it -- so the bring-up and the whole self-test run in a throwaway process per
-    rank FIRST, and the real processes map peer memory only if every probe came back clean.  Returns (ok, seconds)."""
+def layer_probe(dist, world, rank, what):
+    """The first cross-device exchanges of this code base -- peer stores over hipIpc mappings AND RCCL collectives with
+    more than one rank -- happen on the node the scaling bench runs on.  A layer that merely fails its self-test is
+    dropped by itself; one that takes the process down (a fault on a peer mapping) or never returns from its bring-up
+    would take the bench line with it -- so each layer's bring-up and self-test run in a throwaway process per rank FIRST
+    (what = "peer" | "rccl"), and the real processes bring a layer up only if every probe of it came back clean.
+    Returns (ok, seconds)."""
     import socket
     import subprocess
     t0 = time.perf_counter()
@@ -394,17 +407,19 @@ def peer_probe(dist, world, rank):
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_PORT=str(port[0]), MASTER_ADDR="127.0.0.1")
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--peer-probe", "--gpus", str(world)], env=env,
-                           capture_output=True, text=True, timeout=240)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--peer-probe", what, "--gpus", str(world)],
+                           env=env, capture_output=True, text=True, timeout=240)
         ok, note = r.returncode == 0, (r.stderr or "")[-300:]
     except subprocess.TimeoutExpired:
         ok, note = False, "probe timed out"
     every = [None] * world
     dist.all_gather_object(every, (ok, note))
     if rank == 0 and not all(e[0] for e in every):
-        print("bench.py: the peer-memory probe failed on rank(s) %s: RCCL carries the exchanges\n  %s" %
-              ([i for i, e in enumerate(every) if not e[0]], " | ".join(e[1].strip().splitlines()[-1] if e[1].strip() else "-"
-                                                                        for e in every if not e[0])), file=sys.stderr)
+        print("bench.py: the %s probe failed on rank(s) %s: %s\n  %s" %
+              ({"peer": "peer-memory", "rccl": "RCCL"}[what], [i for i, e in enumerate(every) if not e[0]],
+               {"peer": "RCCL carries the exchanges", "rccl": "the peer-memory layer carries the exchanges"}[what],
+               " | ".join(e[1].strip().splitlines()[-1] if e[1].strip() else "-" for e in every if not e[0])),
+              file=sys.stderr)
     return all(e[0] for e in every), time.perf_counter() - t0
 
 
@@ -542,7 +557,7 @@ def main():
     ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MI355OPT_BENCH_LEG_TIMEOUT", "240")),
                     help="N > 1: seconds an exchange layer's leg (or a headline measurement) may take before the "
                          "watchdog prints the line already measured on an earlier layer and ends the run")
-    ap.add_argument("--peer-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--peer-probe", choices=["peer", "rccl"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-peer-probe", action="store_true",
                     help="N > 1: map peer memory in the bench processes without trying it in throwaway ones first")
     args = ap.parse_args()
@@ -575,23 +590,36 @@ def main():
     ctx = capi.Context(0 if one_gpu else local_rank)
     peer_memory = False
     rccl_nranks = 0
-    probe = None
+    probe = rccl_probe = None
+    rccl_up = False
     if use_comm:
-        if not one_gpu:
+        # Each exchange layer is tried in throwaway processes first (layer_probe), and is brought up here only if every
+        # rank's probe of it came back clean: a bring-up that faults or never returns then costs that layer, not the line.
+        # (MI355OPT_BENCH_TRY_RCCL=1: the rehearsal probes RCCL as well -- it refuses the duplicate device, which is the
+        # "RCCL does not come up" branch of a real node; tests/test_gpu_comm.py)
+        want_rccl = not one_gpu or (os.environ.get("MI355OPT_BENCH_TRY_RCCL") == "1" and not args.no_peer_probe)
+        want_peer = args.comm != "rccl" or one_gpu
+        if want_rccl and world > 1 and not args.no_peer_probe:
+            rccl_probe = layer_probe(dist, world, rank, "rccl")
+            want_rccl = rccl_probe[0]
+            want_peer = want_peer or not want_rccl   # (--comm rccl without a working RCCL: the other layer, and say so)
+        if want_rccl:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(world, rank, uid[0])
             rccl_nranks = ctx.comm_rccl_count()
+            rccl_up = True
         # The peer-memory layer (scalar all-reduces and halo rows by xGMI peer stores) is brought up whenever every
         # rank's export / map / self-test succeeds (the self-test includes the folded exchange and all three forms of
         # the halo push between the real peers); which layer the headline uses is decided below.  The one-GPU rehearsal
         # needs it (RCCL refuses duplicate devices).
-        if (args.comm != "rccl" or one_gpu) and world > 1 and not args.no_peer_probe:
-            probe = peer_probe(dist, world, rank)
-        if (args.comm != "rccl" or one_gpu) and (probe is None or probe[0]):
+        if want_peer and world > 1 and not args.no_peer_probe:
+            probe = layer_probe(dist, world, rank, "peer")
+        if want_peer and (probe is None or probe[0]):
             peer_memory = ctx.enable_peer_memory(world, rank, dist, force=True)
-        if one_gpu and not peer_memory:
-            raise SystemExit("one-GPU rehearsal needs the peer-memory layer")
+        if not rccl_up and not peer_memory:
+            raise SystemExit("bench.py: neither exchange layer came up" if not one_gpu else
+                             "one-GPU rehearsal needs the peer-memory layer")
         dist.barrier()
 
     # ---- workload ------------------------------------------------------------------------------
@@ -652,6 +680,8 @@ def main():
             "comm_layer": layer, "comm_layer_choice": choice, "rccl_nranks": rccl_nranks if use_comm else None,
             "comm_ab_legs": legs, "rehearsal_one_gpu": bool(one_gpu) if use_comm else None,
             "peer_memory_probe": ({"passed": probe[0], "seconds": probe[1]} if use_comm and probe is not None else None),
+            "rccl_probe": ({"passed": rccl_probe[0], "seconds": rccl_probe[1]}
+                           if use_comm and rccl_probe is not None else None),
             # the second first-class number: the SAME workload through the generic path any CSR matrix takes
             # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
             "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,
@@ -770,7 +800,7 @@ def main():
     comm_layer, comm_legs, comm_choice, m = None, None, None, None
     wd = Watchdog(rank) if use_comm else None
     if use_comm:
-        layers = (["peer", "peer-separate"] if peer_memory else []) + ([] if one_gpu else ["rccl"])
+        layers = (["peer", "peer-separate"] if peer_memory else []) + (["rccl"] if rccl_up else [])
         inject = os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1"  # (test of the fallback path)
 
         def verifier(layer):

@@ -545,3 +545,35 @@ def test_bench_watchdog_delivers_the_kept_line_when_a_later_layer_hangs():
     d = json.loads(lines[0])
     assert "did not return" in d["watchdog"] and d["comm_layer"] == "peer" and d["value"] > 0 and d["n_gpus"] == 2
     assert [leg["layer"] for leg in d["comm_ab_legs"]] == ["peer"] and d["comm_ab_legs"][0]["verified"]
+
+
+def test_bench_goes_on_without_rccl_when_its_probe_fails():
+    """N > 1 (r04): RCCL with more than one rank has never run before the driver's scaling bench either, so its
+    bring-up (ncclCommInitRank + two all-reduces of known values) is tried in throwaway processes like the peer-memory
+    layer's; if that fails or never returns, the run goes on with the peer-memory layer alone and says so.  Here: two
+    ranks on one GPU with the RCCL probe switched on -- RCCL refuses the duplicate device."""
+    env = dict(os.environ, MI355OPT_BENCH_TRY_RCCL="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "5",
+           "--wakeup-steps", "100", "--ab-steps", "60"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["rccl_probe"] == {"passed": False, "seconds": d["rccl_probe"]["seconds"]} and d["rccl_nranks"] == 0
+    assert d["peer_memory_probe"]["passed"] and d["comm_layer"] == "peer" and d["value"] > 0
+    assert [leg["layer"] for leg in d["comm_ab_legs"]] == ["peer", "peer-separate"]
+    assert "RCCL probe failed" in r.stderr
+
+
+def test_rccl_probe_process_with_one_rank():
+    """the throwaway process of the RCCL probe itself, world = 1: communicator up, ncclCommCount == 1, exact sums"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--peer-probe", "rccl", "--gpus", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
