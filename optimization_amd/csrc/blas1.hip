@@ -69,13 +69,15 @@ __global__ __launch_bounds__(kBlock) void k_dot(size_t n, DotArgs args, double *
 
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_reduce_rows_to_slots(const double *__restrict__ partials,
-                                                                 int count, double *__restrict__ slots) {
+                                                                 int count, double *__restrict__ slots,
+                                                                 size_t batch_stride) {
+  // (workgroup b: the b-th buffer of a batch, batch_stride doubles apart, into slots[b K .. b K + K))
   __shared__ double lds[K * (kWaves + 1)];
   double out[K];
-  reduce_rows<K>(partials, count, out, lds);
+  reduce_rows<K>(partials + (size_t)blockIdx.x * batch_stride, count, out, lds);
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) slots[k] = out[k];
+    for (int k = 0; k < K; ++k) slots[(size_t)blockIdx.x * K + k] = out[k];
   }
 }
 
@@ -90,9 +92,11 @@ int check_same(const mi_vec *a, const mi_vec *b) {
 
 namespace mi {
 
-int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots) {
+int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots, int nbatch,
+                                size_t batch_stride) {
 #define RR(K) \
-  hipLaunchKernelGGL(k_reduce_rows_to_slots<K>, dim3(1), dim3(kBlock), 0, ctx->stream, partials, count, slots)
+  hipLaunchKernelGGL(k_reduce_rows_to_slots<K>, dim3(nbatch), dim3(kBlock), 0, ctx->stream, partials, count, slots, \
+                     batch_stride)
   switch (k) {
     case 1: RR(1); break;
     case 2: RR(2); break;

@@ -726,12 +726,17 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslic
 // Same operations on the same operands as k_residual (one fused multiply-add per element, squares accumulated by fma):
 // R has its bits; the norms differ from its by the grouping of their sums only.
 template <int KC, int HW, int WC, bool FARD, bool RES = false>
-__global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c0,
+__global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c_first, int nruns,
                                                                  const double *__restrict__ X,
                                                                  double *__restrict__ Y,
                                                                  const double *__restrict__ theta = nullptr,
                                                                  double *__restrict__ R = nullptr,
-                                                                 double *__restrict__ partials = nullptr) {
+                                                                 double *__restrict__ partials_all = nullptr) {
+  // blockIdx.y: the pass (KC columns each) -- all passes of a panel in ONE launch (r04): no drain / ramp between them
+  // and, in the residual form, one reduction behind the lot; blockIdx.x: the run of tiles, gridDim.x = nruns rounded
+  // up to whole XCD rounds so that x mod 8 is the XCD in every pass (xcd_remap)
+  const int c0 = c_first + (int)blockIdx.y * KC;
+  double *const partials = RES ? partials_all + (size_t)blockIdx.y * (2 * KC) * kMaxRows : nullptr;
   extern __shared__ __attribute__((aligned(16))) double ring_dyn[];  // KC x (ring rows + zero row)
   __shared__ double vt[256];
   __shared__ double red[RES ? 2 * KC * kWinWaves : 1];
@@ -752,8 +757,9 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
   const int nchunks = (int)A.nslices, ntiles = (nchunks + NW - 1) / NW, per = (ntiles + (int)nb - 1) / (int)nb;
   int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
   if (W.bounds) {
-    t0 = scalar_int(W.bounds, lb);
-    t1 = scalar_int(W.bounds, lb + 1);
+    const unsigned lc = lb < (unsigned)nruns ? lb : (unsigned)nruns;  // (a padding workgroup: the empty run at the end)
+    t0 = scalar_int(W.bounds, lc);
+    t1 = lb < (unsigned)nruns ? scalar_int(W.bounds, lc + 1) : t0;
   }
   if (t0 >= t1) {
     if constexpr (RES) {  // an idle workgroup still owns a partial row: zeros
@@ -1506,11 +1512,30 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
   SellView view = sell_view(A);
   WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
              nullptr};
-  double *partials = res ? ctx->partials2 : nullptr;
-  for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
-    void *args[] = {&view, &wv, &k, &c0, &Xd, &Yd, &theta_dev, &Rd, &partials};
-    MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
-    if (res) MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, wgrid, 16, sums_dev + 16 * (c0 / kSpmmWinCols)));
+  const int npass = (k + kSpmmWinCols - 1) / kSpmmWinCols;
+  const int xgrid = (wgrid + kNumXCD - 1) / kNumXCD * kNumXCD;
+  if (!res || (ctx->comm == nullptr && xgrid <= kMaxRows)) {
+    // all passes in one launch; residual form: the passes' partial rows side by side, one reduction kernel for all
+    void *pr = nullptr;
+    if (res) MI_TRY(pool_alloc(ctx, (size_t)npass * 2 * kSpmmWinCols * kMaxRows * sizeof(double), &pr));
+    double *partials = (double *)pr;
+    int c0 = 0, nruns = wgrid;
+    void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_dev, &Rd, &partials};
+    hipError_t e = hipLaunchKernel(fn, dim3(xgrid, npass), dim3(kWinBlock), args, lds, ctx->stream);
+    int st = e == hipSuccess ? MI_OK : hip_fail(e, "panel product launch", __FILE__, __LINE__);
+    if (st == MI_OK && res)
+      st = launch_reduce_rows_to_slots(ctx, partials, xgrid, 2 * kSpmmWinCols, sums_dev, npass,
+                                       (size_t)2 * kSpmmWinCols * kMaxRows);
+    if (pr) pool_free(ctx, pr);
+    MI_TRY(st);
+  } else {
+    double *partials = ctx->partials2;
+    for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
+      int nruns = wgrid;
+      void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_dev, &Rd, &partials};
+      MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
+      MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, wgrid, 16, sums_dev + 16 * (c0 / kSpmmWinCols)));
+    }
   }
   MI_HIP(hipGetLastError());
   return MI_OK;

@@ -282,7 +282,8 @@ int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out);
 // per-workgroup partials of <x,y>,<y,y>,<x,x> into ctx->partials components 0,1,2
 int launch_dot3_partials(mi_ctx *ctx, size_t n, const double *x, const double *y, int *nparts);
 // one-workgroup kernel: sum `count` partial rows of components [0,k) -> slots[0..k)
-int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
+int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, int k, double *slots, int nbatch = 1,
+                                size_t batch_stride = 0);
 // the same followed by the sum over ranks (one kernel with the peer-memory layer, else reduce kernel +
 // RCCL all-reduce); no-op beyond the local reduction without a communicator
 int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
