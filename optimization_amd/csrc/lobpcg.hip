@@ -367,28 +367,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ?
       accB[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
     }
   const size_t band = 16 * nrow;
+  // the m % 16 leftover rows (m % 4 == 0: whole groups of four) are one more step of the wave whose turn it is, the
+  // groups past m as zeros (r04: this was a kernel of its own per Gram, k_gram_tail, 5 us each plus the drain between)
+  const size_t mend = mfull < m ? mfull + 16 : mfull;
   double4l sa[T], sb[T], na[T], nb[T];
   size_t r0 = rowwave * 16;
-  if (r0 < mfull) {
+  auto fetch = [&](size_t r) {
+    const bool ok = r + lane_off < m;  // (false only in the last, partial step)
+    const size_t rs = ok ? r : 0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      na[t] = *reinterpret_cast<const double4l *>(ps[t] + r0);
-      nb[t] = *reinterpret_cast<const double4l *>(pt[t] + r0);
+      na[t] = *reinterpret_cast<const double4l *>(ps[t] + rs);
+      nb[t] = *reinterpret_cast<const double4l *>(pt[t] + rs);
     }
-  }
-  for (; r0 < mfull; r0 += band) {
+    if (r == mfull) {  // wave-uniform
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          na[t][j] = ok ? na[t][j] : 0.0;
+          nb[t][j] = ok ? nb[t][j] : 0.0;
+        }
+    }
+  };
+  if (r0 < mend) fetch(r0);
+  for (; r0 < mend; r0 += band) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {  // the one wait of the step
       sa[t] = na[t];
       sb[t] = nb[t];
     }
-    if (r0 + band < mfull) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        na[t] = *reinterpret_cast<const double4l *>(ps[t] + r0 + band);
-        nb[t] = *reinterpret_cast<const double4l *>(pt[t] + r0 + band);
-      }
-    }
+    if (r0 + band < mend) fetch(r0 + band);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -437,7 +446,13 @@ __global__ __launch_bounds__(256) void k_gram_tail(size_t m, size_t r_begin, int
 constexpr int kRedElems = 16, kRedGroups = 32;
 __global__ __launch_bounds__(kRedElems *kRedGroups) void k_gram_reduce(int nblocks, int ka, int nelem, int sym,
                                                                        const double *__restrict__ partial,
-                                                                       double *__restrict__ G) {
+                                                                       double *__restrict__ G,
+                                                                       const double *__restrict__ partial2 = nullptr,
+                                                                       double *__restrict__ G2 = nullptr) {
+  if (blockIdx.y == 1) {  // (the second Gram of a pair, same shape: one launch for both)
+    partial = partial2;
+    G = G2;
+  }
   __shared__ double part[kRedGroups][kRedElems];
   const int ex = threadIdx.x % kRedElems, g = threadIdx.x / kRedElems;
   const int e = blockIdx.x * kRedElems + ex;
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
 // 16-row block's operands in flight during the current block's MFMAs.  Lane (i = l & 15, q = l >> 4) of the result
 // holds Y[row0 + i][16 t + q + 4 j], so a store instruction writes four 128-byte segments.  The VALU form above
 // streams the 27 KB coefficient block through the scalar cache once per 64 rows and sits at 40 % of the fp64 rate.
-// Rows are taken in whole 16-row blocks; the m % 16 leftover rows go through the VALU kernel.
+// Rows are taken in 16-row blocks; the m % 16 leftover rows are one more, masked block.
 template <int KS4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_panel_update_mfma(
     size_t nblocks, size_t m, int /*ks == 4 KS4*/, const double *__restrict__ S, const double *__restrict__ Ct, int kc,
@@ -552,10 +567,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
   // no explicit double buffering: with it the 18-step instance needs 292 registers (one wave per SIMD); at <= 256 two
   // waves share a SIMD and one's operand loads overlap the other's MFMA block
-  double cur[KS4];
-  for (size_t b = wave; b < nblocks; b += nwaves) {
+  // PART: the m % 16 leftover rows as one more block -- loads clamped to the last row, stores of rows < m only (r04: this
+  // was a kernel of its own, k_panel_update_tail, 8 us behind the product)
+  auto block = [&](size_t b, auto part) {
+    constexpr bool PART = decltype(part)::value;
+    const size_t rowl = b * 16 + i;
+    const size_t off = PART ? (rowl < m ? rowl : m - 1) - (size_t)i : b * 16;
+    double cur[KS4];
 #pragma unroll
-    for (int kk = 0; kk < KS4; ++kk) cur[kk] = sbase[(size_t)kk * step + b * 16];
+    for (int kk = 0; kk < KS4; ++kk) cur[kk] = sbase[(size_t)kk * step + off];
     double4v acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
@@ -563,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int kk = 0; kk < KS4; ++kk)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[kk][t], cur[kk], acc[t], 0, 0, 0);
-    const size_t row = b * 16 + i;
+    if (PART && rowl >= m) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -573,38 +593,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
           // non-temporal stores (r04): the 0.77 GB of X and P written here are read by nobody before they have left
           // the L2s anyway, and as ordinary stores they push the S lines this kernel is streaming out of them --
           // 449 -> 403 us per call at cfg5 (non-temporal LOADS of S instead: 507 us)
-          if (col < k1) __builtin_nontemporal_store(acc[t][j], Y + (size_t)col * m + row);
-          else __builtin_nontemporal_store(acc[t][j], Y2 + (size_t)(col - k1) * m + row);
+          if (col < k1) __builtin_nontemporal_store(acc[t][j], Y + (size_t)col * m + rowl);
+          else __builtin_nontemporal_store(acc[t][j], Y2 + (size_t)(col - k1) * m + rowl);
         }
       }
-  }
-}
-
-// rows [r_begin, m) (fewer than 16) of the same product, one thread per output element (the VALU kernel above would
-// put all of them on one wave that streams the whole coefficient block: 70 us for 8 rows)
-__global__ __launch_bounds__(256) void k_panel_update_tail(size_t m, size_t r_begin, int ks, int width,
-                                                           const double *__restrict__ S, const double *__restrict__ Ct,
-                                                           int kc, double *__restrict__ Y, int k1,
-                                                           double *__restrict__ Y2) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nrows = m - r_begin;
-  if (e >= nrows * (size_t)kc) return;
-  const size_t r = r_begin + e % nrows;
-  const int col = (int)(e / nrows);
-  double acc = 0;
-  int s_ = 0;
-  for (; s_ + 8 <= ks; s_ += 8) {  // eight independent loads in flight, then the products in order
-    double sv[8], cv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sv[i] = S[(size_t)(s_ + i) * m + r];
-      cv[i] = Ct[(size_t)(s_ + i) * width + col];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc = __builtin_fma(sv[i], cv[i], acc);
-  }
-  for (; s_ < ks; ++s_) acc = __builtin_fma(S[(size_t)s_ * m + r], Ct[(size_t)s_ * width + col], acc);
-  if (col < k1) Y[(size_t)col * m + r] = acc;
-  else Y2[(size_t)(col - k1) * m + r] = acc;
+  };
+  for (size_t b = wave; b < nblocks; b += nwaves) block(b, std::false_type{});
+  if (nblocks * 16 < m && nblocks % nwaves == wave) block(nblocks, std::true_type{});
 }
 
 // columns [c0, c0 + 8): R = AX - BX theta; partial rows of |R_j|^2 (comps 0..7) and |X_j|^2 (comps 8..15)
@@ -1193,7 +1188,7 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
   const size_t mfull = m - m % 16;
   const int occ = kpad <= 32 ? 2 : 1;  // (resident waves per SIMD: 62+16 / 132+48 registers at 1 / 2 tiles, then > 256)
   const size_t nwaves = (std::min<size_t>(4 * (size_t)occ * ctx->num_cu, mfull / 16) + 3) / 4 * 4;
-  const size_t nb = nwaves + (mfull < m ? 1 : 0);
+  const size_t nb = nwaves;  // (the leftover rows are a step of one of the waves)
   GramJob jobs[2] = {{nullptr, nullptr, nelem}, {nullptr, nullptr, nelem}};
   int st = MI_OK;
   // One rank: the reduction kernel writes the two k x k results STRAIGHT into pinned host memory (82 KB over PCIe at
@@ -1220,14 +1215,6 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
   const double *T2 = Ta2 ? Ta2->d : nullptr;
   {
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
-    if (mfull < m) {  // the < 16 leftover rows: one more partial Gram each
-      hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, k, k,
-                         (const double *)S->d, (const double *)Ta1->d, T2, k1a,
-                         (double *)jobs[0].partial + (nb - 1) * (size_t)nelem);
-      hipLaunchKernelGGL(k_gram_tail, dim3((nelem + 255) / 256), dim3(256), 0, ctx->stream, m, mfull, k, k,
-                         (const double *)S->d, (const double *)S->d, (const double *)nullptr, k,
-                         (double *)jobs[1].partial + (nb - 1) * (size_t)nelem);
-    }
 #define GPS(TT)                                                                                                     \
   hipLaunchKernelGGL((k_gram_pair_sym<TT>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, m, k,     \
                      (const double *)S->d, (const double *)Ta1->d, T2, k1a, (double *)jobs[0].partial,              \
@@ -1241,13 +1228,13 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
     }
 #undef GPS
   }
-  for (int i = 0; i < 2; ++i) {
-    hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + kRedElems - 1) / kRedElems), dim3(kRedElems * kRedGroups), 0,
-                       ctx->stream, (int)nb, k, nelem, 1, (const double *)jobs[i].partial, (double *)jobs[i].Gdev);
-    if (ctx->comm)
+  hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + kRedElems - 1) / kRedElems, 2), dim3(kRedElems * kRedGroups), 0,
+                     ctx->stream, (int)nb, k, nelem, 1, (const double *)jobs[0].partial, (double *)jobs[0].Gdev,
+                     (const double *)jobs[1].partial, (double *)jobs[1].Gdev);
+  if (ctx->comm)
+    for (int i = 0; i < 2; ++i)
       for (int off = 0; off < nelem && st == MI_OK; off += 4096)
         st = comm_allreduce(ctx, (double *)jobs[i].Gdev + off, std::min(4096, nelem - off));
-  }
   double *dst[2] = {Ga_host, Gb_host};
   int fin = MI_OK;
   if (zero_copy) {
@@ -1366,12 +1353,7 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
         hipLaunchKernelGGL(k_panel_update_mfma<18>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, ks,
                            (const double *)S->d, (const double *)Cdev + ch.off, kc, Y->d, k1,
                            Y2 ? Y2->d : (double *)nullptr);
-      r_begin = nblocks * 16;
-      if (r_begin < m)
-        hipLaunchKernelGGL(k_panel_update_tail, dim3((unsigned)(((m - r_begin) * 48 + 255) / 256)), dim3(256), 0,
-                           ctx->stream, m, r_begin, ks, 48, (const double *)S->d, (const double *)Cdev + ch.off, kc,
-                           Y->d, k1, Y2 ? Y2->d : (double *)nullptr);
-      continue;
+      continue;  // (the m % 16 leftover rows are the last block of one of the waves)
     }
     switch (ch.width) {
       case 48: UPD(48); break;
