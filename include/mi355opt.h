@@ -391,6 +391,21 @@ MI_API int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, in
  * mirror image, which is also all the reference's eigensolver reads), from ONE pass over S and T.  Ta2 may be null. */
 MI_API int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
                                    const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+/* A panel held as 1 to 3 column blocks that need not be adjacent: block i = the first cols[i] columns of block[i] (a
+ * panel, or a mi_vec_view of some columns of one).  LOBPCG's search basis S = [X, W(:, nc:), P(:, nc:)]
+ * (LOBPCG.h:254-264) is handed over like this -- as its three blocks lie -- instead of being copied together every
+ * iteration once pairs are locked (nc > 0).  The *_blocks entry points below compute what their namesakes compute on
+ * the concatenation of the blocks; shapes their one-pass kernels do not take are copied together internally. */
+typedef struct mi_panel_blocks {
+  int nblocks;
+  const mi_vec *block[3];
+  int cols[3];
+} mi_panel_blocks;
+MI_API int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int k1a, const mi_vec *Ta1,
+                                          const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+MI_API int mi_lobpcg_update2_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int kc, const double *C_host,
+                                    int ldc, mi_vec *Y, int k1, mi_vec *Y2);
+MI_API int mi_csr_spmm_colmajor_blocks(const mi_csr *A, const mi_panel_blocks *X, mi_vec *Y);
 /* Y (m x kc) = S (m x ks) * C (ks x kc column-major host) -- LOBPCG.h:226-227,278,288 */
 MI_API int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S,
                             const double *C_host, int ldc, mi_vec *Y);

@@ -31,6 +31,21 @@ vp = C.c_void_p
 APPLY_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp)
 
 
+class PanelBlocks(C.Structure):
+    """mi_panel_blocks (include/mi355opt.h): a panel as 1..3 column blocks that need not be adjacent"""
+    _fields_ = [("nblocks", C.c_int), ("block", C.c_void_p * 3), ("cols", C.c_int * 3)]
+
+    @classmethod
+    def of(cls, blocks):
+        pb = cls()
+        pb.nblocks = len(blocks)
+        for i, (v, c) in enumerate(blocks):
+            pb.block[i] = v.h
+            pb.cols[i] = c
+        pb._keep = [v for v, _ in blocks]
+        return pb
+
+
 class FusedArgs(C.Structure):
     _fields_ = [("partials", C.POINTER(C.c_double)), ("partial_stride", C.c_size_t), ("max_rows", C.c_int),
                 ("required_rows", C.c_int), ("stream", vp)]
@@ -184,6 +199,9 @@ def load():
         "mi_debug_window_runs": [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)],
         "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_pair_sym": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p, c_double_p],
+        "mi_lobpcg_gram_pair_sym_blocks": [vp, C.c_size_t, vp, C.c_int, vp, vp, c_double_p, c_double_p],
+        "mi_lobpcg_update2_blocks": [vp, C.c_size_t, vp, C.c_int, c_double_p, C.c_int, vp, C.c_int, vp],
+        "mi_csr_spmm_colmajor_blocks": [vp, vp, vp],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
         "mi_vec_view": [vp, C.c_size_t, C.c_size_t, C.POINTER(vp)],
         "mi_comm_unique_id": [C.POINTER(C.c_ubyte)],
@@ -556,6 +574,25 @@ class Context:
                                              _dp(Ga), _dp(Gb)))
         return Ga, Gb
 
+    def lobpcg_gram_pair_sym_blocks(self, m, blocks, Ta1, k1a, Ta2):
+        """the same on a basis held as column blocks [(panel or view, columns), ...] (mi_lobpcg_gram_pair_sym_blocks)"""
+        k = sum(c for _, c in blocks)
+        Ga, Gb = np.zeros((k, k), order="F"), np.zeros((k, k), order="F")
+        pb = PanelBlocks.of(blocks)
+        check(self.L.mi_lobpcg_gram_pair_sym_blocks(self.h, m, C.byref(pb), k1a, Ta1.h,
+                                                    Ta2.h if Ta2 is not None else None, _dp(Ga), _dp(Gb)))
+        return Ga, Gb
+
+    def lobpcg_update2_blocks(self, m, blocks, Cmat, k1):
+        """mi_lobpcg_update2_blocks: S C for a basis held as column blocks, columns [0, k1) and the rest"""
+        Cmat = np.asfortranarray(Cmat, dtype=np.float64)
+        kc = Cmat.shape[1]
+        Y1, Y2 = Vec(self, m * k1), Vec(self, m * max(kc - k1, 1))
+        pb = PanelBlocks.of(blocks)
+        check(self.L.mi_lobpcg_update2_blocks(self.h, m, C.byref(pb), kc, _dp(Cmat), Cmat.shape[0], Y1.h, k1,
+                                              Y2.h if k1 < kc else None))
+        return Y1, Y2
+
     def lobpcg_update(self, m, S, ks, Cmat):
         Cmat = np.asfortranarray(Cmat, dtype=np.float64)
         kc = Cmat.shape[1]
@@ -816,6 +853,14 @@ class Csr:
     def spmm_colmajor(self, k, X, Y=None):
         Y = Y if Y is not None else Vec(self.ctx, self.n * k)
         check(self.L.mi_csr_spmm_colmajor(self.h, k, X.h, Y.h))
+        return Y
+
+    def spmm_colmajor_blocks(self, blocks):
+        """mi_csr_spmm_colmajor_blocks: A [block 0 | block 1 | ...] for column blocks [(panel or view, columns), ...]"""
+        k = sum(c for _, c in blocks)
+        Y = Vec(self.ctx, self.n * k)
+        pb = PanelBlocks.of(blocks)
+        check(self.L.mi_csr_spmm_colmajor_blocks(self.h, C.byref(pb), Y.h))
         return Y
 
     def spmm_colmajor_residual(self, nx, X, theta):

@@ -37,6 +37,19 @@ namespace {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
 
+// A panel held as up to three column blocks that need not be adjacent (r04): LOBPCG's search basis
+// S = [X, W(:, nc:), P(:, nc:)] (LOBPCG.h:254-264) as the three blocks lie, instead of a copy that moves the unlocked
+// columns together every iteration.  Logical column c: [0, n0) -> block 0, [n0, n01) -> block 1, the rest -> block 2.
+// One contiguous panel: base[0] with n0 = n01 = its width.
+struct ColBlocks {
+  const double *base[3];
+  int n0, n01;
+  __host__ __device__ __forceinline__ const double *col(int c, size_t m) const {
+    return c < n0 ? base[0] + (size_t)c * m
+                  : (c < n01 ? base[1] + (size_t)(c - n0) * m : base[2] + (size_t)(c - n01) * m);
+  }
+};
+
 constexpr int kGramRows = 32;       // rows per LDS tile
 constexpr int kGramLd = 34;         // LDS leading dimension
 constexpr int kGramMaxK = 96;       // max panel width
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // gram_direct_body (the loads of step s + 1 are issued before the 120 MFMAs of step s).
 template <int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ? 1 : 2))) void k_gram_pair_sym(
-    size_t mfull, size_t m, int k, const double *__restrict__ S, const double *__restrict__ Tm,
+    size_t mfull, size_t m, int k, ColBlocks S, const double *__restrict__ Tm,
     const double *__restrict__ T2, int k1, double *__restrict__ partialA, double *__restrict__ partialB) {
   const size_t rowwave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nrow = (size_t)gridDim.x * 4;
   const int lane = threadIdx.x & 63;
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ?
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int c = std::min(16 * t + (lane & 15), k - 1);  // (clamped: products of padding columns are never stored)
-    ps[t] = S + (size_t)c * m + lane_off;
+    ps[t] = S.col(c, m) + lane_off;
     pt[t] = (T2 && c >= k1 ? T2 + (size_t)(c - k1) * m : Tm + (size_t)c * m) + lane_off;
   }
   double4v accA[T][T], accB[T][T];  // (only a <= b is used)
@@ -546,13 +559,21 @@ __global__ __launch_bounds__(256) void k_panel_update(size_t m, int ks, const do
 // holds Y[row0 + i][16 t + q + 4 j], so a store instruction writes four 128-byte segments.  The VALU form above
 // streams the 27 KB coefficient block through the scalar cache once per 64 rows and sits at 40 % of the fp64 rate.
 // Rows are taken in 16-row blocks; the m % 16 leftover rows are one more, masked block.
+// The basis may lie in up to three column blocks (mi_panel_blocks): the host cuts it into steps of four columns that
+// never straddle two blocks and hands over the address of each step's first column (wave-uniform: scalar registers, the
+// per-lane part q m + i is shared by all steps).  A block's last step, when the block's width is not a multiple of
+// four, is its LAST four columns, the ones the step before already covered carrying zero coefficients.
+struct StepBases {
+  const double *p[18];
+};
 template <int KS4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_panel_update_mfma(
-    size_t nblocks, size_t m, int /*ks == 4 KS4*/, const double *__restrict__ S, const double *__restrict__ Ct, int kc,
-    double *__restrict__ Y, int k1, double *__restrict__ Y2) {
+    size_t nblocks, size_t m, StepBases S, const double *__restrict__ Ct, int kc, double *__restrict__ Y, int k1,
+    double *__restrict__ Y2) {
   constexpr int NT = 3;  // 48 output columns
   const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-  // coefficients: A operand of step kk, tile t: C[4 kk + q][16 t + i] (zero past ks; Ct is ks x 48 row-major by s)
+  // coefficients: A operand of step kk, tile t: row 4 kk + q of Ct (4 KS4 x 48, row-major; the host has put the
+  // coefficients of the step's four basis columns there), column 16 t + i
   double ca[KS4][NT];
 #pragma unroll
   for (int kk = 0; kk < KS4; ++kk)
@@ -560,10 +581,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     for (int t = 0; t < NT; ++t) {
       ca[kk][t] = Ct[(size_t)(4 * kk + q) * 48 + 16 * t + i];
     }
-  // B operand of step kk: S[row0 + i][4 kk + q] = one per-lane base + kk * (4 m doubles), a wave-uniform offset
-  // (ks == 4 KS4 exactly: other widths take the VALU kernel)
-  const double *sbase = S + (size_t)q * m + i;
-  const size_t step = 4 * m;
+  // B operand of step kk: rows row0 + i of the step's column q
+  const size_t lane_off = (size_t)q * m + i;
   const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
   // no explicit double buffering: with it the 18-step instance needs 292 registers (one wave per SIMD); at <= 256 two
   // waves share a SIMD and one's operand loads overlap the other's MFMA block
@@ -575,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const size_t off = PART ? (rowl < m ? rowl : m - 1) - (size_t)i : b * 16;
     double cur[KS4];
 #pragma unroll
-    for (int kk = 0; kk < KS4; ++kk) cur[kk] = sbase[(size_t)kk * step + off];
+    for (int kk = 0; kk < KS4; ++kk) cur[kk] = S.p[kk][lane_off + off];
     double4v acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (double4v){0.0, 0.0, 0.0, 0.0};
@@ -720,13 +739,16 @@ __global__ __launch_bounds__(256) void k_spmm_colmajor_pk(size_t n, size_t nslic
 // row's own X values are in the ring anyway -- instead of a pass of their own that re-reads AX and X (k_residual).
 // Same operations on the same operands as k_residual (one fused multiply-add per element, squares accumulated by fma):
 // R has its bits; the norms differ from its by the grouping of their sums only.
+// the Ritz values of the residual form travel as kernel arguments (r04: they were a staged upload -- a 4 us copy kernel
+// and a dependent launch -- between the panel update and the product)
+struct ThetaArg {
+  double v[kGramMaxK];
+};
 template <int KC, int HW, int WC, bool FARD, bool RES = false>
 __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, WinView W, int k, int c_first, int nruns,
-                                                                 const double *__restrict__ X,
-                                                                 double *__restrict__ Y,
-                                                                 const double *__restrict__ theta = nullptr,
-                                                                 double *__restrict__ R = nullptr,
-                                                                 double *__restrict__ partials_all = nullptr) {
+                                                                 ColBlocks X, double *__restrict__ Y,
+                                                                 ThetaArg theta, double *__restrict__ R,
+                                                                 double *__restrict__ partials_all) {
   // blockIdx.y: the pass (KC columns each) -- all passes of a panel in ONE launch (r04): no drain / ramp between them
   // and, in the residual form, one reduction behind the lot; blockIdx.x: the run of tiles, gridDim.x = nruns rounded
   // up to whole XCD rounds so that x mod 8 is the XCD in every pass (xcd_remap)
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
     for (int c = 0; c < KC; ++c) {
       nr[c] = 0;
       nxs[c] = 0;
-      th[c] = (c0 + c < k) ? theta[c0 + c] : 0.0;
+      th[c] = (c0 + c < k) ? theta.v[c0 + c] : 0.0;  // (c0 is wave-uniform: scalar loads from the argument segment)
     }
   }
   constexpr int NW = kWinWaves;
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
   const unsigned lane8 = (unsigned)lane * 8u, lane4 = (unsigned)lane * 4u;
   const double *xc[KC];
 #pragma unroll
-  for (int c = 0; c < KC; ++c) xc[c] = X + (size_t)std::min(c0 + c, k - 1) * m;
+  for (int c = 0; c < KC; ++c) xc[c] = X.col(std::min(c0 + c, k - 1), m);
   auto chunk_load = [&](int q, double (&buf)[KC]) {
     const unsigned off = (unsigned)q * 512u + lane8, offs = off < mbytes ? off : 0u;  // past the last row: any valid address
 #pragma unroll
@@ -986,6 +1008,47 @@ int check_panel(mi_ctx *ctx, size_t m, int k, const mi_vec *P, const char *what)
 
 extern "C" {
 
+// ---- panels held as column blocks (mi_panel_blocks, include/mi355opt.h) ----------------------------------------------
+static ColBlocks one_block(const double *d, int k) { return ColBlocks{{d, d, d}, k, k}; }
+// validated kernel-side description of a mi_panel_blocks and its total width
+static int blocks_to_cols(mi_ctx *ctx, size_t m, const mi_panel_blocks *B, ColBlocks *cb, int *k) {
+  MI_REQUIRE(B && B->nblocks >= 1 && B->nblocks <= 3, "a panel has 1 to 3 column blocks");
+  int total = 0;
+  for (int i = 0; i < B->nblocks; ++i) {
+    MI_REQUIRE(B->cols[i] >= 1, "column block %d is empty", i);
+    MI_TRY(check_panel(ctx, m, B->cols[i], B->block[i], "column block"));
+    total += B->cols[i];
+  }
+  MI_REQUIRE(total <= kGramMaxK, "panel width must be in [1,%d]", kGramMaxK);
+  const double *b0 = B->block[0]->d, *b1 = B->nblocks > 1 ? B->block[1]->d : b0,
+               *b2 = B->nblocks > 2 ? B->block[2]->d : b1;
+  const int n0 = B->cols[0], n01 = n0 + (B->nblocks > 1 ? B->cols[1] : 0);
+  *cb = ColBlocks{{b0, b1, b2}, n0, B->nblocks > 2 ? n01 : total};
+  if (B->nblocks == 1) cb->n0 = cb->n01 = total;
+  *k = total;
+  return MI_OK;
+}
+// the blocks copied together into one panel (the fall-back of every *_blocks entry point whose fast kernel does not
+// take the shape at hand); the caller destroys *out
+static int materialize_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *B, mi_vec **out) {
+  int k = 0;
+  for (int i = 0; i < B->nblocks; ++i) k += B->cols[i];
+  MI_TRY(mi_vec_create(ctx, m * (size_t)k, out));
+  size_t off = 0;
+  for (int i = 0; i < B->nblocks; ++i) {
+    const size_t cnt = m * (size_t)B->cols[i];
+    const hipError_t e = hipMemcpyAsync((*out)->d + off, B->block[i]->d, cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                                        ctx->stream);
+    if (e != hipSuccess) {
+      mi_vec_destroy(*out);
+      *out = nullptr;
+      return hip_fail(e, "panel blocks copy", __FILE__, __LINE__);
+    }
+    off += cnt;
+  }
+  return MI_OK;
+}
+
 // a Gram whose kernels are enqueued but whose result has not been read back yet (gram_impl with job != null)
 struct GramJob {
   void *partial = nullptr, *Gdev = nullptr;
@@ -1168,6 +1231,10 @@ int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, 
 // block triangle is formed, the mirror image filled in) and G_B = S' S, both from ONE pass over S and T
 // (k_gram_pair_sym); one synchronisation.  Ta2 may be null (one panel of k columns).  Shapes the fused kernel does not
 // take (k > 80, unaligned panels, fewer than 16 rows) go through mi_lobpcg_gram_pair, which forms all of G_A.
+static bool gram_pair_sym_direct_ok(size_t m, int k, const ColBlocks &S, const mi_vec *Ta1, const mi_vec *Ta2);
+static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &Sb, int k1a, const mi_vec *Ta1,
+                                const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+
 int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
                             const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
   MI_REQUIRE(ctx && S && Ta1 && Ga_host && Gb_host, "null argument");
@@ -1181,9 +1248,42 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
     MI_TRY(check_panel(ctx, m, k, Ta1, "T"));
     k1a = k;
   }
-  const bool direct = k <= 80 && m % 4 == 0 && (uintptr_t)S->d % 32 == 0 && (uintptr_t)Ta1->d % 32 == 0 &&
-                      (!Ta2 || (uintptr_t)Ta2->d % 32 == 0) && m >= 16;
-  if (!direct) return mi_lobpcg_gram_pair(ctx, m, k, S, k1a, Ta1, Ta2, k, S, nullptr, Ga_host, Gb_host);
+  if (!gram_pair_sym_direct_ok(m, k, one_block(S->d, k), Ta1, Ta2))
+    return mi_lobpcg_gram_pair(ctx, m, k, S, k1a, Ta1, Ta2, k, S, nullptr, Ga_host, Gb_host);
+  return gram_pair_sym_direct(ctx, m, k, one_block(S->d, k), k1a, Ta1, Ta2, Ga_host, Gb_host);
+}
+
+int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int k1a, const mi_vec *Ta1,
+                                   const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
+  MI_REQUIRE(ctx && S && Ta1 && Ga_host && Gb_host, "null argument");
+  ColBlocks cb;
+  int k = 0;
+  MI_TRY(blocks_to_cols(ctx, m, S, &cb, &k));
+  if (Ta2) {
+    MI_REQUIRE(k1a >= 1 && k1a < k, "need 1 <= k1 < k");
+    MI_TRY(check_panel(ctx, m, k1a, Ta1, "T1"));
+    MI_TRY(check_panel(ctx, m, k - k1a, Ta2, "T2"));
+  } else {
+    MI_TRY(check_panel(ctx, m, k, Ta1, "T"));
+    k1a = k;
+  }
+  if (gram_pair_sym_direct_ok(m, k, cb, Ta1, Ta2))
+    return gram_pair_sym_direct(ctx, m, k, cb, k1a, Ta1, Ta2, Ga_host, Gb_host);
+  mi_vec *tmp = nullptr;  // shapes the one-pass kernel does not take: the blocks copied together, the general path
+  MI_TRY(materialize_blocks(ctx, m, S, &tmp));
+  const int st = mi_lobpcg_gram_pair_sym(ctx, m, k, tmp, k1a, Ta1, Ta2, Ga_host, Gb_host);
+  mi_vec_destroy(tmp);
+  return st;
+}
+
+static bool gram_pair_sym_direct_ok(size_t m, int k, const ColBlocks &S, const mi_vec *Ta1, const mi_vec *Ta2) {
+  return k <= 80 && m % 4 == 0 && (uintptr_t)S.base[0] % 32 == 0 && (uintptr_t)S.base[1] % 32 == 0 &&
+         (uintptr_t)S.base[2] % 32 == 0 && (uintptr_t)Ta1->d % 32 == 0 && (!Ta2 || (uintptr_t)Ta2->d % 32 == 0) && m >= 16;
+}
+
+// S'[Ta1 | Ta2] and S'S, upper block triangles, one pass (k_gram_pair_sym); arguments validated by the callers
+static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &Sb, int k1a, const mi_vec *Ta1,
+                                const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
   const int nelem = k * k, kpad = (k + 15) / 16 * 16;
   const size_t mfull = m - m % 16;
   const int occ = kpad <= 32 ? 2 : 1;  // (resident waves per SIMD: 62+16 / 132+48 registers at 1 / 2 tiles, then > 256)
@@ -1217,8 +1317,7 @@ int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
 #define GPS(TT)                                                                                                     \
   hipLaunchKernelGGL((k_gram_pair_sym<TT>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, m, k,     \
-                     (const double *)S->d, (const double *)Ta1->d, T2, k1a, (double *)jobs[0].partial,              \
-                     (double *)jobs[1].partial)
+                     Sb, (const double *)Ta1->d, T2, k1a, (double *)jobs[0].partial, (double *)jobs[1].partial)
     switch (kpad / 16) {
       case 1: GPS(1); break;
       case 2: GPS(2); break;
@@ -1289,50 +1388,126 @@ int mi_lobpcg_update(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, con
   return mi_lobpcg_update2(ctx, m, ks, kc, S, C_host, ldc, Y, kc, nullptr);
 }
 
+static int update2_impl(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const mi_panel_blocks *blocks,
+                        const double *C_host, int ldc, mi_vec *Y, int k1, mi_vec *Y2);
+
 int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const double *C_host, int ldc,
                       mi_vec *Y, int k1, mi_vec *Y2) {
   MI_REQUIRE(ctx && C_host, "null argument");
   MI_REQUIRE(ks >= 1 && ks <= kGramMaxK && kc >= 1 && kc <= kGramMaxK && ldc >= ks, "bad small-matrix shape");
-  MI_REQUIRE(k1 >= 1 && k1 <= kc && (k1 == kc || Y2), "bad split of the output columns");
   MI_TRY(check_panel(ctx, m, ks, S, "S"));
+  return update2_impl(ctx, m, ks, kc, S, nullptr, C_host, ldc, Y, k1, Y2);
+}
+
+int mi_lobpcg_update2_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int kc, const double *C_host, int ldc,
+                             mi_vec *Y, int k1, mi_vec *Y2) {
+  MI_REQUIRE(ctx && S && C_host, "null argument");
+  ColBlocks cb;
+  int ks = 0;
+  MI_TRY(blocks_to_cols(ctx, m, S, &cb, &ks));
+  MI_REQUIRE(kc >= 1 && kc <= kGramMaxK && ldc >= ks, "bad small-matrix shape");
+  return update2_impl(ctx, m, ks, kc, nullptr, S, C_host, ldc, Y, k1, Y2);
+}
+
+// S: the basis as one panel, or null with `blocks` (the kernels that do not take blocks then get a copy of them put
+// together)
+static int update2_impl(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, const mi_panel_blocks *blocks,
+                        const double *C_host, int ldc, mi_vec *Y, int k1, mi_vec *Y2) {
+  MI_REQUIRE(k1 >= 1 && k1 <= kc && (k1 == kc || Y2), "bad split of the output columns");
   MI_TRY(check_panel(ctx, m, k1, Y, "Y"));
   touch(Y);
   touch(Y2);
   if (k1 < kc) MI_TRY(check_panel(ctx, m, kc - k1, Y2, "Y2"));
   {  // neither destination may overlap the basis: the update reads S while other rows' results are written
-    const double *s0 = S->d, *s1 = S->d + (size_t)ks * m;
     const double *y0 = Y->d, *y1 = Y->d + (size_t)k1 * m;
-    MI_REQUIRE(y1 <= s0 || y0 >= s1, "in-place panel update is not supported");
-    if (k1 < kc) {
-      const double *z0 = Y2->d, *z1 = Y2->d + (size_t)(kc - k1) * m;
-      MI_REQUIRE(z1 <= s0 || z0 >= s1, "in-place panel update is not supported");
-      MI_REQUIRE(z1 <= y0 || z0 >= y1, "the two destination panels overlap");
+    const double *z0 = k1 < kc ? Y2->d : nullptr, *z1 = k1 < kc ? Y2->d + (size_t)(kc - k1) * m : nullptr;
+    const int nb = blocks ? blocks->nblocks : 1;
+    for (int i = 0; i < nb; ++i) {
+      const double *s0 = blocks ? blocks->block[i]->d : S->d;
+      const double *s1 = s0 + (size_t)(blocks ? blocks->cols[i] : ks) * m;
+      MI_REQUIRE(y1 <= s0 || y0 >= s1, "in-place panel update is not supported");
+      if (z0) MI_REQUIRE(z1 <= s0 || z0 >= s1, "in-place panel update is not supported");
     }
+    if (z0) MI_REQUIRE(z1 <= y0 || z0 >= y1, "the two destination panels overlap");
   }
-  // chunk plan (widest chunk that fits what is left: one pass over S per chunk) and the chunks'
-  // coefficient blocks, each ks x KC row-major by s, zero-padded past kc, packed back to back
+  // The matrix-pipe kernel takes the whole-iteration update -- 48 output columns (one chunk) from a basis that cuts into
+  // 6..18 steps of four columns, none straddling two blocks (see StepBases); every other shape goes through the VALU
+  // kernels, which want the basis in one piece.
+  StepBases steps{};
+  struct StepCols { int logical[4]; };  // basis column behind each of the step's four coefficient rows, -1: zero row
+  std::vector<StepCols> step_cols;
+  bool all_mfma = kc > 32 && kc <= 48 && m >= 16 && !ctx->cfg.no_update_mfma;
+  if (all_mfma) {
+    const int nb = blocks ? blocks->nblocks : 1;
+    int start = 0;
+    for (int bi = 0; bi < nb && all_mfma; ++bi) {
+      const int cb = blocks ? blocks->cols[bi] : ks;
+      const double *base = blocks ? blocks->block[bi]->d : S->d;
+      if (cb < 4) all_mfma = false;
+      for (int j = 0; 4 * j < cb && all_mfma; ++j) {
+        const int first = std::min(4 * j, cb - 4);
+        if (step_cols.size() == 18) { all_mfma = false; break; }
+        steps.p[step_cols.size()] = base + (size_t)first * m;
+        StepCols sc;
+        for (int q = 0; q < 4; ++q) sc.logical[q] = first + q >= 4 * j ? start + first + q : -1;
+        step_cols.push_back(sc);
+      }
+      start += cb;
+    }
+    if (step_cols.size() < 6) all_mfma = false;
+    for (size_t i = step_cols.size(); i < 18; ++i) steps.p[i] = steps.p[0];
+  }
+  // chunk plan (widest chunk that fits what is left: one pass over S per chunk) and the chunks' coefficient blocks,
+  // each ks x KC row-major by s, zero-padded past kc, packed back to back; matrix-pipe form: 4 K4 x 48, one row per
+  // (step, column of the step)
   struct Chunk { int c0, width; size_t off; };
   std::vector<Chunk> chunks;
   size_t total = 0;
-  for (int c0 = 0; c0 < kc;) {
-    const int left = kc - c0;
-    const int width = left > 32 ? 48 : (left > 16 ? 24 : (left > 8 ? 16 : 8));  // 48 = X and P of one iteration
-    chunks.push_back({c0, width, total});
-    total += (size_t)ks * width;
-    c0 += width;
-  }
-  std::vector<double> Ct(total, 0.0);
-  for (const Chunk &ch : chunks)
-    for (int s = 0; s < ks; ++s)
-      for (int c = 0; c < ch.width && ch.c0 + c < kc; ++c)
-        Ct[ch.off + (size_t)s * ch.width + c] = C_host[(size_t)(ch.c0 + c) * ldc + s];
-  void *Cdev = nullptr;
-  MI_TRY(pool_alloc(ctx, total * sizeof(double), &Cdev));
-  if (total * sizeof(double) <= mi_ctx::kStageBytes) {
-    MI_TRY(stage_upload(ctx, Ct.data(), total * sizeof(double), Cdev));  // Ct may die: the bytes are in a pinned slot
+  std::vector<double> Ct;
+  if (all_mfma) {
+    chunks.push_back({0, 48, 0});
+    total = step_cols.size() * 4 * 48;
+    Ct.assign(total, 0.0);
+    for (size_t st_ = 0; st_ < step_cols.size(); ++st_)
+      for (int q = 0; q < 4; ++q) {
+        const int sidx = step_cols[st_].logical[q];
+        if (sidx < 0) continue;
+        for (int c = 0; c < kc; ++c) Ct[(st_ * 4 + q) * 48 + c] = C_host[(size_t)c * ldc + sidx];
+      }
   } else {
-    MI_HIP(hipMemcpyAsync(Cdev, Ct.data(), total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MI_HIP(hipStreamSynchronize(ctx->stream));  // Ct dies with this call
+    for (int c0 = 0; c0 < kc;) {
+      const int left = kc - c0;
+      const int width = left > 32 ? 48 : (left > 16 ? 24 : (left > 8 ? 16 : 8));  // 48 = X and P of one iteration
+      chunks.push_back({c0, width, total});
+      total += (size_t)ks * width;
+      c0 += width;
+    }
+    Ct.assign(total, 0.0);
+    for (const Chunk &ch : chunks)
+      for (int s = 0; s < ks; ++s)
+        for (int c = 0; c < ch.width && ch.c0 + c < kc; ++c)
+          Ct[ch.off + (size_t)s * ch.width + c] = C_host[(size_t)(ch.c0 + c) * ldc + s];
+  }
+  mi_vec *tmp = nullptr;
+  if (!S && !all_mfma) {
+    MI_TRY(materialize_blocks(ctx, m, blocks, &tmp));
+    S = tmp;
+  }
+  void *Cdev = nullptr;
+  int st = pool_alloc(ctx, total * sizeof(double), &Cdev);
+  if (st == MI_OK) {
+    if (total * sizeof(double) <= mi_ctx::kStageBytes) {
+      st = stage_upload(ctx, Ct.data(), total * sizeof(double), Cdev);  // Ct may die: the bytes are in a pinned slot
+    } else {
+      hipError_t e = hipMemcpyAsync(Cdev, Ct.data(), total * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // Ct dies with this call
+      if (e != hipSuccess) st = hip_fail(e, "coefficient upload", __FILE__, __LINE__);
+    }
+  }
+  if (st != MI_OK) {
+    if (Cdev) pool_free(ctx, Cdev);
+    if (tmp) mi_vec_destroy(tmp);
+    return st;
   }
   const int grid = (int)std::min<size_t>((m + 255) / 256, 2048);
   KScope ksc(ctx, MI_K_LOBPCG_UPDATE);
@@ -1340,20 +1515,21 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
 #define UPD(KC)                                                                                       \
   hipLaunchKernelGGL(k_panel_update<KC>, dim3(grid), dim3(256), 0, ctx->stream, m, ks, (const double *)S->d, \
                      (const double *)Cdev + ch.off, ch.c0, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr, r_begin)
-    size_t r_begin = 0;
-    // the whole-iteration update (48 columns from <= 72) on the matrix pipe, leftover rows through the VALU kernel
-    if (ch.width == 48 && ch.c0 == 0 && (ks == 48 || ks == 72) && m >= 16 && !ctx->cfg.no_update_mfma) {
+    const size_t r_begin = 0;
+    if (all_mfma) {  // (the m % 16 leftover rows are the last block of one of the waves)
       const size_t nblocks = m / 16;
       const int mgrid = (int)std::min<size_t>((nblocks + 3) / 4, (size_t)2 * ctx->num_cu);
-      if (ks == 48)
-        hipLaunchKernelGGL(k_panel_update_mfma<12>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, ks,
-                           (const double *)S->d, (const double *)Cdev + ch.off, kc, Y->d, k1,
-                           Y2 ? Y2->d : (double *)nullptr);
-      else
-        hipLaunchKernelGGL(k_panel_update_mfma<18>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, ks,
-                           (const double *)S->d, (const double *)Cdev + ch.off, kc, Y->d, k1,
-                           Y2 ? Y2->d : (double *)nullptr);
-      continue;  // (the m % 16 leftover rows are the last block of one of the waves)
+#define UPM(K4)                                                                                                \
+  case K4:                                                                                                      \
+    hipLaunchKernelGGL(k_panel_update_mfma<K4>, dim3(mgrid), dim3(256), 0, ctx->stream, nblocks, m, steps,       \
+                       (const double *)Cdev + ch.off, kc, Y->d, k1, Y2 ? Y2->d : (double *)nullptr);             \
+    break
+      switch ((int)step_cols.size()) {
+        UPM(6); UPM(7); UPM(8); UPM(9); UPM(10); UPM(11); UPM(12); UPM(13); UPM(14); UPM(15); UPM(16); UPM(17);
+        default: UPM(18);
+      }
+#undef UPM
+      continue;
     }
     switch (ch.width) {
       case 48: UPD(48); break;
@@ -1363,9 +1539,10 @@ int mi_lobpcg_update2(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, co
     }
 #undef UPD
   }
-  MI_HIP(hipGetLastError());
+  st = hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
   pool_free(ctx, Cdev);  // stream-ordered reuse: later allocations are enqueued after these kernels
-  return MI_OK;
+  if (tmp) mi_vec_destroy(tmp);
+  return st;
 }
 
 int mi_lobpcg_residual(mi_ctx *ctx, size_t m, int nx, const mi_vec *AX, const mi_vec *BX, const mi_vec *X,
@@ -1457,9 +1634,9 @@ bool spmm_win_ok(const mi_csr *A) {
          A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n * 8 < ((size_t)1 << 32);
 }
 
-// Y = A X in window form, 8 columns per pass.  theta_dev != nullptr: the fused residual form (k_spmm_colmajor_win<..,
+// Y = A X in window form, 8 columns per pass.  theta_host != nullptr: the fused residual form (k_spmm_colmajor_win<..,
 // RES>): R = Y - X diag(theta) and, per pass, the 16 column sums |R_j|^2, |X_j|^2 reduced into sums_dev + 16 * pass.
-int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const double *theta_dev, double *Rd,
+int spmm_win_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const double *theta_host, double *Rd,
                     double *sums_dev) {
   mi_ctx *ctx = A->ctx;
   // 49 KB of ring at a half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 columns per pass: 313 us
@@ -1468,7 +1645,7 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
   constexpr int kSpmmWinCols = 8;
   const int nc = 2 * kWinWaves + 2 * A->win_chunks;
   const size_t lds = (size_t)kSpmmWinCols * ((size_t)nc * 64 + 1) * sizeof(double);
-  const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1, res = theta_dev != nullptr;
+  const bool hw7 = A->win_head <= 7, wc1 = A->win_chunks == 1, res = theta_host != nullptr;
   const void *fn = nullptr;
   const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
 #define PICK3(HWV, WCV, FV, RV) fn = (const void *)k_spmm_colmajor_win<kSpmmWinCols, HWV, WCV, FV, RV>
@@ -1494,6 +1671,8 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
   SellView view = sell_view(A);
   WinView wv{A->wk, A->wfar, A->win_chunks, nc, A->win_zero, bounds, fard ? (unsigned)A->win_far_pure : 0u,
              nullptr};
+  ThetaArg theta_arg{};
+  if (res) std::copy(theta_host, theta_host + k, theta_arg.v);
   const int npass = (k + kSpmmWinCols - 1) / kSpmmWinCols;
   const int xgrid = (wgrid + kNumXCD - 1) / kNumXCD * kNumXCD;
   if (!res || (ctx->comm == nullptr && xgrid <= kMaxRows)) {
@@ -1502,7 +1681,7 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
     if (res) MI_TRY(pool_alloc(ctx, (size_t)npass * 2 * kSpmmWinCols * kMaxRows * sizeof(double), &pr));
     double *partials = (double *)pr;
     int c0 = 0, nruns = wgrid;
-    void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_dev, &Rd, &partials};
+    void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_arg, &Rd, &partials};
     hipError_t e = hipLaunchKernel(fn, dim3(xgrid, npass), dim3(kWinBlock), args, lds, ctx->stream);
     int st = e == hipSuccess ? MI_OK : hip_fail(e, "panel product launch", __FILE__, __LINE__);
     if (st == MI_OK && res)
@@ -1514,7 +1693,7 @@ int spmm_win_launch(const mi_csr *A, int k, const double *Xd, double *Yd, const 
     double *partials = ctx->partials2;
     for (int c0 = 0; c0 < k; c0 += kSpmmWinCols) {
       int nruns = wgrid;
-      void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_dev, &Rd, &partials};
+      void *args[] = {&view, &wv, &k, &c0, &nruns, &Xd, &Yd, &theta_arg, &Rd, &partials};
       MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds, ctx->stream));
       MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, wgrid, 16, sums_dev + 16 * (c0 / kSpmmWinCols)));
     }
@@ -1543,23 +1722,20 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
   touch(AX);
   touch(R);
   const int nchunks = (nx + 7) / 8;
-  void *thdev = nullptr, *sums = nullptr;
-  MI_TRY(pool_alloc(ctx, (size_t)nx * sizeof(double), &thdev));
-  // one rank: the 2 nx column sums land straight in pinned host memory (the one-workgroup reduction kernel of each pass
-  // stores them there), no copy behind the last kernel; several ranks: device buffer + read-back
+  void *sums = nullptr;
+  // one rank: the 2 nx column sums land straight in pinned host memory (the reduction kernel stores them there), no
+  // copy behind the last kernel; several ranks: device buffer + read-back
   const bool zero_copy = ctx->comm == nullptr && !ctx->cfg.no_zero_copy;
   const size_t nsums = (size_t)nchunks * 16;
   void *zc_host = nullptr;
   int st = zero_copy ? readback_area(ctx, nsums * sizeof(double), &zc_host, &sums)
                      : pool_alloc(ctx, nsums * sizeof(double), &sums);
-  if (st == MI_OK) st = stage_upload(ctx, theta_host, (size_t)nx * sizeof(double), thdev);  // (no host wait)
   if (st == MI_OK) {
     KScope ks(ctx, MI_K_SPMM);
-    st = spmm_win_launch(A, nx, X->d, AX->d, (const double *)thdev, R->d, (double *)sums);
+    st = spmm_win_launch(A, nx, ColBlocks{{X->d, X->d, X->d}, nx, nx}, AX->d, theta_host, R->d, (double *)sums);
   }
-  if (st != MI_OK) {  // (the pool buffers go back on every path)
+  if (st != MI_OK) {  // (the pool buffer goes back on every path)
     if (sums && !zero_copy) pool_free(ctx, sums);
-    pool_free(ctx, thdev);
     return st;
   }
   std::vector<double> out(nsums);
@@ -1575,13 +1751,36 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
     st = readback_sync(ctx, 1, dv, by, hs);
     pool_free(ctx, sums);
   }
-  pool_free(ctx, thdev);
   if (st != MI_OK) return st;
   for (int c = 0; c < nx; ++c) {
     rnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + c % 8]);
     xnorm[c] = std::sqrt(out[(size_t)(c / 8) * 16 + 8 + c % 8]);
   }
   return MI_OK;
+}
+
+int mi_csr_spmm_colmajor_blocks(const mi_csr *A, const mi_panel_blocks *X, mi_vec *Y) {
+  MI_REQUIRE(A && X && Y, "null argument");
+  mi_ctx *ctx = A->ctx;
+  ColBlocks cb;
+  int k = 0;
+  MI_TRY(blocks_to_cols(ctx, A->n, X, &cb, &k));
+  MI_TRY(check_panel(ctx, A->n, k, Y, "Y"));
+  for (int i = 0; i < X->nblocks; ++i) {
+    const double *s0 = X->block[i]->d, *s1 = s0 + (size_t)X->cols[i] * A->n;
+    MI_REQUIRE(Y->d + (size_t)k * A->n <= s0 || Y->d >= s1, "SpMM input and output must not alias");
+  }
+  const bool sharded = A->halo_lo + A->halo_hi + A->send_lo + A->send_hi > 0;
+  if (!sharded && spmm_win_ok(A) && A->n > 0) {
+    touch(Y);
+    KScope ks(ctx, MI_K_SPMM);
+    return spmm_win_launch(A, k, cb, Y->d, nullptr, nullptr, nullptr);
+  }
+  mi_vec *tmp = nullptr;  // (matrix forms whose product kernels want one panel: the blocks copied together)
+  MI_TRY(materialize_blocks(ctx, A->n, X, &tmp));
+  const int st = mi_csr_spmm_colmajor(A, k, tmp, Y);
+  mi_vec_destroy(tmp);
+  return st;
 }
 
 int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
@@ -1617,7 +1816,7 @@ int mi_csr_spmm_colmajor(const mi_csr *A, int k, const mi_vec *X, mi_vec *Y) {
   }
   const int grid = (int)((A->nslices + 3) / 4);
   KScope ks(ctx, MI_K_SPMM);
-  if (spmm_win_ok(A)) return spmm_win_launch(A, k, X->d, Y->d, nullptr, nullptr, nullptr);
+  if (spmm_win_ok(A)) return spmm_win_launch(A, k, ColBlocks{{X->d, X->d, X->d}, k, k}, Y->d, nullptr, nullptr, nullptr);
   if (A->pk) {
     constexpr int chunk = 24;  // (narrower column chunks measured slower: DESIGN 7.5)
     for (int c0 = 0; c0 < k;) {

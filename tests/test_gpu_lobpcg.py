@@ -441,3 +441,87 @@ def test_lobpcg_with_the_tagged_operator_equals_the_plain_one(monkeypatch):
     assert a["num_iters"] == b["num_iters"] and a["nc"] == b["nc"]
     assert np.array_equal(a["Theta"], b["Theta"])
     assert np.array_equal(a["X"], b["X"])
+
+
+def _basis_blocks(ctx, P, m, nx, nc, with_p=True):
+    """S = [X, W(:, nc:), P(:, nc:)] (LOBPCG.h:254-264) as the three blocks lie in the panel [X | W | P]"""
+    Pd = ctx.upload(np.asfortranarray(P).ravel(order="F"))
+    blocks = [(Pd.view(0, m * nx), nx)]
+    if nx - nc > 0:
+        blocks.append((Pd.view((nx + nc) * m, (nx - nc) * m), nx - nc))
+        if with_p:
+            blocks.append((Pd.view((2 * nx + nc) * m, (nx - nc) * m), nx - nc))
+    cols = list(range(nx)) + list(range(nx + nc, 2 * nx)) + (list(range(2 * nx + nc, 3 * nx)) if with_p else [])
+    S = np.asfortranarray(P[:, cols])
+    return Pd, blocks, S
+
+
+@pytest.mark.parametrize("m,nx,nc", [(100_008, 24, 0), (100_008, 24, 1), (65_540, 24, 5), (40_012, 24, 8),
+                                     (200_008, 24, 19), (4099, 24, 7), (30_000, 8, 3), (1000, 24, 22), (126 ** 3, 24, 11)])
+def test_search_basis_held_as_column_blocks(ctx, m, nx, nc):
+    """r04: once pairs are locked (nc > 0) the search basis S = [X, W(:, nc:), P(:, nc:)] is NOT copied together any
+    more (LOBPCG.h:254-264 did; 15 % of the kernel time of a cfg5 run): the Gram pair, the Ritz update and the panel
+    product take it as the three column blocks lie (mi_*_blocks).  Against the same entry points on the assembled panel
+    -- Gram and product bit for bit (same kernels, other column addresses), the update to rounding (its steps of four
+    basis columns are cut per block) -- and against numpy; shapes include widths that are no multiple of four,
+    blocks narrower than a step, and the fall-backs (m odd, narrow panels)."""
+    rng = np.random.default_rng(m % 9973 + 31 * nc)
+    P = rng.normal(size=(m, 3 * nx))
+    Pd, blocks, S = _basis_blocks(ctx, P, m, nx, nc)
+    ns = S.shape[1]
+    Sd = ctx.upload(S.ravel(order="F"))
+    d = rng.uniform(0.5, 3.0, size=m)
+    AS = d[:, None] * S
+    A1 = ctx.upload(np.asfortranarray(AS[:, :nx]).ravel(order="F"))
+    A2 = ctx.upload(np.asfortranarray(AS[:, nx:]).ravel(order="F")) if ns > nx else None
+    # Gram pair
+    Ga, Gb = ctx.lobpcg_gram_pair_sym_blocks(m, blocks, A1, nx, A2)
+    Fa, Fb = ctx.lobpcg_gram_pair_sym(m, Sd, ns, A1, nx, A2)
+    assert np.array_equal(Ga, Fa) and np.array_equal(Gb, Fb)
+    ra, rb = S.T @ AS, S.T @ S
+    tol = 1e-13 * max(1.0, np.sqrt(m) / 30)
+    assert np.abs(Ga - ra).max() <= tol * np.abs(ra).max() and np.abs(Gb - rb).max() <= tol * np.abs(rb).max()
+    # Ritz update: X = S C(:, :nx), P = S(:, nx:) C(nx:, :nx) in one pass (zero rows in the second coefficient block)
+    Cx = rng.normal(size=(ns, nx))
+    Cp = Cx.copy()
+    Cp[:nx] = 0.0
+    Cm = np.hstack([Cx, Cp])
+    Y1, Y2 = ctx.lobpcg_update2_blocks(m, blocks, Cm, nx)
+    Z1, Z2 = ctx.lobpcg_update2(m, Sd, ns, Cm, nx)
+    ref = S @ Cm
+    got = np.hstack([Y1.numpy().reshape(nx, m).T, Y2.numpy()[:m * nx].reshape(nx, m).T])
+    one = np.hstack([Z1.numpy().reshape(nx, m).T, Z2.numpy()[:m * nx].reshape(nx, m).T])
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(got - one).max() <= 1e-13 * np.abs(ref).max()
+    # a destination that overlaps one of the blocks stays refused (or is too small for the result)
+    import ctypes as C
+    from optimization_amd import capi
+    pb, Cf = capi.PanelBlocks.of(blocks), np.asfortranarray(Cm)
+    assert ctx.L.mi_lobpcg_update2_blocks(ctx.h, m, C.byref(pb), 2 * nx, capi._dp(Cf), ns, blocks[0][0].h, nx, Y2.h) != 0
+
+
+@pytest.mark.parametrize("grid,nx,nc", [((40, 37, 31), 24, 0), ((40, 37, 31), 24, 7), ((23, 19, 17), 8, 3),
+                                        ((64, 64, 16), 24, 19), ((126, 126, 126), 24, 10)])
+def test_panel_product_of_column_blocks(ctx, grid, nx, nc):
+    """A [W(:, nc:) | P(:, nc:)] (LOBPCG.h:267 on the part of the basis that is new) straight from the two blocks
+    (mi_csr_spmm_colmajor_blocks): the bits of the product of the assembled panel"""
+    gx, gy, gz = grid
+    m = gx * gy * gz
+    rowptr, col, val = wl.laplacian_3d(gx, gy, gz)
+    A = ctx.csr(m, rowptr, col, val)
+    rng = np.random.default_rng(m % 9973 + nc)
+    P = rng.normal(size=(m, 3 * nx))
+    Pd, blocks, S = _basis_blocks(ctx, P, m, nx, nc)
+    rest = blocks[1:]
+    k = sum(c for _, c in rest)
+    Y = A.spmm_colmajor_blocks(rest).numpy()[:m * k]
+    Sr = ctx.upload(np.asfortranarray(S[:, nx:]).ravel(order="F"))
+    Z = A.spmm_colmajor(k, Sr).numpy()[:m * k]
+    assert np.array_equal(Y, Z)
+    import scipy.sparse as sp
+    ref = sp.csr_matrix((val, col, rowptr), shape=(m, m)) @ S[:, nx:]
+    assert np.abs(Y.reshape(k, m).T - ref).max() <= 1e-13 * np.abs(ref).max()
+    # all three blocks as well (the first iteration applies A to the whole basis, :267)
+    Y3 = A.spmm_colmajor_blocks(blocks).numpy()[:m * S.shape[1]]
+    Z3 = A.spmm_colmajor(S.shape[1], ctx.upload(S.ravel(order="F"))).numpy()[:m * S.shape[1]]
+    assert np.array_equal(Y3, Z3)
