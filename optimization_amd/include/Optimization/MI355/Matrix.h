@@ -180,6 +180,58 @@ class DeviceMatrix {
   mi_vec *view_ = nullptr;
 };
 
+// A panel as up to three column blocks that need not be adjacent (mi_panel_blocks): LOBPCG's search basis
+// S = [X, W(:, nc:), P(:, nc:)] (LOBPCG.h:254-264) as the three blocks lie, instead of a copy that moves the unlocked
+// columns together every iteration.  Holds VIEWS (they share the storage of the matrices they were cut from and keep
+// it alive).
+class PanelBlocks {
+ public:
+  void add(DeviceMatrix &&view) {
+    if (view.cols() == 0) return;
+    if (n_ == 3) throw std::invalid_argument("PanelBlocks: at most three column blocks");
+    if (n_ > 0 && view.rows() != blk_[0].rows()) throw std::invalid_argument("PanelBlocks: row counts differ");
+    blk_[n_++] = std::move(view);
+  }
+  size_t blocks() const { return n_; }
+  size_t rows() const { return n_ ? blk_[0].rows() : 0; }
+  size_t cols() const {
+    size_t k = 0;
+    for (size_t i = 0; i < n_; ++i) k += blk_[i].cols();
+    return k;
+  }
+  mi_ctx *context() const { return n_ ? blk_[0].context() : nullptr; }
+  const DeviceMatrix &block(size_t i) const { return blk_[i]; }
+  // blocks [first, blocks()) (new views of the same storage)
+  PanelBlocks from(size_t first) const {
+    PanelBlocks r;
+    for (size_t i = first; i < n_; ++i) r.add(blk_[i].leftCols(blk_[i].cols()));
+    return r;
+  }
+  mi_panel_blocks raw() const {
+    mi_panel_blocks b{};
+    b.nblocks = (int)n_;
+    for (size_t i = 0; i < n_; ++i) {
+      b.block[i] = blk_[i].handle();
+      b.cols[i] = (int)blk_[i].cols();
+    }
+    return b;
+  }
+  // the blocks copied together into one panel (for operators that are plain callables on a Matrix)
+  DeviceMatrix assembled() const {
+    DeviceMatrix M(context(), rows(), cols());
+    size_t j = 0;
+    for (size_t i = 0; i < n_; ++i) {
+      M.set_cols(j, blk_[i], 0, blk_[i].cols());
+      j += blk_[i].cols();
+    }
+    return M;
+  }
+
+ private:
+  DeviceMatrix blk_[3];
+  size_t n_ = 0;
+};
+
 // ---- panel operations used by LOBPCG (found by ADL) ------------------------------------------------
 
 // G = S' T   (LOBPCG.h:223,271-272) -- fp64 MFMA kernel
@@ -213,6 +265,16 @@ inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const DeviceMatrix &S, co
   HostMatrix GA(S.cols(), S.cols()), GB(S.cols(), S.cols());
   check(mi_lobpcg_gram_pair_sym(S.context(), S.rows(), (int)S.cols(), S.handle(), (int)A1.cols(), A1.handle(),
                                 A2.cols() > 0 ? A2.handle() : nullptr, GA.data(), GB.data()));
+  return {std::move(GA), std::move(GB)};
+}
+// the same for a basis held as column blocks (mi_lobpcg_gram_pair_sym_blocks)
+inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const PanelBlocks &S, const DeviceMatrix &A1,
+                                                       const DeviceMatrix &A2) {
+  const size_t k = S.cols();
+  HostMatrix GA(k, k), GB(k, k);
+  const mi_panel_blocks b = S.raw();
+  check(mi_lobpcg_gram_pair_sym_blocks(S.context(), S.rows(), &b, (int)A1.cols(), A1.handle(),
+                                       A2.cols() > 0 ? A2.handle() : nullptr, GA.data(), GB.data()));
   return {std::move(GA), std::move(GB)};
 }
 // Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
@@ -252,6 +314,19 @@ inline void ritz_update_into(const DeviceMatrix &S, const HostMatrix &C, size_t 
   check(mi_lobpcg_update2(S.context(), S.rows(), (int)ns, (int)(2 * nx), S.handle(), C2.data(), (int)ns, X.handle(),
                           (int)nx, P.handle()));
 }
+// ... and for a basis held as column blocks (mi_lobpcg_update2_blocks)
+inline void ritz_update_into(const PanelBlocks &S, const HostMatrix &C, size_t nx, DeviceMatrix &X, DeviceMatrix &P) {
+  const size_t ns = S.cols();
+  HostMatrix C2(ns, 2 * nx);
+  for (size_t j = 0; j < nx; ++j)
+    for (size_t i = 0; i < ns; ++i) {
+      C2(i, j) = C(i, j);
+      C2(i, nx + j) = i < nx ? 0.0 : C(i, j);
+    }
+  const mi_panel_blocks b = S.raw();
+  check(mi_lobpcg_update2_blocks(S.context(), S.rows(), &b, (int)(2 * nx), C2.data(), (int)ns, X.handle(), (int)nx,
+                                 P.handle()));
+}
 // The sparse operator of a LOBPCG client as a TAGGED callable (put it into the SymmetricLinearOperator<DeviceMatrix>
 // argument `A`): used as a plain callable it is Y = A X (mi_csr_spmm_colmajor); the device LOBPCG loop recognises it
 // (std::function::target) and, when B is absent, asks it for A(X) of the new Ritz block TOGETHER with the residual
@@ -261,6 +336,13 @@ struct DeviceCsrPanelOperator {
   DeviceMatrix operator()(const DeviceMatrix &X) const {
     DeviceMatrix Y(X.context(), X.rows(), X.cols());
     check(mi_csr_spmm_colmajor(A, (int)X.cols(), X.handle(), Y.handle()));
+    return Y;
+  }
+  // A [block 0 | block 1 | ...] of a panel held as column blocks (mi_csr_spmm_colmajor_blocks)
+  DeviceMatrix operator()(const PanelBlocks &X) const {
+    DeviceMatrix Y(X.context(), X.rows(), X.cols());
+    const mi_panel_blocks b = X.raw();
+    check(mi_csr_spmm_colmajor_blocks(A, &b, Y.handle()));
     return Y;
   }
 };
