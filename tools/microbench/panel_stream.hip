@@ -1,4 +1,5 @@
-// panel_stream.hip -- what the ACCESS PATTERN of the LOBPCG panel update can reach on MI355X, without its arithmetic (r04).
+// panel_stream.hip -- what the ACCESS PATTERNS of the LOBPCG panel update and Gram kernels can reach on MI355X, without
+// their arithmetic (r04).
 //
 // k_panel_update_mfma (csrc/lobpcg.hip) reads the 72 columns of a column-major m x 72 basis and writes 48 columns of
 // X and P: 1.92 GB at m = 2 000 376 in 400-430 us = 4.5-4.8 TB/s, with the matrix pipe ~45 % busy, and neither more
@@ -89,6 +90,30 @@ __global__ __launch_bounds__(256) void k_write(size_t nblocks64, size_t m, doubl
   }
 }
 
+// reads only in the Gram kernels' mapping: lane (i = l & 15, q = l >> 4) loads the four rows r0 + 4 q .. + 3 of column
+// 16 t + i with one 32-byte load (a wave instruction = 16 columns x one 128-byte segment), T tiles of 16 columns, twice
+// (S and A(S)); a wave takes every nwaves-th 16-row step
+typedef double double4l __attribute__((ext_vector_type(4)));
+template <int T>
+__global__ __launch_bounds__(256) void k_gram_read(size_t nsteps, size_t m, const double *__restrict__ S,
+                                                   const double *__restrict__ S2, double *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+  const size_t lane_off = 4 * (size_t)(lane >> 4) + (size_t)(lane & 15) * m;
+  double acc = 0;
+  for (size_t b = wave; b < nsteps; b += nwaves) {
+    double4l a[T], c[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      a[t] = *reinterpret_cast<const double4l *>(S + (size_t)16 * t * m + lane_off + b * 16);
+      c[t] = *reinterpret_cast<const double4l *>(S2 + (size_t)16 * t * m + lane_off + b * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc += a[t][0] + a[t][3] + c[t][1] + c[t][2];
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
 int main(int argc, char **argv) {
   const size_t m = argc > 1 ? (size_t)atoll(argv[1]) : 2000376;
   double *S, *Y;
@@ -122,6 +147,20 @@ int main(int argc, char **argv) {
         (double)m * KS * 8 / 1e9);
     run("  row, 48 columns written only", [&] { hipLaunchKernelGGL(k_write, dim3(wg), dim3(256), 0, 0, nb64, m, Y); },
         (double)m * KC * 8 / 1e9);
+  }
+  // the Gram mapping, read only: 2 x 48 and 2 x 80 columns (two panels of 80 columns: S itself serves as both)
+  double *S2;
+  CK(hipMalloc(&S2, m * 80 * sizeof(double)));
+  CK(hipMemset(S2, 0, m * 80 * sizeof(double)));
+  double *S1;
+  CK(hipMalloc(&S1, m * 80 * sizeof(double)));
+  CK(hipMemset(S1, 0, m * 80 * sizeof(double)));
+  for (int wg : {256, 512}) {
+    printf("Gram mapping, %d workgroups\n", wg);
+    run("  3 tiles x 2 panels, read only", [&] { hipLaunchKernelGGL(k_gram_read<3>, dim3(wg), dim3(256), 0, 0, nb16, m, S1, S2, Y); },
+        (double)m * 96 * 8 / 1e9);
+    run("  5 tiles x 2 panels, read only", [&] { hipLaunchKernelGGL(k_gram_read<5>, dim3(wg), dim3(256), 0, 0, nb16, m, S1, S2, Y); },
+        (double)m * 160 * 8 / 1e9);
   }
   return 0;
 }
