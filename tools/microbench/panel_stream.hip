@@ -90,6 +90,23 @@ __global__ __launch_bounds__(256) void k_write(size_t nblocks64, size_t m, doubl
   }
 }
 
+// writes only, 16 and 32 bytes per lane (1 and 2 KB contiguous per wave instruction) -- does the store width matter?
+typedef double double2s __attribute__((ext_vector_type(2)));
+typedef double double4s __attribute__((ext_vector_type(4)));
+template <int W>
+__global__ __launch_bounds__(256) void k_write_wide(size_t nblocks, size_t m, double *__restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+  for (size_t b = wave; b < nblocks; b += nwaves) {
+    const size_t row = (b * 64 + lane) * W;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (W == 2) __builtin_nontemporal_store((double2s){(double)c, 1.0}, reinterpret_cast<double2s *>(Y + (size_t)c * m + row));
+      else __builtin_nontemporal_store((double4s){(double)c, 1.0, 2.0, 3.0}, reinterpret_cast<double4s *>(Y + (size_t)c * m + row));
+    }
+  }
+}
+
 // reads only in the Gram kernels' mapping: lane (i = l & 15, q = l >> 4) loads the four rows r0 + 4 q .. + 3 of column
 // 16 t + i with one 32-byte load (a wave instruction = 16 columns x one 128-byte segment), T tiles of 16 columns, twice
 // (S and A(S)); a wave takes every nwaves-th 16-row step
@@ -146,6 +163,13 @@ int main(int argc, char **argv) {
     run("  row, 72 columns read only", [&] { hipLaunchKernelGGL(k_read, dim3(wg), dim3(256), 0, 0, nb64, m, S, Y); },
         (double)m * KS * 8 / 1e9);
     run("  row, 48 columns written only", [&] { hipLaunchKernelGGL(k_write, dim3(wg), dim3(256), 0, 0, nb64, m, Y); },
+        (double)m * KC * 8 / 1e9);
+  }
+  for (int wg : {512, 2048}) {
+    printf("wide stores, %d workgroups\n", wg);
+    run("  48 columns written, 16 B per lane", [&] { hipLaunchKernelGGL(k_write_wide<2>, dim3(wg), dim3(256), 0, 0, m / 128, m, Y); },
+        (double)m * KC * 8 / 1e9);
+    run("  48 columns written, 32 B per lane", [&] { hipLaunchKernelGGL(k_write_wide<4>, dim3(wg), dim3(256), 0, 0, m / 256, m, Y); },
         (double)m * KC * 8 / 1e9);
   }
   // the Gram mapping, read only: 2 x 48 and 2 x 80 columns (two panels of 80 columns: S itself serves as both)
