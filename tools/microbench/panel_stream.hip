@@ -107,6 +107,25 @@ __global__ __launch_bounds__(256) void k_write_wide(size_t nblocks, size_t m, do
   }
 }
 
+// the same 16 bytes per lane WITHOUT another row-to-lane mapping: a wave still owns 64 rows, lanes 2p and 2p + 1 swap
+// one value each, the even lane then stores rows 2p, 2p + 1 of column c and the odd lane those of column c + 1
+// (512 contiguous bytes per column, two columns per store instruction)
+__global__ __launch_bounds__(256) void k_write_paired(size_t nblocks64, size_t m, double *__restrict__ Y) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+  for (size_t b = wave; b < nblocks64; b += nwaves) {
+    const size_t row2 = b * 64 + (lane & ~1);
+#pragma unroll
+    for (int c = 0; c < KC; c += 2) {
+      const double own0 = (double)c + lane, own1 = (double)c + 1 + lane;           // this lane's row of columns c, c + 1
+      const double give = (lane & 1) ? own0 : own1;
+      const double got = __shfl_xor(give, 1);
+      const double2s v = (lane & 1) ? (double2s){got, own1} : (double2s){own0, got};
+      __builtin_nontemporal_store(v, reinterpret_cast<double2s *>(Y + (size_t)(c + (lane & 1)) * m + row2));
+    }
+  }
+}
+
 // reads only in the Gram kernels' mapping: lane (i = l & 15, q = l >> 4) loads the four rows r0 + 4 q .. + 3 of column
 // 16 t + i with one 32-byte load (a wave instruction = 16 columns x one 128-byte segment), T tiles of 16 columns, twice
 // (S and A(S)); a wave takes every nwaves-th 16-row step
@@ -168,6 +187,8 @@ int main(int argc, char **argv) {
   for (int wg : {512, 2048}) {
     printf("wide stores, %d workgroups\n", wg);
     run("  48 columns written, 16 B per lane", [&] { hipLaunchKernelGGL(k_write_wide<2>, dim3(wg), dim3(256), 0, 0, m / 128, m, Y); },
+        (double)m * KC * 8 / 1e9);
+    run("  48 columns written, paired 16 B", [&] { hipLaunchKernelGGL(k_write_paired, dim3(wg), dim3(256), 0, 0, nb64, m, Y); },
         (double)m * KC * 8 / 1e9);
     run("  48 columns written, 32 B per lane", [&] { hipLaunchKernelGGL(k_write_wide<4>, dim3(wg), dim3(256), 0, 0, m / 256, m, Y); },
         (double)m * KC * 8 / 1e9);
