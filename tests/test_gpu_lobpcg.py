@@ -500,14 +500,18 @@ def test_search_basis_held_as_column_blocks(ctx, m, nx, nc):
     assert ctx.L.mi_lobpcg_update2_blocks(ctx.h, m, C.byref(pb), 2 * nx, capi._dp(Cf), ns, blocks[0][0].h, nx, Y2.h) != 0
 
 
-@pytest.mark.parametrize("grid,nx,nc", [((40, 37, 31), 24, 0), ((40, 37, 31), 24, 7), ((23, 19, 17), 8, 3),
-                                        ((64, 64, 16), 24, 19), ((126, 126, 126), 24, 10)])
-def test_panel_product_of_column_blocks(ctx, grid, nx, nc):
+@pytest.mark.parametrize("grid,nx,nc,weights", [((40, 37, 31), 24, 0, "stencil"), ((40, 37, 31), 24, 7, "stencil"),
+                                                ((23, 19, 17), 8, 3, "stencil"), ((64, 64, 16), 24, 19, "stencil"),
+                                                ((126, 126, 126), 24, 10, "stencil"), ((30, 29, 27), 24, 5, "random")])
+def test_panel_product_of_column_blocks(ctx, grid, nx, nc, weights):
     """A [W(:, nc:) | P(:, nc:)] (LOBPCG.h:267 on the part of the basis that is new) straight from the two blocks
-    (mi_csr_spmm_colmajor_blocks): the bits of the product of the assembled panel"""
+    (mi_csr_spmm_colmajor_blocks): the bits of the product of the assembled panel.  "random": real-valued weights, a
+    matrix without the window form -- the blocks are copied together inside the library."""
     gx, gy, gz = grid
     m = gx * gy * gz
     rowptr, col, val = wl.laplacian_3d(gx, gy, gz)
+    if weights == "random":
+        val = val * np.random.default_rng(5).uniform(0.5, 1.5, size=val.shape)
     A = ctx.csr(m, rowptr, col, val)
     rng = np.random.default_rng(m % 9973 + nc)
     P = rng.normal(size=(m, 3 * nx))
