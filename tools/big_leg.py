@@ -33,7 +33,7 @@ def run(k):
         done += r["iterations"]
 
 
-run(10)
+run(50)   # (a whole solve of the length the timed ones have: the first one of a length pays one-time allocations)
 c.sync()
 t0 = time.perf_counter()
 run(steps)
