@@ -297,7 +297,7 @@ static int ctx_init(mi_ctx *ctx, int device) {
     }
   }
   MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots, hipHostMallocDefault));
-  MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState), hipHostMallocDefault));
+  MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState) + 16, hipHostMallocDefault)  /* + a preconditioner's failure word */);
   MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
                        hipHostMallocMapped | hipHostMallocCoherent));
   memset((void *)ctx->status, 0, sizeof(HostStatus));

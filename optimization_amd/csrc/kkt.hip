@@ -52,7 +52,10 @@ struct KktImpl {
   double *s_val = nullptr, *s_dinv = nullptr;
   double *work = nullptr;                    // b, r, z, p, q: 5 m doubles
   double *info = nullptr;                    // [0] inner iterations of the last application, [1] its relative residual,
-                                             // [2] the largest relative residual any application ended with
+                                             // [2] the largest relative residual any application ended with,
+                                             // [3] STICKY failure word: 0 ok, 1 the inner iteration broke down (p'Sp <= 0
+                                             // or not finite: dependent constraint rows, NaN in r), 2 it stopped at
+                                             // max_inner short of the tolerance; checked behind the solve's own read-back
   double tol = 1e-14;
   int max_inner = 0;
 };
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_kkt_cg(int m, const int *__restrict_
   double rr = bb;
   int it = 0;
   // (all threads hold the same rz, rr, bb: the loop control is uniform)
+  int broke = 0;
   while (it < max_inner && rr > tol * tol * bb && bb > 0) {
     __syncthreads();  // p of the previous step is complete
     double pq = 0;
@@ -255,6 +259,12 @@ __global__ __launch_bounds__(kBlock) void k_kkt_cg(int m, const int *__restrict_
       pq += p[i] * s;
     }
     pq = wg_sum(pq, lds);
+    // S is positive definite for independent constraint rows: anything else (semi-definite S, NaN / Inf in r) would
+    // make alpha garbage and end the loop through a false comparison with a NaN, looking like convergence
+    if (!(pq > 0) || !(pq <= 1.79769313486231571e308)) {
+      broke = 1;
+      break;
+    }
     const double alpha = rz / pq;
     a0 = 0;
     a1 = 0;
@@ -274,10 +284,14 @@ __global__ __launch_bounds__(kBlock) void k_kkt_cg(int m, const int *__restrict_
     ++it;
   }
   if (t == 0) {
-    const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
+    const double rel = bb > 0 ? sqrt(rr / bb) : (bb == 0 ? 0.0 : bb /* NaN */);
     info[0] = (double)it;
     info[1] = rel;
-    if (rel > info[2]) info[2] = rel;
+    if (!(rel <= info[2])) info[2] = rel;  // (a NaN is recorded, and stays)
+    if (broke || !(bb >= 0))
+      info[3] = 1.0;
+    else if (!(rr <= tol * tol * bb) && info[3] == 0.0)
+      info[3] = 2.0;
   }
 }
 
@@ -505,7 +519,7 @@ int mi_precon_create_constraint_csr(mi_ctx *ctx, size_t n, size_t m, const int32
   up((void **)&k->s_col, scol.data(), scol.size() * sizeof(int));
   up((void **)&k->s_val, sval.data(), sval.size() * sizeof(double));
   up((void **)&k->s_dinv, sdinv.data(), m * sizeof(double));
-  const double zeros[3] = {0, 0, 0};
+  const double zeros[4] = {0, 0, 0, 0};
   up((void **)&k->info, zeros, sizeof(zeros));
   if (st == MI_OK) {
     hipError_t e = hipMalloc((void **)&k->work, 5 * m * sizeof(double));
@@ -520,6 +534,7 @@ int mi_precon_create_constraint_csr(mi_ctx *ctx, size_t n, size_t m, const int32
   P->apply_project = kkt_run_csr;
   P->destroy = kkt_destroy_csr;
   P->impl = k;
+  P->fail_word = k->info ? k->info + 3 : nullptr;
   if (st != MI_OK) {
     kkt_destroy_csr(P);
     delete P;
@@ -533,7 +548,7 @@ int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, doubl
                               double *worst_relative_residual) {
   MI_REQUIRE(P && P->kind == 3, "not a constraint preconditioner");
   KktImpl *k = (KktImpl *)P->impl;
-  double h[3] = {0, 0, 0};
+  double h[4] = {0, 0, 0, 0};
   if (k->sparse) {
     MI_HIP(hipMemcpyAsync(h, k->info, sizeof(h), hipMemcpyDeviceToHost, P->ctx->stream));
     MI_HIP(hipStreamSynchronize(P->ctx->stream));
@@ -542,6 +557,13 @@ int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, doubl
   if (last_inner_iterations) *last_inner_iterations = (size_t)h[0];
   if (last_relative_residual) *last_relative_residual = h[1];
   if (worst_relative_residual) *worst_relative_residual = h[2];
+  if (h[3] != 0.0) {
+    set_error(h[3] == 1.0 ? "constraint preconditioner: the inner CG on S = A M^-1 A' broke down (p'Sp <= 0 or not "
+                            "finite: dependent constraint rows, or NaN / Inf in the residual)"
+                          : "constraint preconditioner: the inner CG on S = A M^-1 A' stopped at its iteration limit "
+                            "short of the tolerance");
+    return MI_ERR_INTERNAL;
+  }
   return MI_OK;
 }
 

@@ -550,4 +550,7 @@ struct mi_precon {
   void (*destroy)(mi_precon *self) = nullptr;
   void *impl = nullptr;
   bool borrowed = false;
+  // device address of a sticky failure word (double; 0 = every application since mi_stpcg last cleared it did what it claims), or null.
+  // mi_stpcg copies it behind the solve's own state read-back and answers MI_ERR_INTERNAL if it is set.
+  double *fail_word = nullptr;
 };

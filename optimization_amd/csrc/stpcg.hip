@@ -477,6 +477,17 @@ void mi_stpcg_default_params(mi_stpcg_params *p) {
   p->defer_result = 0;
 }
 
+// the sticky failure word of the solve's preconditioner (mi_precon::fail_word) travels right behind the state copy
+static inline double *precon_fail_host(mi_ctx *ctx) { return reinterpret_cast<double *>(ctx->cg_host + 1); }
+static int precon_fail_check(mi_ctx *ctx) {
+  const double w = *precon_fail_host(ctx);
+  if (w == 0.0) return MI_OK;
+  set_error("the preconditioner of this solve reported a failed application (code %g: 1 = its inner iteration broke "
+            "down, 2 = it stopped at its iteration limit short of its tolerance): the result is not a projected step",
+            w);
+  return MI_ERR_INTERNAL;
+}
+
 int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result) {
   MI_REQUIRE(ctx && result, "null argument");
   MI_REQUIRE(ctx->cg_deferred, "mi_stpcg_collect: no deferred solve is pending on this context");
@@ -499,7 +510,7 @@ int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result) {
   result->exit_reason = f.exit_reason;
   result->rv_final = f.rv;
   result->hvp_calls = ctx->cg_deferred_hvp;
-  return MI_OK;
+  return precon_fail_check(ctx);
 }
 
 int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpcg_params *prm,
@@ -542,6 +553,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // (default depth 3: depth 2 gives the same cfg2 step and -0.6 % on a cfg3 TNT run)
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
   const bool lockstep = (ctx->comm != nullptr && ctx->world_size > 1) || ctx->force_lockstep;
+
+  // the failure word is per solve: a NaN residual in one solve must not condemn the object for the next
+  if (P && P->fail_word) MI_HIP(hipMemsetAsync(P->fail_word, 0, sizeof(double), ctx->stream));
 
   mi_vec *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr;
   MI_TRY(mi_vec_create(ctx, n, &r));
@@ -802,6 +816,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     hipError_t e = hipSuccess;
     if (!ctx->cg_deferred_ev) e = hipEventCreateWithFlags(&ctx->cg_deferred_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    *precon_fail_host(ctx) = 0.0;
+    if (e == hipSuccess && P && P->fail_word)
+      e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipEventRecord(ctx->cg_deferred_ev, st);
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__));
     ctx->cg_deferred = true;
@@ -812,9 +829,13 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     result->rv_final = 0;
   } else {
     hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    *precon_fail_host(ctx) = 0.0;
+    if (e == hipSuccess && P && P->fail_word)
+      e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     ctx->host_syncs++;
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
+    CG_CHECK(precon_fail_check(ctx));
     {
       int ipc_err = 0;
       (void)mi_comm_ipc_error(ctx, &ipc_err);

@@ -200,3 +200,40 @@ def test_projected_stpcg_with_sparse_constraints_matches_the_dense_form(ctx, use
     assert es <= max(1e-10, 3 * floor) and ed <= max(1e-10, 6 * floor)
     assert np.abs(A @ rs["s"].numpy()).max() < 1e-6
     assert Ps.info()[2] <= 1e-13
+
+
+def test_sparse_constraint_preconditioner_reports_a_failed_inner_solve(ctx):
+    """the in-kernel CG on S = A M^-1 A' must not fail silently.  (i) dependent constraint rows (S singular:
+    the iteration cannot reach 1e-14 — breakdown or its iteration limit), (ii) a NaN in the residual, (iii) an iteration
+    limit too small: mi_stpcg answers with an error instead of a step that left null(A); the failure word is PER SOLVE —
+    the same object then solves a healthy system."""
+    import scipy.sparse as sps
+    n, m = 400, 12
+    rng = np.random.default_rng(9)
+    A = _sparse_constraints(n, m, 6, seed=3).toarray()
+    g, D, Minv = rng.uniform(-1, 1, n), rng.uniform(1, 3, n), 1.0 / rng.uniform(1, 3, n)
+    H = ctx.op_diag(ctx.upload(D))
+    kw = dict(Delta=1e300, max_iterations=50, kappa_fgr=1e-8, theta=.7, constraint_At=True)
+    # (iii) one inner iteration cannot solve a 12 x 12 system to 1e-14
+    Pshort = ctx.precon_constraint_csr(sps.csr_matrix(A), Minv, inner_max_iterations=1)
+    with pytest.raises(capi.MiError, match="preconditioner"):
+        ctx.stpcg(ctx.upload(g), H, Pshort, **kw)
+    # (i) dependent rows
+    Adep = A.copy()
+    Adep[m - 1] = 2 * Adep[0] - Adep[1]
+    # (S is then semi-definite but S lambda = A M^-1 r stays consistent: CG either still converges — lambda is not
+    # unique, A' lambda is, and the step must lie in null(A) — or the failure is REPORTED; silence + garbage is the bug)
+    Pdep = ctx.precon_constraint_csr(sps.csr_matrix(Adep), Minv)
+    try:
+        rdep = ctx.stpcg(ctx.upload(g), H, Pdep, **kw)
+        assert np.abs(Adep @ rdep["s"].numpy()).max() < 1e-8
+    except capi.MiError as e:
+        assert "preconditioner" in str(e)
+    # (ii) NaN in g, then the same object on a clean right-hand side
+    P = ctx.precon_constraint_csr(sps.csr_matrix(A), Minv)
+    gn = g.copy()
+    gn[7] = np.nan
+    with pytest.raises(capi.MiError, match="preconditioner"):
+        ctx.stpcg(ctx.upload(gn), H, P, **kw)
+    r = ctx.stpcg(ctx.upload(g), H, P, **kw)
+    assert np.abs(A @ r["s"].numpy()).max() < 1e-9 and P.info()[2] <= 1e-13
