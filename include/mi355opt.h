@@ -86,8 +86,10 @@ enum {
 /* The library's switches (A/B forms of its kernels, verification hooks of the multi-rank path) are read from the
  * environment ONCE per context, in mi_ctx_create: MI355OPT_<NAME>=<integer> for NAME in FORCE_SLOT_PATH,
  * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
- * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA (DESIGN.md
- * says what each selects).  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
+ * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA,
+ * NO_ZERO_COPY, SO3_SORT_NBR (DESIGN.md says what each selects).  A value that is not an integer counts as 1 unless it
+ * is "no" / "false" / "off"; any other MI355OPT_* variable found in the environment (a removed or misspelt switch)
+ * gets one warning on stderr.  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
  * prefix); format switches (NO_PACKED) act when a matrix is created, the communication ones before the layer they
  * concern is brought up.  Nothing else in the library reads the environment. */
 MI_API int mi_ctx_set_option(mi_ctx *ctx, const char *name, long value);
@@ -110,8 +112,9 @@ MI_API int mi_timer_stop(mi_ctx *ctx, double *ms);  /* sync: records, waits, ret
 MI_API int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out); /* `Vector v;` + sizing; pooled */
 MI_API int mi_vec_destroy(mi_vec *v);                           /* returns storage to the pool */
 /* non-owning window [offset, offset+n) of `base` (e.g. a column block of a column-major panel:
- * `S.leftCols(ns)`, `S.middleCols(..)` LOBPCG.h:254-268); destroy with mi_vec_destroy; `base` must
- * outlive it */
+ * `S.leftCols(ns)`, `S.middleCols(..)` LOBPCG.h:254-268); destroy with mi_vec_destroy.  Destruction order is free:
+ * an owner destroyed while views of it are alive keeps its storage until the last view is destroyed (a handle to the
+ * destroyed owner itself must of course not be used again). */
 MI_API int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out);
 MI_API int mi_vec_len(const mi_vec *v, size_t *n);
 MI_API int mi_vec_data(const mi_vec *v, void **device_ptr);

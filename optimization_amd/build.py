@@ -179,10 +179,37 @@ def build_harness(force=False):
     return out
 
 
+class SanitizerUnavailable(RuntimeError):
+    """The host has no usable ASan / UBSan toolchain or runtime: a reason to SKIP the sanitizer target, never a reason
+    to refuse the GPU library."""
+
+
+def _sanitizer_probe(tdir, san):
+    """Can this host compile, link and RUN a trivial program under the sanitizers (libasan / libubsan installed, no
+    ptrace / seccomp restriction on LeakSanitizer)?  Returns the ASAN_OPTIONS to run with, or raises."""
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=tdir) as d:
+        src, exe = os.path.join(d, "p.c"), os.path.join(d, "p")
+        with open(src, "w") as f:
+            f.write("#include <stdlib.h>\nint main(void){void*p=malloc(8);free(p);return 0;}\n")
+        try:
+            r = subprocess.run(["gcc"] + san + [src, "-o", exe], capture_output=True, text=True)
+        except FileNotFoundError as e:
+            raise SanitizerUnavailable(str(e))
+        if r.returncode != 0:
+            raise SanitizerUnavailable("gcc cannot build with -fsanitize=address,undefined here:\n" + r.stderr[-800:])
+        for opts in ("detect_leaks=1:abort_on_error=0", "detect_leaks=0:abort_on_error=0"):
+            r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS=opts))
+            if r.returncode == 0:
+                return opts
+        raise SanitizerUnavailable("a trivial sanitized program does not run here:\n" + r.stderr[-800:])
+
+
 def build_sanitize(force=False, run=True):
     """tests/cpp/sanitize_host: the template layer on a host vector (the host harness's translation unit + a main that
-    drives TNT, GradientDescent, LSQR, TNLS, LOBPCG once) under -fsanitize=address,undefined; run here, any report is a
-    build failure (the sanitizer / host-hardening target)."""
+    drives TNT, GradientDescent, LSQR, TNLS, LOBPCG once) under -fsanitize=address,undefined; run here, any REPORT is a
+    build failure (the sanitizer / host-hardening target).  A host without the sanitizer runtime raises
+    SanitizerUnavailable, which __graft_entry__.build() turns into a warning."""
     tdir = os.path.join(ROOT, "tests", "cpp")
     odir = os.path.join(ROOT, "oracle")
     exe = os.path.join(tdir, "sanitize_host")
@@ -191,6 +218,7 @@ def build_sanitize(force=False, run=True):
         glob.glob(os.path.join(odir, "*.[ch]")) + [os.path.join(tdir, "harness_host.cpp")]
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1",
            "-ffp-contract=off"]
+    asan_opts = _sanitizer_probe(tdir, san)
     if force or _newer(src, exe, deps):
         objs = []
         for c in ("oracle.c", "problems.c"):
@@ -207,7 +235,7 @@ def build_sanitize(force=False, run=True):
             raise RuntimeError("sanitizer build failed:\n" + r.stderr[-6000:])
     if run:
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+                           env=dict(os.environ, ASAN_OPTIONS=asan_opts, UBSAN_OPTIONS="print_stacktrace=1"))
         if r.returncode != 0 or "sanitize_host: ok" not in r.stdout:
             raise RuntimeError("the template layer failed under ASan/UBSan:\n" + r.stdout[-2000:] + r.stderr[-6000:])
     return exe

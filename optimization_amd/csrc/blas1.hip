@@ -157,6 +157,19 @@ int mi_vec_create(mi_ctx *ctx, size_t n, mi_vec **out) {
 
 int mi_vec_destroy(mi_vec *v) {
   if (!v) return MI_OK;
+  if (v->root) {  // a view: the last one out releases an owner that was destroyed before it
+    mi_vec *root = v->root;
+    delete v;
+    if (--root->views == 0 && root->zombie) {
+      if (root->owned) pool_free(root->ctx, root->d);
+      delete root;
+    }
+    return MI_OK;
+  }
+  if (v->views) {  // live views: keep storage and generation counter until the last of them is destroyed
+    v->zombie = true;
+    return MI_OK;
+  }
   if (v->owned) pool_free(v->ctx, v->d);
   delete v;
   return MI_OK;
@@ -167,7 +180,9 @@ int mi_vec_view(const mi_vec *base, size_t offset, size_t n, mi_vec **out) {
   MI_REQUIRE(offset + n <= base->n, "view [%zu, %zu) exceeds the base vector (%zu)", offset, offset + n, base->n);
   // an odd offset only costs alignment: gfx950 global 16-byte accesses need 4-byte alignment
   mi_vec *root = base->root ? base->root : const_cast<mi_vec *>(base);
+  MI_REQUIRE(!root->zombie, "view of a destroyed vector");
   *out = new mi_vec{base->ctx, n, base->d + offset, false, ++base->ctx->vec_serial, 0, root};
+  ++root->views;
   return MI_OK;
 }
 

@@ -1,6 +1,8 @@
 // context.hip -- context, stream, pooled allocator, event timing, error reporting.
 #include "mi_internal.h"
 #include <cstring>
+#include <strings.h>
+#include <unistd.h>
 
 #include <dlfcn.h>
 
@@ -204,11 +206,39 @@ const OptionDesc kOptions[] = {
     {"NO_ZERO_COPY", opt_no_zero_copy},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
 };
+// value of a switch: an integer; anything else that is not empty ("yes", "true", "on" -- and the presence-only
+// `MI355OPT_X=` of the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off
+long option_value(const char *e) {
+  char *end = nullptr;
+  const long v = strtol(e, &end, 0);
+  if (end != e && *end == '\0') return v;
+  if (!strcasecmp(e, "no") || !strcasecmp(e, "false") || !strcasecmp(e, "off")) return 0;
+  return 1;
+}
 void config_from_env(mi_ctx *ctx) {
   for (const OptionDesc &o : kOptions) {
     char name[64];
     snprintf(name, sizeof(name), "MI355OPT_%s", o.name);
-    if (const char *e = getenv(name)) (void)o.set(ctx, atol(e));
+    if (const char *e = getenv(name)) (void)o.set(ctx, option_value(e));
+  }
+  // A removed or misspelt switch must not turn an A/B script into two runs of the default path without a word: warn
+  // once per process about every MI355OPT_* variable that is neither a switch of the library nor one of the names the
+  // harness around it owns (MI355OPT_LIB, _COMM, _BUILD_TAG, _EXTRA_CFLAGS, _NO_UNITY, _BENCH_*).
+  static bool warned = false;
+  if (warned || !environ) return;
+  warned = true;
+  for (char **ep = environ; *ep; ++ep) {
+    if (strncmp(*ep, "MI355OPT_", 9) != 0) continue;
+    const char *nm = *ep + 9, *eq = strchr(nm, '=');
+    const size_t len = eq ? (size_t)(eq - nm) : strlen(nm);
+    bool known = false;
+    for (const OptionDesc &o : kOptions) known |= strlen(o.name) == len && strncmp(o.name, nm, len) == 0;
+    for (const char *h : {"LIB", "COMM", "BUILD_TAG", "EXTRA_CFLAGS", "NO_UNITY"})
+      known |= strlen(h) == len && strncmp(h, nm, len) == 0;
+    known |= len >= 6 && strncmp(nm, "BENCH_", 6) == 0;
+    if (!known)
+      fprintf(stderr, "[mi355opt] warning: environment variable MI355OPT_%.*s is not a switch of this build (removed "
+                      "or misspelt?); it changes nothing\n", (int)len, nm);
   }
 }
 }  // namespace

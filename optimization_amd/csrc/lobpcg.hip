@@ -1347,7 +1347,10 @@ static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &S
   } else {
     fin = gram_finish(ctx, jobs, 2, dst);
   }
-  if (st == MI_OK) st = hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+  if (st == MI_OK) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) st = hip_fail(e, "symmetric Gram pair launch", __FILE__, __LINE__);
+  }
   return st != MI_OK ? st : fin;
 }
 
@@ -1539,7 +1542,10 @@ static int update2_impl(mi_ctx *ctx, size_t m, int ks, int kc, const mi_vec *S, 
     }
 #undef UPD
   }
-  st = hipGetLastError() == hipSuccess ? MI_OK : MI_ERR_HIP;
+  {
+    const hipError_t e = hipGetLastError();
+    st = e == hipSuccess ? MI_OK : hip_fail(e, "panel update launch", __FILE__, __LINE__);
+  }
   pool_free(ctx, Cdev);  // stream-ordered reuse: later allocations are enqueued after these kernels
   if (tmp) mi_vec_destroy(tmp);
   return st;

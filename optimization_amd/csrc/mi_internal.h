@@ -197,6 +197,11 @@ struct mi_vec {
   uint64_t serial = 0;
   uint64_t gen = 0;
   mi_vec *root = nullptr;
+  // Lifetime across the C ABI (r05, ADVICE): an owner counts its live views; mi_vec_destroy on an owner that still has
+  // views only marks it `zombie` — storage and generation counter stay until the last view goes — so a plain C client
+  // that destroys in the wrong order gets neither a host use-after-free in touch() nor a recycled device pointer.
+  uint32_t views = 0;
+  bool zombie = false;
 };
 namespace mi {
 inline void touch(mi_vec *v) {

@@ -88,6 +88,10 @@ def test_template_layer_is_clean_under_asan_and_ubsan():
     Rayleigh-Ritz -- built with g++ -fsanitize=address,undefined -fno-sanitize-recover=all and run; any report (heap
     error, leak, signed overflow, misaligned or out-of-bounds access ...) fails."""
     from optimization_amd import build as b
-    exe = b.build_sanitize(run=True)   # raises with the sanitizer's report on any finding
+    try:
+        exe = b.build_sanitize(run=True)   # raises with the sanitizer's report on any finding
+    except b.SanitizerUnavailable as e:    # (no libasan / libubsan, or LeakSanitizer may not run here)
+        import pytest
+        pytest.skip(str(e))
     import os
     assert os.path.exists(exe)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import rel_err
+from optimization_amd import capi
 
 pytestmark = pytest.mark.gpu
 
@@ -253,3 +254,34 @@ def test_profiler_ranges_nest_around_a_solve(ctx):
     r = ctx.stpcg(ctx.upload(g), ctx.op_diag(ctx.upload(D)), Delta=1e9, max_iterations=40, kappa_fgr=1e-10, theta=1.0)
     ctx.range_pop()
     assert np.abs(r["s"].numpy() + g / D).max() < 1e-8
+
+
+def test_view_outlives_its_owner_across_the_c_abi(ctx):
+    """a plain C client may destroy a vector before the views of it.  The owner then keeps storage and
+    generation counter until its last view goes: writes through the view still land (and `touch` has a live counter),
+    and the pool does not hand the same device memory to the next vector while a view still points into it."""
+    import ctypes as C
+    L = ctx.L
+    n = 4096
+    base = capi.vp()
+    capi.check(L.mi_vec_create(ctx.h, n, C.byref(base)))
+    v1, v2 = capi.vp(), capi.vp()
+    capi.check(L.mi_vec_view(base, 1024, 1024, C.byref(v1)))
+    capi.check(L.mi_vec_view(v1, 512, 256, C.byref(v2)))          # a view of a view counts on the owner
+    p_base = capi.vp()
+    capi.check(L.mi_vec_data(base, C.byref(p_base)))
+    capi.check(L.mi_vec_destroy(base))                             # wrong order on purpose
+    other = capi.Vec(ctx, n)                                       # same size class: must NOT recycle base's storage
+    assert other.data_ptr() != p_base.value
+    other.fill(7.0)
+    a, b = capi.Vec(ctx, 0, handle=v1), capi.Vec(ctx, 0, handle=v2)
+    a.owned = b.owned = False
+    a.fill(1.0)
+    b.fill(2.0)                                                    # writes + touch through both views
+    x = a.numpy()
+    assert (x[:512] == 1).all() and (x[512:768] == 2).all() and (x[768:] == 1).all()
+    assert (other.numpy() == 7).all()
+    capi.check(L.mi_vec_destroy(v1))
+    capi.check(L.mi_vec_destroy(v2))                               # the last view releases the owner
+    again = capi.Vec(ctx, n)                                       # now the storage is back in the pool
+    del again, other
