@@ -156,8 +156,8 @@ def extra_leg(ctx, nx, p, steps, warmup, packed, label):
                         "unit": "GB/s", "frac": per[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
                         "algorithmic_bytes_per_launch": kb[dom], "avg_launch_us_event_pairs": per[dom]["avg_us"],
                         "timing": "raw HIP event pairs around every launch"},
-           "sum_kernel_us_over_step_us": sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / min(steps, 100)
-                                         / (1e6 * dt / steps),
+           "sum_kernel_us_over_step_us_event_pairs": sum(per[k]["avg_us"] * per[k]["launches"] for k in ran)
+                                                     / min(steps, 100) / (1e6 * dt / steps),
            "kernels": {k: v for k, v in per.items() if v["launches"]}}
     del g, H, s_out, X, prob, A
     return out
@@ -186,7 +186,7 @@ def generic_leg_in_its_own_process(n, p, packed, label):
             "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                 "algorithmic_bytes_per_launch", "avg_launch_us",
                                                 "avg_launch_us_event_pairs", "frac_event_pairs_uncorrected", "timing")},
-            "sum_kernel_us_over_step_us": rf.get("sum_kernel_us_over_step_us"),
+            "sum_kernel_us_over_step_us_event_pairs": rf.get("sum_kernel_us_over_step_us_event_pairs"),
             "kernels": {k: v for k, v in (rf.get("kernels") or {}).items() if v.get("launches")}}
 
 
@@ -203,7 +203,35 @@ def run_steps(ctx, g, H, s_out, steps):
     return solves
 
 
-def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, peer_memory=False):
+_ORACLE_10 = {}   # (grid, p) -> rank 0's oracle solve of the verification problem, computed once per run
+
+
+def oracle_ten_iterations(nx, ny, nz, p, Xb_glob):
+    """CHECKER, rank 0 only, outside every timed region: the plain-C restatement of the reference (oracle/liboracle.so,
+    == the reference's templates bit for bit, tests/test_cpu_oracle_templates.py) on the GLOBAL problem of the
+    verification solve: 10 STPCG iterations from the same iterate.  None when the checker library is not there."""
+    key = (nx, ny, nz, p)
+    if key not in _ORACLE_10:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            O = oracle_py.Oracle()
+            rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+            oprob = O.stiefel_rq(nx * ny * nz, p, rowptr, col, val)
+            x = np.ascontiguousarray(Xb_glob).ravel()
+            go = O.eval_grad(oprob, x)
+            t0 = time.perf_counter()
+            o = O.stpcg_problem(oprob, x, go, 1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0, trace_cap=16)
+            o["seconds"] = time.perf_counter() - t0
+            O.free(oprob)
+            _ORACLE_10[key] = o
+        except Exception as e:  # noqa: BLE001  (no checker library on this box: say so, do not fail the run)
+            print(f"bench.py: oracle check of the sharded solve unavailable: {e}", file=sys.stderr)
+            _ORACLE_10[key] = None
+    return _ORACLE_10[key]
+
+
+def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, peer_memory=False, info=None):
     """Cheap end-to-end checks of the N-rank data path before anything is timed (the 8-GPU node is the first
     place the cross-device exchanges ever run).  Returns a list of failure strings (empty = all good), the same
     on every rank."""
@@ -226,10 +254,39 @@ def verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank, p
     if not abs(d - p) < 1e-11 * p:
         fails.append(f"rank {rank}: all-reduced <E,E> = {d!r}, expected {p}")
     # replicated control flow: a short fused solve must report the same bits everywhere
-    X = ctx.upload(np.ascontiguousarray(wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)[0][n0:n1]))
+    Xb_glob = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-3, seed=7)[0]
+    X = ctx.upload(np.ascontiguousarray(Xb_glob[n0:n1]))
     g, H = prob.model(X)
-    r = ctx.stpcg(g, H, Delta=1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0)
+    r = ctx.stpcg(g, H, Delta=1e3, max_iterations=10, kappa_fgr=1e-12, theta=1.0, trace_cap=16)
     mine = (r["iterations"], r["exit_reason"], float(r["M_norm"]).hex(), r["hvp_calls"], ctx.comm_ipc_error())
+    # ... and it must be the REFERENCE's solve, not merely the same wrong one everywhere (r04 verdict): rank 0 runs the
+    # CPU oracle on the global problem; every rank compares its rows of the step, the counts and the alpha / beta traces
+    o = oracle_ten_iterations(nx, ny, nz, p, Xb_glob) if rank == 0 else None
+    box = [None if o is None else {k: o[k] for k in ("iterations", "exit_reason", "M_norm", "seconds")} |
+           {"alpha": o["trace"]["alpha"], "beta": o["trace"]["beta"]}]
+    dist.broadcast_object_list(box, src=0)
+    slabs = [None]
+    dist.scatter_object_list(slabs, [np.ascontiguousarray(o["s"].reshape(-1, p)[nx * ny * a: nx * ny * b])
+                                     for a, b in wl.shard_rows(nz, world)] if o is not None else [None] * world, src=0)
+    if box[0] is not None:
+        ob, s_mine = box[0], r["s"].numpy().reshape(-1, p)
+        import torch
+        acc = torch.tensor([float(((s_mine - slabs[0]) ** 2).sum()), float((slabs[0] ** 2).sum())], dtype=torch.float64)
+        dist.all_reduce(acc)
+        es = float(np.sqrt(acc[0] / acc[1]))
+        ea = float(np.max(np.abs(r["trace"]["alpha"] / ob["alpha"] - 1)))
+        eb = float(np.max(np.abs(r["trace"]["beta"] / ob["beta"] - 1)))
+        if (r["iterations"], r["exit_reason"]) != (ob["iterations"], ob["exit_reason"]):
+            fails.append(f"rank {rank}: sharded solve ({r['iterations']}, exit {r['exit_reason']}) != oracle "
+                         f"({ob['iterations']}, exit {ob['exit_reason']})")
+        if not (es <= 1e-10 and ea <= 1e-10 and eb <= 1e-10 and abs(r["M_norm"] / ob["M_norm"] - 1) <= 1e-10):
+            fails.append(f"rank {rank}: sharded 10-iteration solve vs the CPU oracle: s {es:.2e}, alpha {ea:.2e}, "
+                         f"beta {eb:.2e} (bar 1e-10)")
+        if info is not None:
+            info.update(oracle_check={"s_rel": es, "alpha_rel": ea, "beta_rel": eb, "iterations": ob["iterations"],
+                                      "oracle_seconds": ob["seconds"], "bar": 1e-10})
+    elif info is not None:
+        info.update(oracle_check=None)
     if peer_memory and os.environ.get("MI355OPT_NO_FOLD") != "1":
         # the exchanges folded into the CG / Hessian kernels (scalars in the prologues, halo rows in the direction
         # kernel's stores) against the separate exchange kernels: bit-identical by construction, so any difference
@@ -473,7 +530,8 @@ class Watchdog:
 
 def comm_set_layer(ctx, layer, peer_up=True):
     """switch the exchange layer of a context (the same call on every rank); peer_up: the peer-memory layer is mapped"""
-    if layer == "rccl":
+    ctx.set_option("HALO_RPRIME", 1 if layer in ("rccl2", "peer-separate-rprime") else 0)
+    if layer in ("rccl", "rccl2"):
         if peer_up:
             ctx.comm_ipc_enable(False)
     else:
@@ -486,7 +544,13 @@ LAYER_TEXT = {"peer": "peer-memory layer (hipIpc-mapped arenas over xGMI), scala
               "peer-separate": "peer-memory layer with separate one-workgroup exchange kernels and a halo-push kernel: "
                                "6 launches per iteration",
               "rccl": "RCCL: in-stream ncclAllReduce of the partial rows (2 per iteration, each one group = one launch) "
-                      "and an ncclSend/ncclRecv group for the halo rows"}
+                      "and an ncclSend/ncclRecv group for the halo rows",
+              "peer-separate-rprime": "peer-memory layer, separate exchange kernels, r'-halo form (the rows of the new "
+                                      "residual are pushed, halo(p') is formed locally): the transport-independent part "
+                                      "of `rccl2`, which a one-GPU rehearsal can exercise",
+              "rccl2": "RCCL, r'-halo form: the boundary rows of the new RESIDUAL ride in the RCCL group of the <r,v> "
+                       "all-reduce and every rank forms halo(p') = -halo(r') + beta halo(p) itself -- 2 dependent "
+                       "collectives per iteration instead of 3 (same bits)"}
 
 
 def comm_ab_leg(ctx, dist, prob, X, s_out, layer, steps, world, rank, verify, peer_up):
@@ -497,8 +561,9 @@ def comm_ab_leg(ctx, dist, prob, X, s_out, layer, steps, world, rank, verify, pe
     dist.barrier()
     if os.environ.get("MI355OPT_BENCH_INJECT_HANG") == layer:   # (test of the watchdog: a layer that never returns)
         time.sleep(1e9)
-    fails = verify()
-    leg = {"layer": layer, "what": LAYER_TEXT[layer], "verified": not fails}
+    vinfo = {}
+    fails = verify(vinfo)
+    leg = {"layer": layer, "what": LAYER_TEXT[layer], "verified": not fails, **vinfo}
     if fails:
         leg["failures"] = fails[:4]
         return leg
@@ -551,7 +616,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the plain-matrix and beyond-cache legs")
     ap.add_argument("--comm", default=os.environ.get("MI355OPT_COMM", "auto"),
-                    choices=["auto", "peer", "peer-separate", "rccl"],
+                    choices=["auto", "peer", "peer-separate", "peer-separate-rprime", "rccl", "rccl2"],
                     help="exchange layer of the headline at N > 1 (auto: the fastest layer that verifies)")
     ap.add_argument("--ab-steps", type=int, default=300, help="timed steps of each exchange-layer A/B leg at N > 1")
     ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MI355OPT_BENCH_LEG_TIMEOUT", "240")),
@@ -598,7 +663,7 @@ def main():
         # (MI355OPT_BENCH_TRY_RCCL=1: the rehearsal probes RCCL as well -- it refuses the duplicate device, which is the
         # "RCCL does not come up" branch of a real node; tests/test_gpu_comm.py)
         want_rccl = not one_gpu or (os.environ.get("MI355OPT_BENCH_TRY_RCCL") == "1" and not args.no_peer_probe)
-        want_peer = args.comm != "rccl" or one_gpu
+        want_peer = args.comm not in ("rccl", "rccl2") or one_gpu
         if want_rccl and world > 1 and not args.no_peer_probe:
             rccl_probe = layer_probe(dist, world, rank, "rccl")
             want_rccl = rccl_probe[0]
@@ -763,9 +828,19 @@ def main():
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_bytes.sh on this " \
-                                     "workload; not collected in this run)"
+                    rec = json.load(open(tf)).get(dom)
+                    # a committed measurement only stands for THIS build's kernel: same kernel name, same algorithmic
+                    # bytes per launch (a changed format or workload changes them); anything else is refused, not quoted
+                    if rec is None:
+                        traffic_source = f"profiles/pmc_traffic.json has no record of '{dom}': refused (stale file?)"
+                    elif rec.get("algorithmic_bytes") != kb[dom]:
+                        traffic_source = (f"profiles/pmc_traffic.json was measured on a '{dom}' of "
+                                          f"{rec.get('algorithmic_bytes')} algorithmic bytes per launch, this build's moves "
+                                          f"{kb[dom]}: refused as stale (re-run tools/pmc_bytes.sh)")
+                    else:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc_bytes.sh on this " \
+                                         "workload and kernel, algorithmic bytes matching; not collected in this run)"
                 except Exception:  # noqa
                     traffic = None
             sum_kernel_us = sum(per[k]["avg_us"] * per[k]["launches"] for k in ran) / tsteps
@@ -774,9 +849,10 @@ def main():
                         "traffic_source": traffic_source,
                         "algorithmic_bytes_per_launch": kb[dom],
                         "avg_launch_us": net_us,
-                        # sum of the kernels' durations over the un-instrumented step: 1.0 = no gaps between kernels
-                        "sum_kernel_us_over_step_us": (sum_kernel_us - ev_overhead * launches_per_step)
-                                                      / (dt / args.steps * 1e6),
+                        # raw pair-timed kernel time over the un-instrumented step (> 1 by the pairs' own cost).  The NET
+                        # ratio is 1 by construction (that is how the pairs' cost is measured) and is not reported;
+                        # the independent evidence for "no gaps" is rocprofv3's kernel total against the step
+                        # (profiles/r05_summary.md)
                         "sum_kernel_us_over_step_us_event_pairs": sum_kernel_us / (dt / args.steps * 1e6),
                         "avg_launch_us_event_pairs": per[dom]["avg_us"],
                         "event_record_overhead_us_per_launch": ev_overhead,
@@ -800,14 +876,14 @@ def main():
     comm_layer, comm_legs, comm_choice, m = None, None, None, None
     wd = Watchdog(rank) if use_comm else None
     if use_comm:
-        layers = (["peer", "peer-separate"] if peer_memory else []) + (["rccl"] if rccl_up else [])
+        layers = (["peer", "peer-separate", "peer-separate-rprime"] if peer_memory else []) + (["rccl", "rccl2"] if rccl_up else [])
         inject = os.environ.get("MI355OPT_BENCH_INJECT_VERIFY_FAILURE") == "1"  # (test of the fallback path)
 
         def verifier(layer):
-            def verify():
+            def verify(info=None):
                 f = verify_distributed(ctx, dist, A, prob, nx, ny, nz, z0, z1, p, world, rank,
-                                       peer_memory=(layer == "peer"))
-                if inject and layer != "rccl":
+                                       peer_memory=(layer == "peer"), info=info)
+                if inject and layer not in ("rccl", "rccl2"):
                     f = f + ["injected failure (test of the fallback path)"]
                 return f
             return verify
@@ -818,7 +894,7 @@ def main():
             comm_legs.append(leg)
             if not leg["verified"] and rank == 0:
                 print(f"bench.py: exchange layer '{leg['layer']}' failed verification" +
-                      (", falling back to RCCL" if leg["layer"] != "rccl" else "") + ":\n  " +
+                      (", falling back to RCCL" if leg["layer"] not in ("rccl", "rccl2") else "") + ":\n  " +
                       "\n  ".join(leg.get("failures", [])), file=sys.stderr)
             if leg["verified"] and not leg.get("ipc_error") and kept is None:
                 wd.arm(f"headline on '{L}'", args.leg_timeout)
@@ -838,7 +914,7 @@ def main():
         wd.arm(f"headline on '{comm_layer}'", args.leg_timeout)
         m = kept[1] if kept[0] == comm_layer else measure(comm_layer)
         wd.disarm()
-        peer_memory = comm_layer != "rccl"
+        peer_memory = comm_layer not in ("rccl", "rccl2")
         dist.barrier()
     else:
         m = measure(None)
@@ -865,6 +941,22 @@ def main():
         if not args.no_cpu_baseline:
             cpu, cpu_all = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, moved_bytes, bytes_per_step)
 
+    if rank == 0 and use_comm and not args.no_cpu_baseline:
+        # N > 1 (r04 verdict): the reference's CPU path "in the same run" here too.  Rank 0 times it AFTER the timed region
+        # while the other ranks sit at the barrier below, on the PER-GPU problem -- a grid the size of one rank's slab
+        # (the same 1e6 x 3 unknowns per GPU as at N = 1), not the N-fold global one -- so that `cores` (1) and the
+        # bounded sample stay what they are at N = 1; the line says so.
+        try:
+            lx, ly, lz = nx, ny, z1 - z0
+            Xl, _ = wl.stiefel_bench_iterate(lx, ly, lz, p, eps=1e-3, seed=7)
+            cpu, cpu_all = cpu_baseline(lx, ly, lz, p, *wl.laplacian_3d(lx, ly, lz), Xl, moved_bytes, bytes_per_step)
+            for c_ in (cpu, cpu_all):
+                c_["sample"] += (f"; N = {world}: the PER-GPU problem (a {lx}x{ly}x{lz} grid of its own, the size of one "
+                                 "rank's slab), timed on rank 0's host cores after the timed region -- multiply by nothing: "
+                                 "one CPU process against ONE GPU's share of the job")
+                c_["per_gpu_problem"] = True
+        except Exception as e:  # noqa: BLE001  (the baseline must never take the headline down with it)
+            print("bench.py: CPU baseline at N > 1 failed: %s" % e, file=sys.stderr)
     if rank == 0:
         out = make_line(m, comm_layer, comm_choice, comm_legs, plain_leg, big_leg, cpu, cpu_all)
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())

@@ -46,6 +46,8 @@ struct Comm {
   uint64_t timeout = kIpcTimeoutTicks;   // bound of every device-side wait, in 100 MHz ticks
   // a halo push folded into the kernel that wrote the vector (comm_halo_fold_next), not yet consumed
   struct { const mi_csr *A = nullptr; const double *V = nullptr; int p = 0; uint64_t seq = 0; } pushed;
+  // r'-halo form: the halo of this (A, p, V) was formed locally (comm_rprime_mark), not yet consumed
+  struct { const mi_csr *A = nullptr; const double *V = nullptr; int p = 0; } formed;
   // kernels this layer launched itself: [0] scalar exchanges, [1] halo pushes, and [2] halo pushes that rode in the
   // producer kernel instead (mi_comm_kernel_launches)
   unsigned long long launched[4] = {0, 0, 0, 0};  // ([3]: of the folded pushes, those in the early form)
@@ -352,12 +354,19 @@ bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, H
 }
 
 void comm_halo_fold_drop(mi_ctx *ctx) {
-  if (ctx->comm) ((Comm *)ctx->comm)->pushed = {};
+  if (ctx->comm) {
+    ((Comm *)ctx->comm)->pushed = {};
+    ((Comm *)ctx->comm)->formed = {};
+  }
 }
 
 int comm_halo_exchange_or_wait(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloWait *w) {
   *w = HaloWait{};
   Comm *c = (Comm *)ctx->comm;
+  if (c && c->formed.A && c->formed.A == A && c->formed.V == V && c->formed.p == p) {
+    c->formed = {};  // r'-halo form: the rows are in A->halo_cur() already (stream order), nothing to wait for
+    return MI_OK;
+  }
   if (c && c->pushed.seq && c->pushed.A == A && c->pushed.V == V && c->pushed.p == p) {
     const int rk = ctx->rank, ws = ctx->world_size;
     w->mine = reinterpret_cast<const IpcMailbox *>(c->peer[rk]);
@@ -377,6 +386,7 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
   if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return MI_OK;
   Comm *c = (Comm *)ctx->comm;
   c->pushed = {};
+  c->formed = {};
   const int rk = ctx->rank, ws = ctx->world_size;
   if (c->ipc_enabled && A->halo_in_arena) {
     // this exchange's buffer (mi_csr::halo_stride); every rank counts the exchanges of a matrix identically
@@ -410,6 +420,77 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
     if (A->halo_hi)
       MI_NCCL(ncclRecv(const_cast<double *>(A->halo_cur()) + A->halo_lo * p, A->halo_hi * p, ncclDouble, rk + 1, c->nccl,
                        ctx->stream));
+  }
+  MI_NCCL(ncclGroupEnd());
+  return MI_OK;
+}
+
+// ---- r'-halo form (comm_ipc.h) -------------------------------------------------------------------------------------------
+bool comm_rprime_enabled(const mi_ctx *ctx, const mi_csr *A) {
+  if (!ctx->cfg.halo_rprime || ctx->world_size <= 1 || !ctx->comm || !A || !A->halo) return false;
+  return A->halo_lo + A->halo_hi + A->send_lo + A->send_hi > 0;
+}
+
+static int rprime_alloc(mi_ctx *ctx, const mi_csr *A) {
+  if (A->halo_r) return MI_OK;
+  // (every rank gets here at the same point of the same solve: the arena's bump allocator stays in step)
+  return comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo_r, &A->halo_r_in_arena, &A->halo_r_off);
+}
+
+void comm_rprime_buffers(const mi_ctx *, const mi_csr *A, int p, const double **halo_r, double **halo_p, size_t *count) {
+  *halo_r = A->halo_r + (A->halo_r_exchanges & 1) * A->halo_stride;
+  *halo_p = const_cast<double *>(A->halo_cur());
+  *count = (A->halo_lo + A->halo_hi) * (size_t)p;
+}
+
+void comm_rprime_mark(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
+  Comm *c = (Comm *)ctx->comm;
+  c->pushed = {};
+  c->formed.A = A; c->formed.V = V; c->formed.p = p;
+}
+
+int comm_rprime_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *R, double *partials, int k) {
+  Comm *c = (Comm *)ctx->comm;
+  MI_TRY(rprime_alloc(ctx, A));
+  const int rk = ctx->rank, ws = ctx->world_size;
+  if (c->ipc_enabled && A->halo_in_arena && A->halo_r_in_arena) {
+    // peer-memory layer, separate kernels: the scalar exchange is the caller's own kernel; the rows by peer stores
+    MI_REQUIRE(!partials, "r'-halo form: rows all-reduce and the peer-memory layer do not go together");
+    const size_t buf_off = A->halo_r_off + (++A->halo_r_exchanges & 1) * A->halo_stride * sizeof(double);
+    const size_t lo = A->send_lo * p, hi = A->send_hi * p;
+    const size_t work = std::max(lo, hi);
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((work + 255) / 256, 64));
+    KScope ks(ctx, MI_K_COMM_HALO);
+    hipLaunchKernelGGL(k_ipc_halo_push, dim3(grid), dim3(256), 0, ctx->stream, R, A->n * (size_t)p, lo, hi,
+                       (char *const *)c->peer_dev, ws, rk, buf_off + A->peer_lo_rows * p * sizeof(double), buf_off,
+                       (int)(rk > 0 && A->halo_lo + A->send_lo > 0), (int)(rk + 1 < ws && A->halo_hi + A->send_hi > 0),
+                       ++c->halo_seq, c->err_dev, c->timeout);
+    ++c->launched[1];
+    MI_HIP(hipGetLastError());
+    return MI_OK;
+  }
+  MI_REQUIRE(c->nccl, "r'-halo form needs RCCL or the enabled peer-memory layer");
+  double *dst = A->halo_r + (A->halo_r_exchanges & 1) * A->halo_stride;  // (in-stream collectives: one buffer will do)
+  KScope ks(ctx, partials ? MI_K_COMM_ALLREDUCE : MI_K_COMM_HALO);
+  MI_NCCL(ncclGroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (int j = 0; j < k && partials && r == ncclSuccess; ++j) {
+    double *seg = partials + (size_t)j * kMaxRows;
+    r = ncclAllReduce(seg, seg, (size_t)(ctx->uniform_grid ? kMaxGrid : kMaxRows), ncclDouble, ncclSum, c->nccl, ctx->stream);
+  }
+  if (rk > 0) {
+    if (A->send_lo && r == ncclSuccess) r = ncclSend(R, A->send_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream);
+    if (A->halo_lo && r == ncclSuccess) r = ncclRecv(dst, A->halo_lo * p, ncclDouble, rk - 1, c->nccl, ctx->stream);
+  }
+  if (rk + 1 < ws) {
+    if (A->send_hi && r == ncclSuccess)
+      r = ncclSend(R + (A->n - A->send_hi) * p, A->send_hi * p, ncclDouble, rk + 1, c->nccl, ctx->stream);
+    if (A->halo_hi && r == ncclSuccess)
+      r = ncclRecv(dst + A->halo_lo * p, A->halo_hi * p, ncclDouble, rk + 1, c->nccl, ctx->stream);
+  }
+  if (r != ncclSuccess) {
+    (void)ncclGroupEnd();
+    MI_NCCL(r);
   }
   MI_NCCL(ncclGroupEnd());
   return MI_OK;

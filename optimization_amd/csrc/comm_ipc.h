@@ -260,6 +260,25 @@ bool comm_halo_fold_next(mi_ctx *ctx, const mi_csr *A, int p, const double *V, H
 int comm_halo_exchange_or_wait(mi_ctx *ctx, const mi_csr *A, int p, const double *V, HaloWait *w);
 // forget a folded push nobody consumed (the solve ended behind it; the next exchange is a whole one again)
 void comm_halo_fold_drop(mi_ctx *ctx);
+// ---- r'-halo form (Config::halo_rprime; IterativeSolvers.h:377,408-420) ------------------------------------------------
+// The halo rows of the next direction p' = -r' + beta p (:420) can only travel once beta is known, i.e. behind the SECOND
+// all-reduce of an iteration: three dependent collectives per iteration on the RCCL layer.  r' (:377) is final one kernel
+// earlier: its boundary rows can ride in the same RCCL group as the all-reduce of <r',v'> (:408), and every rank then forms
+// halo(p') = -halo(r') + beta halo(p) from the halo rows of p it already holds -- the SAME expression, on the same bits,
+// as the owner of those rows evaluates for them (k_cg_pupdate), so the result is bit-identical to exchanging p'.
+// usable for this matrix on this context right now? (several ranks, a halo, the switch on)
+bool comm_rprime_enabled(const mi_ctx *ctx, const struct mi_csr *A);
+// all-reduce of the k component rows of `partials` (rows mode) AND the boundary rows of the n x p field R into A's r'-halo
+// buffer: one RCCL group; with the peer-memory layer's separate kernels, the scalar exchange is the caller's and this
+// only pushes the rows (partials == null)
+int comm_rprime_exchange(mi_ctx *ctx, const struct mi_csr *A, int p, const double *R, double *partials, int k);
+// the buffers k_halo_dir combines: the r' rows just received, the halo of p the next Hessian pass will read, and their
+// length in doubles
+void comm_rprime_buffers(const mi_ctx *ctx, const struct mi_csr *A, int p, const double **halo_r, double **halo_p,
+                         size_t *count);
+// the halo of the n x p field V over A's pattern is in place (formed locally): the next comm_halo_exchange_or_wait of
+// exactly (A, p, V) exchanges nothing
+void comm_rprime_mark(mi_ctx *ctx, const struct mi_csr *A, int p, const double *V);
 
 // host: arguments of the next folded exchange on this context (comm.hip).  peers == nullptr when the peer-memory
 // layer is not carrying the exchanges or folding is switched off (MI355OPT_NO_FOLD=1): separate exchange kernels.

@@ -109,6 +109,9 @@ struct Config {
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
+  bool halo_rprime = false;         // HALO_RPRIME: sharded STPCG exchanges the halo of r' (with the <r,v> all-reduce) and every
+                                    // rank forms halo(p') = -halo(r') + beta halo(p) itself: 2 collectives per iteration
+                                    // instead of 3 on the RCCL layer (`--comm rccl2`)
   int so3_sort_nbr = 0;             // SO3_SORT_NBR: mi_so3n_create orders a node's incidences by neighbour (experiment)
 };
 
@@ -474,6 +477,12 @@ struct mi_csr {
   size_t halo_stride = 0;
   mutable unsigned long long halo_exchanges = 0;
   const double *halo_cur() const { return halo ? halo + (halo_exchanges & 1) * halo_stride : nullptr; }
+  // r'-halo form of the sharded STPCG (Config::halo_rprime, comm.hip comm_rprime_*): where the neighbours' boundary rows of
+  // the new RESIDUAL land (same layout and double-buffering as `halo`); allocated on first use, by every rank alike
+  mutable double *halo_r = nullptr;
+  mutable bool halo_r_in_arena = false;
+  mutable size_t halo_r_off = 0;
+  mutable unsigned long long halo_r_exchanges = 0;
 };
 
 namespace mi {

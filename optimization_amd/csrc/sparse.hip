@@ -692,6 +692,7 @@ int mi_csr_destroy(mi_csr *A) {
   (void)hipFree(A->wk16);
   for (auto &kv : A->win_plans) (void)hipFree(kv.second.bounds);
   if (A->halo) comm_halo_free(A->ctx, A->halo, A->halo_in_arena);
+  if (A->halo_r) comm_halo_free(A->ctx, A->halo_r, A->halo_r_in_arena);
   delete A;
   return MI_OK;
 }

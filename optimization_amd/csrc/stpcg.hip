@@ -133,6 +133,17 @@ __device__ __forceinline__ void step_b(CgState &s, const CgConst &c, double red)
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// r'-halo form of the sharded solve (comm_ipc.h comm_rprime_*): halo(p') = -halo(r') + beta halo(p), the expression
+// k_cg_pupdate evaluates for the rows it owns (:420) -- same TU, same contraction, same bits -- applied by every rank to
+// the halo rows it holds.  `st` is the state k_cg_pupdate left: a direction update happened iff it still says CG_RUN.
+__global__ __launch_bounds__(256) void k_halo_dir(const CgState *__restrict__ st, const double *__restrict__ hr,
+                                                  double *__restrict__ hp, size_t count) {
+  if (st->mode != CG_RUN) return;
+  const double beta = st->beta;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+    hp[i] = -hr[i] + beta * hp[i];
+}
+
 
 // r = g; s = 0*g (:211,214); v = P r (:231/234); p = -v (:256); partial <r,v> (:266)
 template <int PRE>
@@ -605,6 +616,8 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // scalar exchanges of an iteration are folded into the prologues of their consumers (no exchange kernels).  Every
   // other combination keeps the separate exchange kernels.
   const bool folded = sharded && recur && comm_fold_enabled(ctx) && !ctx->force_slot_path;
+  // r'-halo form (Config::halo_rprime): the halo rows of r' travel with the <r,v> all-reduce, halo(p') is formed locally
+  const bool rprime = recur && !folded && dgp->halo_A && comm_rprime_enabled(ctx, dgp->halo_A);
   // unpreconditioned recurrence form: initialisation and the first direction's Gram rows in one pass
   // (k_cg_init_dirgram); one rank, nothing to exchange: G(p0), G(r0) set by k_cg_scalar_init itself
   const bool init_fused = recur && n == dgp->n * (size_t)dgp->p;
@@ -795,12 +808,25 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
           hipLaunchKernelGGL((k_cg_pupdate_s80<false, 0, FoldArgs>), dim3(grid), dim3(kBlock), 0, st, PUPD_ARGS, fold_b);
       } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials_b, grid, 1, slots_b));
+        if (rprime) CG_CHECK(comm_rprime_exchange(ctx, dgp->halo_A, dgp->p, r->d, nullptr, 0));
         KScope ks(ctx, MI_K_CG_PUPDATE);
         LAUNCH_PUPD(k_cg_pupdate_s80, k_cg_pupdate_s80, true);
       } else {
-        if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
+        if (rows && rprime) CG_CHECK(comm_rprime_exchange(ctx, dgp->halo_A, dgp->p, r->d, ctx->partials_b, 1));
+        else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
         LAUNCH_PUPD(k_cg_pupdate, k_cg_pupdate_s80, false);
+      }
+      if (rprime && (sharded || rows)) {
+        const double *hr = nullptr;
+        double *hp = nullptr;
+        size_t cnt = 0;
+        comm_rprime_buffers(ctx, dgp->halo_A, dgp->p, &hr, &hp, &cnt);
+        if (cnt) {
+          const int hg = (int)std::max<size_t>(1, std::min<size_t>((cnt + 255) / 256, 512));
+          hipLaunchKernelGGL(k_halo_dir, dim3(hg), dim3(256), 0, st, (const CgState *)st0, hr, hp, cnt);
+        }
+        comm_rprime_mark(ctx, dgp->halo_A, dgp->p, p->d);
       }
 #undef LAUNCH_PUPD
 #undef PUPD
