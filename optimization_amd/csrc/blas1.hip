@@ -81,6 +81,28 @@ __global__ __launch_bounds__(kBlock) void k_reduce_rows_to_slots(const double *_
   }
 }
 
+// any width (the 15 ... 64 components of the Stiefel kernels with p = 5 ... 8): wave w sums components w, w + 16, ...
+// exactly as reduce_rows does (a lane's rows in row order, then the wave reduction)
+__global__ __launch_bounds__(kBlock) void k_reduce_rows_to_slots_any(const double *__restrict__ partials, int count, int K,
+                                                                     double *__restrict__ slots, size_t batch_stride) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double *base = partials + (size_t)blockIdx.x * batch_stride;
+  for (int c = w; c < K; c += kWaves) {
+    const double *src = base + (size_t)c * kMaxRows;
+    double t[kMaxRows / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (r < count) ? src[r] : 0.0;
+    }
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+    if (lane == 0) slots[(size_t)blockIdx.x * K + c] = v;
+  }
+}
+
 int check_same(const mi_vec *a, const mi_vec *b) {
   MI_REQUIRE(a && b, "null vector");
   MI_REQUIRE(a->ctx == b->ctx, "vectors belong to different contexts");
@@ -106,7 +128,11 @@ int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, 
     case 9: RR(9); break;
     case 10: RR(10); break;
     case 16: RR(16); break;
-    default: set_error("unsupported reduction width %d", k); return MI_ERR_INTERNAL;
+    default:
+      MI_REQUIRE(k >= 1 && k <= kMaxComps, "unsupported reduction width %d", k);
+      hipLaunchKernelGGL(k_reduce_rows_to_slots_any, dim3(nbatch), dim3(kBlock), 0, ctx->stream, partials, count, k, slots,
+                         batch_stride);
+      break;
   }
 #undef RR
   MI_HIP(hipGetLastError());

@@ -311,7 +311,10 @@ int comm_allreduce_rows(mi_ctx *ctx, double *partials, int k) {
 
 int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots) {
   Comm *c = (Comm *)ctx->comm;
-  if (c && c->ipc_enabled && k <= kIpcVals)
+  // (the exchange kernel re-reduces the rows itself for the widths it is instantiated for; any other width -- the
+  // Stiefel components of p >= 5 -- is reduced to slots first and exchanged in padded chunks by comm_allreduce)
+  const bool ix = k == 1 || k == 2 || k == 3 || k == 4 || k == 6 || k == 9 || k == 10 || k == 16;
+  if (c && c->ipc_enabled && ix)
     return ipc_exchange(ctx, c, partials, count, nullptr, k, true, slots);
   MI_TRY(launch_reduce_rows_to_slots(ctx, partials, count, k, slots));
   return comm_allreduce(ctx, slots, k);
@@ -867,7 +870,7 @@ int mi_debug_set_rank(mi_ctx *ctx, int world_size, int rank) {
 
 int mi_debug_csr_set_halo(mi_csr *A, int p, const double *halo_rows_host) {
   MI_REQUIRE(A && halo_rows_host, "null argument");
-  MI_REQUIRE(p >= 1 && p <= 4, "halo buffers hold at most 4 columns");
+  MI_REQUIRE(p >= 1 && p <= kMaxP, "halo buffers hold at most %d columns", kMaxP);
   const size_t rows = A->halo_lo + A->halo_hi;
   if (rows)
     MI_HIP(hipMemcpy(const_cast<double *>(A->halo_cur()), halo_rows_host, rows * (size_t)p * sizeof(double), hipMemcpyHostToDevice));

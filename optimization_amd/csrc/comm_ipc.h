@@ -131,7 +131,10 @@ template <int K>
 __device__ __forceinline__ void fold_maybe(double (&)[K], const NoFold &, double *) {}
 template <int K>
 __device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldArgs &f, double *lds) {
-  if (f.peers) fold_exchange_sum<K>(d, f, lds);
+  // (wider sums -- the Stiefel components of p >= 5 -- are never folded: the host keeps the separate exchange, stpcg.hip)
+  if constexpr (K <= kIpcVals) {
+    if (f.peers) fold_exchange_sum<K>(d, f, lds);
+  }
 }
 struct FoldPush;
 template <int K>
@@ -248,7 +251,9 @@ __device__ __forceinline__ void halo_wait(const HaloWait &w) {
 
 template <int K>
 __device__ __forceinline__ void fold_maybe(double (&d)[K], const FoldPush &fp, double *lds) {
-  if (fp.f.peers) fold_exchange_sum<K>(d, fp.f, lds);
+  if constexpr (K <= kIpcVals) {
+    if (fp.f.peers) fold_exchange_sum<K>(d, fp.f, lds);
+  }
 }
 
 // host (comm.hip): fold the NEXT halo exchange of the n x p field `V` over A's pattern.  True: `push` goes to the

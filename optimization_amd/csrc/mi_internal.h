@@ -26,12 +26,14 @@ namespace mi {
 constexpr int kWave = 64;
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / kWave;  // 16
+constexpr int kMaxP = 8;                // widest Stiefel / tall-skinny field the templated kernels are instantiated for
 constexpr int kMaxGrid = 512;
 constexpr int kMaxRows = 1024;          // partial rows per component (the streaming kernels leave <= kMaxGrid; the
                                         // window kernels, with their smaller workgroups, up to kMaxRows)
-constexpr int kMaxComps = 16;           // components per partial buffer (component-major layout)
+constexpr int kMaxComps = 64;           // components per partial buffer (component-major layout): 3 curvature dots + the 36
+                                        // packed entries of an 8 x 8 symmetric Gram (Stiefel p = 8); the raw 8 x 8 Gram of mi_stiefel_gram: 64
 constexpr int kNumXCD = 8;
-constexpr int kScalarSlots = 96;        // device scalar file (doubles)
+constexpr int kScalarSlots = 256;       // device scalar file (doubles)
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -297,9 +299,13 @@ int launch_reduce_rows_to_slots(mi_ctx *ctx, const double *partials, int count, 
 int reduce_rows_allreduce(mi_ctx *ctx, const double *partials, int count, int k, double *slots);
 
 // scalar-file slot map
-// SLOT_GDIR: packed symmetric Gram of the CG residual [0,NS) and of the direction [16, 16+NS) (recurrence form of
-// mi_op::dirgram, stpcg.hip); SLOT_GRAM doubles as the 3+NS-component slot file of that form
-enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GDIR_P = 16 /* offset of G(p) inside SLOT_GDIR */, SLOT_MISC = 48, SLOT_GDIR = 64 };
+// SLOT_GDIR: packed symmetric Gram of the CG residual [0,NS) and of the direction [40, 40+NS) (recurrence form of
+// mi_op::dirgram, stpcg.hip; NS = p(p+1)/2 <= 36 for p <= 8); SLOT_GRAM doubles as the 3+NS-component slot file of
+// that form (<= 39 slots); SLOT_RAW: the raw p x p Gram of mi_stiefel_gram (<= 64 slots)
+enum { SLOT_USER = 0, SLOT_CG = 8, SLOT_GRAM = 16, SLOT_GDIR_P = 40 /* offset of G(p) inside SLOT_GDIR */, SLOT_MISC = 56, SLOT_GDIR = 64,
+       SLOT_RAW = 192 };
+static_assert(SLOT_GRAM + 3 + 36 <= SLOT_MISC && SLOT_GDIR + SLOT_GDIR_P + 36 <= SLOT_RAW && SLOT_RAW + 64 <= kScalarSlots,
+              "slot map");
 
 // ---- device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ double wave_reduce_sum(double v) {
@@ -364,10 +370,44 @@ __device__ __forceinline__ void block_partials_store_nw(const double (&acc)[K], 
 // workgroup, ~2-4 us at the head of every consumer kernel.)
 // after_issue(): called once the row loads are in the queue and before they are waited for -- the place for a
 // consumer's own first loads (they then return BEHIND the rows, in order, and do not delay the reduction).
+// K > 16 (the 3 + 15 ... 36 components of a Stiefel solve with p = 5 ... 8): wave w takes components w, w + 16, ...
+// in rounds -- same row order, same wave reduction per component; lds: >= K doubles.
+template <int K, class F>
+__device__ __forceinline__ void reduce_rows_wide(const double *__restrict__ partials, int count, double (&out)[K],
+                                                 double *lds, F &&after_issue) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int R = (K + kWaves - 1) / kWaves;
+  double v[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int c = w + q * kWaves;
+    double t[kMaxRows / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (c < K && r < count) ? partials[(size_t)c * kMaxRows + r] : 0.0;
+    }
+    if (q == 0) after_issue();
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) a += t[j];
+    v[q] = wave_reduce_sum(a);
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+    if (lane == 0 && w + q * kWaves < K) lds[w + q * kWaves] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = lds[k];
+  __syncthreads();
+}
 template <int K, class F>
 __device__ __forceinline__ void reduce_rows(const double *__restrict__ partials, int count,
                                             double (&out)[K], double *lds, F &&after_issue) {
-  static_assert(K <= kWaves, "one wave per component");
+  if constexpr (K > kWaves) {
+    reduce_rows_wide<K>(partials, count, out, lds, after_issue);
+    return;
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double t[kMaxRows / 64];
 #pragma unroll
@@ -463,7 +503,7 @@ struct mi_csr {
   // [n+halo_lo, n+halo_lo+halo_hi) = first halo_hi rows of rank+1.
   size_t halo_lo = 0, halo_hi = 0;  // rows received from rank-1 / rank+1
   size_t send_lo = 0, send_hi = 0;  // rows sent to rank-1 (our first rows) / rank+1 (our last rows)
-  double *halo = nullptr;           // device, (halo_lo + halo_hi) * 4 doubles (p <= 4)
+  double *halo = nullptr;           // device, (halo_lo + halo_hi) * kMaxP doubles (p <= kMaxP = 8)
   // peer-memory (IPC) exchange: the halo lives in this rank's arena at byte offset halo_off (the same
   // offset on every rank); peer_lo_rows = halo_lo of rank-1 (our first rows land behind them there)
   bool halo_in_arena = false;

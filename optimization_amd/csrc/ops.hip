@@ -207,7 +207,7 @@ int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out) {
 
 int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out) {
   MI_REQUIRE(ctx && A && out, "null argument");
-  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4]");
+  MI_REQUIRE(p >= 1 && p <= kMaxP, "p must be in [1,%d]", kMaxP);
   const size_t n = A->n;
   mi_op *op = new mi_op();
   op->ctx = ctx;

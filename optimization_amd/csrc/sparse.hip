@@ -1,5 +1,5 @@
 // sparse.hip -- sparse SPD operator storage (CSR in, sliced-ELL-64 in HBM) and W = A V for
-// tall-skinny V (n x p row-major, p <= 4).  This is the user-side HVP building block: the reference
+// tall-skinny V (n x p row-major, p <= 8).  This is the user-side HVP building block: the reference
 // has no sparse code (its HVP is a user callable invoked at IterativeSolvers.h:294, TNT.h:512).
 //
 // Algorithmic bytes: 12*nnz + 4*(n+1) + 16*n*p.
@@ -550,7 +550,7 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
   SellView view = sell_view(A);
   KScope ks(ctx, MI_K_SPMM);
   const bool no_stream = ctx->cfg.no_spmm_stream;
-  if (!no_stream && p >= 1 && p <= 4 && sell_stream_ok(A, p)) {
+  if (!no_stream && p >= 1 && p <= kMaxP && sell_stream_ok(A, p)) {
     const int sgrid = (int)std::min<size_t>(ngroups, 256);  // one workgroup per CU, one round
 #define SS(PV, HL, PKV) \
   hipLaunchKernelGGL((k_spmm_stream<PV, HL, PKV>), dim3(sgrid), dim3(kBlock), 0, ctx->stream, view, V, W)
@@ -561,7 +561,11 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
       case 1: SSP(1); break;
       case 2: SSP(2); break;
       case 3: SSP(3); break;
-      default: SSP(4); break;
+      case 4: SSP(4); break;
+      case 5: SSP(5); break;
+      case 6: SSP(6); break;
+      case 7: SSP(7); break;
+      default: SSP(8); break;
     }
 #undef SSP
 #undef SS
@@ -573,7 +577,11 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
     case 2: hipLaunchKernelGGL(k_spmm<2>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
     case 3: hipLaunchKernelGGL(k_spmm<3>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
     case 4: hipLaunchKernelGGL(k_spmm<4>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
-    default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT;
+    case 5: hipLaunchKernelGGL(k_spmm<5>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 6: hipLaunchKernelGGL(k_spmm<6>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 7: hipLaunchKernelGGL(k_spmm<7>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    case 8: hipLaunchKernelGGL(k_spmm<8>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, V, W); break;
+    default: set_error("p must be in [1,%d], got %d", kMaxP, p); return MI_ERR_INVALID_ARGUMENT;
   }
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -584,7 +592,7 @@ int csr_spmm_launch(const mi_csr *A, int p, const double *V, double *W) {
 // the product + k_cg_dot3)
 int csr_spmm_dots(const mi_csr *A, int p, const mi_vec *V, mi_vec *W, int *nparts, bool *unsupported) {
   mi_ctx *ctx = A->ctx;
-  *unsupported = !(p >= 1 && p <= 4 && sell_stream_ok(A, p)) || A->n == 0;
+  *unsupported = !(p >= 1 && p <= kMaxP && sell_stream_ok(A, p)) || A->n == 0;
   if (*unsupported) return MI_OK;
   MI_TRY(comm_halo_exchange(ctx, A, p, V->d));
   int grid = uniform_grid(ctx, sell_groups(A));
@@ -601,7 +609,11 @@ int csr_spmm_dots(const mi_csr *A, int p, const mi_vec *V, mi_vec *W, int *npart
     case 1: SDP(1); break;
     case 2: SDP(2); break;
     case 3: SDP(3); break;
-    default: SDP(4); break;
+    case 4: SDP(4); break;
+    case 5: SDP(5); break;
+    case 6: SDP(6); break;
+    case 7: SDP(7); break;
+    default: SDP(8); break;
   }
 #undef SDP
 #undef SD
@@ -699,7 +711,7 @@ int mi_csr_destroy(mi_csr *A) {
 
 int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W) {
   MI_REQUIRE(A && V && W, "null argument");
-  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  MI_REQUIRE(p >= 1 && p <= kMaxP, "p must be in [1,%d], got %d", kMaxP, p);
   MI_REQUIRE(V->n == A->n * (size_t)p && W->n == A->n * (size_t)p,
              "SpMM dimension mismatch: A has %zu rows, p=%d, V %zu, W %zu", A->n, p, V->n, W->n);
   MI_REQUIRE(V->d != W->d, "SpMM input and output must not alias");
@@ -773,7 +785,7 @@ int mi_csr_create_sharded(mi_ctx *ctx, size_t n_global, size_t row_begin, size_t
                                      &max_halo_rows);
   if (st == MI_OK) {
     // same size on every rank, so that the arena offsets of the peer-memory layer agree
-    A->halo_stride = std::max<size_t>(1, max_halo_rows * 4);  // doubles per buffer (p <= 4); two buffers
+    A->halo_stride = std::max<size_t>(1, max_halo_rows * kMaxP);  // doubles per buffer (p <= kMaxP); two buffers
     st = comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo, &A->halo_in_arena, &A->halo_off);
   }
   if (st == MI_OK && !(A->send_lo <= n && A->send_hi <= n)) {

@@ -95,7 +95,8 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
 // V, a column-major V -- and the rest of the 33 us is the prologue reduction and the ramp-down.
 // PK: the matrix is read from its value-indexed packed copy (one dword per entry: (col - row) << 8 | value
 // index; `vt` = the 256-entry value table, staged in LDS by the caller) -- 4 instead of 12 bytes per entry.
-template <int P, bool HALO, bool PK, class Epi>
+// NW: the waves of the workgroup (the wave takes every NW-th slice of [first, end)).
+template <int P, bool HALO, bool PK, class Epi, int NW = kWaves>
 __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, size_t end, int lane,
                                             const double *__restrict__ V, const double *vt, Epi &epi) {
   constexpr int CH = MI_SPMM_CHUNK;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
   // bounds of the wave's NEXT slice, requested a whole slice ahead: a scalar load issued where its result is
   // needed costs a full memory latency per slice while the vector queue is saturated (measured: a young
   // wave waited 4-6 us for its first pair)
-  size_t cand = slice + kWaves;
+  size_t cand = slice + NW;
   long long q0 = k, q1 = b1;
   if (cand < end) { q0 = slice_bound(A.slice_ptr, cand); q1 = slice_bound(A.slice_ptr, cand + 1); }
   Ops cur;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
     }
     if (!have_next) break;
     if (row_done) {  // moved on to `cand`: request the bounds of the slice after it
-      cand += kWaves;
+      cand += NW;
       if (cand < end) { q0 = slice_bound(A.slice_ptr, cand); q1 = slice_bound(A.slice_ptr, cand + 1); }
     }
     slice = nslice; k = nk; b1 = nb1;

@@ -1,4 +1,4 @@
-// stiefel.hip -- Stiefel manifold St(n,p) (p <= 4, embedded metric) kernels and the Rayleigh-quotient
+// stiefel.hip -- Stiefel manifold St(n,p) (p <= 8, embedded metric) kernels and the Rayleigh-quotient
 // problem  f(X) = .5 tr(X' A X):  the Objective / QuadraticModel / RiemannianMetric / Retraction
 // callables a TNT client supplies (Riemannian/Concepts.h:44-112).  The reference ships only the
 // S^2 = St(3,1) lambdas of tests/TNT_unit_test.cpp:73-117; these are their n x p generalisation:
@@ -511,7 +511,21 @@ __global__ __launch_bounds__(kBlock) void k_st_polar(size_t n, double *__restric
     case 2: { constexpr int P = 2; __VA_ARGS__; } break;            \
     case 3: { constexpr int P = 3; __VA_ARGS__; } break;            \
     case 4: { constexpr int P = 4; __VA_ARGS__; } break;            \
-    default: set_error("p must be in [1,4], got %d", p); return MI_ERR_INVALID_ARGUMENT; \
+    case 5: { constexpr int P = 5; __VA_ARGS__; } break;            \
+    case 6: { constexpr int P = 6; __VA_ARGS__; } break;            \
+    case 7: { constexpr int P = 7; __VA_ARGS__; } break;            \
+    case 8: { constexpr int P = 8; __VA_ARGS__; } break;            \
+    default: set_error("p must be in [1,%d], got %d", kMaxP, p); return MI_ERR_INVALID_ARGUMENT; \
+  }
+// the instantiations tuned for narrow rows (the one-pass Hessian in its p <= 4 forms: per-thread P x P matrices in
+// registers, 1024-thread workgroups, the LDS-window forms); p >= 5 takes k_st_hess_wide
+#define DISPATCH_P4(p, ...)                                         \
+  switch (p) {                                                      \
+    case 1: { constexpr int P = 1; __VA_ARGS__; } break;            \
+    case 2: { constexpr int P = 2; __VA_ARGS__; } break;            \
+    case 3: { constexpr int P = 3; __VA_ARGS__; } break;            \
+    case 4: { constexpr int P = 4; __VA_ARGS__; } break;            \
+    default: set_error("internal: narrow-row kernel asked for p = %d", p); return MI_ERR_INTERNAL; \
   }
 
 inline int row_grid(const mi_ctx *ctx, size_t n) { return grid_for(ctx, n, 2); }
@@ -574,7 +588,7 @@ int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double 
 
 int check_np(mi_ctx *ctx, size_t n, int p, const mi_vec *a, const mi_vec *b, const mi_vec *c) {
   MI_REQUIRE(ctx, "ctx is null");
-  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  MI_REQUIRE(p >= 1 && p <= kMaxP, "p must be in [1,%d], got %d", kMaxP, p);
   const mi_vec *vs[3] = {a, b, c};
   for (const mi_vec *v : vs) {
     if (!v) continue;
@@ -715,7 +729,7 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   }
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
 #define HF3(F, HL, RC, PKV, HWV)                                                                              \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV, HWV>), dim3(grid), dim3(block), 0,     \
+  DISPATCH_P4(p, hipLaunchKernelGGL((k_st_hess_fused<P, F, HL, RC, PKV, HWV>), dim3(grid), dim3(block), 0,     \
                                    ctx->stream, view, wv, (const CgState *)ctx->cg_live,                     \
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,  \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,     \
@@ -727,14 +741,14 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   if (A->pk) { HF3(F, HL, RC, true, 0); }                                      \
   else { HF3(F, HL, RC, false, 0); }
 #define HF3D(HWV, FARV)                                                                                       \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, false, true, true, HWV, FARV>), dim3(grid),      \
+  DISPATCH_P4(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, false, true, true, HWV, FARV>), dim3(grid),      \
                                    dim3(block), 0, ctx->stream, view, wv, (const CgState *)ctx->cg_live,      \
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
                                    out->d, ctx->partials, hw_none))
 #define HF3DH(HWV)                                                                                            \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, true, true, true, HWV, 1>), dim3(grid),         \
+  DISPATCH_P4(p, hipLaunchKernelGGL((k_st_hess_fused<P, false, true, true, true, HWV, 1>), dim3(grid),         \
                                    dim3(block), 0, ctx->stream, view, wv, (const CgState *)ctx->cg_live,      \
                                    (const double *)in->d, (const double *)q->X->d, (const double *)q->Y->d,   \
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
@@ -808,9 +822,9 @@ int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec 
   DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
-  double *slots = ctx->scalars + SLOT_GRAM;
+  double *slots = ctx->scalars + SLOT_RAW;
   MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, p * p, slots));
-  return read_slots_sync(ctx, SLOT_GRAM, p * p, G_host);
+  return read_slots_sync(ctx, SLOT_RAW, p * p, G_host);
 }
 
 int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, mi_vec *out) {
@@ -848,7 +862,7 @@ int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
 
 int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stiefel_rq **out) {
   MI_REQUIRE(ctx && A && out, "null argument");
-  MI_REQUIRE(p >= 1 && p <= 4, "p must be in [1,4], got %d", p);
+  MI_REQUIRE(p >= 1 && p <= kMaxP, "p must be in [1,%d], got %d", kMaxP, p);
   MI_REQUIRE(A->n == n && A->ctx == ctx, "matrix has %zu rows, expected %zu", A->n, n);
   mi_stiefel_rq *q = new mi_stiefel_rq();
   q->ctx = ctx;
@@ -856,8 +870,8 @@ int mi_stiefel_rq_create(mi_ctx *ctx, const mi_csr *A, size_t n, int p, mi_stief
   q->n = n;
   q->p = p;
   q->X = nullptr;
-  MI_HIP(hipMalloc((void **)&q->S_dev, 16 * sizeof(double)));
-  MI_HIP(hipMemsetAsync(q->S_dev, 0, 16 * sizeof(double), ctx->stream));
+  MI_HIP(hipMalloc((void **)&q->S_dev, kMaxP * kMaxP * sizeof(double)));
+  MI_HIP(hipMemsetAsync(q->S_dev, 0, kMaxP * kMaxP * sizeof(double), ctx->stream));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Z));
   MI_TRY(mi_vec_create(ctx, n * (size_t)p, &q->Y));
   q->hess.ctx = ctx;
@@ -895,7 +909,7 @@ int mi_stiefel_rq_objective(mi_stiefel_rq *q, const mi_vec *X, double *f) {
   double *slots = ctx->scalars + SLOT_GRAM;
   const int ns = nsym(q->p);
   MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, count, ns, slots));
-  double G[16];
+  double G[kMaxP * (kMaxP + 1) / 2];
   MI_TRY(read_slots_sync(ctx, SLOT_GRAM, ns, G));
   double tr = 0;
   for (int a = 0, idx = 0; a < q->p; ++a) {  // diagonal entries of the packed symmetric Gram
@@ -963,7 +977,7 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
     MI_TRY(mi_vec_create(ctx, N, &q->Y_next));
     MI_TRY(mi_vec_create(ctx, N, &q->grad_next));
     MI_TRY(mi_vec_create(ctx, N, &q->Hh));
-    MI_HIP(hipMalloc((void **)&q->S_next, 16 * sizeof(double)));
+    MI_HIP(hipMalloc((void **)&q->S_next, kMaxP * kMaxP * sizeof(double)));
   }
   q->trial_X = nullptr;
   // (a) Hess h, then |h|^2, <g,h>, <h, Hess h> in one pass (as MI355::dot_batch does)
@@ -1021,7 +1035,7 @@ int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *
     MI_TRY(mi_vec_create(ctx, N, &q->Y_next));
     MI_TRY(mi_vec_create(ctx, N, &q->grad_next));
     MI_TRY(mi_vec_create(ctx, N, &q->Hh));
-    MI_HIP(hipMalloc((void **)&q->S_next, 16 * sizeof(double)));
+    MI_HIP(hipMalloc((void **)&q->S_next, kMaxP * kMaxP * sizeof(double)));
   }
   q->trial_X = nullptr;
   touch(X_trial);

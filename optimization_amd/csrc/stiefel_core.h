@@ -18,9 +18,10 @@ struct SymIdx {
 template <int P>
 struct DirComps {
   static constexpr int NS = SymIdx<P>::NS;
-  static constexpr int value = (3 + NS <= 4) ? 4 : (3 + NS <= 6) ? 6 : (3 + NS <= 9) ? 9 : 16;
+  // (p <= 4: the widths the exchange kernels are instantiated for; p = 5 ... 8: 18, 24, 31, 39 -- exactly 3 + NS)
+  static constexpr int value = (3 + NS <= 4) ? 4 : (3 + NS <= 6) ? 6 : (3 + NS <= 9) ? 9 : (3 + NS <= 16) ? 16 : 3 + NS;
 };
-inline int dir_comps(int p) { return p == 1 ? 4 : p == 2 ? 6 : p == 3 ? 9 : 16; }
+inline int dir_comps(int p) { return p == 1 ? 4 : p == 2 ? 6 : p == 3 ? 9 : p == 4 ? 16 : 3 + p * (p + 1) / 2; }
 
 // per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
 template <int P>

@@ -248,26 +248,27 @@ __global__ __launch_bounds__(kBlock) void k_cg_dot3(size_t n, const CgState *__r
   block_partials_store<3>(a, lds, partials);
 }
 
-// G(p0) (packed symmetric, gns <= kWaves components, wave w sums component w's `count` partial rows in fixed order)
+// G(p0) (packed symmetric, gns components, wave w sums the `count` partial rows of components w, w + 16, ... in fixed order)
 // into gdir[SLOT_GDIR_P..), and G(r0) = -G(p0) (p0 = -r0) into gdir[0..)
 __device__ __forceinline__ void gdir_from_rows(const double *__restrict__ partials, int count, int gns,
                                                double *__restrict__ gdir) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (w >= gns) return;
-  const double *src = partials + (size_t)w * kMaxRows;
-  double t[kMaxRows / 64];
+  const int lane = threadIdx.x & 63;
+  for (int w = threadIdx.x >> 6; w < gns; w += kWaves) {  // (gns > kWaves: p >= 6, in rounds)
+    const double *src = partials + (size_t)w * kMaxRows;
+    double t[kMaxRows / 64];
 #pragma unroll
-  for (int j = 0; j < kMaxRows / 64; ++j) {
-    const int r = lane + 64 * j;
-    t[j] = (r < count) ? src[r] : 0.0;
-  }
-  double v = 0;
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (r < count) ? src[r] : 0.0;
+    }
+    double v = 0;
 #pragma unroll
-  for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
-  v = wave_reduce_sum(v);
-  if (lane == 0) {
-    gdir[SLOT_GDIR_P + w] = v;
-    gdir[w] = -v;
+    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+    if (lane == 0) {
+      gdir[SLOT_GDIR_P + w] = v;
+      gdir[w] = -v;
+    }
   }
 }
 
@@ -450,12 +451,10 @@ __global__ __launch_bounds__(kBlock) void k_cg_gdir_init(const double *__restric
     gdir_from_rows(partials, count, ns, gdir);
     return;
   }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (w >= ns) return;
-  const double v = slots[w];
-  if (lane == 0) {
-    gdir[SLOT_GDIR_P + w] = v;
-    gdir[w] = -v;
+  if (threadIdx.x < ns) {
+    const double v = slots[threadIdx.x];
+    gdir[SLOT_GDIR_P + threadIdx.x] = v;
+    gdir[threadIdx.x] = -v;
   }
 }
 
@@ -559,7 +558,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const bool rows = rows_mode(ctx);
   // direction-Gram fusion (mi_op::dirgram): one-pass Hessian, the Gram rows come from the direction kernel
   const mi_dirgram *dgp = (!ctx->no_dirgram && H->dirgram && H->apply_dir) ? H->dirgram : nullptr;
-  MI_REQUIRE(!dgp || (dgp->p >= 1 && dgp->p <= 4 && dgp->n * (size_t)dgp->p == g->n),
+  MI_REQUIRE(!dgp || (dgp->p >= 1 && dgp->p <= kMaxP && dgp->n * (size_t)dgp->p == g->n),
              "operator's direction-Gram description does not match the problem dimension");
   // (default depth 3: depth 2 gives the same cfg2 step and -0.6 % on a cfg3 TNT run)
   const int run_ahead = prm->run_ahead > 0 ? prm->run_ahead : 3;
@@ -615,7 +614,8 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // Several ranks through the peer-memory layer, unpreconditioned recurrence form (the cfg2 / cfg4 hot loop): the two
   // scalar exchanges of an iteration are folded into the prologues of their consumers (no exchange kernels).  Every
   // other combination keeps the separate exchange kernels.
-  const bool folded = sharded && recur && comm_fold_enabled(ctx) && !ctx->force_slot_path;
+  // (the folded exchange carries at most kIpcVals = 16 values: p <= 4)
+  const bool folded = sharded && recur && kc <= kIpcVals && comm_fold_enabled(ctx) && !ctx->force_slot_path;
   // r'-halo form (Config::halo_rprime): the halo rows of r' travel with the <r,v> all-reduce, halo(p') is formed locally
   const bool rprime = recur && !folded && dgp->halo_A && comm_rprime_enabled(ctx, dgp->halo_A);
   // unpreconditioned recurrence form: initialisation and the first direction's Gram rows in one pass
@@ -660,7 +660,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       case 1: INIT_DG(1); break;
       case 2: INIT_DG(2); break;
       case 3: INIT_DG(3); break;
-      default: INIT_DG(4); break;
+      case 4: INIT_DG(4); break;
+      case 5: INIT_DG(5); break;
+      case 6: INIT_DG(6); break;
+      case 7: INIT_DG(7); break;
+      default: INIT_DG(8); break;
     }
 #undef INIT_DG
   } else {
@@ -680,7 +684,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
         case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
         case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-        default: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 4: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
       }
     }
     if (recur && !gdir_in_scalar_init) {
@@ -747,7 +755,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 4: hipLaunchKernelGGL((KN<PRE_NONE, FS, 4, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
     case 6: hipLaunchKernelGGL((KN<PRE_NONE, FS, 6, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
     case 9: hipLaunchKernelGGL((KN<PRE_NONE, FS, 9, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
-    default: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    case 16: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    case 18: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 18, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    case 24: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 24, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    case 31: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 31, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    default: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 39, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
   }
         if (sharded && folded) {
           // the sum over the ranks completes in the kernel's own prologue (comm_ipc.h): no exchange kernel
@@ -793,7 +805,11 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 1: PUPD(KN1, FS, 1); break;            \
     case 2: PUPD(k_cg_pupdate, FS, 2); break;   \
     case 3: PUPD(k_cg_pupdate, FS, 3); break;   \
-    default: PUPD(k_cg_pupdate, FS, 4); break;  \
+    case 4: PUPD(k_cg_pupdate, FS, 4); break;   \
+    case 5: PUPD(k_cg_pupdate, FS, 5); break;   \
+    case 6: PUPD(k_cg_pupdate, FS, 6); break;   \
+    case 7: PUPD(k_cg_pupdate, FS, 7); break;   \
+    default: PUPD(k_cg_pupdate, FS, 8); break;  \
   }
       if (sharded && folded) {
         const FoldArgs fold_b = comm_fold_next(ctx);  // (folded <=> recurrence form <=> sp == 0)
