@@ -301,10 +301,11 @@ static int ctx_init(mi_ctx *ctx, int device) {
            prop.name[0] ? prop.name : "AMD Instinct", prop.gcnArchName, prop.multiProcessorCount);
   ctx->num_cu = prop.multiProcessorCount;
   MI_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  // All small control buffers (partial rows, scalar slots, the two CG states) come out of ONE 2 MB
-  // allocation (one translation for everything a kernel prologue touches).
+  // All small control buffers (partial rows, scalar slots, the two CG states) come out of ONE allocation.  (r05: 4 MB
+  // -- the component-major partial buffers grew from 16 to 64 components for Stiefel p <= 8; what a p <= 4 prologue
+  // touches, components 0 ... 15 of each buffer, lies where it lay.)
   const size_t pbytes = sizeof(double) * kMaxComps * kMaxRows;
-  const size_t slab_bytes = 2u << 20;
+  const size_t slab_bytes = 4u << 20;
   MI_HIP(hipMalloc((void **)&ctx->control_slab, slab_bytes));
   // (on the context's own stream: it is a non-blocking stream, which does not order itself behind the null stream)
   MI_HIP(hipMemsetAsync(ctx->control_slab, 0, slab_bytes, ctx->stream));

@@ -375,6 +375,106 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
 #endif
 }
 
+// ---- rows wider than 4 doubles (p = 5 ... 8) ------------------------------------------------------------------------------
+// The one-pass Hessian in its recurrence form for wide rows.  Same schedule and the same per-row arithmetic as
+// k_st_hess_fused<P, ., ., RECUR = true, ...> -- Z = A V - V S, out = Z - X M with M = G(p) from STPCG's recurrence, the
+// three curvature dots and the packed Gram sym(Y'out - (X'out) S) of the output in the epilogue of the only pass -- but
+// laid out for what p = 8 costs: a row is 64 bytes, three P x P products per row, 3 + P (P + 1) / 2 <= 39 accumulators
+// per lane.  So: 256-thread workgroups (one wave per SIMD, the whole vector register file to itself instead of the 128
+// registers a 1024-thread workgroup leaves a wave), S and M in LDS (every lane reads the same address: broadcast reads,
+// no bank conflicts) instead of 2 x 64 replicated registers, up to kMaxRows partial rows.
+constexpr int kWideBlock = 256, kWideWaves = kWideBlock / 64;
+template <int P, bool HALO, bool PK>
+__global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const CgState *__restrict__ st,
+                                                             const double *__restrict__ V, const double *__restrict__ X,
+                                                             const double *__restrict__ Y, const double *__restrict__ S,
+                                                             const double *__restrict__ gdir, double *__restrict__ out,
+                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
+  constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
+  __shared__ double lds[KC * kWideWaves];
+  __shared__ double vt[PK ? 256 : 1];
+  __shared__ double Sm[P * P], Mm[P * P];
+  if (st && st->mode != CG_RUN) return;
+  if constexpr (HALO) halo_wait(hwait.w);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) vt[threadIdx.x] = A.vtab[threadIdx.x];
+  if (threadIdx.x < P * P) {
+    const int aa = threadIdx.x / P, b = threadIdx.x % P;
+    Sm[threadIdx.x] = S[threadIdx.x];
+    Mm[threadIdx.x] = gdir[SLOT_GDIR_P + (aa <= b ? SymIdx<P>::at(aa, b) : SymIdx<P>::at(b, aa))];
+  }
+  __syncthreads();
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  double a[KC];
+#pragma unroll
+  for (int i = 0; i < KC; ++i) a[i] = 0;
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ X, *__restrict__ Y, *__restrict__ V;
+    double *__restrict__ out;
+    const double *Sm, *Mm;
+    double (&a)[KC];
+    int lane;
+    double x[P], y[P], v[P];
+    __device__ __forceinline__ unsigned lane_off(size_t slice) const {
+      return ((unsigned)slice * 64u + (unsigned)lane < (unsigned)A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+    }
+    __device__ __forceinline__ const double *row_of(const double *F, size_t slice, unsigned off) const {
+      return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F) + (unsigned)slice * (unsigned)(64 * P * 8) + off);
+    }
+    __device__ __forceinline__ void begin(size_t slice) {
+      const unsigned off = lane_off(slice);
+      const double *xs = row_of(X, slice, off), *vs = row_of(V, slice, off), *ys = row_of(Y, slice, off);
+#pragma unroll
+      for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; y[c] = ys[c]; }
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
+      if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
+      // (S and M are re-read from LDS for every row: loop-invariant code motion must not park 128 doubles in registers)
+      asm volatile("" ::: "memory");
+      double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (unsigned)slice * (unsigned)(64 * P * 8) +
+                                              lane_off(slice));
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
+        acc[b] -= t;  // Z = A V - V S
+      }
+      double o[P];
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
+        o[b] = acc[b] - t;  // Z - X M
+        os[b] = o[b];
+        a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
+      }
+      double os_[P];  // packed sym(y o' - x (o S)'): the Gram of this output row
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
+        os_[b] = t;
+      }
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa)
+#pragma unroll
+        for (int b = aa; b < P; ++b) {
+          const double gab = y[aa] * o[b] - x[aa] * os_[b];
+          const double gba = y[b] * o[aa] - x[b] * os_[aa];
+          a[3 + SymIdx<P>::at(aa, b)] += (aa == b) ? gab : .5 * (gab + gba);
+        }
+    }
+  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  sell_stream<P, HALO, PK, Epi, kWideWaves>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+  block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
+}
+
 // Gram partial rows of two dense n x P fields.
 //   VARIANT 0: gram(X,Z)              1: Y = X + Z written to out, gram(Y,Y)
 //           2: Z' = dinv_rows .* Z written to out, gram(X,Z')
@@ -679,8 +779,48 @@ int window_occupancy(int p, bool halo, int hw, bool fard) {
   return slot;
 }
 
+// p = 5 ... 8: the recurrence form through k_st_hess_wide (stpcg.hip asks for nothing else at these widths)
+int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
+  mi_ctx *ctx = q->ctx;
+  const mi_csr *A = q->A;
+  const int p = q->p;
+  MI_REQUIRE(gram_count < 0, "internal: rows wider than 4 doubles take the one-pass Hessian in its recurrence form only");
+  // 256-thread workgroups, at most two per CU resident (register budget): one round of <= 512 partial rows; several
+  // ranks in rows mode need exactly kMaxGrid of them
+  const size_t wgs = (A->nslices + kWideWaves - 1) / kWideWaves;
+  int grid = ctx->uniform_grid ? kMaxGrid : (int)std::max<size_t>(1, std::min<size_t>(wgs, 512));
+  if (!ctx->uniform_grid && ctx->max_grid < kMaxGrid) grid = std::min(grid, ctx->max_grid);
+  HaloWaitArg<true> hw_halo;
+  HaloWaitArg<false> hw_none;
+  MI_TRY(comm_halo_exchange_or_wait(ctx, A, p, in->d, &hw_halo.w));
+  hw_halo.halo_lo = (unsigned)A->halo_lo;
+  hw_halo.halo_hi = (unsigned)A->halo_hi;
+  SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
+  KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
+#define HWIDE(PV, HL, PKV, HWARG)                                                                                       \
+  hipLaunchKernelGGL((k_st_hess_wide<PV, HL, PKV>), dim3(grid), dim3(kWideBlock), 0, ctx->stream, view,              \
+                     (const CgState *)ctx->cg_live, (const double *)in->d, (const double *)q->X->d,                   \
+                     (const double *)q->Y->d, (const double *)q->S_dev, (const double *)(ctx->scalars + SLOT_GDIR),   \
+                     out->d, ctx->partials, HWARG)
+#define HWIDE_P(PV)                                                                                  \
+  if (A->halo) { if (A->pk) { HWIDE(PV, true, true, hw_halo); } else { HWIDE(PV, true, false, hw_halo); } } \
+  else { if (A->pk) { HWIDE(PV, false, true, hw_none); } else { HWIDE(PV, false, false, hw_none); } }
+  switch (p) {
+    case 5: HWIDE_P(5); break;
+    case 6: HWIDE_P(6); break;
+    case 7: HWIDE_P(7); break;
+    default: HWIDE_P(8); break;
+  }
+#undef HWIDE_P
+#undef HWIDE
+  *nparts = grid;
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
 int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
   mi_stiefel_rq *q = (mi_stiefel_rq *)self->impl;
+  if (q->p > 4) return rq_apply_dir_wide(q, in, out, gram_count, nparts);
   mi_ctx *ctx = q->ctx;
   const mi_csr *A = q->A;
   const int p = q->p;

@@ -558,6 +558,9 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   const bool rows = rows_mode(ctx);
   // direction-Gram fusion (mi_op::dirgram): one-pass Hessian, the Gram rows come from the direction kernel
   const mi_dirgram *dgp = (!ctx->no_dirgram && H->dirgram && H->apply_dir) ? H->dirgram : nullptr;
+  // rows wider than 4 doubles (Stiefel p = 5 ... 8) have the one-pass operator in its recurrence form only (no
+  // preconditioner); with one, the operator keeps its two passes and the direction kernel its flat form
+  if (dgp && dgp->p > 4 && (pre != PRE_NONE || ctx->dirgram_direct)) dgp = nullptr;
   MI_REQUIRE(!dgp || (dgp->p >= 1 && dgp->p <= kMaxP && dgp->n * (size_t)dgp->p == g->n),
              "operator's direction-Gram description does not match the problem dimension");
   // (default depth 3: depth 2 gives the same cfg2 step and -0.6 % on a cfg3 TNT run)
@@ -755,13 +758,24 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 4: hipLaunchKernelGGL((KN<PRE_NONE, FS, 4, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
     case 6: hipLaunchKernelGGL((KN<PRE_NONE, FS, 6, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
     case 9: hipLaunchKernelGGL((KN<PRE_NONE, FS, 9, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break;   \
-    case 16: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
-    case 18: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 18, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
-    case 24: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 24, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
-    case 31: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 31, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
-    default: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 39, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
+    default: hipLaunchKernelGGL((k_cg_update_s80<PRE_NONE, FS, 16, FT>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, FV); break; \
   }
-        if (sharded && folded) {
+  // p = 5 ... 8: 18, 24, 31, 39 components (3 + p (p + 1) / 2).  Never folded (the host keeps the separate exchange for
+  // them), and launched from the uncapped kernel: 39 reduced values per thread do not fit the 64 vector registers the
+  // two-workgroups-per-CU twins are held to
+#define UPD_WIDE(FS)                                                                                                        \
+  switch (kc) {                                                                                                             \
+    case 18: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 18, NoFold>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break; \
+    case 24: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 24, NoFold>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break; \
+    case 31: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 31, NoFold>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break; \
+    default: hipLaunchKernelGGL((k_cg_update<PRE_NONE, FS, 39, NoFold>), dim3(grid), dim3(kBlock), 0, st, UPD_ARGS, NoFold{}); break; \
+  }
+        if (kc > 16) {
+          if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, kc, slots_g));
+          else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials, kc));
+          KScope ks(ctx, MI_K_CG_UPDATE);
+          if (sharded) { UPD_WIDE(true); } else { UPD_WIDE(false); }
+        } else if (sharded && folded) {
           // the sum over the ranks completes in the kernel's own prologue (comm_ipc.h): no exchange kernel
           const FoldArgs fold_a = comm_fold_next(ctx);
           KScope ks(ctx, MI_K_CG_UPDATE);
@@ -776,6 +790,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
           UPD_RECUR(k_cg_update, false, NoFold, NoFold{});
         }
 #undef UPD_RECUR
+#undef UPD_WIDE
       } else if (sharded) {
         CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials, nparts, 3, slots_a));
         KScope ks(ctx, MI_K_CG_UPDATE);
@@ -805,11 +820,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     case 1: PUPD(KN1, FS, 1); break;            \
     case 2: PUPD(k_cg_pupdate, FS, 2); break;   \
     case 3: PUPD(k_cg_pupdate, FS, 3); break;   \
-    case 4: PUPD(k_cg_pupdate, FS, 4); break;   \
-    case 5: PUPD(k_cg_pupdate, FS, 5); break;   \
-    case 6: PUPD(k_cg_pupdate, FS, 6); break;   \
-    case 7: PUPD(k_cg_pupdate, FS, 7); break;   \
-    default: PUPD(k_cg_pupdate, FS, 8); break;  \
+    default: PUPD(k_cg_pupdate, FS, 4); break;  \
   }
       if (sharded && folded) {
         const FoldArgs fold_b = comm_fold_next(ctx);  // (folded <=> recurrence form <=> sp == 0)

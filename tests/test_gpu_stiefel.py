@@ -24,7 +24,7 @@ def _random_csr(n, seed, max_row=9, empty_every=0):
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 5000])
-@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_spmm_ragged_vs_oracle(ctx, oracle, n, p):
     import ctypes as C
     rowptr, col, val = _random_csr(n, seed=100 * n + p, empty_every=5 if n > 4 else 0)
@@ -471,7 +471,7 @@ def test_spmm_packed_matrix_ragged_vs_plain_and_oracle(oracle, monkeypatch, n, p
     assert np.array_equal(out["packed"], Wo)  # same per-row order, products and sums rounded separately
 
 
-@pytest.mark.parametrize("p", [1, 2, 3, 4])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 8])
 def test_fused_trial_step_has_the_bits_of_the_separate_calls(ctx, p):
     """mi_stiefel_rq_trial (reference Riemannian/TNT.h:493-512,573-585 as one launch chain, one read-back) against
     the separate calls it replaces -- dot products, retraction, objective, model at the trial point: bit for bit."""
@@ -687,3 +687,156 @@ def test_symmetry_check_edge_cases(ctx, oracle):
     assert not one_pass([0, 2, 4, 5], [0, 1, 0, 1, 2], [2.0, 0.0, -0.0, 2.0, 1.0], 3)
     # value asymmetry in the last bit
     assert not one_pass([0, 2, 4], [0, 1, 0, 1], [2.0, -1.0, np.nextafter(-1.0, 0), 2.0], 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# Stiefel(n, p) for p = 5 ... 8 (r05; VERDICT r04: "a Stiefel object that stops at p = 4 is a benchmark object, not a
+# manifold"): every kernel family of the problem object against the CPU oracle, as for p <= 4
+# ----------------------------------------------------------------------------------------------
+WIDE_P = [5, 6, 7, 8]
+
+
+@pytest.mark.parametrize("p", WIDE_P)
+def test_wide_rows_manifold_operations_vs_oracle(ctx, oracle, p):
+    """Gram, tangent projection, polar retraction, objective, gradient and (two-pass) Hessian of the Rayleigh-quotient
+    problem for rows of 5 ... 8 doubles against the oracle, plus the properties the reference's own TNT test checks on
+    its sphere (tests/TNT_unit_test.cpp:73-117): tangency, orthonormality after the retraction, a self-adjoint Hessian,
+    and a finite-difference check of gradient and Hessian."""
+    nx, ny, nz = 13, 11, 9
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = wl.random_stiefel(n, p, seed=3 + p)
+    A = ctx.csr(n, rowptr, col, val)
+    prob = ctx.stiefel_rq(A, n, p)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    rng = np.random.default_rng(p)
+    Z = rng.normal(size=(n, p))
+    X, Zd = ctx.upload(X0), ctx.upload(Z)
+    assert np.allclose(ctx.stiefel_gram(n, p, X, Zd), X0.T @ Z, rtol=1e-12, atol=1e-13)
+    Pz = ctx.stiefel_project(n, p, X, Zd).numpy().reshape(n, p)
+    M = X0.T @ Z
+    assert np.allclose(Pz, Z - X0 @ (0.5 * (M + M.T)), atol=1e-13)
+    Sk = X0.T @ Pz
+    assert np.abs(Sk + Sk.T).max() < 1e-13
+    V = 0.3 * Pz
+    Y = ctx.stiefel_retract(n, p, X, ctx.upload(V)).numpy().reshape(n, p)
+    Yo = oracle.eval_retract(oprob, X0.ravel(), V.ravel()).reshape(n, p)
+    assert rel_err(Y, Yo) < 1e-13 and np.abs(Y.T @ Y - np.eye(p)).max() < 1e-13
+    f, fo = prob.objective(X), oracle.eval_f(oprob, X0.ravel())
+    assert abs(f - fo) <= 1e-13 * abs(fo)
+    g, H = prob.model(X)
+    go = oracle.eval_grad(oprob, X0.ravel())
+    assert rel_err(g.numpy(), go) < 1e-13
+    Vt = ctx.stiefel_project(n, p, X, ctx.upload(rng.normal(size=(n, p))))
+    Hv = H.apply(Vt)
+    assert rel_err(Hv.numpy(), oracle.eval_hess(oprob, X0.ravel(), Vt.numpy())) < 1e-13
+    U = ctx.stiefel_project(n, p, X, ctx.upload(rng.normal(size=(n, p))))
+    a, b = U.dot(Hv), Vt.dot(H.apply(U))
+    assert abs(a - b) <= 1e-12 * max(abs(a), abs(b))
+    # finite differences along the retraction: f(R(tV)) = f + t <g,V> + t^2/2 <V,HV> + O(t^3)
+    vn = np.linalg.norm(Vt.numpy())
+    Vu = Vt.numpy() / vn                                             # unit tangent direction
+    t = 1e-4
+    fp = prob.objective(ctx.stiefel_retract(n, p, X, ctx.upload(t * Vu)))
+    fm = prob.objective(ctx.stiefel_retract(n, p, X, ctx.upload(-t * Vu)))
+    gV, VHV = g.dot(Vt) / vn, Vt.dot(Hv) / vn ** 2
+    assert abs((fp - fm) / (2 * t) - gV) <= 1e-6 * max(1.0, abs(gV))
+    assert abs((fp - 2 * f + fm) / (t * t) - VHV) <= 1e-4 * max(1.0, abs(VHV))
+    oracle.free(oprob)
+
+
+@pytest.mark.parametrize("fmt", ["packed", "plain"])
+@pytest.mark.parametrize("p", WIDE_P)
+def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p, fmt):
+    """STPCG on rows of 5 ... 8 doubles: the one-pass Hessian in its recurrence form (k_st_hess_wide: 256-thread
+    workgroups, S and M in LDS, 3 + p (p + 1) / 2 = 18 ... 39 partial components re-reduced in k_cg_update's prologue)
+    against the two-pass operator (MI355OPT_NO_DIRGRAM=1) and the oracle: counts, exit, alpha / beta traces, the step
+    to 1e-10 -- on the value-indexed matrix and on plain 12-byte entries.  MI355OPT_DIRGRAM_DIRECT (the direction
+    kernel forming the Gram rows) is defined for p <= 4 only: at these widths it keeps the two passes."""
+    from optimization_amd import capi
+    nx, ny, nz = 19, 14, 11          # 2926 rows: 46 slices, ragged last one
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=11 + p)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
+    ob = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e-3, max_iterations=40, kappa_fgr=1e-8, theta=1.0)  # boundary exit
+    oracle.free(oprob)
+    monkeypatch.setenv("MI355OPT_NO_PACKED", "1" if fmt == "plain" else "0")
+    res = {}
+    for mode, (no_dirgram, direct) in {"recurrence": ("0", "0"), "direct": ("0", "1"), "two-pass": ("1", "0")}.items():
+        monkeypatch.setenv("MI355OPT_NO_DIRGRAM", no_dirgram)
+        monkeypatch.setenv("MI355OPT_DIRGRAM_DIRECT", direct)
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            prob = c.stiefel_rq(A, n, p)
+            g, H = prob.model(c.upload(Xb))
+            names = ("stiefel_hess_fused", "stiefel_finish_dots")
+            for k in names:
+                c.ktime_enable(k, True)
+            c.ktime_reset()
+            r = c.stpcg(g, H, Delta=1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
+            launches = {k: c.ktime_read(k)[0] for k in names}
+            rb = c.stpcg(g, H, Delta=1e-3, max_iterations=40, kappa_fgr=1e-8, theta=1.0)
+            res[mode] = dict(r, s=r["s"].numpy().copy(), launches=launches, b=dict(rb, s=rb["s"].numpy().copy()))
+        finally:
+            c.close()
+    assert res["recurrence"]["launches"] == {"stiefel_hess_fused": res["recurrence"]["hvp_calls"], "stiefel_finish_dots": 0}
+    for mode in ("direct", "two-pass"):
+        assert res[mode]["launches"]["stiefel_hess_fused"] == 0 and res[mode]["launches"]["stiefel_finish_dots"] > 0
+    for mode, r in res.items():
+        assert r["iterations"] == o["iterations"] and r["exit_reason"] == o["exit_reason"], mode
+        assert np.allclose(r["trace"]["alpha"], o["trace"]["alpha"], rtol=1e-9), mode
+        assert np.allclose(r["trace"]["beta"], o["trace"]["beta"], rtol=1e-8), mode
+        assert rel_err(r["s"], o["s"]) < 1e-10, mode
+        assert (r["b"]["iterations"], r["b"]["exit_reason"]) == (ob["iterations"], ob["exit_reason"]), mode
+        assert rel_err(r["b"]["s"], ob["s"]) < 1e-10 and abs(r["b"]["M_norm"] - ob["M_norm"]) <= 1e-12 * ob["M_norm"], mode
+    assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
+
+
+@pytest.mark.parametrize("p", [6, 8])
+def test_wide_rows_preconditioned_and_sharded_slot_forms(oracle, monkeypatch, p):
+    """The other routes a wide-row solve can take: the problem's preconditioner (two-pass operator, flat direction kernel)
+    and the multi-GPU code path on one rank (MI355OPT_FORCE_SLOT_PATH: 39 components through the generic-width
+    reduce-to-slots kernel and k_cg_update<., FROM_SLOTS>), each against the oracle / the plain path."""
+    from optimization_amd import capi
+    nx, ny, nz = 12, 11, 10
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
+    kw = dict(Delta=1e3, max_iterations=30, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
+    out = {}
+    for mode in ("plain", "slots"):
+        monkeypatch.setenv("MI355OPT_FORCE_SLOT_PATH", "1" if mode == "slots" else "0")
+        c = capi.Context(0)
+        try:
+            A = c.csr(n, rowptr, col, val)
+            prob = c.stiefel_rq(A, n, p)
+            g, H = prob.model(c.upload(Xb))
+            r = c.stpcg(g, H, **kw)
+            out[mode] = dict(r, s=r["s"].numpy().copy())
+            if mode == "plain":
+                # the problem's own tangent-space preconditioner P_X(D^-1 r) (mi_stiefel_rq_precon: external
+                # preconditioner, two-pass operator, flat direction kernel at these widths) against the oracle's
+                # preconditioned solve of the same problem, as test_rq_projected_jacobi_precon_vs_oracle does for p = 3
+                diag = np.array([val[rowptr[i]:rowptr[i + 1]][col[rowptr[i]:rowptr[i + 1]] == i][0] for i in range(n)])
+                dinv = 1.0 / (diag * np.linspace(0.5, 2.0, n))
+                oprob = oracle.stiefel_rq(n, p, rowptr, col, val, dinv=dinv)
+                go = oracle.eval_grad(oprob, Xb.ravel())
+                Xd = c.upload(Xb)
+                g, H = prob.model(Xd)
+                P = prob.precon(Xd, c.upload(dinv))
+                assert rel_err(P.apply(g).numpy(), oracle.eval_precon(oprob, Xb.ravel(), go)) < 1e-12
+                rp = c.stpcg(g, H, P, Delta=1e3, max_iterations=40, kappa_fgr=1e-4, trace_cap=64)
+                op = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-4, trace_cap=64)
+                oracle.free(oprob)
+                assert rp["iterations"] == op["iterations"] and rp["exit_reason"] == op["exit_reason"]
+                assert np.allclose(rp["trace"]["alpha"], op["trace"]["alpha"], rtol=1e-9)
+                assert rel_err(rp["s"].numpy(), op["s"]) < 1e-9
+        finally:
+            c.close()
+    a, b = out["plain"], out["slots"]
+    assert (a["iterations"], a["exit_reason"]) == (b["iterations"], b["exit_reason"])
+    assert np.array_equal(a["trace"]["alpha"], b["trace"]["alpha"]) and np.array_equal(a["s"], b["s"])
