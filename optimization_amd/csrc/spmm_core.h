@@ -96,10 +96,12 @@ __device__ __forceinline__ void sell_row_times(const SellView &A, size_t slice, 
 // PK: the matrix is read from its value-indexed packed copy (one dword per entry: (col - row) << 8 | value
 // index; `vt` = the 256-entry value table, staged in LDS by the caller) -- 4 instead of 12 bytes per entry.
 // NW: the waves of the workgroup (the wave takes every NW-th slice of [first, end)).
-template <int P, bool HALO, bool PK, class Epi, int NW = kWaves>
+// CHK: entries per chunk (rows of 8 doubles gather 64 bytes per entry: two of them in flight per lane keep the
+// register cost of a chunk what four 24-byte gathers cost).
+template <int P, bool HALO, bool PK, class Epi, int NW = kWaves, int CHK = MI_SPMM_CHUNK>
 __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, size_t end, int lane,
                                             const double *__restrict__ V, const double *vt, Epi &epi) {
-  constexpr int CH = MI_SPMM_CHUNK;
+  constexpr int CH = CHK;
   if (first >= end) return;
   size_t slice = first;
   long long k = slice_bound(A.slice_ptr, slice), b1 = slice_bound(A.slice_ptr, slice + 1);

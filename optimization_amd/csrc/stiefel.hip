@@ -384,8 +384,28 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
 // registers a 1024-thread workgroup leaves a wave), S and M in LDS (every lane reads the same address: broadcast reads,
 // no bank conflicts) instead of 2 x 64 replicated registers, up to kMaxRows partial rows.
 constexpr int kWideBlock = 256, kWideWaves = kWideBlock / 64;
+// (a scheduling fence behind every column of the three P x P products: without it the scheduler issues all 192 LDS
+// reads of a row up front -- 128 more live doubles -- and the kernel loses its second wave per SIMD)
+#ifndef MI_WIDE_NO_SCHED
+#define MI_WIDE_SCHED() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MI_WIDE_SCHED()
+#endif
+#ifndef MI_WIDE_CHUNK
+#define MI_WIDE_CHUNK 2
+#endif
+#ifndef MI_WIDE_CHUNK_FROM
+#define MI_WIDE_CHUNK_FROM 7   // rows of >= this many doubles gather in chunks of MI_WIDE_CHUNK entries
+#endif
+#ifndef MI_WIDE_WAVES
+#define MI_WIDE_WAVES 2        // waves per SIMD the kernel is held to (measured: 3 -- 168 registers, p <= 7 -- is 3-6 % slower)
+#endif
+template <int P>
+struct WideWaves {
+  static constexpr int value = P <= 7 ? MI_WIDE_WAVES : 2;
+};
 template <int P, bool HALO, bool PK>
-__global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const CgState *__restrict__ st,
+__global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(WideWaves<P>::value, WideWaves<P>::value))) void k_st_hess_wide(SellView A, const CgState *__restrict__ st,
                                                              const double *__restrict__ V, const double *__restrict__ X,
                                                              const double *__restrict__ Y, const double *__restrict__ S,
                                                              const double *__restrict__ gdir, double *__restrict__ out,
@@ -441,6 +461,7 @@ __global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const C
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
         acc[b] -= t;  // Z = A V - V S
+        MI_WIDE_SCHED();
       }
       double o[P];
 #pragma unroll
@@ -451,6 +472,7 @@ __global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const C
         o[b] = acc[b] - t;  // Z - X M
         os[b] = o[b];
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
+        MI_WIDE_SCHED();
       }
       double os_[P];  // packed sym(y o' - x (o S)'): the Gram of this output row
 #pragma unroll
@@ -459,6 +481,7 @@ __global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const C
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
         os_[b] = t;
+        MI_WIDE_SCHED();
       }
 #pragma unroll
       for (int aa = 0; aa < P; ++aa)
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(kWideBlock) void k_st_hess_wide(SellView A, const C
     }
   } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  sell_stream<P, HALO, PK, Epi, kWideWaves>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+  sell_stream<P, HALO, PK, Epi, kWideWaves, (P >= MI_WIDE_CHUNK_FROM ? MI_WIDE_CHUNK : MI_SPMM_CHUNK)>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
 }
 
@@ -785,10 +808,11 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   const mi_csr *A = q->A;
   const int p = q->p;
   MI_REQUIRE(gram_count < 0, "internal: rows wider than 4 doubles take the one-pass Hessian in its recurrence form only");
-  // 256-thread workgroups, at most two per CU resident (register budget): one round of <= 512 partial rows; several
-  // ranks in rows mode need exactly kMaxGrid of them
+  // 256-thread workgroups, as many per CU as the kernel is held to (WideWaves<P>: one wave per SIMD each): one resident
+  // round, at most kMaxRows partial rows; several ranks in rows mode need exactly kMaxGrid of them
   const size_t wgs = (A->nslices + kWideWaves - 1) / kWideWaves;
-  int grid = ctx->uniform_grid ? kMaxGrid : (int)std::max<size_t>(1, std::min<size_t>(wgs, 512));
+  const int resident = ctx->num_cu * (p <= 7 ? MI_WIDE_WAVES : 2);
+  int grid = ctx->uniform_grid ? kMaxGrid : (int)std::max<size_t>(1, std::min<size_t>(wgs, std::min(resident, kMaxRows)));
   if (!ctx->uniform_grid && ctx->max_grid < kMaxGrid) grid = std::min(grid, ctx->max_grid);
   HaloWaitArg<true> hw_halo;
   HaloWaitArg<false> hw_none;

@@ -124,6 +124,57 @@ def cfg5(ctx):
     print(json.dumps(out))
 
 
+def wide(ctx, ps=(3, 4, 5, 6, 8), nx=100):
+    """St(nx^3, p) for rows wider than the bench line's p = 3: one fused STPCG inner iteration (recurrence form: one-pass
+    Hessian, k_cg_update, k_cg_pupdate) on the same 7-point Laplacian, priced like bench.py prices cfg2 -- compulsory
+    bytes of the kernels that ran: 4 nnz + 4 (n + 1) + 32 N for the Hessian pass on the value-indexed matrix, 24 N and
+    40 N for the two CG kernels (N = n p)."""
+    n = nx ** 3
+    rowptr, col, val = wl.laplacian_3d(nx, nx, nx)
+    A = ctx.csr(n, rowptr, col, val)
+    nnz = int(rowptr[-1])
+    for p in ps:
+        prob = ctx.stiefel_rq(A, n, p)
+        Xb, _ = wl.stiefel_bench_iterate(nx, nx, nx, p, eps=1e-3, seed=7)
+        X = ctx.upload(Xb)
+        g, H = prob.model(X)
+        s_out = ctx.vec(n * p)
+        N = n * p
+        kb = {"stiefel_hess_fused": 4 * nnz + 4 * (n + 1) + 32 * N, "cg_update": 24 * N, "cg_pupdate": 40 * N}
+
+        def run(steps):
+            done = 0
+            while done < steps:
+                r = ctx.stpcg(g, H, Delta=1e3, max_iterations=min(50, steps - done), kappa_fgr=1e-12, theta=1.0,
+                              s_out=s_out)
+                if r["iterations"] == 0:
+                    raise RuntimeError("no progress (exit %d)" % r["exit_reason"])
+                done += r["iterations"]
+        run(1500 if p == ps[0] else 300)   # (the first configuration also wakes the device up)
+        ctx.sync()
+        t0 = time.perf_counter()
+        steps = 500
+        run(steps)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        for k in kb:
+            ctx.ktime_enable(k, True)
+        ctx.ktime_reset()
+        run(200)
+        per = {}
+        for k in kb:
+            cnt, ms = ctx.ktime_read(k)
+            ctx.ktime_enable(k, False)
+            per[k] = {"launches": cnt, "avg_us_event_pairs": 1e3 * ms / max(cnt, 1), "bytes": kb[k],
+                      "frac_of_8TBps_event_pairs": kb[k] / (1e3 * ms / max(cnt, 1) * 1e-6) / 8e12}
+        moved = sum(kb.values())
+        print(json.dumps({"config": f"St({n},{p}) Rayleigh quotient, 7-pt Laplacian {nx}^3 + 0.1 I, fused STPCG step",
+                          "p": p, "us_per_step": 1e6 * dt / steps, "moved_bytes_per_step": moved,
+                          "GBps": steps * moved / dt / 1e9, "frac_of_8TBps": steps * moved / dt / 8e12,
+                          "working_set_MB": (6 * 8 * N + 4 * nnz) / 1e6, "kernels": per}))
+        del prob, X, g, H, s_out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg3", "cfg5"]
     c = capi.Context(0)
@@ -131,4 +182,6 @@ if __name__ == "__main__":
         cfg3(c)
     if "cfg5" in which:
         cfg5(c)
+    if "wide" in which:
+        wide(c)
     c.close()
