@@ -149,7 +149,7 @@ MI_API int mi_vec_dot_batch(mi_ctx *ctx, int k, const mi_vec *const *x, const mi
 MI_API int mi_csr_create(mi_ctx *ctx, size_t n, size_t nnz, const int32_t *rowptr,
                          const int32_t *col, const double *val, mi_csr **out); /* sync (upload) */
 MI_API int mi_csr_destroy(mi_csr *A);
-/* W (n x p row-major) = A V ; p in {1,2,3,4} */
+/* W (n x p row-major) = A V ; 1 <= p <= 8 */
 MI_API int mi_csr_spmm(const mi_csr *A, int p, const mi_vec *V, mi_vec *W);
 
 /* ---------------------------------------------------------------------------------------------
@@ -313,9 +313,11 @@ MI_API int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_l
 
 
 /* ---------------------------------------------------------------------------------------------
- * (6) Stiefel manifold St(n,p), p in {1,2,3,4}, embedded metric -- the callables a client of
+ * (6) Stiefel manifold St(n,p), 1 <= p <= 8, embedded metric -- the callables a client of
  *     TNT supplies (Objective, QuadraticModel, RiemannianMetric, Retraction; sphere analogue in
- *     the reference: tests/TNT_unit_test.cpp:73-117)
+ *     the reference: tests/TNT_unit_test.cpp:73-117).  p <= 4: rows in registers, 1024-thread workgroups, the
+ *     LDS-window form of the one-pass Hessian for p <= 3; p = 5 ... 8: the wide-row one-pass Hessian (256-thread
+ *     workgroups, the p x p matrices in LDS) in STPCG's recurrence form, the two-pass operator with a preconditioner
  * ------------------------------------------------------------------------------------------- */
 MI_API int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z,
                            double *G_host /* p*p row-major, sync */);

@@ -1,5 +1,5 @@
 // Optimization/MI355/Stiefel.h -- ready-made device callables for optimisation on the Stiefel
-// manifold St(n,p) (p <= 4, embedded metric, polar retraction), in the shape the reference's
+// manifold St(n,p) (p <= 8, embedded metric, polar retraction), in the shape the reference's
 // templates expect (Objective, QuadraticModel, RiemannianMetric, Retraction of
 // Optimization/Riemannian/Concepts.h).  The reference ships no manifold code beyond the S^2 lambdas
 // of its tests (tests/TNT_unit_test.cpp:73-117); this is their n x p, GPU-resident generalisation,
