@@ -408,6 +408,12 @@ typedef struct mi_panel_blocks {
 } mi_panel_blocks;
 MI_API int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int k1a, const mi_vec *Ta1,
                                           const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+/* The generalized problem (a B operator, LOBPCG.h:131-140,268,272; tests/LOBPCG_unit_test.cpp:178-225): the upper block
+ * triangles of S' A(S) and S' B(S) -- both symmetric, SymmetricLinearOperator -- with S, A(S) and B(S) each held as column
+ * blocks of the same total width ([X | W(:, nc:) | P(:, nc:)], [AX | A(W..) | A(P..)], [BX | B(W..) | B(P..)]): nothing is
+ * copied together (r05).  One launch per Gram on the matrix pipe, one reduction, one read-back. */
+MI_API int mi_lobpcg_gram_pair_gen_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, const mi_panel_blocks *AS,
+                                          const mi_panel_blocks *BS, double *Ga_host, double *Gb_host);
 MI_API int mi_lobpcg_update2_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int kc, const double *C_host,
                                     int ldc, mi_vec *Y, int k1, mi_vec *Y2);
 MI_API int mi_csr_spmm_colmajor_blocks(const mi_csr *A, const mi_panel_blocks *X, mi_vec *Y);

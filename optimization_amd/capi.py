@@ -200,6 +200,7 @@ def load():
         "mi_lobpcg_gram_pair": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_pair_sym": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_pair_sym_blocks": [vp, C.c_size_t, vp, C.c_int, vp, vp, c_double_p, c_double_p],
+        "mi_lobpcg_gram_pair_gen_blocks": [vp, C.c_size_t, vp, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_update2_blocks": [vp, C.c_size_t, vp, C.c_int, c_double_p, C.c_int, vp, C.c_int, vp],
         "mi_csr_spmm_colmajor_blocks": [vp, vp, vp],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
@@ -581,6 +582,14 @@ class Context:
         pb = PanelBlocks.of(blocks)
         check(self.L.mi_lobpcg_gram_pair_sym_blocks(self.h, m, C.byref(pb), k1a, Ta1.h,
                                                     Ta2.h if Ta2 is not None else None, _dp(Ga), _dp(Gb)))
+        return Ga, Gb
+
+    def lobpcg_gram_pair_gen_blocks(self, m, S_blocks, AS_blocks, BS_blocks):
+        """(S'A(S), S'B(S)) of the generalized problem, all three panels as column blocks (mi_lobpcg_gram_pair_gen_blocks)"""
+        k = sum(c for _, c in S_blocks)
+        Ga, Gb = np.zeros((k, k), order="F"), np.zeros((k, k), order="F")
+        ps, pa, pb = PanelBlocks.of(S_blocks), PanelBlocks.of(AS_blocks), PanelBlocks.of(BS_blocks)
+        check(self.L.mi_lobpcg_gram_pair_gen_blocks(self.h, m, C.byref(ps), C.byref(pa), C.byref(pb), _dp(Ga), _dp(Gb)))
         return Ga, Gb
 
     def lobpcg_update2_blocks(self, m, blocks, Cmat, k1):

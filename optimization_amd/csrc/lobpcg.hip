@@ -357,10 +357,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // compiler keeps them in the accumulation half of the 512-entry file) + two operand sets of 2 x T double4 (160): one
 // wave per SIMD (amdgpu_waves_per_eu(1, 1)); the overlap of loads and MFMAs is the software pipeline of
 // gram_direct_body (the loads of step s + 1 are issued before the 120 MFMAs of step s).
-template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ? 1 : 2))) void k_gram_pair_sym(
-    size_t mfull, size_t m, int k, ColBlocks S, const double *__restrict__ Tm,
-    const double *__restrict__ T2, int k1, double *__restrict__ partialA, double *__restrict__ partialB) {
+// r05, HALF (k mod 16 in 1 ... 8, e.g. cfg5's ns = 72 = 4.5 tiles): the last tile column of BOTH Grams is at most half
+// full, so the two half columns share ONE 16-wide B operand -- lanes 0-7 of the operand hold columns 16 (T-1) + i of
+// T = A(S), lanes 8-15 the same columns of S -- and one MFMA per (a, k-step) yields S'A(S)(:, last) in result columns
+// 0-7 and S'S(:, last) in columns 8-15: T (T + 1) - T tiles instead of T (T + 1) (25 instead of 30 at T = 5), 8 T
+// accumulator registers fewer, no extra loads (the operand is one load per lane either way; which panel a lane reads
+// is decided once, in the pointer set-up).  Every product is the product the separate tiles form: same bits.
+// PAIR = false: S'T alone (upper block triangle) -- the generalized problem forms S'A(S) and S'B(S) with two launches
+// of it (r05); T as column blocks like S, so [AX | A(W) | A(P)] need not be assembled either.
+#ifndef MI_GRAM_DEEP
+#define MI_GRAM_DEEP 1
+#endif
+template <int T, bool HALF, bool PAIR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (PAIR ? T >= 4 : T >= 5) ? 1 : 2))) void k_gram_pair_sym(
+    size_t mfull, size_t m, int k, ColBlocks S, ColBlocks Tb, double *__restrict__ partialA,
+    double *__restrict__ partialB) {
+  static_assert(!HALF || PAIR, "the shared last tile column is a property of the pair");
   const size_t rowwave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nrow = (size_t)gridDim.x * 4;
   const int lane = threadIdx.x & 63;
   const size_t lane_off = 4 * (size_t)(lane >> 4);
@@ -369,48 +381,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ?
   for (int t = 0; t < T; ++t) {
     const int c = std::min(16 * t + (lane & 15), k - 1);  // (clamped: products of padding columns are never stored)
     ps[t] = S.col(c, m) + lane_off;
-    pt[t] = (T2 && c >= k1 ? T2 + (size_t)(c - k1) * m : Tm + (size_t)c * m) + lane_off;
+    pt[t] = Tb.col(c, m) + lane_off;
+    if (HALF && t == T - 1) {  // the shared operand: columns 16 (T-1) + i of T in lanes i < 8, of S in lanes 8 + i
+      const int i = lane & 15, c2 = std::min(16 * t + (i & 7), k - 1);
+      pt[t] = (i < 8 ? Tb.col(c2, m) : S.col(c2, m)) + lane_off;
+    }
   }
-  double4v accA[T][T], accB[T][T];  // (only a <= b is used)
+  constexpr int TB = HALF ? T - 1 : T;  // tile columns of the second Gram that have tiles of their own
+  double4v accA[T][T], accB[PAIR ? T : 1][PAIR ? T : 1];  // (only a <= b is used)
 #pragma unroll
   for (int a = 0; a < T; ++a)
 #pragma unroll
     for (int b = 0; b < T; ++b) {
       accA[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
-      accB[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
+      if (PAIR) accB[a][b] = (double4v){0.0, 0.0, 0.0, 0.0};
     }
   const size_t band = 16 * nrow;
   // the m % 16 leftover rows (m % 4 == 0: whole groups of four) are one more step of the wave whose turn it is, the
   // groups past m as zeros (r04: this was a kernel of its own per Gram, k_gram_tail, 5 us each plus the drain between)
   const size_t mend = mfull < m ? mfull + 16 : mfull;
   double4l sa[T], sb[T], na[T], nb[T];
+  // DEEP (r05): the operands of TWO steps ahead are in flight (fa / fb).  One step's MFMA block -- 100 MFMAs at T = 5 with
+  // the shared last column, ~1.5 us -- is shorter than a loaded memory round trip, so with one step of look-ahead the
+  // wave waits for memory every step and the MFMAs the shared column saves buy nothing (measured: 527 us either way).
+  constexpr bool DEEP = MI_GRAM_DEEP && PAIR && T >= 4;
+  double4l fa[DEEP ? T : 1], fb[DEEP ? T : 1];
   size_t r0 = rowwave * 16;
-  auto fetch = [&](size_t r) {
+  auto fetch = [&](double4l(&va)[DEEP ? T : T], double4l(&vb)[DEEP ? T : T], size_t r) {
     const bool ok = r + lane_off < m;  // (false only in the last, partial step)
     const size_t rs = ok ? r : 0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      na[t] = *reinterpret_cast<const double4l *>(ps[t] + rs);
-      nb[t] = *reinterpret_cast<const double4l *>(pt[t] + rs);
+      va[t] = *reinterpret_cast<const double4l *>(ps[t] + rs);
+      vb[t] = *reinterpret_cast<const double4l *>(pt[t] + rs);
     }
     if (r == mfull) {  // wave-uniform
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          na[t][j] = ok ? na[t][j] : 0.0;
-          nb[t][j] = ok ? nb[t][j] : 0.0;
+          va[t][j] = ok ? va[t][j] : 0.0;
+          vb[t][j] = ok ? vb[t][j] : 0.0;
         }
     }
   };
-  if (r0 < mend) fetch(r0);
-  for (; r0 < mend; r0 += band) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) {  // the one wait of the step
-      sa[t] = na[t];
-      sb[t] = nb[t];
-    }
-    if (r0 + band < mend) fetch(r0 + band);
+  auto mma = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -418,21 +433,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, T >= 4 ?
 #pragma unroll
         for (int b = a; b < T; ++b) {
           accA[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a][j], sb[b][j], accA[a][b], 0, 0, 0);
-          accB[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a][j], sa[b][j], accB[a][b], 0, 0, 0);
+          if (PAIR && b < TB) accB[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[a][j], sa[b][j], accB[a][b], 0, 0, 0);
         }
+  };
+  if constexpr (DEEP) {
+    if (r0 < mend) fetch(na, nb, r0);
+    if (r0 + band < mend) fetch(fa, fb, r0 + band);
+    for (; r0 < mend; r0 += band) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {  // the one wait of the step: loads issued two MFMA blocks ago
+        sa[t] = na[t];
+        sb[t] = nb[t];
+        na[t] = fa[t];
+        nb[t] = fb[t];
+      }
+      if (r0 + 2 * band < mend) fetch(fa, fb, r0 + 2 * band);
+      mma();
+    }
+  } else {
+    if (r0 < mend) fetch(na, nb, r0);
+    for (; r0 < mend; r0 += band) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {  // the one wait of the step
+        sa[t] = na[t];
+        sb[t] = nb[t];
+      }
+      if (r0 + band < mend) fetch(na, nb, r0 + band);
+      mma();
+    }
   }
-  double *outA = partialA + rowwave * (size_t)k * k, *outB = partialB + rowwave * (size_t)k * k;
+  double *outA = partialA + rowwave * (size_t)k * k, *outB = PAIR ? partialB + rowwave * (size_t)k * k : nullptr;
 #pragma unroll
   for (int a = 0; a < T; ++a)
 #pragma unroll
     for (int b = a; b < T; ++b) {
-      const int col = b * 16 + (lane & 15);
+      const int i = lane & 15;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = a * 16 + (lane >> 4) + 4 * j;
-        if (row < k && col < k) {
-          outA[(size_t)col * k + row] = accA[a][b][j];
-          outB[(size_t)col * k + row] = accB[a][b][j];
+        if (HALF && b == T - 1) {  // the shared tile: result columns 0-7 belong to the first Gram, 8-15 to the second
+          const int col = b * 16 + (i & 7);
+          if (row < k && col < k) (i < 8 ? outA : outB)[(size_t)col * k + row] = accA[a][b][j];
+        } else {
+          const int col = b * 16 + i;
+          if (row < k && col < k) {
+            outA[(size_t)col * k + row] = accA[a][b][j];
+            if (PAIR) outB[(size_t)col * k + row] = accB[a][b][j];
+          }
         }
       }
     }
@@ -1233,7 +1280,8 @@ int mi_lobpcg_gram_pair(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, 
 // take (k > 80, unaligned panels, fewer than 16 rows) go through mi_lobpcg_gram_pair, which forms all of G_A.
 static bool gram_pair_sym_direct_ok(size_t m, int k, const ColBlocks &S, const mi_vec *Ta1, const mi_vec *Ta2);
 static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &Sb, int k1a, const mi_vec *Ta1,
-                                const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+                                const mi_vec *Ta2, double *Ga_host, double *Gb_host,
+                                const ColBlocks *Tab = nullptr, const ColBlocks *Tbb = nullptr);
 
 int mi_lobpcg_gram_pair_sym(mi_ctx *ctx, size_t m, int k, const mi_vec *S, int k1a, const mi_vec *Ta1,
                             const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
@@ -1276,14 +1324,45 @@ int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks 
   return st;
 }
 
+// The generalized problem (B present, LOBPCG.h:268,272): upper block triangles of S'A(S) and S'B(S) with S, A(S) and
+// B(S) each held as column blocks of the same total width.
+int mi_lobpcg_gram_pair_gen_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, const mi_panel_blocks *AS,
+                                   const mi_panel_blocks *BS, double *Ga_host, double *Gb_host) {
+  MI_REQUIRE(ctx && S && AS && BS && Ga_host && Gb_host, "null argument");
+  ColBlocks cs, ca, cb;
+  int k = 0, ka = 0, kb = 0;
+  MI_TRY(blocks_to_cols(ctx, m, S, &cs, &k));
+  MI_TRY(blocks_to_cols(ctx, m, AS, &ca, &ka));
+  MI_TRY(blocks_to_cols(ctx, m, BS, &cb, &kb));
+  MI_REQUIRE(ka == k && kb == k, "A(S) and B(S) must have the width of S (%d): got %d and %d", k, ka, kb);
+  auto aligned = [](const ColBlocks &c) {
+    return (uintptr_t)c.base[0] % 32 == 0 && (uintptr_t)c.base[1] % 32 == 0 && (uintptr_t)c.base[2] % 32 == 0;
+  };
+  if (k <= 80 && m % 4 == 0 && m >= 16 && aligned(cs) && aligned(ca) && aligned(cb))
+    return gram_pair_sym_direct(ctx, m, k, cs, k, nullptr, nullptr, Ga_host, Gb_host, &ca, &cb);
+  // shapes the one-pass kernels do not take: everything copied together, the general pair
+  mi_vec *s = nullptr, *a = nullptr, *b = nullptr;
+  int st = materialize_blocks(ctx, m, S, &s);
+  if (st == MI_OK) st = materialize_blocks(ctx, m, AS, &a);
+  if (st == MI_OK) st = materialize_blocks(ctx, m, BS, &b);
+  if (st == MI_OK) st = mi_lobpcg_gram_pair(ctx, m, k, s, k, a, nullptr, k, b, nullptr, Ga_host, Gb_host);
+  mi_vec_destroy(s);
+  mi_vec_destroy(a);
+  mi_vec_destroy(b);
+  return st;
+}
+
 static bool gram_pair_sym_direct_ok(size_t m, int k, const ColBlocks &S, const mi_vec *Ta1, const mi_vec *Ta2) {
   return k <= 80 && m % 4 == 0 && (uintptr_t)S.base[0] % 32 == 0 && (uintptr_t)S.base[1] % 32 == 0 &&
          (uintptr_t)S.base[2] % 32 == 0 && (uintptr_t)Ta1->d % 32 == 0 && (!Ta2 || (uintptr_t)Ta2->d % 32 == 0) && m >= 16;
 }
 
 // S'[Ta1 | Ta2] and S'S, upper block triangles, one pass (k_gram_pair_sym); arguments validated by the callers
+// Tab / Tbb (r05, the generalized problem): T = A(S) and B(S) as column blocks; the second Gram is then S'B(S) instead
+// of S'S, each Gram one launch of k_gram_pair_sym<., false, PAIR = false> (Ta1 / Ta2 unused)
 static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &Sb, int k1a, const mi_vec *Ta1,
-                                const mi_vec *Ta2, double *Ga_host, double *Gb_host) {
+                                const mi_vec *Ta2, double *Ga_host, double *Gb_host, const ColBlocks *Tab,
+                                const ColBlocks *Tbb) {
   const int nelem = k * k, kpad = (k + 15) / 16 * 16;
   const size_t mfull = m - m % 16;
   const int occ = kpad <= 32 ? 2 : 1;  // (resident waves per SIMD: 62+16 / 132+48 registers at 1 / 2 tiles, then > 256)
@@ -1312,20 +1391,44 @@ static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &S
     }
     return st;
   }
-  const double *T2 = Ta2 ? Ta2->d : nullptr;
+  if (Tab) {  // generalized problem: S'A(S) and S'B(S), one single-Gram launch each
+    KScope ks(ctx, MI_K_LOBPCG_GRAM);
+    for (int i = 0; i < 2; ++i) {
+      const ColBlocks &Tc = i == 0 ? *Tab : *Tbb;
+#define GS1(TT)                                                                                                      \
+  hipLaunchKernelGGL((k_gram_pair_sym<TT, false, false>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream,    \
+                     mfull, m, k, Sb, Tc, (double *)jobs[i].partial, (double *)nullptr)
+      switch (kpad / 16) {
+        case 1: GS1(1); break;
+        case 2: GS1(2); break;
+        case 3: GS1(3); break;
+        case 4: GS1(4); break;
+        default: GS1(5); break;
+      }
+#undef GS1
+    }
+  } else {
+  const double *T2 = Ta2 ? Ta2->d : Ta1->d;
+  const ColBlocks Tcb{{Ta1->d, T2, T2}, k1a, k};
+  // (the last tile column at most half full: it is shared by the two Grams, k_gram_pair_sym<., HALF>)
+  const bool half = k % 16 >= 1 && k % 16 <= 8 && !ctx->cfg.no_gram_half;
   {
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
-#define GPS(TT)                                                                                                     \
-  hipLaunchKernelGGL((k_gram_pair_sym<TT>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, m, k,     \
-                     Sb, (const double *)Ta1->d, T2, k1a, (double *)jobs[0].partial, (double *)jobs[1].partial)
+#define GPS(TT, HF)                                                                                                 \
+  hipLaunchKernelGGL((k_gram_pair_sym<TT, HF, true>), dim3((unsigned)(nwaves / 4)), dim3(256), 0, ctx->stream, mfull, \
+                     m, k, Sb, Tcb, (double *)jobs[0].partial, (double *)jobs[1].partial)
+#define GPSH(TT) \
+  if (half) { GPS(TT, true); } else { GPS(TT, false); }
     switch (kpad / 16) {
-      case 1: GPS(1); break;
-      case 2: GPS(2); break;
-      case 3: GPS(3); break;
-      case 4: GPS(4); break;
-      default: GPS(5); break;
+      case 1: GPSH(1); break;
+      case 2: GPSH(2); break;
+      case 3: GPSH(3); break;
+      case 4: GPSH(4); break;
+      default: GPSH(5); break;
     }
+#undef GPSH
 #undef GPS
+  }
   }
   hipLaunchKernelGGL(k_gram_reduce, dim3((nelem + kRedElems - 1) / kRedElems, 2), dim3(kRedElems * kRedGroups), 0,
                      ctx->stream, (int)nb, k, nelem, 1, (const double *)jobs[0].partial, (double *)jobs[0].Gdev,

@@ -139,69 +139,54 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
   R = residual_and_norms(AX, BX, X, Theta, r, xnorm);
   nc = 0;  // :233
 
-  // B absent: the basis is never assembled.  S = [X, W(:, nc:), P(:, nc:)] (:254-264) goes to the Gram, update and
-  // product kernels as the three column blocks lie (MI355::PanelBlocks) -- with locked pairs (nc > 0) the reference's
-  // middleCols assignments would move 2 (nx - nc) columns together every iteration (15 % of a cfg5 run's kernel time).
+  // The basis is never assembled.  S = [X, W(:, nc:), P(:, nc:)] (:254-264) goes to the Gram, update and product
+  // kernels as the three column blocks lie (MI355::PanelBlocks) -- with locked pairs (nc > 0) the reference's middleCols
+  // assignments would move 2 (nx - nc) columns together every iteration (15 % of a cfg5 run's kernel time).  r05: with a
+  // B operator too (the generalized problem took the assembled basis and full Grams until r04).
   const auto *fused_op = B ? nullptr : A.template target<MI355::DeviceCsrPanelOperator>();
   for (num_iters = 1; num_iters < max_iters; ++num_iters) {  // :237
     if (T) W = (*T)(R);  // preconditioned residuals (T absent: W is R itself, no copy)   :247
 
-    Matrix Sns;               // B present: the assembled basis (a view of *Scur)
-    MI355::PanelBlocks Sblk;  // B absent: its blocks
+    MI355::PanelBlocks Sblk;  // the basis, as its blocks
     auto gram_of_blocks = [&]() {
       Sblk.add(X.leftCols(nx));
       Sblk.add((T ? W : R).middleCols(nc, nx - nc));
       if (num_iters > 1) Sblk.add(P.middleCols(nc, nx - nc));
       ns = Sblk.cols();
       // A(S) (:267) column by column is [A(X) | A([W P])], and A(X) is the AX of the previous iteration (:281; the
-      // start block's AX was rotated, :226, so the first iteration applies A to all of S)
+      // start block's AX was rotated, :226, so the first iteration applies A to all of S); likewise B(S) (:268,282)
       const bool reuse_x = num_iters > 1 && ns > nx;
       const MI355::PanelBlocks rest = reuse_x ? Sblk.from(1) : Sblk.from(0);
-      const Matrix AS = fused_op ? (*fused_op)(rest) : A(rest.assembled());  // :267
-      const Matrix none;
-      // S'A(S) and S'S from ONE pass over S, the upper block triangle of each (A is a SymmetricLinearOperator, so both
-      // are symmetric, and one triangle is all the reference's eigensolver reads); one read-back (:271-275)
-      return reuse_x ? gram_pair_sym(Sblk, AX, AS) : gram_pair_sym(Sblk, AS, none);
-    };
-    auto gram_of_assembled = [&]() {
-      // S = [X, W(not converged), P(not converged)]  (soft locking drops the FIRST nc columns)  :254-264
-      Matrix &S = *Scur;
-      const bool in_place = in_basis && nc == 0;  // [X | R | P] already sit where the basis wants them
-      if (!in_basis) S.set_cols(0, X, 0, nx);
-      if (T) {
-        S.set_cols(nx, W, nc, nx - nc);
-      } else if (!in_place) {
-        if (in_basis) {  // R is a view of S itself: shift its unlocked columns through a copy
-          const Matrix Rc = R;
-          S.set_cols(nx, Rc, nc, nx - nc);
-        } else {
-          S.set_cols(nx, R, nc, nx - nc);
-        }
+      if (!B) {
+        const Matrix AS = fused_op ? (*fused_op)(rest) : A(rest.assembled());  // :267
+        const Matrix none;
+        // S'A(S) and S'S from ONE pass over S, the upper block triangle of each (A is a SymmetricLinearOperator, so
+        // both are symmetric, and one triangle is all the reference's eigensolver reads); one read-back (:271-275)
+        return reuse_x ? gram_pair_sym(Sblk, AX, AS) : gram_pair_sym(Sblk, AS, none);
       }
-      if (num_iters > 1) {
-        if (!in_place) {
-          if (in_basis) {
-            const Matrix Pc = P;
-            S.set_cols(2 * nx - nc, Pc, nc, nx - nc);
-          } else {
-            S.set_cols(2 * nx - nc, P, nc, nx - nc);
-          }
-        }
-        ns = 3 * nx - 2 * nc;
+      // B present: A and B are plain callables on a Matrix.  They are applied to the blocks of S as they lie (a block
+      // is a contiguous view) -- to [R | P] in one call while nothing is locked and they sit next to each other in the
+      // basis panel -- and S'A(S), S'B(S) are formed from the blocks of S, A(S), B(S): upper block triangles, one
+      // launch each on the matrix pipe, one read-back (:271-275).  Column for column the same operator results as
+      // A(S), B(S) on the assembled basis.
+      MI355::PanelBlocks ASb, BSb;
+      if (reuse_x) {
+        ASb.add(AX.leftCols(nx));
+        BSb.add(BX.leftCols(nx));
+      }
+      if (reuse_x && rest.blocks() == 2 && in_basis && !T && nc == 0) {
+        const Matrix RP = Scur->middleCols(nx, 2 * nx);  // view: R and P are blocks 1 and 2 of the current panel
+        ASb.add(A(RP));
+        BSb.add((*B)(RP));
       } else {
-        ns = 2 * nx - nc;
+        for (size_t i = 0; i < rest.blocks(); ++i) {
+          ASb.add(A(rest.block(i)));
+          BSb.add((*B)(rest.block(i)));
+        }
       }
-      Sns = S.leftCols(ns);  // view
-      // (A(X) and B(X) of the previous iteration are kept, :281-282: the same columns through the same operators)
-      const bool reuse_x = num_iters > 1 && ns > nx;
-      const Matrix Srest = reuse_x ? S.middleCols(nx, ns - nx) : Matrix();
-      const Matrix AS = reuse_x ? A(Srest) : A(Sns);                  // :267
-      const Matrix BS = reuse_x ? (*B)(Srest) : (*B)(Sns);            // :268
-      const Matrix none;
-      // both Grams enqueued back to back, one read-back (:271-275)
-      return reuse_x ? gram_pair(Sns, AX, AS, BX, BS) : gram_pair(Sns, AS, none, BS, none);
+      return gram_pair_gen(Sblk, ASb, BSb);
     };
-    auto gg = B ? gram_of_assembled() : gram_of_blocks();
+    auto gg = gram_of_blocks();
     // only the nx lowest Ritz pairs are read below (:278,288,293-318): the solver that forms just those columns
     auto tc = rayleigh_ritz_lowest(gg.first, gg.second, nx);
     Theta = Vector(std::move(tc.first));
@@ -212,8 +197,7 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
     // (the blocks keep the storage of the old X, R, P alive while their names move on to the other panel)
     X = Snext->leftCols(nx);
     P = Snext->middleCols(2 * nx, nx);
-    if (B) ritz_update_into(Sns, C, nx, X, P);
-    else ritz_update_into(Sblk, C, nx, X, P);
+    ritz_update_into(Sblk, C, nx, X, P);
     R = Snext->middleCols(nx, nx);   // residuals into its second block
     if (fused_op) {
       // B absent and A a tagged sparse operator: A(X) (:281), the residual (:285) and the norms (:293,302) in one pass

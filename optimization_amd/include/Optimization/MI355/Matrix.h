@@ -277,6 +277,14 @@ inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const PanelBlocks &S, con
                                        A2.cols() > 0 ? A2.handle() : nullptr, GA.data(), GB.data()));
   return {std::move(GA), std::move(GB)};
 }
+// the generalized problem: (S'A(S), S'B(S)), everything as column blocks (mi_lobpcg_gram_pair_gen_blocks)
+inline std::pair<HostMatrix, HostMatrix> gram_pair_gen(const PanelBlocks &S, const PanelBlocks &AS, const PanelBlocks &BS) {
+  const size_t k = S.cols();
+  HostMatrix GA(k, k), GB(k, k);
+  const mi_panel_blocks s = S.raw(), a = AS.raw(), b = BS.raw();
+  check(mi_lobpcg_gram_pair_gen_blocks(S.context(), S.rows(), &s, &a, &b, GA.data(), GB.data()));
+  return {std::move(GA), std::move(GB)};
+}
 // Y = S C[row0 : row0+S.cols(), 0 : kc]   (LOBPCG.h:226-227,278,288)
 inline DeviceMatrix times_small(const DeviceMatrix &S, const HostMatrix &C, size_t row0, size_t kc) {
   DeviceMatrix Y(S.context(), S.rows(), kc);

@@ -529,3 +529,65 @@ def test_panel_product_of_column_blocks(ctx, grid, nx, nc, weights):
     Y3 = A.spmm_colmajor_blocks(blocks).numpy()[:m * S.shape[1]]
     Z3 = A.spmm_colmajor(S.shape[1], ctx.upload(S.ravel(order="F"))).numpy()[:m * S.shape[1]]
     assert np.array_equal(Y3, Z3)
+
+
+@pytest.mark.parametrize("m,k,k1", [(100_004, 72, 24), (65_540, 72, 0), (200_012, 40, 24), (40_000, 66, 22), (30_000, 17, 5),
+                                    (4_100, 8, 0), (126 ** 3, 72, 24), (50_000, 73, 24)])
+def test_gram_pair_with_the_shared_last_tile_column_has_the_bits_of_the_padded_form(m, k, k1):
+    """r05: when the last 16-wide tile column of the two Grams is at most half full (k mod 16 in
+    1..8; cfg5's ns = 72) its two halves -- columns of A(S) and of S -- share ONE matrix-pipe operand: 25 tiles instead
+    of 30 at ns = 72, the same products in the same order, so every entry has the bits of the r04 kernel
+    (MI355OPT_NO_GRAM_HALF=1); k = 73 (no half column) takes the r04 form either way."""
+    from optimization_amd import capi
+    rng = np.random.default_rng(m % 9973 + k)
+    S = rng.normal(size=(m, k))
+    AS = rng.uniform(0.5, 3.0, size=m)[:, None] * S
+    out = {}
+    for mode in ("half", "padded"):
+        c = capi.Context(0)
+        try:
+            c.set_option("NO_GRAM_HALF", 1 if mode == "padded" else 0)
+            Sd = c.upload(np.asfortranarray(S).ravel(order="F"))
+            if k1:
+                A1 = c.upload(np.asfortranarray(AS[:, :k1]).ravel(order="F"))
+                A2 = c.upload(np.asfortranarray(AS[:, k1:]).ravel(order="F"))
+            else:
+                A1, A2 = c.upload(np.asfortranarray(AS).ravel(order="F")), None
+            out[mode] = c.lobpcg_gram_pair_sym(m, Sd, k, A1, k1 or k, A2)
+        finally:
+            c.close()
+    assert np.array_equal(out["half"][0], out["padded"][0]) and np.array_equal(out["half"][1], out["padded"][1])
+    ra, rb = S.T @ AS, S.T @ S
+    tol = 1e-13 * max(1.0, np.sqrt(m) / 30)
+    assert np.abs(out["half"][0] - ra).max() <= tol * np.abs(ra).max()
+    assert np.abs(out["half"][1] - rb).max() <= tol * np.abs(rb).max()
+
+
+@pytest.mark.parametrize("m,nx,nc", [(100_008, 24, 0), (65_540, 24, 5), (200_008, 24, 19), (4099, 24, 7), (30_000, 8, 3),
+                                     (126 ** 3, 24, 11)])
+def test_generalized_gram_pair_on_column_blocks(ctx, m, nx, nc):
+    """r05: S'A(S) and S'B(S) of the generalized problem (LOBPCG.h:268,271-272) from S, A(S), B(S) each
+    held as the column blocks [X | W(:, nc:) | P(:, nc:)] lie -- nothing copied together -- against numpy, against the
+    general pair on assembled panels, exact symmetry across tile blocks; incl. the fall-back (m odd)."""
+    rng = np.random.default_rng(m % 9973 + 7 * nc)
+    P = rng.normal(size=(m, 3 * nx))
+    Pd, blocks, S = _basis_blocks(ctx, P, m, nx, nc)
+    ns = S.shape[1]
+    da, db = rng.uniform(-3.0, 3.0, size=m), rng.uniform(0.5, 2.0, size=m)
+    PA, PB = da[:, None] * P, db[:, None] * P
+    _, ablocks, AS = _basis_blocks(ctx, PA, m, nx, nc)
+    _, bblocks, BS = _basis_blocks(ctx, PB, m, nx, nc)
+    s0 = ctx.sync_count()
+    Ga, Gb = ctx.lobpcg_gram_pair_gen_blocks(m, blocks, ablocks, bblocks)
+    assert ctx.sync_count() - s0 == 1
+    ra, rb = S.T @ AS, S.T @ BS
+    tol = 1e-13 * max(1.0, np.sqrt(m) / 30)
+    assert np.abs(Ga - ra).max() <= tol * np.abs(ra).max() and np.abs(Gb - rb).max() <= tol * np.abs(rb).max()
+    Sd, Ad, Bd = (ctx.upload(np.asfortranarray(Z).ravel(order="F")) for Z in (S, AS, BS))
+    Fa, Fb = ctx.lobpcg_gram_pair(m, Sd, ns, Ad, ns, None, Bd, ns, None)
+    assert np.abs(Ga - Fa).max() <= tol * np.abs(ra).max() and np.abs(Gb - Fb).max() <= tol * np.abs(rb).max()
+    if m % 4 == 0:
+        for G in (Ga, Gb):
+            iu = np.arange(ns)
+            lower = (iu[:, None] // 16) > (iu[None, :] // 16)
+            assert np.array_equal(G[lower], G.T[lower])
