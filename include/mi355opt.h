@@ -408,6 +408,10 @@ typedef struct mi_panel_blocks {
 } mi_panel_blocks;
 MI_API int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, int k1a, const mi_vec *Ta1,
                                           const mi_vec *Ta2, double *Ga_host, double *Gb_host);
+/* mi_lobpcg_gram_pair_sym_blocks with T = A(S) held as column blocks as well (a plain-callable operator applied to the
+ * blocks of S one by one). */
+MI_API int mi_lobpcg_gram_pair_sym_tblocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, const mi_panel_blocks *T,
+                                           double *Ga_host, double *Gb_host);
 /* The generalized problem (a B operator, LOBPCG.h:131-140,268,272; tests/LOBPCG_unit_test.cpp:178-225): the upper block
  * triangles of S' A(S) and S' B(S) -- both symmetric, SymmetricLinearOperator -- with S, A(S) and B(S) each held as column
  * blocks of the same total width ([X | W(:, nc:) | P(:, nc:)], [AX | A(W..) | A(P..)], [BX | B(W..) | B(P..)]): nothing is

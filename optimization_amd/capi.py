@@ -201,6 +201,7 @@ def load():
         "mi_lobpcg_gram_pair_sym": [vp, C.c_size_t, C.c_int, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_pair_sym_blocks": [vp, C.c_size_t, vp, C.c_int, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_gram_pair_gen_blocks": [vp, C.c_size_t, vp, vp, vp, c_double_p, c_double_p],
+        "mi_lobpcg_gram_pair_sym_tblocks": [vp, C.c_size_t, vp, vp, c_double_p, c_double_p],
         "mi_lobpcg_update2_blocks": [vp, C.c_size_t, vp, C.c_int, c_double_p, C.c_int, vp, C.c_int, vp],
         "mi_csr_spmm_colmajor_blocks": [vp, vp, vp],
         "mi_panel_rowscale": [vp, C.c_size_t, C.c_int, vp, vp, vp],
@@ -582,6 +583,14 @@ class Context:
         pb = PanelBlocks.of(blocks)
         check(self.L.mi_lobpcg_gram_pair_sym_blocks(self.h, m, C.byref(pb), k1a, Ta1.h,
                                                     Ta2.h if Ta2 is not None else None, _dp(Ga), _dp(Gb)))
+        return Ga, Gb
+
+    def lobpcg_gram_pair_sym_tblocks(self, m, S_blocks, T_blocks):
+        """(S'A(S), S'S), S and A(S) as column blocks (mi_lobpcg_gram_pair_sym_tblocks)"""
+        k = sum(c for _, c in S_blocks)
+        Ga, Gb = np.zeros((k, k), order="F"), np.zeros((k, k), order="F")
+        ps, pt = PanelBlocks.of(S_blocks), PanelBlocks.of(T_blocks)
+        check(self.L.mi_lobpcg_gram_pair_sym_tblocks(self.h, m, C.byref(ps), C.byref(pt), _dp(Ga), _dp(Gb)))
         return Ga, Gb
 
     def lobpcg_gram_pair_gen_blocks(self, m, S_blocks, AS_blocks, BS_blocks):

@@ -1324,6 +1324,30 @@ int mi_lobpcg_gram_pair_sym_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks 
   return st;
 }
 
+// (S'A(S), S'S) like mi_lobpcg_gram_pair_sym_blocks with T = A(S) held as column blocks too: what a plain-callable
+// operator applied to the blocks of S one by one leaves ([AX | A(W(:, nc:)) | A(P(:, nc:))]).
+int mi_lobpcg_gram_pair_sym_tblocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, const mi_panel_blocks *T,
+                                    double *Ga_host, double *Gb_host) {
+  MI_REQUIRE(ctx && S && T && Ga_host && Gb_host, "null argument");
+  ColBlocks cs, ct;
+  int k = 0, kt = 0;
+  MI_TRY(blocks_to_cols(ctx, m, S, &cs, &k));
+  MI_TRY(blocks_to_cols(ctx, m, T, &ct, &kt));
+  MI_REQUIRE(kt == k, "A(S) must have the width of S (%d): got %d", k, kt);
+  auto aligned = [](const ColBlocks &c) {
+    return (uintptr_t)c.base[0] % 32 == 0 && (uintptr_t)c.base[1] % 32 == 0 && (uintptr_t)c.base[2] % 32 == 0;
+  };
+  if (k <= 80 && m % 4 == 0 && m >= 16 && aligned(cs) && aligned(ct))
+    return gram_pair_sym_direct(ctx, m, k, cs, k, nullptr, nullptr, Ga_host, Gb_host, &ct, nullptr);
+  mi_vec *s = nullptr, *t = nullptr;
+  int st = materialize_blocks(ctx, m, S, &s);
+  if (st == MI_OK) st = materialize_blocks(ctx, m, T, &t);
+  if (st == MI_OK) st = mi_lobpcg_gram_pair_sym(ctx, m, k, s, k, t, nullptr, Ga_host, Gb_host);
+  mi_vec_destroy(s);
+  mi_vec_destroy(t);
+  return st;
+}
+
 // The generalized problem (B present, LOBPCG.h:268,272): upper block triangles of S'A(S) and S'B(S) with S, A(S) and
 // B(S) each held as column blocks of the same total width.
 int mi_lobpcg_gram_pair_gen_blocks(mi_ctx *ctx, size_t m, const mi_panel_blocks *S, const mi_panel_blocks *AS,
@@ -1391,7 +1415,7 @@ static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &S
     }
     return st;
   }
-  if (Tab) {  // generalized problem: S'A(S) and S'B(S), one single-Gram launch each
+  if (Tab && Tbb) {  // generalized problem: S'A(S) and S'B(S), one single-Gram launch each
     KScope ks(ctx, MI_K_LOBPCG_GRAM);
     for (int i = 0; i < 2; ++i) {
       const ColBlocks &Tc = i == 0 ? *Tab : *Tbb;
@@ -1408,8 +1432,8 @@ static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &S
 #undef GS1
     }
   } else {
-  const double *T2 = Ta2 ? Ta2->d : Ta1->d;
-  const ColBlocks Tcb{{Ta1->d, T2, T2}, k1a, k};
+  const double *T2 = Ta2 ? Ta2->d : (Ta1 ? Ta1->d : nullptr);
+  const ColBlocks Tcb = Tab ? *Tab : ColBlocks{{Ta1->d, T2, T2}, k1a, k};  // (Tab alone: T = A(S) as column blocks)
   // (the last tile column at most half full: it is shared by the two Grams, k_gram_pair_sym<., HALF>)
   const bool half = k % 16 >= 1 && k % 16 <= 8 && !ctx->cfg.no_gram_half;
   {

@@ -157,33 +157,34 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
       // start block's AX was rotated, :226, so the first iteration applies A to all of S); likewise B(S) (:268,282)
       const bool reuse_x = num_iters > 1 && ns > nx;
       const MI355::PanelBlocks rest = reuse_x ? Sblk.from(1) : Sblk.from(0);
-      if (!B) {
-        const Matrix AS = fused_op ? (*fused_op)(rest) : A(rest.assembled());  // :267
+      if (fused_op) {  // B absent, A a tagged sparse operator: all of A([W P]) from one panel product
+        const Matrix AS = (*fused_op)(rest);  // :267
         const Matrix none;
         // S'A(S) and S'S from ONE pass over S, the upper block triangle of each (A is a SymmetricLinearOperator, so
         // both are symmetric, and one triangle is all the reference's eigensolver reads); one read-back (:271-275)
         return reuse_x ? gram_pair_sym(Sblk, AX, AS) : gram_pair_sym(Sblk, AS, none);
       }
-      // B present: A and B are plain callables on a Matrix.  They are applied to the blocks of S as they lie (a block
-      // is a contiguous view) -- to [R | P] in one call while nothing is locked and they sit next to each other in the
-      // basis panel -- and S'A(S), S'B(S) are formed from the blocks of S, A(S), B(S): upper block triangles, one
-      // launch each on the matrix pipe, one read-back (:271-275).  Column for column the same operator results as
-      // A(S), B(S) on the assembled basis.
+      // A (and B) plain callables on a Matrix.  They are applied to the blocks of S as they lie (a block is a
+      // contiguous view) -- to [R | P] in one call while nothing is locked and they sit next to each other in the basis
+      // panel -- and the Grams are formed from the blocks of S, A(S) (and B(S)): upper block triangles on the matrix
+      // pipe, one read-back (:271-275).  Column for column the same operator results as A(S), B(S) on the assembled
+      // basis, which is never formed (r05: also without B; r04 copied the blocks together for a plain callable).
       MI355::PanelBlocks ASb, BSb;
       if (reuse_x) {
         ASb.add(AX.leftCols(nx));
-        BSb.add(BX.leftCols(nx));
+        if (B) BSb.add(BX.leftCols(nx));
       }
       if (reuse_x && rest.blocks() == 2 && in_basis && !T && nc == 0) {
         const Matrix RP = Scur->middleCols(nx, 2 * nx);  // view: R and P are blocks 1 and 2 of the current panel
         ASb.add(A(RP));
-        BSb.add((*B)(RP));
+        if (B) BSb.add((*B)(RP));
       } else {
         for (size_t i = 0; i < rest.blocks(); ++i) {
           ASb.add(A(rest.block(i)));
-          BSb.add((*B)(rest.block(i)));
+          if (B) BSb.add((*B)(rest.block(i)));
         }
       }
+      if (!B) return gram_pair_sym(Sblk, ASb);
       return gram_pair_gen(Sblk, ASb, BSb);
     };
     auto gg = gram_of_blocks();

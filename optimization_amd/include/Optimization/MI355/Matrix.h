@@ -277,6 +277,14 @@ inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const PanelBlocks &S, con
                                        A2.cols() > 0 ? A2.handle() : nullptr, GA.data(), GB.data()));
   return {std::move(GA), std::move(GB)};
 }
+// (S'A(S), S'S) with A(S) as column blocks too (mi_lobpcg_gram_pair_sym_tblocks)
+inline std::pair<HostMatrix, HostMatrix> gram_pair_sym(const PanelBlocks &S, const PanelBlocks &AS) {
+  const size_t k = S.cols();
+  HostMatrix GA(k, k), GB(k, k);
+  const mi_panel_blocks s = S.raw(), a = AS.raw();
+  check(mi_lobpcg_gram_pair_sym_tblocks(S.context(), S.rows(), &s, &a, GA.data(), GB.data()));
+  return {std::move(GA), std::move(GB)};
+}
 // the generalized problem: (S'A(S), S'B(S)), everything as column blocks (mi_lobpcg_gram_pair_gen_blocks)
 inline std::pair<HostMatrix, HostMatrix> gram_pair_gen(const PanelBlocks &S, const PanelBlocks &AS, const PanelBlocks &BS) {
   const size_t k = S.cols();

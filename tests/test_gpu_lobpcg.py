@@ -584,6 +584,12 @@ def test_generalized_gram_pair_on_column_blocks(ctx, m, nx, nc):
     tol = 1e-13 * max(1.0, np.sqrt(m) / 30)
     assert np.abs(Ga - ra).max() <= tol * np.abs(ra).max() and np.abs(Gb - rb).max() <= tol * np.abs(rb).max()
     Sd, Ad, Bd = (ctx.upload(np.asfortranarray(Z).ravel(order="F")) for Z in (S, AS, BS))
+    # the standard problem with A(S) as blocks too (a plain-callable A applied block by block): the bits of the form
+    # that takes A(S) in two contiguous pieces
+    Ta, Tb = ctx.lobpcg_gram_pair_sym_tblocks(m, blocks, ablocks)
+    Ua, Ub = ctx.lobpcg_gram_pair_sym_blocks(m, blocks, Ad, ns, None)
+    assert np.array_equal(Ta, Ua) and np.array_equal(Tb, Ub)
+    assert np.abs(Ta - ra).max() <= 1e-13 * max(1.0, np.sqrt(m) / 30) * np.abs(ra).max()
     Fa, Fb = ctx.lobpcg_gram_pair(m, Sd, ns, Ad, ns, None, Bd, ns, None)
     assert np.abs(Ga - Fa).max() <= tol * np.abs(ra).max() and np.abs(Gb - Fb).max() <= tol * np.abs(rb).max()
     if m % 4 == 0:
