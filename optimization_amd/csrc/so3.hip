@@ -70,13 +70,18 @@ __device__ __forceinline__ void q_hat_basis(const double *Q, int m, double *M) {
 // weight, in the incidences' own component-major slot order -- static, built once by mi_so3n_create.  Gathered from
 // the edge arrays they were 72 bytes at a random place per incidence (1.56 cache lines on average, each edge fetched
 // from both ends: ~600 MB per assembly at N = 5e5); as a stream they are 216 MB.
-__global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
-                                                   const double *__restrict__ Sinc, const double *__restrict__ winc,
-                                                   double *__restrict__ grad,
-                                                   double *__restrict__ Dinv, double *__restrict__ Bblk,
-                                                   double *__restrict__ Dsl) {
-  const int lane = threadIdx.x & 63;
-  const size_t slice = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+// r05: the OBJECTIVE rides along.  f(R) = 1/2 sum_e w_e |R_j - R_i Rt_e|^2 is 1/4 of the same sum over INCIDENCES (every
+// edge is seen from both ends, |R_j - R_i Rt| = |R_i - R_j Rt'|), and the term R_i - R_j S is formed here anyway for the
+// gradient: its squared norm costs 9 multiply-adds per incidence instead of an edge pass of its own with two more
+// 72-byte gathers per edge (k_so3_objective: 61 us and 416 MB at the fabric per trial step at N = 5e5).  MODEL = false:
+// the objective alone (mi_so3n_objective) -- the same loop, the same partial sums, the same bits.
+// fpartials: one partial row per workgroup (<= kMaxRows workgroups: a workgroup walks groups of 4 slices).
+template <bool MODEL>
+__device__ __forceinline__ void so3_model_slice(const IncView &inc, const double *__restrict__ R,
+                                                const double *__restrict__ Sinc, const double *__restrict__ winc,
+                                                double *__restrict__ grad, double *__restrict__ Dinv,
+                                                double *__restrict__ Bblk, double *__restrict__ Dsl, size_t slice,
+                                                int lane, double &facc) {
   if (slice >= inc.nslices) return;
   const int node = inc.perm[slice * 64 + lane];
   const bool live = node >= 0;
@@ -102,9 +107,16 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
       for (int c = 0; c < 9; ++c) S[c] = Sinc[((size_t)k * 9 + c) * 64 + lane];
       double RjS[9];
       mat3_mul(Rj, S, RjS);
+      double q = 0;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) EG[c] += we * (Ri[c] - RjS[c]);
+      for (int c = 0; c < 9; ++c) {
+        const double d = Ri[c] - RjS[c];
+        EG[c] += we * d;
+        q += d * d;
+      }
+      facc += we * q;
       degw += we;
+      if (!MODEL) continue;
       double Q[9];
       mat3_mul_at(Ri, Rj, Q);  // R_i' R_j
 #pragma unroll
@@ -118,9 +130,12 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
         Bk[2 * 3 + m] = we * col[2];
       }
     }
+    if (MODEL) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) Bblk[((size_t)k * 9 + c) * 64 + lane] = Bk[c];
+      for (int c = 0; c < 9; ++c) Bblk[((size_t)k * 9 + c) * 64 + lane] = Bk[c];
+    }
   }
+  if (!MODEL) return;
   if (!live) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) Dsl[(slice * 9 + c) * 64 + lane] = 0.0;
@@ -149,6 +164,38 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
   Di[0] = c00 / det; Di[1] = c01 / det; Di[2] = c02 / det;
   Di[3] = c01 / det; Di[4] = c11 / det; Di[5] = c12 / det;
   Di[6] = c02 / det; Di[7] = c12 / det; Di[8] = c22 / det;
+}
+
+template <bool MODEL>
+__global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
+                                                   const double *__restrict__ Sinc, const double *__restrict__ winc,
+                                                   double *__restrict__ grad,
+                                                   double *__restrict__ Dinv, double *__restrict__ Bblk,
+                                                   double *__restrict__ Dsl, double *__restrict__ fpartials) {
+  __shared__ double flds[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double facc = 0;
+  const size_t ngroups = (inc.nslices + 3) / 4;
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
+    so3_model_slice<MODEL>(inc, R, Sinc, winc, grad, Dinv, Bblk, Dsl, grp * 4 + w, lane, facc);
+  // the workgroup's partial of the objective: workgroup b -> row b % kMaxRows of component b / kMaxRows (one workgroup
+  // per group of slices keeps the dynamic balance of ~2000 short workgroups: a grid capped at kMaxRows rows cost the
+  // assembly 30 us at N = 5e5); the components are added in fixed order by k_sum_slots
+  facc = wave_reduce_sum(facc);
+  if (lane == 0) flds[w] = facc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fpartials[(size_t)(blockIdx.x / kMaxRows) * kMaxRows + blockIdx.x % kMaxRows] = (flds[0] + flds[1]) + (flds[2] + flds[3]);
+    // the rows of the last component past the last workgroup read as zero (the buffer is shared with other reductions)
+    const size_t total = (size_t)((gridDim.x + kMaxRows - 1) / kMaxRows) * kMaxRows, z = (size_t)gridDim.x + blockIdx.x;
+    if (z < total) fpartials[z] = 0.0;
+  }
+}
+// dst[0] = src[0] + ... + src[k-1] in index order (one thread)
+__global__ void k_sum_slots(const double *__restrict__ src, int k, double *__restrict__ dst) {
+  double s = 0;
+  for (int i = 0; i < k; ++i) s += src[i];
+  dst[0] = s;
 }
 
 // h = D xi - sum B_ij xi_j, fused with the three curvature dots (one 256-thread workgroup = 4 slices)
@@ -205,33 +252,6 @@ __global__ __launch_bounds__(kBlock) void k_bsr3_spmv(IncView inc, const CgState
     }
   }
   if (DOTS) block_partials_store<3>(a, lds, partials);
-}
-
-// partial rows of sum_e w |R_j - R_i Rt|^2 (one thread per edge)
-__global__ __launch_bounds__(kBlock) void k_so3_objective(size_t E, const int *__restrict__ ei,
-                                                          const int *__restrict__ ej,
-                                                          const double *__restrict__ Rt,
-                                                          const double *__restrict__ w,
-                                                          const double *__restrict__ R,
-                                                          double *__restrict__ partials) {
-  __shared__ double lds[kWaves];
-  double acc[1] = {0};
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
-    const size_t i = (size_t)ei[e], j = (size_t)ej[e];
-    double Ri[9], S[9], T[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) { Ri[c] = R[9 * i + c]; S[c] = Rt[9 * e + c]; }
-    mat3_mul(Ri, S, T);
-    double q = 0;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const double d = R[9 * j + c] - T[c];
-      q += d * d;
-    }
-    acc[0] += w[e] * q;
-  }
-  block_partials_store<1>(acc, lds, partials);
 }
 
 // Y_i = R_i exp(hat(xi_i))  (Rodrigues; same series switch as oracle/problems.c: orc_so3_exp)
@@ -302,6 +322,23 @@ struct mi_so3n {
 };
 
 namespace {
+
+// workgroups of the model assembly: one per group of 4 slices while their objective partials fit 8 components of
+// kMaxRows rows (N <= 2.1e6 rotations), a grid-stride walk beyond
+constexpr int kModelComps = 8;
+int model_grid(const mi_so3n *q) { return (int)std::min<size_t>((q->nslices + 3) / 4, (size_t)kModelComps * kMaxRows); }
+// the objective partials the assembly left in ctx->partials2 -> one (all-reduced) sum in slots[0]
+int model_objective_to_slot(mi_so3n *q, int grid, double *slot) {
+  mi_ctx *ctx = q->ctx;
+  const int comps = (grid + kMaxRows - 1) / kMaxRows;
+  if (comps == 1) return reduce_rows_allreduce(ctx, ctx->partials2, grid, 1, slot);
+  // (the rows of the last component past the last workgroup were zeroed by the kernel itself)
+  double *tmp = ctx->scalars + SLOT_RAW;  // (free outside mi_stiefel_gram)
+  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, kMaxRows, comps, tmp));
+  hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(1), 0, ctx->stream, (const double *)tmp, comps, slot);
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
 
 IncView view(const mi_so3n *q) {
   return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr, q->edge, q->dir};
@@ -484,15 +521,17 @@ int mi_so3n_objective(mi_so3n *q, const mi_vec *R, double *f) {
   MI_REQUIRE(q && R && f, "null argument");
   MI_REQUIRE(R->ctx == q->ctx && R->n == 9 * q->N, "R must hold N row-major 3x3 blocks");
   mi_ctx *ctx = q->ctx;
-  const int grid = grid_for(ctx, q->E, 1);
-  hipLaunchKernelGGL(k_so3_objective, dim3(grid), dim3(kBlock), 0, ctx->stream, q->E, (const int *)q->ei,
-                     (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R->d,
-                     ctx->partials2);
-  double *slots = ctx->scalars + SLOT_MISC;
-  MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, 1, slots));
+  // the incidence form of the sum (r05): the loop of the model assembly without its outputs -- what mi_so3n_trial gets
+  // from the assembly at the trial point itself, bit for bit
+  const int grid = model_grid(q);
+  hipLaunchKernelGGL(k_so3_model<false>, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
+                     (const double *)q->Sinc, (const double *)q->winc, (double *)nullptr, (double *)nullptr,
+                     (double *)nullptr, (double *)nullptr, ctx->partials2);
+  MI_HIP(hipGetLastError());
+  MI_TRY(model_objective_to_slot(q, grid, ctx->scalars + SLOT_MISC));
   double s = 0;
   MI_TRY(read_slots_sync(ctx, SLOT_MISC, 1, &s));
-  *f = .5 * s;
+  *f = .25 * s;  // (every edge from both ends)
   return MI_OK;
 }
 
@@ -510,10 +549,9 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
     q->bj.data = q->Dinv->d;
     MI_TRY(mi_vec_copy(grad, q->grad_next));
   } else {
-    const int grid = (int)((q->nslices + 3) / 4);
-    hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
+    hipLaunchKernelGGL(k_so3_model<true>, dim3(model_grid(q)), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
                        (const double *)q->Sinc, (const double *)q->winc, grad->d, q->Dinv->d, q->Bblk,
-                       q->Dsl);
+                       q->Dsl, ctx->partials2);
     MI_HIP(hipGetLastError());
   }
   q->trial_R = nullptr;
@@ -566,21 +604,15 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   }
   // (b) R+ = R exp(hat h)
   MI_TRY(mi_so3n_retract(q, R, h, R_trial));
-  // (c) f(R+), reduced exactly as mi_so3n_objective does
+  // (c) + (d) the model at R+ into the second set of arrays, with f(R+) from the same pass (r05: the objective was an
+  // edge pass of its own, 61 us and 416 MB at the fabric) -- reduced exactly as mi_so3n_objective does
   {
-    const int grid = grid_for(ctx, q->E, 1);
-    hipLaunchKernelGGL(k_so3_objective, dim3(grid), dim3(kBlock), 0, ctx->stream, q->E, (const int *)q->ei,
-                       (const int *)q->ej, (const double *)q->Rt, (const double *)q->w, (const double *)R_trial->d,
-                       ctx->partials2);
-    MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, grid, 1, ctx->scalars + SLOT_MISC + 3));
-  }
-  // (d) the model at R+ into the second set of arrays
-  {
-    const int grid = (int)((q->nslices + 3) / 4);
-    hipLaunchKernelGGL(k_so3_model, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
+    const int grid = model_grid(q);
+    hipLaunchKernelGGL(k_so3_model<true>, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
                        (const double *)q->Sinc, (const double *)q->winc, q->grad_next->d,
-                       q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
+                       q->Dinv_next->d, q->Bblk_next, q->Dsl_next, ctx->partials2);
     MI_HIP(hipGetLastError());
+    MI_TRY(model_objective_to_slot(q, grid, ctx->scalars + SLOT_MISC + 3));
   }
   {
     const double *xs[1] = {q->grad_next->d}, *ys[1] = {q->grad_next->d};
@@ -599,7 +631,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   static_assert(SLOT_MISC + 6 <= SLOT_GDIR, "slot map");
   double buf[6];
   MI_TRY(read_slots_sync(ctx, SLOT_MISC, with_precon ? 6 : 5, buf));
-  out[0] = .5 * buf[3];
+  out[0] = .25 * buf[3];
   out[1] = buf[0];
   out[2] = buf[1];
   out[3] = buf[2];
