@@ -76,7 +76,17 @@ __device__ __forceinline__ void q_hat_basis(const double *Q, int m, double *M) {
 // 72-byte gathers per edge (k_so3_objective: 61 us and 416 MB at the fabric per trial step at N = 5e5).  MODEL = false:
 // the objective alone (mi_so3n_objective) -- the same loop, the same partial sums, the same bits.
 // fpartials: one partial row per workgroup (<= kMaxRows workgroups: a workgroup walks groups of 4 slices).
-template <bool MODEL>
+// SQ (r05): the measurements are stored as unit quaternions (w, x, y, z) -- 32 instead of 72 bytes per incidence of the
+// assembly's largest read stream (227 -> 101 MB at N = 5e5) -- and expanded here (12 products).  Chosen at creation, only
+// when every measurement is a rotation to rounding (|S'S - I| <= 1e-13, det > 0): the expansion re-orthonormalises what it
+// is given, which must not change the problem.
+__device__ __forceinline__ void quat_to_mat(double w, double x, double y, double z, double *S) {
+  const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+  S[0] = 1 - 2 * (yy + zz); S[1] = 2 * (xy - wz);     S[2] = 2 * (xz + wy);
+  S[3] = 2 * (xy + wz);     S[4] = 1 - 2 * (xx + zz); S[5] = 2 * (yz - wx);
+  S[6] = 2 * (xz - wy);     S[7] = 2 * (yz + wx);     S[8] = 1 - 2 * (xx + yy);
+}
+template <bool MODEL, bool SQ>
 __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double *__restrict__ R,
                                                 const double *__restrict__ Sinc, const double *__restrict__ winc,
                                                 double *__restrict__ grad, double *__restrict__ Dinv,
@@ -103,8 +113,13 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
 #pragma unroll
       for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
       // head: term R_i - R_j Rt (j = tail); tail: R_i - R_j Rt'  (the transposition is in Sinc)
+      if (SQ) {
+        const double *sq = Sinc + (size_t)k * 4 * 64 + lane;
+        quat_to_mat(sq[0], sq[64], sq[128], sq[192], S);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) S[c] = Sinc[((size_t)k * 9 + c) * 64 + lane];
+        for (int c = 0; c < 9; ++c) S[c] = Sinc[((size_t)k * 9 + c) * 64 + lane];
+      }
       double RjS[9];
       mat3_mul(Rj, S, RjS);
       double q = 0;
@@ -166,7 +181,7 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
   Di[6] = c02 / det; Di[7] = c12 / det; Di[8] = c22 / det;
 }
 
-template <bool MODEL>
+template <bool MODEL, bool SQ>
 __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
                                                    const double *__restrict__ Sinc, const double *__restrict__ winc,
                                                    double *__restrict__ grad,
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
   double facc = 0;
   const size_t ngroups = (inc.nslices + 3) / 4;
   for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
-    so3_model_slice<MODEL>(inc, R, Sinc, winc, grad, Dinv, Bblk, Dsl, grp * 4 + w, lane, facc);
+    so3_model_slice<MODEL, SQ>(inc, R, Sinc, winc, grad, Dinv, Bblk, Dsl, grp * 4 + w, lane, facc);
   // the workgroup's partial of the objective: workgroup b -> row b % kMaxRows of component b / kMaxRows (one workgroup
   // per group of slices keeps the dynamic balance of ~2000 short workgroups: a grid capped at kMaxRows rows cost the
   // assembly 30 us at N = 5e5); the components are added in fixed order by k_sum_slots
@@ -302,7 +317,8 @@ struct mi_so3n {
   signed char *dir = nullptr;
   mi_vec *Dinv = nullptr;  // 9N (node order): the inverse diagonal blocks, the block-Jacobi preconditioner
   double *Bblk = nullptr;                   // padded * 9
-  double *Sinc = nullptr, *winc = nullptr;  // padded * 9, padded: per-incidence measurement and weight (k_so3_model)
+  double *Sinc = nullptr, *winc = nullptr;  // padded * 9 (or * 4: sinc_quat), padded: per-incidence measurement and weight
+  bool sinc_quat = false;                   // Sinc holds unit quaternions (all measurements are rotations to rounding)
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
   mi_op hess;
   mi_precon bj;
@@ -327,6 +343,19 @@ namespace {
 // kMaxRows rows (N <= 2.1e6 rotations), a grid-stride walk beyond
 constexpr int kModelComps = 8;
 int model_grid(const mi_so3n *q) { return (int)std::min<size_t>((q->nslices + 3) / 4, (size_t)kModelComps * kMaxRows); }
+IncView view(const mi_so3n *q) {
+  return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr, q->edge, q->dir};
+}
+// the assembly (model = true) or its objective alone, objective partials into ctx->partials2
+void launch_model(mi_so3n *q, bool model, int grid, const double *R, double *grad, double *Dinv, double *Bblk, double *Dsl) {
+  mi_ctx *ctx = q->ctx;
+#define SO3M(MV, SQV)                                                                                           \
+  hipLaunchKernelGGL((k_so3_model<MV, SQV>), dim3(grid), dim3(256), 0, ctx->stream, view(q), R,                  \
+                     (const double *)q->Sinc, (const double *)q->winc, grad, Dinv, Bblk, Dsl, ctx->partials2)
+  if (model) { if (q->sinc_quat) SO3M(true, true); else SO3M(true, false); }
+  else { if (q->sinc_quat) SO3M(false, true); else SO3M(false, false); }
+#undef SO3M
+}
 // the objective partials the assembly left in ctx->partials2 -> one (all-reduced) sum in slots[0]
 int model_objective_to_slot(mi_so3n *q, int grid, double *slot) {
   mi_ctx *ctx = q->ctx;
@@ -340,9 +369,6 @@ int model_objective_to_slot(mi_so3n *q, int grid, double *slot) {
   return MI_OK;
 }
 
-IncView view(const mi_so3n *q) {
-  return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr, q->edge, q->dir};
-}
 
 int so3_apply_common(mi_op *self, const mi_vec *in, mi_vec *out, bool dots, int *nparts) {
   mi_so3n *q = (mi_so3n *)self->impl;
@@ -450,7 +476,35 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
       }
     }
   // the measurement and weight of every incidence in slot order (k_so3_model streams them)
-  std::vector<double> sinc(std::max<size_t>(1, padded * 9), 0.0), winc(std::max<size_t>(1, padded), 0.0);
+  // ... the measurements as unit quaternions when every one of them is a rotation to rounding (k_so3_model<., SQ>)
+  bool all_rot = !ctx->cfg.so3_no_quat;
+  for (size_t e = 0; e < E && all_rot; ++e) {
+    const double *M = Rt + 9 * e;
+    for (int a = 0; a < 3 && all_rot; ++a)
+      for (int b = 0; b < 3; ++b) {
+        const double d = M[a] * M[b] + M[3 + a] * M[3 + b] + M[6 + a] * M[6 + b] - (a == b ? 1.0 : 0.0);
+        if (!(std::fabs(d) <= 1e-13)) all_rot = false;
+      }
+    const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+    if (!(det > 0)) all_rot = false;
+  }
+  auto to_quat = [](const double *M, double *qv) {  // Shepperd's branch on the largest of (trace, m00, m11, m22)
+    const double tr = M[0] + M[4] + M[8];
+    double w, x, y, z;
+    if (tr >= M[0] && tr >= M[4] && tr >= M[8]) {
+      w = 1 + tr; x = M[7] - M[5]; y = M[2] - M[6]; z = M[3] - M[1];
+    } else if (M[0] >= M[4] && M[0] >= M[8]) {
+      w = M[7] - M[5]; x = 1 + M[0] - M[4] - M[8]; y = M[1] + M[3]; z = M[2] + M[6];
+    } else if (M[4] >= M[8]) {
+      w = M[2] - M[6]; x = M[1] + M[3]; y = 1 - M[0] + M[4] - M[8]; z = M[5] + M[7];
+    } else {
+      w = M[3] - M[1]; x = M[2] + M[6]; y = M[5] + M[7]; z = 1 - M[0] - M[4] + M[8];
+    }
+    const double nrm = std::sqrt(w * w + x * x + y * y + z * z);
+    qv[0] = w / nrm; qv[1] = x / nrm; qv[2] = y / nrm; qv[3] = z / nrm;
+  };
+  const int scomp = all_rot ? 4 : 9;
+  std::vector<double> sinc(std::max<size_t>(1, padded * scomp), 0.0), winc(std::max<size_t>(1, padded), 0.0);
   for (size_t s = 0; s < nslices; ++s)
     for (long long k = sp[s]; k < sp[s + 1]; ++k)
       for (int lane = 0; lane < 64; ++lane) {
@@ -458,9 +512,16 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
         const int e = edge[e0];
         if (e < 0) continue;
         winc[e0] = w[e];
+        double Sm[9];
         for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c)
-            sinc[((size_t)k * 9 + r * 3 + c) * 64 + lane] = dir[e0] > 0 ? Rt[9 * (size_t)e + r * 3 + c] : Rt[9 * (size_t)e + c * 3 + r];
+          for (int c = 0; c < 3; ++c) Sm[r * 3 + c] = dir[e0] > 0 ? Rt[9 * (size_t)e + r * 3 + c] : Rt[9 * (size_t)e + c * 3 + r];
+        if (all_rot) {
+          double qv[4];
+          to_quat(Sm, qv);
+          for (int c = 0; c < 4; ++c) sinc[((size_t)k * 4 + c) * 64 + lane] = qv[c];
+        } else {
+          for (int c = 0; c < 9; ++c) sinc[((size_t)k * 9 + c) * 64 + lane] = Sm[c];
+        }
       }
   mi_so3n *q = new mi_so3n();
   q->ctx = ctx;
@@ -469,6 +530,7 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
   q->nslices = nslices;
   q->nnzb = nnzb;
   q->padded = padded;
+  q->sinc_quat = all_rot;
   MI_TRY(upload((void **)&q->ei, ei, E * sizeof(int)));
   MI_TRY(upload((void **)&q->ej, ej, E * sizeof(int)));
   MI_TRY(upload((void **)&q->Rt, Rt, 9 * E * sizeof(double)));
@@ -524,9 +586,7 @@ int mi_so3n_objective(mi_so3n *q, const mi_vec *R, double *f) {
   // the incidence form of the sum (r05): the loop of the model assembly without its outputs -- what mi_so3n_trial gets
   // from the assembly at the trial point itself, bit for bit
   const int grid = model_grid(q);
-  hipLaunchKernelGGL(k_so3_model<false>, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
-                     (const double *)q->Sinc, (const double *)q->winc, (double *)nullptr, (double *)nullptr,
-                     (double *)nullptr, (double *)nullptr, ctx->partials2);
+  launch_model(q, false, grid, R->d, nullptr, nullptr, nullptr, nullptr);
   MI_HIP(hipGetLastError());
   MI_TRY(model_objective_to_slot(q, grid, ctx->scalars + SLOT_MISC));
   double s = 0;
@@ -549,9 +609,7 @@ int mi_so3n_model(mi_so3n *q, const mi_vec *R, mi_vec *grad, mi_op **hess, mi_pr
     q->bj.data = q->Dinv->d;
     MI_TRY(mi_vec_copy(grad, q->grad_next));
   } else {
-    hipLaunchKernelGGL(k_so3_model<true>, dim3(model_grid(q)), dim3(256), 0, ctx->stream, view(q), (const double *)R->d,
-                       (const double *)q->Sinc, (const double *)q->winc, grad->d, q->Dinv->d, q->Bblk,
-                       q->Dsl, ctx->partials2);
+    launch_model(q, true, model_grid(q), R->d, grad->d, q->Dinv->d, q->Bblk, q->Dsl);
     MI_HIP(hipGetLastError());
   }
   q->trial_R = nullptr;
@@ -608,9 +666,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   // edge pass of its own, 61 us and 416 MB at the fabric) -- reduced exactly as mi_so3n_objective does
   {
     const int grid = model_grid(q);
-    hipLaunchKernelGGL(k_so3_model<true>, dim3(grid), dim3(256), 0, ctx->stream, view(q), (const double *)R_trial->d,
-                       (const double *)q->Sinc, (const double *)q->winc, q->grad_next->d,
-                       q->Dinv_next->d, q->Bblk_next, q->Dsl_next, ctx->partials2);
+    launch_model(q, true, grid, R_trial->d, q->grad_next->d, q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
     MI_HIP(hipGetLastError());
     MI_TRY(model_objective_to_slot(q, grid, ctx->scalars + SLOT_MISC + 3));
   }
