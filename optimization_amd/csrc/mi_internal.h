@@ -110,6 +110,7 @@ struct Config {
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
+  bool no_update_pair = false;      // NO_UPDATE_PAIR: the matrix-pipe panel update in 16-row blocks, 8 bytes per lane (r04 form)
   bool no_gram_half = false;        // NO_GRAM_HALF: the fused Gram pair with a tile column of its own per Gram (r04 form)
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
   bool halo_rprime = false;         // HALO_RPRIME: sharded STPCG exchanges the halo of r' (with the <r,v> all-reduce) and every

@@ -597,3 +597,26 @@ def test_generalized_gram_pair_on_column_blocks(ctx, m, nx, nc):
             iu = np.arange(ns)
             lower = (iu[:, None] // 16) > (iu[None, :] // 16)
             assert np.array_equal(G[lower], G.T[lower])
+
+
+@pytest.mark.parametrize("m,ks", [(100_008, 72), (65_536, 48), (4098, 72), (1000, 72), (40, 48), (200_014, 60), (126 ** 3, 72)])
+def test_panel_update_in_paired_rows_has_the_bits_of_the_16_row_blocks(m, ks):
+    """r05 (VERDICT r04 item 3 i): the matrix-pipe Ritz update in 32-row blocks of two interleaved tiles (a lane owns two
+    consecutive rows: 16-byte loads and stores) forms the same MFMAs on the same operands as the 16-row form
+    (MI355OPT_NO_UPDATE_PAIR=1): identical bits, incl. the m % 32 leftover rows; and against numpy."""
+    from optimization_amd import capi
+    rng = np.random.default_rng(ks + m % 1009)
+    S = rng.normal(size=(m, ks))
+    Cm = rng.normal(size=(ks, 48))
+    out = {}
+    for mode in ("paired", "r04"):
+        c = capi.Context(0)
+        try:
+            c.set_option("NO_UPDATE_PAIR", 1 if mode == "r04" else 0)
+            Y1, Y2 = c.lobpcg_update2(m, c.upload(S.ravel(order="F")), ks, Cm, 24)
+            out[mode] = np.hstack([Y1.numpy().reshape(24, m).T, Y2.numpy()[:24 * m].reshape(24, m).T])
+        finally:
+            c.close()
+    assert np.array_equal(out["paired"], out["r04"])
+    ref = S @ Cm
+    assert np.abs(out["paired"] - ref).max() <= 1e-13 * np.abs(ref).max() * ks
