@@ -3,7 +3,7 @@
 #   bash tools/round_profiles.sh r04     then, in the build container:   python tools/profile_summary.py r04
 # and copy gpurun_out/<tag>_keep/* into profiles/.  One artifact set per round (no per-experiment refreshes).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 K=$REPO/gpurun_out/${TAG}_keep
 mkdir -p "$K"
@@ -11,13 +11,18 @@ mkdir -p "$K"
 (timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -15) > "$K/${TAG}_gputest_full_suite.log"
 # bench line, side benches, kernel trace, PMC bytes, fetch calibration
 bash tools/profile_run.sh "$TAG" > "$K/${TAG}_profile_run.log" 2>&1
-# cfg3: per-kernel figures + fabric bytes, and the neighbour-sorted incidence order (experiment)
+# cfg3: per-kernel figures + fabric bytes of the inner step, the pieces of the outer iteration and their fabric bytes
 python tools/bench_extra.py cfg3 2>/dev/null | tail -1 > "$K/${TAG}_cfg3.json"
-MI355OPT_SO3_SORT_NBR=1 python tools/bench_extra.py cfg3 2>/dev/null | tail -1 > "$K/${TAG}_cfg3_sorted_by_neighbour.json"
-for v in 0 1; do
-  MI355OPT_SO3_SORT_NBR=$v PMC_CMD="python $REPO/tools/bench_extra.py cfg3" bash tools/pmc_bytes.sh gpurun_out/${TAG}_pmc_cfg3_$v > /dev/null 2>&1
-  cp gpurun_out/${TAG}_pmc_cfg3_$v/bytes.json "$K/${TAG}_pmc_traffic_cfg3_sort$v.json"
-done
+PMC_CMD="python $REPO/tools/bench_extra.py cfg3" bash tools/pmc_bytes.sh gpurun_out/${TAG}_pmc_cfg3 > /dev/null 2>&1
+cp gpurun_out/${TAG}_pmc_cfg3/bytes.json "$K/${TAG}_pmc_traffic_cfg3.json"
+python tools/time_so3_model.py 2>/dev/null | tail -1 > "$K/${TAG}_cfg3_outer_pieces.json"
+PMC_CMD="python $REPO/tools/time_so3_model.py" bash tools/pmc_bytes.sh gpurun_out/${TAG}_pmc_cfg3_outer > /dev/null 2>&1
+cp gpurun_out/${TAG}_pmc_cfg3_outer/bytes.json "$K/${TAG}_pmc_traffic_cfg3_outer.json"
+# Stiefel(1e6, p) for p = 3 ... 8 (the wide-row one-pass Hessian), the Gram pair and the Ritz update A/B, the generalized LOBPCG
+python tools/bench_extra.py wide 2>/dev/null > "$K/${TAG}_wide_rows.jsonl"
+python tools/time_gram.py 2>/dev/null | tail -1 > "$K/${TAG}_gram_pair_ab.json"
+python tools/time_update.py 2>/dev/null | tail -1 > "$K/${TAG}_update_ab.json"
+python tools/lobpcg_gen.py 2>/dev/null | tail -1 > "$K/${TAG}_lobpcg_generalized.json"
 # cfg5: side bench, the run to convergence, kernel stats of 22 iterations
 python tools/bench_extra.py cfg5 2>/dev/null | tail -1 > "$K/${TAG}_cfg5.json"
 python tools/cfg5_converge.py max_iters=8000 --json-out "$K/${TAG}_cfg5_converge.json" > /dev/null 2>&1
