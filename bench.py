@@ -890,7 +890,18 @@ def main():
         comm_legs, kept = [], None
         for L in layers:
             wd.arm(f"exchange layer '{L}'", args.leg_timeout)
-            leg = comm_ab_leg(ctx, dist, prob, X, s_out, L, args.ab_steps, world, rank, verifier(L), peer_up)
+            # a layer that RAISES (a library error, the same on every rank: e.g. a buffer it cannot place) costs that
+            # layer, not the line: every rank reports, and the leg counts as not verified if any of them failed
+            try:
+                leg, exc = comm_ab_leg(ctx, dist, prob, X, s_out, L, args.ab_steps, world, rank, verifier(L), peer_up), None
+            except capi.MiError as e:
+                leg, exc = None, str(e)
+            every = [None] * world
+            dist.all_gather_object(every, exc)
+            if any(every):
+                ctx.sync()
+                leg = {"layer": L, "what": LAYER_TEXT[L], "verified": False,
+                       "failures": [f"rank {i}: {e_}" for i, e_ in enumerate(every) if e_][:4]}
             comm_legs.append(leg)
             if not leg["verified"] and rank == 0:
                 print(f"bench.py: exchange layer '{leg['layer']}' failed verification" +

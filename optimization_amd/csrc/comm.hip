@@ -27,7 +27,8 @@ namespace {
 // error word, never a hang); the layer is switched on only after a collective self-test passed on
 // every rank, else RCCL stays in charge.
 // (mailbox layout and the device-side wait / folded exchange: comm_ipc.h)
-constexpr size_t kIpcArenaBytes = 16u << 20;   // mailbox + halo regions
+constexpr size_t kIpcArenaBytes = 64u << 20;   // mailbox + halo regions (r05: 16 -> 64 MB: halo buffers hold kMaxP = 8 columns, and
+                                               // the r'-halo form keeps a second pair per matrix: 2 x 10.2 MB at cfg4's 200 x 200 plane)
 constexpr uint64_t kIpcTimeoutTicks = 2000000000ull;  // default: 20 s of the 100 MHz wall clock (MI355OPT_IPC_TIMEOUT_MS)
 
 struct Comm {
@@ -429,15 +430,21 @@ int comm_halo_exchange(mi_ctx *ctx, const mi_csr *A, int p, const double *V) {
 }
 
 // ---- r'-halo form (comm_ipc.h) -------------------------------------------------------------------------------------------
-bool comm_rprime_enabled(const mi_ctx *ctx, const mi_csr *A) {
-  if (!ctx->cfg.halo_rprime || ctx->world_size <= 1 || !ctx->comm || !A || !A->halo) return false;
-  return A->halo_lo + A->halo_hi + A->send_lo + A->send_hi > 0;
-}
-
 static int rprime_alloc(mi_ctx *ctx, const mi_csr *A) {
   if (A->halo_r) return MI_OK;
   // (every rank gets here at the same point of the same solve: the arena's bump allocator stays in step)
   return comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo_r, &A->halo_r_in_arena, &A->halo_r_off);
+}
+
+bool comm_rprime_enabled(const mi_ctx *ctx, const mi_csr *A) {
+  if (!ctx->cfg.halo_rprime || ctx->world_size <= 1 || !ctx->comm || !A || !A->halo) return false;
+  if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return false;
+  // the r' rows need a buffer pair of their own where the layer in use can reach it: inside the arena for peer stores
+  // (the same decision on every rank: same sizes, same allocation order), anywhere for RCCL
+  const Comm *c = (const Comm *)ctx->comm;
+  if (rprime_alloc(const_cast<mi_ctx *>(ctx), A) != MI_OK) return false;
+  if (c->ipc_enabled && A->halo_in_arena) return A->halo_r_in_arena;
+  return c->nccl != nullptr;
 }
 
 void comm_rprime_buffers(const mi_ctx *, const mi_csr *A, int p, const double **halo_r, double **halo_p, size_t *count) {

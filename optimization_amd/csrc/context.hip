@@ -187,6 +187,7 @@ OPT_BOOL(opt_halo_rprime, cfg.halo_rprime)
 OPT_BOOL(opt_no_gram_half, cfg.no_gram_half)
 OPT_BOOL(opt_so3_no_quat, cfg.so3_no_quat)
 OPT_BOOL(opt_no_update_pair, cfg.no_update_pair)
+OPT_BOOL(opt_two_kernel_step, cfg.two_kernel_step)
 #undef OPT_BOOL
 int opt_max_grid(mi_ctx *c, long v) {
   c->max_grid = (int)std::min<long>(kMaxGrid, std::max<long>(1, v));
@@ -208,7 +209,7 @@ const OptionDesc kOptions[] = {
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
     {"NO_ZERO_COPY", opt_no_zero_copy},
-    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
+    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
 };
 // value of a switch: an integer; anything else that is not empty ("yes", "true", "on" -- and the presence-only
 // `MI355OPT_X=` of the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off

@@ -110,6 +110,8 @@ struct Config {
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
+  bool two_kernel_step = false;     // TWO_KERNEL_STEP: opt-in experiment (r05): <r+,r+> by recurrence, the two CG kernels of an
+                                    // unpreconditioned Stiefel(n,3) iteration merged (changes the rounding of IterativeSolvers.h:408)
   bool no_update_pair = false;      // NO_UPDATE_PAIR: the matrix-pipe panel update in 16-row blocks, 8 bytes per lane (r04 form)
   bool no_gram_half = false;        // NO_GRAM_HALF: the fused Gram pair with a tile column of its own per Gram (r04 form)
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe
@@ -154,6 +156,7 @@ struct mi_ctx {
   mi::CgState *cg = nullptr;        // device, copy 0
   mi::CgState *cg1 = nullptr;       // device, copy 1
   mi::CgState *cg_host = nullptr;   // pinned copy for read-back
+  const double *twok_r = nullptr;   // two-kernel step: the residual the Hessian pass reads (set by mi_stpcg around apply_dir)
   const mi::CgState *cg_live = nullptr;  // state copy operators may consult to skip work after exit
   // mi_stpcg with defer_result: the state copy into cg_host is in flight behind this event (mi_stpcg_collect)
   hipEvent_t cg_deferred_ev = nullptr;
@@ -593,6 +596,7 @@ struct mi_dirgram {
   // the matrix whose halo exchange precedes every apply_dir (null: none).  STPCG may fold the push half of the NEXT
   // exchange into its direction kernel (comm_ipc.h comm_halo_fold_next); apply_dir then only waits.
   const struct mi_csr *halo_A = nullptr;
+  bool twok = false;  // apply_dir(gram_count = -2) exists: the Hessian pass of the two-kernel step (Config::two_kernel_step)
 };
 
 struct mi_precon {

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
 // ring and every entry's row is read from LDS at an address the host worked out (spmm_core.h sell_window); HW = the
 // entries per slice.  Same arithmetic, bit-identical results.
 // FAR (window form, unsharded): 0 far columns loaded; 1 computed (pure far structure); 2 computed + 16-bit words
-template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW, int FAR = 0>
+// TWOK (r05, opt-in experiment TWO_KERNEL_STEP, window form only): the pass also reads the residual r and leaves the
+// partial rows of <r,out> and <V,r> (components KC-2, KC-1): with them <r+,r+> = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp>
+// is known without a pass over r+, and the two CG kernels of an iteration merge into one (stpcg.hip k_cg_step2).
+template <int P, bool FROM_SLOTS, bool HALO, bool RECUR, bool PK, int HW, int FAR = 0, bool TWOK = false>
 __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(SellView A, WinView Wv, const CgState *__restrict__ st,
                                                           const double *__restrict__ V,
                                                           const double *__restrict__ X,
@@ -206,9 +209,11 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
                                                           const double *__restrict__ slots,
                                                           const double *__restrict__ gdir,
                                                           double *__restrict__ out,
-                                                          double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
+                                                          double *__restrict__ partials, HaloWaitArg<HALO> hwait,
+                                                          const double *__restrict__ Rres = nullptr) {
   constexpr bool WIN = HW > 0 && P <= 3;  // (P = 4: ring + parked rows would need > 160 KB of LDS; never dispatched)
-  constexpr int NS = SymIdx<P>::NS, KC = RECUR ? DirComps<P>::value : 3;
+  static_assert(!TWOK || (WIN && RECUR), "the two-kernel step exists in the window form only");
+  constexpr int NS = SymIdx<P>::NS, KC = TWOK ? 3 + NS + 2 : (RECUR ? DirComps<P>::value : 3);
   constexpr int kLds = (NS * (kWaves + 1) > KC * kWaves) ? NS * (kWaves + 1) : KC * kWaves;
   __shared__ double lds[kLds];
   __shared__ double vt[PK ? 256 : 1];  // PK: the matrix's value table
@@ -254,6 +259,8 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
     double (&a)[KC];
     int lane;
     double x[P], y[P], v[P];
+    const double *__restrict__ Rr;
+    double rr[TWOK ? P : 1], rn[TWOK ? P : 1];
     // rows of the slice from a scalar base + a 32-bit lane offset (lanes past the last row read its first)
     // (32-bit arithmetic: the fields span < 4 GiB, sell_stream_ok)
     __device__ __forceinline__ unsigned lane_off(size_t slice) const {
@@ -292,6 +299,11 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
 #pragma unroll
         for (int c = 0; c < P; ++c) yn[WIN ? c : 0] = pinned_load(ys + c);
       }
+      if (TWOK) {
+        const double *rs = row_of(Rr, slice, off);
+#pragma unroll
+        for (int c = 0; c < P; ++c) rn[TWOK ? c : 0] = pinned_load(rs + c);
+      }
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&vrow)[P]) {
 #pragma unroll
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
         v[c] = vrow[c];
         x[c] = xn[WIN ? c : 0];
         if (RECUR) y[c] = yn[WIN ? c : 0];
+        if (TWOK) rr[TWOK ? c : 0] = rn[TWOK ? c : 0];
       }
       end(slice, acc);
     }
@@ -322,6 +335,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
         o[b] = acc[b] - t;  // Z - X M
         os[b] = o[b];
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
+        if (TWOK) { a[KC - 2] += rr[TWOK ? b : 0] * o[b]; a[KC - 1] += v[b] * rr[TWOK ? b : 0]; }
       }
       if (RECUR) {  // packed sym(y o' - x (o S)'): the Gram of this output row
         double os_[P];
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
           }
       }
     }
-  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}, {}, {}};
+  } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}, Rres, {}, {}, {}, {}};
   // the wave index as a scalar: slice bounds then come from scalar loads and the loop control is scalar
   const int wu = __builtin_amdgcn_readfirstlane(w);
   if constexpr (WIN) {
@@ -918,7 +932,17 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
                                    (const double *)q->S_dev, (const double *)ctx->partials2, gram_count,      \
                                    (const double *)slots, (const double *)(ctx->scalars + SLOT_GDIR),         \
                                    out->d, ctx->partials, hw_halo))
-  if (win && w16) {  // the window form with computed far columns and 16-bit words
+  if (gram_count == -2) {  // the two-kernel step (opt-in experiment): stpcg.hip asked for it only where twok says it exists
+    MI_REQUIRE(win && fard && !halo && !w16 && p == 3 && ctx->twok_r, "internal: two-kernel step without its Hessian form");
+#define HF2K(HWV)                                                                                                       \
+  hipLaunchKernelGGL((k_st_hess_fused<3, false, false, true, true, HWV, 1, true>), dim3(grid), dim3(block), 0,          \
+                     ctx->stream, view, wv, (const CgState *)ctx->cg_live, (const double *)in->d,                       \
+                     (const double *)q->X->d, (const double *)q->Y->d, (const double *)q->S_dev,                        \
+                     (const double *)ctx->partials2, gram_count, (const double *)slots,                                 \
+                     (const double *)(ctx->scalars + SLOT_GDIR), out->d, ctx->partials, hw_none, ctx->twok_r)
+    if (A->win_head <= 7) { HF2K(7); } else { HF2K(8); }
+#undef HF2K
+  } else if (win && w16) {  // the window form with computed far columns and 16-bit words
     if (A->win_head <= 7) { HF3D(7, 2); } else { HF3D(8, 2); }
   } else if (win && fard && halo) {  // ... with computed far columns, some of them halo columns
     if (A->win_head <= 7) { HF3DH(7); } else { HF3DH(8); }
@@ -1110,6 +1134,10 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   q->dg.Y = q->Y->d;
   q->dg.S = q->S_dev;
   q->dg.halo_A = q->A->halo ? q->A : nullptr;
+  // (the opt-in two-kernel step: p = 3, window form with computed far columns, one rank)
+  q->dg.twok = q->p == 3 && !q->A->halo && q->A->wk && q->A->win_chunks > 0 && q->A->win_far_pure > 0 &&
+               q->A->win_far_pure < ((size_t)1 << 31) && !q->ctx->cfg.no_window && !q->ctx->cfg.no_far_computed &&
+               !q->ctx->uniform_grid;
   // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator -- and so does
   // a matrix that is not symmetric (checked at creation): the one-pass form replaces X'(A p) by (A X)'p
   q->hess.dirgram = (sell_stream_ok(q->A, q->p) && q->A->symmetric) ? &q->dg : nullptr;

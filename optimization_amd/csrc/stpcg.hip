@@ -378,6 +378,110 @@ static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 #undef CG_UPDATE_NAME
 #undef CG_PUPDATE_NAME
 
+// ---- opt-in experiment (r05; Config::two_kernel_step) -------------------------------------------------
+// ONE kernel for the A-step and the B-step of an unpreconditioned iteration over rows of Stiefel(n,3) (v == r).  Without
+// a preconditioner <r+,r+> = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp> is known once the Hessian pass has also left
+// <r,Hp> (k_st_hess_fused<..., TWOK>: it reads r, 8 N more bytes there), so r+ = r + alpha Hp (:377), s += alpha p (:374)
+// and p+ = -r+ + beta p (:420) are one pass: reads r, Hp, p, s and writes r, p, s = 56 N bytes instead of 24 N + 40 N, and
+// one kernel boundary fewer.  It CHANGES THE ROUNDING of :408 -- beta comes from a three-term recurrence that cancels
+// as the residual falls, not from a sum over the new residual -- which is why it is opt-in and never the default; the
+// distance from the reference it costs is measured in EXPERIMENTS.md.  The kernel test (:305-337) is served by a fifth
+// extra partial, <p,r>, so every exit of STPCG is taken inside this kernel: an iteration is two launches.
+template <int NS>
+__global__ __launch_bounds__(kBlock) void k_cg_step2(size_t n, CgConst cc, const CgState *__restrict__ st_in,
+                                                     CgState *__restrict__ st_out, const double *__restrict__ partials_a,
+                                                     int nparts_a, const double *__restrict__ Hp, double *__restrict__ r,
+                                                     double *__restrict__ p, double *__restrict__ s, HostStatus *hs,
+                                                     double *__restrict__ trace, size_t trace_cap, DirGramArgs dg) {
+  constexpr int KC = 3 + NS + 2;
+  __shared__ double lds[3 * (kWaves + 1)];
+  static_assert(KC <= kWaves, "one wave per component");
+  CgState cs = load_state(st_in);
+  const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+  if (cs.mode == CG_DONE) {
+    if (leader) store_state(st_out, cs);
+    return;
+  }
+  const size_t n2 = n >> 1, stride = (size_t)gridDim.x * kBlock, i0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  double2 hv0 = make_double2(0, 0), rv0 = hv0, pv0 = hv0, sv0 = hv0;
+  auto prefetch = [&] {
+    if (i0 < n2) {
+      hv0 = reinterpret_cast<const double2 *>(Hp)[i0];
+      rv0 = reinterpret_cast<double2 *>(r)[i0];
+      pv0 = reinterpret_cast<double2 *>(p)[i0];
+      sv0 = reinterpret_cast<double2 *>(s)[i0];
+    }
+  };
+  double d[KC];
+  reduce_rows<KC>(partials_a, nparts_a, d, lds, prefetch);
+  step_a(cs, cc, d[0], d[1], d[2]);
+  const int mode_a = cs.mode;
+  double red = 0;
+  {
+#pragma clang fp contract(off)
+    if (mode_a == CG_RUN) red = cs.rv + 2 * cs.alpha * d[KC - 2] + cs.alpha * cs.alpha * d[1];  // <r+,r+>  (:408)
+    else if (mode_a == CG_KERNEL_PENDING) red = d[KC - 1];                                        // <p,r>   (:320)
+  }
+  step_b(cs, cc, red);
+  cs.launches = cs.launches + 1;
+  if (leader) {
+    store_state(st_out, cs);
+    if (mode_a == CG_RUN && trace && cs.k - 1 < trace_cap) {
+      const size_t k = (size_t)(cs.k - 1);
+      trace[k] = cs.alpha;
+      trace[trace_cap + k] = cs.beta;
+      trace[2 * trace_cap + k] = cs.kappa;
+      trace[3 * trace_cap + k] = cs.rv;
+    }
+    publish(hs, cs.launches, cs.mode == CG_DONE);
+    if (mode_a == CG_RUN) {
+      for (int i = 0; i < NS; ++i) dg.gdir[i] = dg.gdir[i] + cs.alpha * d[3 + i];  // G(r) += alpha G(Hp)
+      if (cs.mode == CG_RUN)
+        for (int i = 0; i < NS; ++i) dg.gdir[SLOT_GDIR_P + i] = -dg.gdir[i] + cs.beta * dg.gdir[SLOT_GDIR_P + i];
+    }
+  }
+  if (mode_a != CG_RUN) {  // boundary step (:359-361) or kernel step (:324-336): s += sigma p, and the solve is over
+    const double sigma = cs.sigma;
+    for (size_t i = i0; i < n2; i += stride) {
+      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+      double2 sv = reinterpret_cast<double2 *>(s)[i];
+      sv.x += sigma * pv.x; sv.y += sigma * pv.y;
+      reinterpret_cast<double2 *>(s)[i] = sv;
+    }
+    if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
+    return;
+  }
+  const double alpha = cs.alpha, beta = cs.beta;
+  const bool dir = cs.mode == CG_RUN;
+  double2 hv = hv0, rv = rv0, pv = pv0, sv = sv0;
+  for (size_t i = i0; i < n2;) {
+    const size_t inext = i + stride;
+    double2 hn = hv, rn = rv, pn = pv, sn = sv;
+    if (inext < n2) {
+      hn = reinterpret_cast<const double2 *>(Hp)[inext];
+      rn = reinterpret_cast<double2 *>(r)[inext];
+      pn = reinterpret_cast<double2 *>(p)[inext];
+      sn = reinterpret_cast<double2 *>(s)[inext];
+    }
+    rv.x += alpha * hv.x; rv.y += alpha * hv.y;
+    reinterpret_cast<double2 *>(r)[i] = rv;
+    sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
+    reinterpret_cast<double2 *>(s)[i] = sv;
+    if (dir) {
+      pv.x = -rv.x + beta * pv.x; pv.y = -rv.y + beta * pv.y;
+      reinterpret_cast<double2 *>(p)[i] = pv;
+    }
+    i = inext; hv = hn; rv = rn; pv = pn; sv = sn;
+  }
+  if ((n & 1) && leader) {
+    const size_t i = n - 1;
+    const double rn_ = r[i] + alpha * Hp[i];
+    r[i] = rn_;
+    s[i] = s[i] + alpha * p[i];
+    if (dir) p[i] = -rn_ + beta * p[i];
+  }
+}
+
 // partial rows of sym(Y'p - (X'p) S) for the FIRST direction (p = -v, :256); later ones come from k_cg_pupdate
 template <int SP>
 __global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const double *__restrict__ p, DirGramArgs dg) {
@@ -625,6 +729,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // (k_cg_init_dirgram); one rank, nothing to exchange: G(p0), G(r0) set by k_cg_scalar_init itself
   const bool init_fused = recur && n == dgp->n * (size_t)dgp->p;
   const bool gdir_in_scalar_init = recur && !sharded && !rows;
+  // opt-in experiment: the two-kernel step (k_cg_step2; one rank, Stiefel(n,3) in the window form)
+  const bool twok = ctx->cfg.two_kernel_step && recur && dgp->twok && dgp->p == 3 && !sharded && !rows && !lockstep &&
+                    init_fused && gdir_in_scalar_init;
+  CgState *st_final = st0;
   double *tr = tcap ? ctx->trace_dev : nullptr;
   int ret = MI_OK;
   ctx->cg_live = st0;
@@ -737,6 +845,22 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
 
       // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials
       int nparts = 0;
+      if (twok) {  // two launches per iteration; the state ping-pongs between st0 and st1 ACROSS iterations
+        CgState *cur = (k & 1) ? st1 : st0, *nxt = (k & 1) ? st0 : st1;
+        ctx->cg_live = cur;
+        ctx->twok_r = r->d;
+        CG_CHECK(H->apply_dir(H, p, Hp, -2, &nparts));
+        ctx->twok_r = nullptr;
+        ++hvp;
+        {
+          KScope ks(ctx, MI_K_CG_UPDATE);
+          hipLaunchKernelGGL(k_cg_step2<6>, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)cur, nxt,
+                             (const double *)ctx->partials, nparts, (const double *)Hp->d, r->d, p->d, s_out->d,
+                             ctx->status_dev, tr, tcap, dga);
+        }
+        st_final = nxt;
+        continue;
+      }
       if (dgp) {
         CG_CHECK(H->apply_dir(H, p, Hp, recur ? -1 : grid, &nparts));
       } else if (H->apply_dots) {
@@ -868,7 +992,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     // the copy travels behind the solve; whoever waits for the stream next (or mi_stpcg_collect) completes it
     hipError_t e = hipSuccess;
     if (!ctx->cg_deferred_ev) e = hipEventCreateWithFlags(&ctx->cg_deferred_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
     *precon_fail_host(ctx) = 0.0;
     if (e == hipSuccess && P && P->fail_word)
       e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
@@ -881,7 +1005,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     result->exit_reason = -1;
     result->rv_final = 0;
   } else {
-    hipError_t e = hipMemcpyAsync(ctx->cg_host, st0, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
     *precon_fail_host(ctx) = 0.0;
     if (e == hipSuccess && P && P->fail_word)
       e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);

@@ -185,3 +185,38 @@ def test_full_cfg2_tnt_run_matches_the_reference_trace(cfg2, oracle):
     fx_floor = floor or dict(x=0.0, subspace=0.0)
     assert dist <= max(1e-10, 3 * fx_floor["subspace"])
     assert ex <= max(1e-10, 3 * fx_floor["x"])
+
+
+def test_two_kernel_step_experiment(cfg2, bench_solve):
+    """r05, VERDICT r04 item 8 -- an OPT-IN experiment, never the default: with MI355OPT_TWO_KERNEL_STEP the Hessian pass
+    also leaves <r,Hp> and <p,r>, <r+,r+> = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp> replaces the sum over the new residual
+    (IterativeSolvers.h:408), and the two CG kernels of an iteration are one (k_cg_step2).  The deliverable is the DISTANCE
+    FROM THE REFERENCE next to the conditioning floor at the bench point (N = 3e6, 50 iterations), printed here; the
+    assertions only hold the experiment to being a CG solve of the same system: same count and exit, iterate to 1e-6."""
+    from optimization_amd import capi
+    prm, o, fl = bench_solve["prm"], bench_solve["o"], bench_solve["floor"] or dict(s=0.0, alpha=0.0, beta=0.0)
+    out = {}
+    c = capi.Context(0)
+    try:
+        rowptr, col, val = cfg2["csr"]
+        A = c.csr(N, rowptr, col, val)
+        prob = c.stiefel_rq(A, N, P)
+        g, H = prob.model(c.upload(bench_solve["Xb"]))
+        for mode in (0, 1):
+            c.set_option("TWO_KERNEL_STEP", mode)
+            c.ktime_enable("cg_pupdate", True)
+            c.ktime_reset()
+            r = c.stpcg(g, H, Delta=prm["Delta"], max_iterations=prm["max_iterations"], kappa_fgr=prm["kappa_fgr"],
+                        theta=prm["theta"], trace_cap=64)
+            out[mode] = dict(r, s=r["s"].numpy().copy(), pupdates=c.ktime_read("cg_pupdate")[0])
+    finally:
+        c.close()
+    assert out[0]["pupdates"] >= 50 and out[1]["pupdates"] == 0          # the merged kernel really replaced both
+    for mode, name in ((0, "three kernels"), (1, "two kernels (recurrence for <r+,r+>)")):
+        r = out[mode]
+        ea = float(np.max(np.abs(r["trace"]["alpha"] / o["trace"]["alpha"] - 1)))
+        eb = float(np.max(np.abs(r["trace"]["beta"] / o["trace"]["beta"] - 1)))
+        print(f"{name}: s {rel_err(r['s'], o['s']):.2e} (floor {fl['s']:.2e}), alpha {ea:.2e} ({fl['alpha']:.2e}), "
+              f"beta {eb:.2e} ({fl['beta']:.2e}), |s|_M {abs(r['M_norm'] - o['M_norm']) / o['M_norm']:.2e}")
+        assert r["iterations"] == o["iterations"] == 50 and r["exit_reason"] == o["exit_reason"]
+    assert rel_err(out[1]["s"], o["s"]) < 1e-6

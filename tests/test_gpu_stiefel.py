@@ -840,3 +840,41 @@ def test_wide_rows_preconditioned_and_sharded_slot_forms(oracle, monkeypatch, p)
     a, b = out["plain"], out["slots"]
     assert (a["iterations"], a["exit_reason"]) == (b["iterations"], b["exit_reason"])
     assert np.array_equal(a["trace"]["alpha"], b["trace"]["alpha"]) and np.array_equal(a["s"], b["s"])
+
+
+@pytest.mark.parametrize("Delta,kappa,maxit", [(1e3, 1e-8, 40), (1e-3, 1e-8, 40), (1e3, 1e-12, 7), (0.05, .1, 50)])
+def test_two_kernel_step_takes_every_exit_of_stpcg(oracle, Delta, kappa, maxit):
+    """The opt-in two-kernel step (MI355OPT_TWO_KERNEL_STEP; stpcg.hip k_cg_step2) on a problem whose matrix takes the
+    window form with computed far columns (a 3-D stencil): residual, boundary and iteration-limit exits inside the
+    merged kernel -- same count and exit as the default three-kernel step and the oracle, |s|_M and the step to the
+    accuracy a changed rounding of <r+,r+> leaves (asserted loosely; the measured distance is the experiment's result,
+    tests/test_gpu_cfg2_full.py)."""
+    from optimization_amd import capi
+    nx, ny, nz, p = 24, 22, 20, 3
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=4)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, Delta, max_iterations=maxit, kappa_fgr=kappa, theta=1.0)
+    oracle.free(oprob)
+    c = capi.Context(0)
+    try:
+        A = c.csr(n, rowptr, col, val)
+        assert A.window_info()[0] > 0 and A.window_info()[2] == nx * ny      # window form, pure far structure
+        prob = c.stiefel_rq(A, n, p)
+        g, H = prob.model(c.upload(Xb))
+        res = {}
+        for mode in (0, 1):
+            c.set_option("TWO_KERNEL_STEP", mode)
+            c.ktime_enable("cg_pupdate", True)
+            c.ktime_reset()
+            r = c.stpcg(g, H, Delta=Delta, max_iterations=maxit, kappa_fgr=kappa, theta=1.0)
+            res[mode] = dict(r, s=r["s"].numpy().copy(), pupdates=c.ktime_read("cg_pupdate")[0])
+    finally:
+        c.close()
+    assert res[1]["pupdates"] == 0 and (res[0]["pupdates"] > 0 or res[0]["iterations"] == 0)
+    for mode in (0, 1):
+        assert (res[mode]["iterations"], res[mode]["exit_reason"]) == (o["iterations"], o["exit_reason"]), mode
+        assert abs(res[mode]["M_norm"] - o["M_norm"]) <= 1e-9 * o["M_norm"]
+    assert rel_err(res[0]["s"], o["s"]) < 1e-10 and rel_err(res[1]["s"], o["s"]) < 1e-7
