@@ -80,6 +80,15 @@ class ShardedStiefel:
     def spmm(self, V):
         return self.A @ self.halo_exchange(V)
 
+    def halo_of(self, V):
+        """the halo rows alone (what the neighbours sent): [halo_lo; halo_hi]"""
+        return self.halo_exchange(V)[self.n:]
+
+    def hess_with_halo(self, V, halo):
+        """hess(V) with the halo rows of V supplied by the caller instead of exchanged here"""
+        Z = self.A @ np.vstack([V, halo]) - V @ self.S
+        return Z - self.X @ self.sym_gram(self.X, Z)
+
     def sym_gram(self, X, Z):
         G = allreduce(X.T @ Z)
         return .5 * (G + G.T)
@@ -122,6 +131,36 @@ def main():
     O = oracle_py.Oracle()
     res = O.stpcg(g.ravel(), H, inner=ip, Delta=0.05, max_iterations=40, kappa_fgr=1e-6, theta=.5, trace_cap=64)
     res2 = O.stpcg(g.ravel(), H, inner=ip, Delta=1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0, trace_cap=64)
+    # r'-halo form of the sharded CG (`--comm rccl2`): the halo rows of the new RESIDUAL travel (they are final
+    # one step earlier: on RCCL they share the collective of <r,r>), and every rank forms halo(p') = -halo(r') + beta halo(p)
+    # from the halo rows of p it holds -- the owner's own expression for those rows, so the halo and every iterate must
+    # have the BITS of the form that exchanges p'
+    def plain_cg(form, iters=12):
+        r = g.copy()
+        pd = -r
+        sacc = np.zeros_like(r)
+        halo = prob.halo_of(pd)
+        rr = float(allreduce(np.array([np.sum(r * r)]))[0])
+        halos = []
+        for _ in range(iters):
+            Hp = prob.hess_with_halo(pd, halo)
+            alpha = rr / float(allreduce(np.array([np.sum(pd * Hp)]))[0])
+            sacc = sacc + alpha * pd
+            r = r + alpha * Hp
+            rr_new = float(allreduce(np.array([np.sum(r * r)]))[0])
+            beta = rr_new / rr
+            rr = rr_new
+            p_new = -r + beta * pd
+            halo = prob.halo_of(p_new) if form == "plain" else -prob.halo_of(r) + beta * halo
+            pd = p_new
+            halos.append(halo.copy())
+        return sacc, halos
+    s_plain, h_plain = plain_cg("plain")
+    s_rp, h_rp = plain_cg("rprime")
+    rprime_same = bool(np.array_equal(s_plain, s_rp) and all(np.array_equal(a, b) for a, b in zip(h_plain, h_rp))
+                       and (prob.need_lo + prob.need_hi > 0))
+    every_rp = [None] * world
+    dist.all_gather_object(every_rp, rprime_same)
     # gather the sharded iterates on rank 0
     pieces = [None] * world
     dist.all_gather_object(pieces, (res["s"], res2["s"], prob.need_lo, prob.need_hi, prob.send_lo, prob.send_hi))
@@ -133,6 +172,7 @@ def main():
             it1=res["iterations"], exit1=res["exit_reason"], M1=res["M_norm"], it2=res2["iterations"],
             exit2=res2["exit_reason"], M2=res2["M_norm"], alpha2=res2["trace"]["alpha"].tolist(),
             halo=[list(pp[2:]) for pp in pieces], same_scalars=all(d == dec[0] for d in dec), n_local=n_local,
+            rprime_same=all(every_rp),
             n_glob=n_glob), open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()

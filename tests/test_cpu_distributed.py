@@ -51,6 +51,9 @@ def test_sharded_stpcg_matches_unsharded(oracle, oracle_omp, tmp_path, world):
     o1 = oracle.stpcg_problem(prob, Xb.ravel(), g, 0.05, max_iterations=40, kappa_fgr=1e-6, theta=.5)
     o2 = oracle.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0, trace_cap=64)
     assert d["same_scalars"]                       # every rank saw identical all-reduced scalars
+    # r05: the r'-halo form of the sharded CG (2 dependent collectives per iteration on RCCL instead of 3) has the bits of
+    # the form that exchanges the new direction: halo rows and iterates, 12 iterations, every rank
+    assert d["rprime_same"]
     assert d["it1"] == o1["iterations"] and d["exit1"] == o1["exit_reason"]
     assert d["it2"] == o2["iterations"] and d["exit2"] == o2["exit_reason"]
     # Iteration counts and exit branches agree exactly.  The iterates: 1e-10 relative, or the conditioning floor of
