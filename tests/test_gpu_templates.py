@@ -360,6 +360,39 @@ def test_tnt_stiefel_device_medium_vs_oracle(harness, oracle, oracle_omp):
     oracle.free(oprob)
 
 
+@pytest.mark.parametrize("p", [5, 8])
+def test_tnt_stiefel_wide_rows_device_vs_oracle(harness, oracle, oracle_omp, p):
+    """r05: the whole drop-in TNT (fused inner solves through the wide-row one-pass Hessian, fused trial steps, deferred
+    results) on St(n, p) for p = 5 and 8 against the CPU oracle's run on the same arrays: counts, accept sequence,
+    traces, final iterate at max(1e-10, 3 x the conditioning floor)."""
+    nx, ny, nz = 30, 28, 26
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = wl.random_stiefel(n, p, seed=17 + p)
+    prm = oracle.default_params(gradient_tolerance=1e-6, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=10,
+                                max_TPCG_iterations=40)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    o = oracle.tnt(oprob, X0.ravel(), prm)
+    r = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 0)
+    assert r["rc"] == 0, r.get("err")
+    assert r["outer_iterations"] == o["outer_iterations"]
+    assert list(r["inner_iterations"]) == list(o["inner_iterations"])
+    assert r["accepted"] == o["accepted"]
+    assert np.allclose(r["objective_values"], o["objective_values"], rtol=1e-11)
+    assert np.allclose(r["gradient_norms"], o["gradient_norms"], rtol=1e-7, atol=1e-12)
+    ex, floor = rel_err(r["x"], o["x"]), None
+    if oracle_omp is not None:
+        op = oracle_omp.stiefel_rq(n, p, rowptr, col, val)
+        floor = rel_err(oracle_omp.tnt(op, X0.ravel(), prm)["x"], o["x"])
+        oracle_omp.free(op)
+    print(f"tnt stiefel p = {p}: iterate error {ex:.2e}, re-associated reference {floor}")
+    assert ex <= floor_or(1e-10, floor)
+    X = r["x"].reshape(n, p)
+    assert np.abs(X.T @ X - np.eye(p)).max() < 1e-12
+    oracle.free(oprob)
+
+
 # ----------------------------------------------------------------------------------------------
 # LSQR and TNLS on DeviceVector (generic loops of the drop-in headers through the Vector concept)
 # ----------------------------------------------------------------------------------------------
