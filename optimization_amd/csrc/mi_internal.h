@@ -444,6 +444,41 @@ __device__ __forceinline__ void reduce_rows(const double *__restrict__ partials,
                                             double (&out)[K], double *lds) {
   reduce_rows<K>(partials, count, out, lds, [] {});
 }
+// The same for a workgroup of NW waves (r05: the 256-thread kernels of Stiefel rows wider than 4 doubles): wave w sums
+// components w, w + NW, ... in rounds; a lane's rows in row order, then the wave reduction.  lds: >= K doubles.
+template <int K, int NW>
+__device__ __forceinline__ void reduce_rows_nw(const double *__restrict__ partials, int count, double (&out)[K],
+                                               double *lds) {
+  if constexpr (NW == kWaves) {
+    reduce_rows<K>(partials, count, out, lds);
+  } else {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = w; c < K; c += NW) {
+      const double *src = partials + (size_t)c * kMaxRows;
+      double t[kMaxRows / 64];
+#pragma unroll
+      for (int j = 0; j < kMaxRows / 64; ++j) {
+        const int r = lane + 64 * j;
+        t[j] = (r < count) ? src[r] : 0.0;
+      }
+      double a = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxRows / 64; ++j) a += t[j];
+      a = wave_reduce_sum(a);
+      if (lane == 0) lds[c] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = lds[k];
+    __syncthreads();
+  }
+}
+// block_partials_store for a workgroup of NW waves (NW == 16: the 1024-thread form, same bits as ever)
+template <int K, int NW>
+__device__ __forceinline__ void block_partials_store_w(const double (&acc)[K], double *lds, double *__restrict__ partials) {
+  if constexpr (NW == kWaves) block_partials_store<K>(acc, lds, partials);
+  else block_partials_store_nw<K, NW>(acc, lds, partials);
+}
 
 // XCD-aware workgroup remap (guide T1): consecutive logical tiles land on the same XCD so that a
 // contiguous row range shares one L2.  Bijective for any grid size.

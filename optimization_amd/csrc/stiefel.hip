@@ -29,6 +29,24 @@ namespace {
 
 enum { POST_SYM = 1, POST_INVSQRT = 2 };
 
+// (a scheduling fence behind every column of the three P x P products: without it the scheduler issues all 192 LDS
+// reads of a row up front -- 128 more live doubles -- and the kernel loses its second wave per SIMD)
+#ifndef MI_WIDE_NO_SCHED
+#define MI_WIDE_SCHED() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MI_WIDE_SCHED()
+#endif
+#ifndef MI_WIDE_CHUNK
+#define MI_WIDE_CHUNK 2
+#endif
+#ifndef MI_WIDE_CHUNK_FROM
+#define MI_WIDE_CHUNK_FROM 7   // rows of >= this many doubles gather in chunks of MI_WIDE_CHUNK entries
+#endif
+#ifndef MI_WIDE_WAVES
+#define MI_WIDE_WAVES 2        // waves per SIMD the kernel is held to (measured: 3 -- 168 registers, p <= 7 -- is 3-6 % slower)
+#endif
+
+
 // ---- small dense helpers (device) --------------------------------------------------------
 template <int P>
 __device__ void dev_sym_invsqrt(const double *G, double *out) {
@@ -71,6 +89,63 @@ __device__ void dev_sym_invsqrt(const double *G, double *out) {
       for (int k = 0; k < P; ++k) acc += Q[i * P + k] * (1.0 / sqrt(M[k * P + k])) * Q[j * P + k];
       out[i * P + j] = acc;
     }
+}
+
+// G^-1/2 for rows wider than 4 doubles (r05), by ONE WAVE with the matrices in LDS: the coupled Newton-Schulz iteration
+//     Y0 = G / s, Z0 = I;  T = Z Y;  Y <- Y (3 I - T) / 2,  Z <- (3 I - T) Z / 2;   Z -> (G / s)^-1/2,  s = |G|_F
+// (eigenvalues of G / s lie in (0, 1], so |I - G / s| < 1: it converges for every SPD G, quadratically; the polar
+// retraction's G = (X + V)'(X + V) = I + V'V for a tangent V has its spectrum in [1, s]: log2(s) + ~6 iterations).
+// Three 8 x 8 matrix products per iteration, lane (i, j) one entry each: ~1 us per iteration.  dev_sym_invsqrt's
+// cyclic Jacobi is strictly serial -- ~300 rotations with three dependent divisions / square roots each, M and Q in
+// scratch memory at P = 8: the retraction took 1.7 ms at n = 1e6; as a wave-parallel Jacobi in LDS still 0.65 ms -- and
+// stays the p <= 4 path (same rotations as the oracle's).  Here the result agrees with it to rounding (tested at 1e-13).
+// T, Y, Z: P x P doubles of LDS each (work[0 .. 3 P P)); out may be LDS.  All 64 lanes of the calling wave call it.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int P>
+__device__ void dev_sym_invsqrt_wave(const double *G, double *work, double *out) {
+  double *T = work, *Y = work + P * P, *Z = work + 2 * P * P;
+  const int l = threadIdx.x & 63, i = (l < P * P ? l : 0) / P, j = (l < P * P ? l : 0) % P;
+  const bool mine = l < P * P;
+  double s2 = 0;
+  for (int k = 0; k < P * P; ++k) s2 += G[k] * G[k];
+  const double sc = sqrt(s2);
+  if (mine) {
+    Y[l] = G[l] / sc;
+    Z[l] = (i == j) ? 1.0 : 0.0;
+  }
+  wave_lds_sync();
+  bool last = false;
+  for (int it = 0; it < 100; ++it) {
+    double t = 0;
+    for (int k = 0; k < P; ++k) t += Z[i * P + k] * Y[k * P + j];
+    if (mine) T[l] = t;
+    wave_lds_sync();
+    double err = 0;  // |Z Y - I|_F^2, the same number in every lane
+    for (int k = 0; k < P * P; ++k) {
+      const double d = T[k] - ((k / P == k % P) ? 1.0 : 0.0);
+      err += d * d;
+    }
+    double yn = 0, zn = 0;
+    for (int k = 0; k < P; ++k) {
+      const double rkj = ((k == j) ? 3.0 : 0.0) - T[k * P + j], rik = ((i == k) ? 3.0 : 0.0) - T[i * P + k];
+      yn += Y[i * P + k] * rkj;
+      zn += rik * Z[k * P + j];
+    }
+    wave_lds_sync();
+    if (mine) {
+      Y[l] = .5 * yn;
+      Z[l] = .5 * zn;
+    }
+    wave_lds_sync();
+    if (last) break;
+    if (!(err > 1e-26)) last = true;  // (converged to ~1e-13: one more quadratic step finishes it; NaN ends it too)
+  }
+  if (mine) out[l] = Z[l] / sqrt(sc);
+  wave_lds_sync();
 }
 
 // ---- kernels -----------------------------------------------------------------------------
@@ -128,25 +203,31 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram(SellView A, const CgSta
 // V (mi_op::dirgram).  So no second pass over Z, X, V is needed (k_st_finish: 8 (4N) bytes saved).
 // k_st_spmm_gram on the lean pipelined core (packed matrix when there is one); same arithmetic per row
 template <int P, bool HALO, bool PK>
-__global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, const CgState *__restrict__ st,
+__global__ __launch_bounds__(StBlk<P>::threads) void k_st_spmm_gram_stream(SellView A, const CgState *__restrict__ st,
                                                                 const double *__restrict__ V,
                                                                 const double *__restrict__ X,
                                                                 const double *__restrict__ S,
                                                                 double *__restrict__ Z,
                                                                 double *__restrict__ partials) {
-  __shared__ double lds[SymIdx<P>::NS * kWaves];
+  constexpr int NW = StBlk<P>::waves;
+  constexpr bool WIDE = P > 4;  // (rows wider than 4 doubles: 256-thread workgroups, S in LDS: stiefel_core.h StBlk)
+  __shared__ double lds[SymIdx<P>::NS * NW];
   __shared__ double vt[PK ? 256 : 1];
+  __shared__ double SmL[WIDE ? P * P : 1];
   if (st && st->mode != CG_RUN) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (PK) {
     if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
-    __syncthreads();
   }
+  if (WIDE && threadIdx.x < P * P) SmL[threadIdx.x] = S ? S[threadIdx.x] : 0.0;
+  if (PK || WIDE) __syncthreads();
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
   const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
-  double Sm[P * P];
+  double SmR[WIDE ? 1 : P * P];
+  if (!WIDE) {
 #pragma unroll
-  for (int i = 0; i < P * P; ++i) Sm[i] = S ? S[i] : 0.0;
+    for (int i = 0; i < P * P; ++i) SmR[i] = S ? S[i] : 0.0;
+  }
   double G[P * P];
 #pragma unroll
   for (int i = 0; i < P * P; ++i) G[i] = 0;
@@ -154,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
     const SellView &A;
     const double *__restrict__ X, *__restrict__ V;
     double *__restrict__ Z;
-    const double (&Sm)[P * P];
+    const double (&SmR)[WIDE ? 1 : P * P];  // S in registers (p <= 4) ...
+    const double *SmL;                      // ... or in LDS
     double (&G)[P * P];
     int lane;
     double x[P], v[P];
@@ -170,22 +252,25 @@ __global__ __launch_bounds__(kBlock) void k_st_spmm_gram_stream(SellView A, cons
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
       if (slice * 64 + lane >= A.n) return;
+      if (WIDE) asm volatile("" ::: "memory");  // (S is re-read from LDS per row, not parked in 64 registers)
       double *zs = reinterpret_cast<double *>(reinterpret_cast<char *>(Z + slice * 64 * P) + lane_off(slice));
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
 #pragma unroll
-        for (int a = 0; a < P; ++a) t += v[a] * Sm[a * P + b];
+        for (int a = 0; a < P; ++a) t += v[a] * (WIDE ? SmL[a * P + b] : SmR[WIDE ? 0 : a * P + b]);
         acc[b] -= t;
         zs[b] = acc[b];
+        if (WIDE) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int a = 0; a < P; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * acc[b];
     }
-  } epi{A, X, V, Z, Sm, G, lane, {}, {}};
-  sell_stream<P, HALO, PK>(A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
+  } epi{A, X, V, Z, SmR, SmL, G, lane, {}, {}};
+  sell_stream<P, HALO, PK, Epi, NW, (P >= MI_WIDE_CHUNK_FROM ? MI_WIDE_CHUNK : MI_SPMM_CHUNK)>(
+      A, s0 + (size_t)__builtin_amdgcn_readfirstlane(w), s1, lane, V, vt, epi);
   store_sym_partials<P>(G, lds, partials);
 }
 
@@ -398,22 +483,6 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
 // registers a 1024-thread workgroup leaves a wave), S and M in LDS (every lane reads the same address: broadcast reads,
 // no bank conflicts) instead of 2 x 64 replicated registers, up to kMaxRows partial rows.
 constexpr int kWideBlock = 256, kWideWaves = kWideBlock / 64;
-// (a scheduling fence behind every column of the three P x P products: without it the scheduler issues all 192 LDS
-// reads of a row up front -- 128 more live doubles -- and the kernel loses its second wave per SIMD)
-#ifndef MI_WIDE_NO_SCHED
-#define MI_WIDE_SCHED() __builtin_amdgcn_sched_barrier(0)
-#else
-#define MI_WIDE_SCHED()
-#endif
-#ifndef MI_WIDE_CHUNK
-#define MI_WIDE_CHUNK 2
-#endif
-#ifndef MI_WIDE_CHUNK_FROM
-#define MI_WIDE_CHUNK_FROM 7   // rows of >= this many doubles gather in chunks of MI_WIDE_CHUNK entries
-#endif
-#ifndef MI_WIDE_WAVES
-#define MI_WIDE_WAVES 2        // waves per SIMD the kernel is held to (measured: 3 -- 168 registers, p <= 7 -- is 3-6 % slower)
-#endif
 template <int P>
 struct WideWaves {
   static constexpr int value = P <= 7 ? MI_WIDE_WAVES : 2;
@@ -517,17 +586,18 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 //           2: Z' = dinv_rows .* Z written to out, gram(X,Z')
 //   SYM: symmetrised partials (P(P+1)/2 components) else raw (P*P components)
 template <int P, int VARIANT, bool SYM>
-__global__ __launch_bounds__(kBlock) void k_st_gram(size_t n, const double *__restrict__ X,
+__global__ __launch_bounds__(StBlk<P>::threads) void k_st_gram(size_t n, const double *__restrict__ X,
                                                     const double *__restrict__ Zin,
                                                     const double *__restrict__ dinv,
                                                     double *__restrict__ out,
                                                     double *__restrict__ partials) {
-  __shared__ double lds[P * P * kWaves];
+  constexpr int BLK = StBlk<P>::threads, NW = StBlk<P>::waves;
+  __shared__ double lds[P * P * NW];
   double G[P * P];
 #pragma unroll
   for (int i = 0; i < P * P; ++i) G[i] = 0;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
+  const size_t stride = (size_t)gridDim.x * BLK;
+  for (size_t row = (size_t)blockIdx.x * BLK + threadIdx.x; row < n; row += stride) {
     double x[P], z[P];
 #pragma unroll
     for (int c = 0; c < P; ++c) { x[c] = X[row * P + c]; z[c] = Zin[row * P + c]; }
@@ -545,13 +615,13 @@ __global__ __launch_bounds__(kBlock) void k_st_gram(size_t n, const double *__re
       for (int b = 0; b < P; ++b) G[a * P + b] += x[a] * z[b];
   }
   if (SYM) store_sym_partials<P>(G, lds, partials);
-  else block_partials_store<P * P>(G, lds, partials);
+  else block_partials_store_w<P * P, NW>(G, lds, partials);
 }
 
 // prologue: M = sym Gram (re-reduced by every workgroup, or read from all-reduced slots);
 // body: out = Z - X M;  DOTS: partial rows of <Vin,out>, <out,out>, <Vin,Vin>;  M_out (nullable): M
 template <int P, bool DOTS, bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *__restrict__ st,
+__global__ __launch_bounds__(StBlk<P>::threads) void k_st_finish(size_t n, const CgState *__restrict__ st,
                                                       const double *__restrict__ X,
                                                       const double *__restrict__ Z,
                                                       const double *__restrict__ Vin,
@@ -560,10 +630,13 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
                                                       double *__restrict__ M_out,
                                                       double *__restrict__ out,
                                                       double *__restrict__ partials) {
+  constexpr int BLK = StBlk<P>::threads, NW = StBlk<P>::waves;
+  constexpr bool WIDE = P > 4;  // (256-thread workgroups, M in LDS: stiefel_core.h StBlk)
   __shared__ double lds[SymIdx<P>::NS * (kWaves + 1) + 3 * kWaves];
+  __shared__ double MmL[WIDE ? P * P : 1];
   if (st && st->mode != CG_RUN) return;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  const size_t row0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * BLK;
+  const size_t row0 = (size_t)blockIdx.x * BLK + threadIdx.x;
   // prefetch the first grid-stride step before the prologue's reduction (hides its latency)
   double x[P], z[P], vi[P];
 #pragma unroll
@@ -582,6 +655,13 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
 #pragma unroll
     for (int i = 0; i < P * P; ++i) M_out[i] = Mm[i];
   }
+  if (WIDE) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < P * P; ++i) MmL[i] = Mm[i];
+    }
+    __syncthreads();
+  }
   double a[3] = {0, 0, 0};
   for (size_t row = row0; row < n;) {
     const size_t rnext = row + stride;
@@ -596,46 +676,63 @@ __global__ __launch_bounds__(kBlock) void k_st_finish(size_t n, const CgState *_
         if (DOTS) vn[c] = Vin[rnext * P + c];
       }
     }
+    if (WIDE) asm volatile("" ::: "memory");  // (M is re-read from LDS per row, not parked in 64 registers)
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       double t = 0;
 #pragma unroll
-      for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
+      for (int aa = 0; aa < P; ++aa) t += x[aa] * (WIDE ? MmL[aa * P + b] : Mm[aa * P + b]);
       const double o = z[b] - t;
       out[row * P + b] = o;
       if (DOTS) { a[0] += vi[b] * o; a[1] += o * o; a[2] += vi[b] * vi[b]; }
+      if (WIDE) MI_WIDE_SCHED();
     }
     row = rnext;
 #pragma unroll
     for (int c = 0; c < P; ++c) { x[c] = xn[c]; z[c] = zn[c]; vi[c] = vn[c]; }
   }
-  if (DOTS) block_partials_store<3>(a, lds, partials);
+  if (DOTS) block_partials_store_w<3, NW>(a, lds, partials);
 }
 
 // retraction finish: Y <- Y (Y'Y)^-1/2, the P x P inverse square root computed once per workgroup
 template <int P, bool FROM_SLOTS>
-__global__ __launch_bounds__(kBlock) void k_st_polar(size_t n, double *__restrict__ Y,
+__global__ __launch_bounds__(StBlk<P>::threads) void k_st_polar(size_t n, double *__restrict__ Y,
                                                      const double *__restrict__ gram_partials, int count,
                                                      const double *__restrict__ slots) {
+  constexpr int BLK = StBlk<P>::threads;
+  constexpr bool WIDE = P > 4;
   __shared__ double lds[SymIdx<P>::NS * (kWaves + 1)];
   __shared__ double Minv[P * P];
+  __shared__ double jac[WIDE ? 4 * P * P : 1];  // WIDE: the Gram and the three work matrices of dev_sym_invsqrt_wave
   double G[P * P];
   load_sym<P, FROM_SLOTS>(gram_partials, count, slots, G, lds);
-  if (threadIdx.x == 0) dev_sym_invsqrt<P>(G, Minv);
-  __syncthreads();
-  double Mm[P * P];
+  if (WIDE) {
+    if (threadIdx.x == 0) {
 #pragma unroll
-  for (int i = 0; i < P * P; ++i) Mm[i] = Minv[i];
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += stride) {
+      for (int i = 0; i < P * P; ++i) jac[i] = G[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) dev_sym_invsqrt_wave<P>(jac, jac + P * P, Minv);
+  } else {
+    if (threadIdx.x == 0) dev_sym_invsqrt<P>(G, Minv);
+  }
+  __syncthreads();
+  double Mm[WIDE ? 1 : P * P];
+  if (!WIDE) {
+#pragma unroll
+    for (int i = 0; i < P * P; ++i) Mm[i] = Minv[i];
+  }
+  const size_t stride = (size_t)gridDim.x * BLK;
+  for (size_t row = (size_t)blockIdx.x * BLK + threadIdx.x; row < n; row += stride) {
     double y[P];
 #pragma unroll
     for (int c = 0; c < P; ++c) y[c] = Y[row * P + c];
+    if (WIDE) asm volatile("" ::: "memory");
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       double t = 0;
 #pragma unroll
-      for (int a = 0; a < P; ++a) t += y[a] * Mm[a * P + b];
+      for (int a = 0; a < P; ++a) t += y[a] * (WIDE ? Minv[a * P + b] : Mm[WIDE ? 0 : a * P + b]);
       Y[row * P + b] = t;
     }
   }
@@ -666,6 +763,13 @@ __global__ __launch_bounds__(kBlock) void k_st_polar(size_t n, double *__restric
   }
 
 inline int row_grid(const mi_ctx *ctx, size_t n) { return grid_for(ctx, n, 2); }
+// rows wider than 4 doubles run 256-thread workgroups (StBlk): up to kMaxRows of them (one partial row each)
+inline int row_grid(const mi_ctx *ctx, size_t n, int p) {
+  if (p <= 4 || ctx->uniform_grid) return row_grid(ctx, n);
+  size_t blocks = std::max<size_t>(1, (n + 511) / 512);
+  blocks = std::min<size_t>(blocks, std::min<size_t>(kMaxRows, 2 * (size_t)ctx->max_grid));
+  return (int)blocks;
+}
 inline int nsym(int p) { return p * (p + 1) / 2; }
 
 // sharded only: partial rows -> slots -> all-reduce
@@ -681,17 +785,21 @@ int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, con
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_SPMM_GRAM);
   const bool no_stream = ctx->cfg.no_spmm_stream;
-  if (!no_stream && sell_stream_ok(A, p)) {
+  // (rows wider than 4 doubles exist in the pipelined form only: 256-thread workgroups, stiefel_core.h StBlk)
+  MI_REQUIRE(p <= 4 || sell_stream_ok(A, p), "Stiefel rows of %d doubles need fields below 4 GiB", p);
+  if ((!no_stream || p > 4) && sell_stream_ok(A, p)) {
     if (!ctx->uniform_grid && grid > 256) grid = 256;  // one workgroup per CU, one round
+    if (p > 4 && !ctx->uniform_grid)                   // 256-thread workgroups: two per CU
+      grid = (int)std::max<size_t>(1, std::min<size_t>((A->nslices + 3) / 4, std::min<size_t>(2 * (size_t)ctx->num_cu, 2 * (size_t)ctx->max_grid)));
 #define SG(HL, PKV)                                                                                            \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_spmm_gram_stream<P, HL, PKV>), dim3(grid), dim3(kBlock), 0, ctx->stream, \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_spmm_gram_stream<P, HL, PKV>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, \
                                    view, st, V, X, S, Z, ctx->partials2))
     if (A->halo) { if (A->pk) { SG(true, true); } else { SG(true, false); } }
     else { if (A->pk) { SG(false, true); } else { SG(false, false); } }
 #undef SG
   } else {
-    DISPATCH_P(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
-                                     X, S, Z, ctx->partials2));
+    DISPATCH_P4(p, hipLaunchKernelGGL(k_st_spmm_gram<P>, dim3(grid), dim3(kBlock), 0, ctx->stream, view, st, V,
+                                      X, S, Z, ctx->partials2));
   }
   *count = grid;
   return MI_OK;
@@ -700,7 +808,7 @@ int launch_spmm_gram(mi_ctx *ctx, const mi_csr *A, int p, const CgState *st, con
 // out = Z - X sym(Gram) where the symmetrised Gram partial rows are in ctx->partials2
 int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double *X, const double *Z,
                   const double *Vin, int count, double *M_out, double *out, bool dots, int *nparts) {
-  const int grid = row_grid(ctx, n);
+  const int grid = row_grid(ctx, n, p);
   double *slots = ctx->scalars + SLOT_GRAM;
   // several ranks: all-reduce the Gram partial rows themselves and keep the prologue re-reduction
   // (no one-workgroup reduce kernel); the slot variant stays reachable through MI355OPT_FORCE_SLOT_PATH
@@ -709,7 +817,7 @@ int launch_finish(mi_ctx *ctx, size_t n, int p, const CgState *st, const double 
   if (sharded) MI_TRY(sharded_reduce(ctx, count, nsym(p), slots));
   KScope ks(ctx, MI_K_STIEFEL_FINISH_DOTS);
 #define FIN(D, F)                                                                                       \
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, D, F>), dim3(grid), dim3(kBlock), 0, ctx->stream, n, st, \
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_finish<P, D, F>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n, st, \
                                    X, Z, Vin, (const double *)ctx->partials2, count,                    \
                                    (const double *)slots, M_out, out, ctx->partials))
   if (dots) {
@@ -981,9 +1089,9 @@ int rq_precon_apply(mi_precon *self, const mi_vec *r, mi_vec *v) {
   RqPreconImpl *im = (RqPreconImpl *)self->impl;
   mi_stiefel_rq *q = im->q;
   mi_ctx *ctx = q->ctx;
-  const int grid = row_grid(q->ctx, q->n);
   const int p = q->p;
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, q->n,
+  const int grid = row_grid(q->ctx, q->n, p);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 2, true>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, q->n,
                                    (const double *)im->X->d, (const double *)r->d,
                                    (const double *)im->dinv->d, q->Z->d, ctx->partials2));
   return launch_finish(ctx, q->n, q->p, nullptr, im->X->d, q->Z->d, nullptr, grid, nullptr, v->d, false,
@@ -1006,8 +1114,8 @@ __attribute__((visibility("default"))) int mi_debug_stamp_buffer(void *dev_ptr) 
 int mi_stiefel_gram(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_vec *Z, double *G_host) {
   MI_TRY(check_np(ctx, n, p, X, Z, nullptr));
   MI_REQUIRE(X && Z && G_host, "null argument");
-  const int grid = row_grid(ctx, n);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+  const int grid = row_grid(ctx, n, p);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, false>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
   double *slots = ctx->scalars + SLOT_RAW;
@@ -1019,8 +1127,8 @@ int mi_stiefel_project(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
   MI_TRY(check_np(ctx, n, p, X, Z, out));
   MI_REQUIRE(X && Z && out, "null argument");
   touch(out);
-  const int grid = row_grid(ctx, n);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+  const int grid = row_grid(ctx, n, p);
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 0, true>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)Z->d, (const double *)nullptr,
                                    (double *)nullptr, ctx->partials2));
   return launch_finish(ctx, n, p, nullptr, X->d, Z->d, nullptr, grid, nullptr, out->d, false, nullptr);
@@ -1030,18 +1138,18 @@ int mi_stiefel_retract(mi_ctx *ctx, size_t n, int p, const mi_vec *X, const mi_v
   MI_TRY(check_np(ctx, n, p, X, V, Y));
   MI_REQUIRE(X && V && Y, "null argument");
   touch(Y);
-  const int grid = row_grid(ctx, n);
+  const int grid = row_grid(ctx, n, p);
   KScope ks(ctx, MI_K_STIEFEL_RETRACT);
-  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+  DISPATCH_P(p, hipLaunchKernelGGL((k_st_gram<P, 1, true>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n,
                                    (const double *)X->d, (const double *)V->d, (const double *)nullptr,
                                    Y->d, ctx->partials2));
   double *slots = ctx->scalars + SLOT_GRAM;
   if (ctx->comm != nullptr || ctx->force_slot_path) {
     MI_TRY(sharded_reduce(ctx, grid, nsym(p), slots));
-    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, true>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n,
                                      Y->d, (const double *)ctx->partials2, grid, (const double *)slots));
   } else {
-    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, n,
+    DISPATCH_P(p, hipLaunchKernelGGL((k_st_polar<P, false>), dim3(grid), dim3(StBlk<P>::threads), 0, ctx->stream, n,
                                      Y->d, (const double *)ctx->partials2, grid, (const double *)slots));
   }
   MI_HIP(hipGetLastError());

@@ -23,6 +23,16 @@ struct DirComps {
 };
 inline int dir_comps(int p) { return p == 1 ? 4 : p == 2 ? 6 : p == 3 ? 9 : p == 4 ? 16 : 3 + p * (p + 1) / 2; }
 
+// Workgroup shape of the row-wise Stiefel kernels: rows of up to 4 doubles keep their p x p matrices in registers and run
+// 1024-thread workgroups (128 registers per wave); wider rows (r05) run 256-thread workgroups -- one wave per SIMD, the
+// register file to itself -- with the uniform p x p matrices in LDS.  (As 1024-thread instantiations the p = 8 kernels
+// spilled 130 ... 1500 bytes per lane: the retraction took 1.7 ms at n = 1e6, the model assembly 450 us.)
+template <int P>
+struct StBlk {
+  static constexpr int threads = P > 4 ? 256 : kBlock;
+  static constexpr int waves = threads / 64;
+};
+
 // per-thread raw Gram accumulators -> this workgroup's partial row of the SYMMETRISED Gram
 template <int P>
 __device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], double *lds,
@@ -34,7 +44,7 @@ __device__ __forceinline__ void store_sym_partials(const double (&G)[P * P], dou
 #pragma unroll
     for (int b = a; b < P; ++b)
       Gs[SymIdx<P>::at(a, b)] = (a == b) ? G[a * P + a] : .5 * (G[a * P + b] + G[b * P + a]);
-  block_partials_store<NS>(Gs, lds, partials);
+  block_partials_store_w<NS, StBlk<P>::waves>(Gs, lds, partials);
 }
 
 // every thread: full symmetric P x P matrix M from the reduced rows (or all-reduced slots)
@@ -48,7 +58,7 @@ __device__ __forceinline__ void load_sym(const double *__restrict__ partials, in
 #pragma unroll
     for (int i = 0; i < NS; ++i) s[i] = slots[i];
   } else {
-    reduce_rows<NS>(partials, count, s, lds);
+    reduce_rows_nw<NS, StBlk<P>::waves>(partials, count, s, lds);
   }
 #pragma unroll
   for (int a = 0; a < P; ++a)

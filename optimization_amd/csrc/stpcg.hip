@@ -483,22 +483,35 @@ __global__ __launch_bounds__(kBlock) void k_cg_step2(size_t n, CgConst cc, const
 }
 
 // partial rows of sym(Y'p - (X'p) S) for the FIRST direction (p = -v, :256); later ones come from k_cg_pupdate
+// (rows wider than 4 doubles, r05: 256-thread workgroups and S in LDS -- stiefel_core.h StBlk; as 1024-thread
+// instantiations these two kernels spilled 250 ... 350 bytes per lane at p = 8)
 template <int SP>
-__global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const double *__restrict__ p, DirGramArgs dg) {
-  __shared__ double lds[SymIdx<SP>::NS * kWaves];
-  double Sm[SP * SP], G[SP * SP];
+__global__ __launch_bounds__(StBlk<SP>::threads) void k_cg_dirgram(size_t nrows, const double *__restrict__ p, DirGramArgs dg) {
+  constexpr int BLK = StBlk<SP>::threads, NW = StBlk<SP>::waves;
+  constexpr bool WIDE = SP > 4;
+  __shared__ double lds[SymIdx<SP>::NS * NW];
+  __shared__ double SmL[WIDE ? SP * SP : 1];
+  double Sm[WIDE ? 1 : SP * SP], G[SP * SP];
 #pragma unroll
-  for (int i = 0; i < SP * SP; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+  for (int i = 0; i < SP * SP; ++i) G[i] = 0;
+  if (WIDE) {
+    if (threadIdx.x < SP * SP) SmL[threadIdx.x] = dg.S[threadIdx.x];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < SP * SP; ++i) Sm[WIDE ? 0 : i] = dg.S[i];
+  }
+  const size_t stride = (size_t)gridDim.x * BLK;
+  for (size_t row = (size_t)blockIdx.x * BLK + threadIdx.x; row < nrows; row += stride) {
     double x[SP], y[SP], pv[SP];
 #pragma unroll
     for (int c = 0; c < SP; ++c) { x[c] = dg.X[row * SP + c]; y[c] = dg.Y[row * SP + c]; pv[c] = p[row * SP + c]; }
+    if (WIDE) asm volatile("" ::: "memory");
 #pragma unroll
     for (int b = 0; b < SP; ++b) {
       double t = 0;
 #pragma unroll
-      for (int a = 0; a < SP; ++a) t += pv[a] * Sm[a * SP + b];
+      for (int a = 0; a < SP; ++a) t += pv[a] * (WIDE ? SmL[a * SP + b] : Sm[WIDE ? 0 : a * SP + b]);
 #pragma unroll
       for (int a = 0; a < SP; ++a) G[a * SP + b] += y[a] * pv[b] - x[a] * t;
     }
@@ -511,17 +524,27 @@ __global__ __launch_bounds__(kBlock) void k_cg_dirgram(size_t nrows, const doubl
 // kernels at cfg2).  Row r of every field belongs to the thread k_cg_dirgram gives it, so the Gram rows have its bits;
 // the partial rows of <r,v> group their terms by rows instead of by pairs of elements.
 template <int SP>
-__global__ __launch_bounds__(kBlock) void k_cg_init_dirgram(size_t nrows, const double *__restrict__ g,
+__global__ __launch_bounds__(StBlk<SP>::threads) void k_cg_init_dirgram(size_t nrows, const double *__restrict__ g,
                                                             double *__restrict__ r, double *__restrict__ p,
                                                             double *__restrict__ s, double *__restrict__ partials,
                                                             DirGramArgs dg) {
-  __shared__ double lds[SymIdx<SP>::NS * kWaves];
-  double Sm[SP * SP], G[SP * SP];
+  constexpr int BLK = StBlk<SP>::threads, NW = StBlk<SP>::waves;
+  constexpr bool WIDE = SP > 4;
+  __shared__ double lds[SymIdx<SP>::NS * NW];
+  __shared__ double SmL[WIDE ? SP * SP : 1];
+  double Sm[WIDE ? 1 : SP * SP], G[SP * SP];
 #pragma unroll
-  for (int i = 0; i < SP * SP; ++i) { Sm[i] = dg.S[i]; G[i] = 0; }
+  for (int i = 0; i < SP * SP; ++i) G[i] = 0;
+  if (WIDE) {
+    if (threadIdx.x < SP * SP) SmL[threadIdx.x] = dg.S[threadIdx.x];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int i = 0; i < SP * SP; ++i) Sm[WIDE ? 0 : i] = dg.S[i];
+  }
   double acc[1] = {0};
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+  const size_t stride = (size_t)gridDim.x * BLK;
+  for (size_t row = (size_t)blockIdx.x * BLK + threadIdx.x; row < nrows; row += stride) {
     double x[SP], y[SP], gv[SP], pv[SP];
 #pragma unroll
     for (int c = 0; c < SP; ++c) { x[c] = dg.X[row * SP + c]; y[c] = dg.Y[row * SP + c]; gv[c] = g[row * SP + c]; }
@@ -533,18 +556,19 @@ __global__ __launch_bounds__(kBlock) void k_cg_init_dirgram(size_t nrows, const 
       p[row * SP + c] = pv[c];
       acc[0] += gv[c] * gv[c];             // <r,v>  (:266)
     }
+    if (WIDE) asm volatile("" ::: "memory");
 #pragma unroll
     for (int b = 0; b < SP; ++b) {
       double t = 0;
 #pragma unroll
-      for (int a = 0; a < SP; ++a) t += pv[a] * Sm[a * SP + b];
+      for (int a = 0; a < SP; ++a) t += pv[a] * (WIDE ? SmL[a * SP + b] : Sm[WIDE ? 0 : a * SP + b]);
 #pragma unroll
       for (int a = 0; a < SP; ++a) G[a * SP + b] += y[a] * pv[b] - x[a] * t;
     }
   }
   store_sym_partials<SP>(G, lds, dg.gpartials);
   __syncthreads();
-  block_partials_store<1>(acc, lds, partials);
+  block_partials_store_w<1, NW>(acc, lds, partials);
 }
 
 // recurrence form: G(p0) from the rows k_cg_dirgram left (or the all-reduced slots); G(r0) = -G(p0) (p0 = -r0)
@@ -765,7 +789,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     KScope ks(ctx, MI_K_CG_INIT);
     const size_t nrows = dgp->n;
 #define INIT_DG(SPV)                                                                                       \
-  hipLaunchKernelGGL(k_cg_init_dirgram<SPV>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)g->d, \
+  hipLaunchKernelGGL(k_cg_init_dirgram<SPV>, dim3(grid), dim3(StBlk<SPV>::threads), 0, st, nrows, (const double *)g->d, \
                      r->d, p->d, s_out->d, ctx->partials_b, dga)
     switch (dgp->p) {
       case 1: INIT_DG(1); break;
@@ -796,10 +820,10 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
         case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
         case 4: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-        case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-        case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-        case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
-        default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(kBlock), 0, st, nrows, (const double *)p->d, dga); break;
+        case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(StBlk<5>::threads), 0, st, nrows, (const double *)p->d, dga); break;
+        case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(StBlk<6>::threads), 0, st, nrows, (const double *)p->d, dga); break;
+        case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(StBlk<7>::threads), 0, st, nrows, (const double *)p->d, dga); break;
+        default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(StBlk<8>::threads), 0, st, nrows, (const double *)p->d, dga); break;
       }
     }
     if (recur && !gdir_in_scalar_init) {
