@@ -538,6 +538,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
       asm volatile("" ::: "memory");
       double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (unsigned)slice * (unsigned)(64 * P * 8) +
                                               lane_off(slice));
+#ifndef MI_WIDE_ABLATE_MATH  // (timing experiment only: wrong results)
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
@@ -546,12 +547,15 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
         acc[b] -= t;  // Z = A V - V S
         MI_WIDE_SCHED();
       }
+#endif
       double o[P];
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
+#ifndef MI_WIDE_ABLATE_MATH
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
+#endif
         o[b] = acc[b] - t;  // Z - X M
         os[b] = o[b];
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
@@ -561,11 +565,14 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
+#ifndef MI_WIDE_ABLATE_MATH
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
+#endif
         os_[b] = t;
         MI_WIDE_SCHED();
       }
+#ifndef MI_WIDE_ABLATE_GRAM
 #pragma unroll
       for (int aa = 0; aa < P; ++aa)
 #pragma unroll
@@ -574,6 +581,9 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
           const double gba = y[b] * o[aa] - x[b] * os_[aa];
           a[3 + SymIdx<P>::at(aa, b)] += (aa == b) ? gab : .5 * (gab + gba);
         }
+#else
+      a[3] += y[0] * os_[0] + x[P - 1];
+#endif
     }
   } epi{A, X, Y, V, out, Sm, Mm, a, lane, {}, {}, {}};
   const int wu = __builtin_amdgcn_readfirstlane(w);
