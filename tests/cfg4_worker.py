@@ -21,7 +21,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out_dir = os.environ["CFG4_WORKER_OUT"]
     nx, ny, nz = (int(v) for v in os.environ.get("CFG4_GRID", "200,200,200").split(","))
-    p = 3
+    p = int(os.environ.get("CFG4_P", "3"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     # All ranks share ONE GPU and the consumer kernels wait for their peers in their prologue; the push a waiter needs
     # comes from workgroup 0 of the SAME kernel of every other rank, so that workgroup must get a slot while the

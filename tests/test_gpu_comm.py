@@ -357,6 +357,36 @@ def test_folded_exchanges_give_the_bits_of_the_exchange_kernels():
         assert o["comm_kernels"][0] >= 2 * it and o["comm_kernels"][1] >= it and o["comm_kernels"][2] == 0, o
 
 
+@pytest.mark.parametrize("p,world", [(6, 2), (8, 3)])
+def test_wide_rows_sharded_on_one_gpu_vs_oracle(oracle, p, world):
+    """r05: Stiefel rows of 6 and 8 doubles on the multi-rank path -- 8-column halo buffers, the wide one-pass Hessian
+    with a halo, 24 / 39 partial components through the generic-width reduce-to-slots kernel and the exchange in padded
+    chunks, `k_cg_update<., FROM_SLOTS, 24 / 39>`, never folded -- over 2 and 3 real processes on GPU 0 against the CPU
+    oracle on the global problem: counts, exit, alpha / beta traces, step to 1e-10; replicated scalars bit-identical."""
+    from optimization_amd import workloads as wl
+    grid = (30, 26, 12 * world + 1)
+    nx, ny, nz = grid
+    n = nx * ny * nz
+    Xb, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=9)
+    outs, s_sh, g_sh = _run_cfg4_workers(world, grid, Xb, extra_env={"CFG4_P": str(p)}, port=29620 + p)
+    assert all(o["enabled"] and o["ipc_error"] == 0 for o in outs), outs
+    for k in ("f", "iters", "exit", "M", "rv", "hvp", "alpha", "beta"):
+        assert all(o[k] == outs[0][k] for o in outs), k
+    assert all(o["one_pass_launches"] >= outs[0]["iters"] for o in outs)      # the wide one-pass Hessian ran
+    assert all(o["comm_kernels"][2] == 0 for o in outs)                       # nothing folded at these widths
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    oprob = oracle.stiefel_rq(n, p, rowptr, col, val)
+    go = oracle.eval_grad(oprob, Xb.ravel())
+    o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
+    oracle.free(oprob)
+    assert (outs[0]["iters"], outs[0]["exit"]) == (o["iterations"], o["exit_reason"])
+    al = np.array([float.fromhex(a) for a in outs[0]["alpha"]])
+    be = np.array([float.fromhex(a) for a in outs[0]["beta"]])
+    assert rel_err(g_sh, go) < 1e-12
+    assert float(np.max(np.abs(al / o["trace"]["alpha"] - 1))) < 1e-9 and float(np.max(np.abs(be / o["trace"]["beta"] - 1))) < 1e-8
+    assert rel_err(s_sh, o["s"]) < 1e-10
+
+
 @pytest.fixture(scope="module")
 def cfg4_oracle(oracle, oracle_omp):
     """The CPU oracle (== the reference's templates bit for bit) on BASELINE cfg4 at FULL size -- St(8e6,3), 200^3 grid, the
