@@ -87,7 +87,8 @@ enum {
  * environment ONCE per context, in mi_ctx_create: MI355OPT_<NAME>=<integer> for NAME in FORCE_SLOT_PATH,
  * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
  * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA,
- * NO_ZERO_COPY, SO3_SORT_NBR (DESIGN.md says what each selects).  A value that is not an integer counts as 1 unless it
+ * NO_ZERO_COPY, NO_GRAM_HALF, NO_UPDATE_PAIR, SO3_NO_QUAT, SO3_SORT_NBR, HALO_RPRIME, TWO_KERNEL_STEP, WIDE_QUAD,
+ * NO_POLLED_SYNC (DESIGN.md / INTEGRATION.md say what each selects).  A value that is not an integer counts as 1 unless it
  * is "no" / "false" / "off"; any other MI355OPT_* variable found in the environment (a removed or misspelt switch)
  * gets one warning on stderr.  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
  * prefix); format switches (NO_PACKED) act when a matrix is created, the communication ones before the layer they

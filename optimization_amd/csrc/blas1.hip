@@ -160,11 +160,33 @@ int dot_batch_to_slots(mi_ctx *ctx, int k, const double *const *x, const double 
   return reduce_rows_allreduce(ctx, ctx->partials_user, grid, k, ctx->scalars + slot0);
 }
 
+// the slots land in the pinned words and the polled flag follows them: no copy engine, no wake-up (stream_wait)
+__global__ void k_slots_to_host(double *host, const double *__restrict__ src, int k, unsigned long long *flag,
+                                unsigned long long seq) {
+  for (int i = threadIdx.x; i < k; i += blockDim.x) host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out) {
-  MI_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + slot0, sizeof(double) * k,
-                        hipMemcpyDeviceToHost, ctx->stream));
-  MI_HIP(hipStreamSynchronize(ctx->stream));
+  unsigned long long *flag = nullptr;
+  double *hdev = nullptr;
+  unsigned long long seq = poll_begin(ctx, &flag);
+  if (seq && hipHostGetDevicePointer((void **)&hdev, ctx->host_scalars, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    seq = 0;
+  }
   ctx->host_syncs++;
+  if (seq) {
+    hipLaunchKernelGGL(k_slots_to_host, dim3(1), dim3(64), 0, ctx->stream, hdev, (const double *)(ctx->scalars + slot0),
+                       k, flag, seq);
+    MI_TRY(poll_finish(ctx, seq, "scalar read-back"));
+  } else {
+    MI_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + slot0, sizeof(double) * k,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    MI_HIP(hipStreamSynchronize(ctx->stream));
+  }
   for (int i = 0; i < k; ++i) out[i] = ctx->host_scalars[i];
   return MI_OK;
 }

@@ -1,5 +1,6 @@
 // context.hip -- context, stream, pooled allocator, event timing, error reporting.
 #include "mi_internal.h"
+#include <chrono>
 #include <cstring>
 #include <strings.h>
 #include <unistd.h>
@@ -42,6 +43,40 @@ int readback_area(mi_ctx *ctx, size_t bytes, void **host, void **dev) {
   *host = ctx->readback_host;
   MI_HIP(hipHostGetDevicePointer(dev, ctx->readback_host, 0));
   return MI_OK;
+}
+__global__ void k_host_flag(unsigned long long *flag, unsigned long long seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// device pointers of the polled word and of a coherent pinned area; 0 if polling is off (or the mapping failed)
+unsigned long long poll_begin(mi_ctx *ctx, unsigned long long **flag_dev) {
+  if (!ctx->poll_flag || ctx->cfg.no_polled_sync) return 0;
+  if (hipHostGetDevicePointer((void **)flag_dev, ctx->poll_flag, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return ++ctx->poll_seq;
+}
+// Poll for `seq` (stored by a kernel the caller enqueued behind the work).  Bounded: a kernel that faulted never
+// stores the flag -- the synchronisation below then reports the error -- and a long queue is better slept on than
+// spun on.
+int poll_finish(mi_ctx *ctx, unsigned long long seq, const char *what) {
+  if (seq && hipGetLastError() == hipSuccess) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+      if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) == seq) return MI_OK;
+      if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+  }
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+  return MI_OK;
+}
+int stream_wait(mi_ctx *ctx, const char *what) {
+  ctx->host_syncs++;
+  unsigned long long *dev = nullptr;
+  const unsigned long long seq = poll_begin(ctx, &dev);
+  if (seq) hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, ctx->stream, dev, seq);
+  return poll_finish(ctx, seq, what);
 }
 int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host) {
   size_t total = 0;
@@ -182,6 +217,7 @@ OPT_BOOL(opt_words16, cfg.words16)
 OPT_BOOL(opt_no_spmm_stream, cfg.no_spmm_stream)
 OPT_BOOL(opt_no_spmm_win, cfg.no_spmm_win)
 OPT_BOOL(opt_no_zero_copy, cfg.no_zero_copy)
+OPT_BOOL(opt_no_polled_sync, cfg.no_polled_sync)
 OPT_BOOL(opt_no_update_mfma, cfg.no_update_mfma)
 OPT_BOOL(opt_halo_rprime, cfg.halo_rprime)
 OPT_BOOL(opt_no_gram_half, cfg.no_gram_half)
@@ -191,6 +227,10 @@ OPT_BOOL(opt_two_kernel_step, cfg.two_kernel_step)
 #undef OPT_BOOL
 int opt_max_grid(mi_ctx *c, long v) {
   c->max_grid = (int)std::min<long>(kMaxGrid, std::max<long>(1, v));
+  return MI_OK;
+}
+int opt_wide_quad(mi_ctx *c, long v) {
+  c->cfg.wide_quad = v < 0 ? -1 : v != 0;
   return MI_OK;
 }
 int opt_so3_sort_nbr(mi_ctx *c, long v) {
@@ -208,7 +248,7 @@ const OptionDesc kOptions[] = {
     {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
-    {"NO_ZERO_COPY", opt_no_zero_copy},
+    {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
 };
 // value of a switch: an integer; anything else that is not empty ("yes", "true", "on" -- and the presence-only
@@ -332,10 +372,13 @@ static int ctx_init(mi_ctx *ctx, int device) {
       return MI_ERR_INTERNAL;
     }
   }
-  MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots, hipHostMallocDefault));
+  MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots,
+                       hipHostMallocMapped | hipHostMallocCoherent));  // (written by k_slots_to_host, blas1.hip)
   MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState) + 16, hipHostMallocDefault)  /* + a preconditioner's failure word */);
   MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
                        hipHostMallocMapped | hipHostMallocCoherent));
+  MI_HIP(hipHostMalloc((void **)&ctx->poll_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  *ctx->poll_flag = 0;
   memset((void *)ctx->status, 0, sizeof(HostStatus));
   MI_HIP(hipHostGetDevicePointer((void **)&ctx->status_dev, (void *)ctx->status, 0));
   config_from_env(ctx);
@@ -381,6 +424,7 @@ int mi_ctx_destroy(mi_ctx *ctx) {
   (void)hipFree(ctx->trace_dev);
   (void)hipHostFree(ctx->host_scalars);
   if (ctx->readback_host) (void)hipHostFree(ctx->readback_host);
+  if (ctx->poll_flag) (void)hipHostFree(ctx->poll_flag);
   if (ctx->cg_deferred_ev) (void)hipEventDestroy(ctx->cg_deferred_ev);
   (void)hipHostFree(ctx->cg_host);
   (void)hipHostFree((void *)ctx->status);

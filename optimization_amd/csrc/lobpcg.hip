@@ -1521,9 +1521,7 @@ static int gram_pair_sym_direct(mi_ctx *ctx, size_t m, int k, const ColBlocks &S
   double *dst[2] = {Ga_host, Gb_host};
   int fin = MI_OK;
   if (zero_copy) {
-    const hipError_t e = hipStreamSynchronize(ctx->stream);
-    ctx->host_syncs++;
-    if (e != hipSuccess) fin = hip_fail(e, "gram read-back", __FILE__, __LINE__);
+    fin = stream_wait(ctx, "gram read-back");
     for (int i = 0; i < 2; ++i) {
       if (fin == MI_OK) memcpy(dst[i], zc_host + (size_t)i * slot, (size_t)nelem * sizeof(double));
       pool_free(ctx, jobs[i].partial);
@@ -1937,10 +1935,8 @@ int mi_csr_spmm_colmajor_residual(const mi_csr *A, int nx, const mi_vec *X, cons
   }
   std::vector<double> out(nsums);
   if (zero_copy) {
-    const hipError_t e = hipStreamSynchronize(ctx->stream);
-    ctx->host_syncs++;
-    if (e != hipSuccess) st = hip_fail(e, "residual norms read-back", __FILE__, __LINE__);
-    else memcpy(out.data(), zc_host, nsums * sizeof(double));
+    st = stream_wait(ctx, "residual norms read-back");
+    if (st == MI_OK) memcpy(out.data(), zc_host, nsums * sizeof(double));
   } else {
     const void *dv[1] = {sums};
     const size_t by[1] = {nsums * sizeof(double)};

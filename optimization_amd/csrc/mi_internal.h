@@ -110,6 +110,9 @@ struct Config {
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
+  int wide_quad = -1;               // WIDE_QUAD: the one-pass Hessian of rows of 5 ... 8 doubles in the quad layout (4 lanes per
+                                    // row): -1 = where it measured faster (p = 8), 0 = never (one lane per row), 1 = always
+  bool no_polled_sync = false;      // NO_POLLED_SYNC: stream_wait is hipStreamSynchronize (no flag kernel + host poll)
   bool two_kernel_step = false;     // TWO_KERNEL_STEP: opt-in experiment (r05): <r+,r+> by recurrence, the two CG kernels of an
                                     // unpreconditioned Stiefel(n,3) iteration merged (changes the rounding of IterativeSolvers.h:408)
   bool no_update_pair = false;      // NO_UPDATE_PAIR: the matrix-pipe panel update in 16-row blocks, 8 bytes per lane (r04 form)
@@ -179,6 +182,10 @@ struct mi_ctx {
   // goes through the runtime's own staging buffers with a blit kernel and an internal wait (15 us per 41 KB Gram)
   void *readback_host = nullptr;
   size_t readback_bytes = 0;
+  // stream_wait (context.hip): a one-thread kernel behind the work stores the next sequence number into this coherent
+  // pinned word and the host polls it -- the wake-up of hipStreamSynchronize costs more than the kernel
+  unsigned long long *poll_flag = nullptr;
+  unsigned long long poll_seq = 0;
   // timing
   mi::KTimer ktime[MI_K_COUNT];
   std::vector<hipEvent_t> event_pool;
@@ -236,6 +243,12 @@ int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *byte
 // of pinned memory, as a host pointer and as the device pointer of the same memory.  One user at a time: whoever asks
 // next may get the same bytes.
 int readback_area(mi_ctx *ctx, size_t bytes, void **host, void **dev);
+// wait until everything enqueued on the context's stream so far has finished (counts as one host synchronisation)
+int stream_wait(mi_ctx *ctx, const char *what);
+// the two halves of stream_wait for a caller whose own last kernel stores the flag: the sequence number to store
+// (0: polling is off) and the device address of the word; then the bounded poll with hipStreamSynchronize behind it
+unsigned long long poll_begin(mi_ctx *ctx, unsigned long long **flag_dev);
+int poll_finish(mi_ctx *ctx, unsigned long long seq, const char *what);
 int ensure_device();
 
 // workgroups for an n-element streaming kernel in which each thread handles `per_thread` elements

@@ -32,8 +32,8 @@ struct IncView {
   const long long *__restrict__ slice_ptr;
   const int *__restrict__ perm;   // node owned by (slice, lane), -1 for the padding lanes of the last window
   const int *__restrict__ nbr;    // neighbour node j (padding: own node)
-  const int *__restrict__ edge;   // edge id (padding: -1)
-  const signed char *__restrict__ dir;  // +1: this node is the head j of e=(i->j), uses Rt; -1: tail, uses Rt'
+  // (padding entries carry weight 0 in winc, which is what the kernels test: the edge ids and the head/tail flags the
+  // packing uses stay on the host, 4 + 1 bytes per incidence entry nobody streams)
 };
 
 __device__ __forceinline__ void mat3_mul(const double *A, const double *B, double *C) {
@@ -104,11 +104,10 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
   const long long b0 = inc.slice_ptr[slice], b1 = inc.slice_ptr[slice + 1];
   for (long long k = b0; k < b1; ++k) {
     const size_t e0 = (size_t)k * 64 + lane;
-    const int eid = inc.edge[e0];
+    const double we = winc[e0];
     double Bk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (live && eid >= 0) {
+    if (live && we != 0) {
       const size_t j = (size_t)inc.nbr[e0];
-      const double we = winc[e0];
       double S[9], Rj[9];
 #pragma unroll
       for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
@@ -310,11 +309,8 @@ int upload(void **dst, const void *src, size_t bytes) {
 struct mi_so3n {
   mi_ctx *ctx = nullptr;
   size_t N = 0, E = 0, nslices = 0, nnzb = 0, padded = 0;
-  int *ei = nullptr, *ej = nullptr;
-  double *Rt = nullptr, *w = nullptr;
   long long *slice_ptr = nullptr;
-  int *perm = nullptr, *nbr = nullptr, *edge = nullptr;
-  signed char *dir = nullptr;
+  int *perm = nullptr, *nbr = nullptr;
   mi_vec *Dinv = nullptr;  // 9N (node order): the inverse diagonal blocks, the block-Jacobi preconditioner
   double *Bblk = nullptr;                   // padded * 9
   double *Sinc = nullptr, *winc = nullptr;  // padded * 9 (or * 4: sinc_quat), padded: per-incidence measurement and weight
@@ -344,7 +340,7 @@ namespace {
 constexpr int kModelComps = 8;
 int model_grid(const mi_so3n *q) { return (int)std::min<size_t>((q->nslices + 3) / 4, (size_t)kModelComps * kMaxRows); }
 IncView view(const mi_so3n *q) {
-  return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr, q->edge, q->dir};
+  return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr};
 }
 // the assembly (model = true) or its objective alone, objective partials into ctx->partials2
 void launch_model(mi_so3n *q, bool model, int grid, const double *R, double *grad, double *Dinv, double *Bblk, double *Dsl) {
@@ -531,16 +527,10 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
   q->nnzb = nnzb;
   q->padded = padded;
   q->sinc_quat = all_rot;
-  MI_TRY(upload((void **)&q->ei, ei, E * sizeof(int)));
-  MI_TRY(upload((void **)&q->ej, ej, E * sizeof(int)));
-  MI_TRY(upload((void **)&q->Rt, Rt, 9 * E * sizeof(double)));
-  MI_TRY(upload((void **)&q->w, w, E * sizeof(double)));
   MI_TRY(upload((void **)&q->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
   MI_TRY(upload((void **)&q->perm, perm.data(), perm.size() * sizeof(int)));
   MI_HIP(hipMalloc((void **)&q->Dsl, nslices * 9 * 64 * sizeof(double)));
   MI_TRY(upload((void **)&q->nbr, nbr.data(), padded * sizeof(int)));
-  MI_TRY(upload((void **)&q->edge, edge.data(), padded * sizeof(int)));
-  MI_TRY(upload((void **)&q->dir, dir.data(), padded * sizeof(signed char)));
   MI_HIP(hipMalloc((void **)&q->Bblk, std::max<size_t>(1, padded * 9) * sizeof(double)));
   MI_TRY(upload((void **)&q->Sinc, sinc.data(), sinc.size() * sizeof(double)));
   MI_TRY(upload((void **)&q->winc, winc.data(), winc.size() * sizeof(double)));
@@ -565,8 +555,7 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
 int mi_so3n_destroy(mi_so3n *q) {
   if (!q) return MI_OK;
   (void)hipStreamSynchronize(q->ctx->stream);
-  (void)hipFree(q->ei); (void)hipFree(q->ej); (void)hipFree(q->Rt); (void)hipFree(q->w);
-  (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr); (void)hipFree(q->edge); (void)hipFree(q->dir);
+  (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr);
   (void)hipFree(q->Bblk); (void)hipFree(q->perm); (void)hipFree(q->Dsl);
   (void)hipFree(q->Sinc); (void)hipFree(q->winc);
   (void)hipFree(q->Bblk_next); (void)hipFree(q->Dsl_next);

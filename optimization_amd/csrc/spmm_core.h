@@ -166,6 +166,9 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const char *base = reinterpret_cast<const char *>(V);
+#ifdef MI_ABLATE_GATHER_OWN  // (timing experiment only: every entry reads the lane's own row -- wrong results)
+      ci[j] = (unsigned)(slice * 64) + (unsigned)lane < nloc ? (unsigned)(slice * 64) + (unsigned)lane : 0u;
+#endif
       unsigned boff = ci[j] * (unsigned)(P * 8);
       if (HALO && ci[j] >= nloc) {
         base = reinterpret_cast<const char *>(A.halo);
@@ -202,6 +205,167 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
     }
     slice = nslice; k = nk; b1 = nb1;
     cur = nxt;
+  }
+}
+
+// ---- quad layout of sell_stream for rows of 5 ... 8 doubles ----------------------------------------------------
+// With one lane per row a 64-byte row makes every 16-byte load of a wave touch 64 different half-lines: measured on
+// St(1e6,8) (profiles/r05_wide_ablation.txt) the L1 then delivers about one LANE per clock -- a pass that only loads
+// the direction's rows eight times, all of them L1 hits, takes 51 us of the wide Hessian's 101.  Here a QUAD of lanes
+// owns a row: lane (g, q) = (lane >> 2, lane & 3) holds columns 2q, 2q + 1 of row 16 t + g of the wave's slice, and
+// the wave goes through its slice in four UNITS t = 0..3 of 16 rows, so a quad reads 64 contiguous bytes and a wave
+// instruction covers 16 whole rows -- consecutive rows (own rows, +-1 neighbours) are one contiguous kilobyte.  The
+// matrix words of a unit are 16 consecutive words of the sliced-ELL chunk (one 64-byte line, each read by the four
+// lanes of its quad).  Columns >= P (P < 8) are loaded from a valid address and never used: the epilogue zeroes them.
+//       epi.begin(slice, t, x, v, y)        issue the loads the epilogue of the unit will need (into x, v, y)
+//       epi.end(slice, t, acc, x, v, y)     consume acc[c] = (A V)(row slice*64 + 16 t + g, column 2 q + c)
+// Same arithmetic per element as sell_stream: product and sum rounded separately, entries in storage order.
+template <int P>
+struct QuadCols {
+  // byte offsets of the lane's two columns inside a row (a column that does not exist re-reads the lane's first,
+  // or column 0 for a lane without columns)
+  __device__ __forceinline__ static unsigned off0(int q) { return (unsigned)((2 * q < P ? 2 * q : 0) * 8); }
+  __device__ __forceinline__ static unsigned off1(int q) { return (unsigned)((2 * q + 1 < P ? 2 * q + 1 : (2 * q < P ? 2 * q : 0)) * 8); }
+  // (one 32-bit byte offset from the field's base -- a scalar -- per access: global_load with saddr, no 64-bit adds)
+  __device__ __forceinline__ static void load(const char *base, unsigned row_off, unsigned o0, unsigned o1, double &d0,
+                                              double &d1) {
+    if constexpr (P % 2 == 0) {  // rows are 16-byte aligned and the two columns adjacent (or both unused)
+      const double2 d = *reinterpret_cast<const double2 *>(base + (row_off + o0));
+      d0 = d.x; d1 = d.y;
+    } else {
+      d0 = *reinterpret_cast<const double *>(base + (row_off + o0));
+      d1 = *reinterpret_cast<const double *>(base + (row_off + o1));
+    }
+  }
+};
+
+// Software pipeline over the wave's CHUNK STEPS (unit by unit, CH entries each; a stencil row is one step at CH = 8):
+// while step s is consumed, the row pieces of step s + 1 (its gathers and the unit's own rows of X, V, Y) and the
+// matrix words of step s + 2 are in flight.  Every step issues the SAME loads in the same order -- own rows too, again
+// for every further chunk of a long row -- because the wait counters are in-order and counted statically: loads behind
+// a branch make the compiler drain the queue where the paths meet (the lane-per-row form does, at every slice
+// boundary, and loses the prefetch of its epilogue's operands there).
+template <int P, bool HALO, bool PK, class Epi, int NW, int CHK>
+__device__ __forceinline__ void sell_stream_quad(const SellView &A, size_t first, size_t end, int lane,
+                                                 const double *__restrict__ V, const double *vt, Epi &epi) {
+  constexpr int CH = CHK;
+  if (first >= end) return;
+  const int q = lane & 3, g = lane >> 2;
+  const unsigned o0 = QuadCols<P>::off0(q), o1 = QuadCols<P>::off1(q);
+  const unsigned nloc = (unsigned)A.n;
+  struct Pos {  // one chunk step: entries [k, k + CH) of unit t of `slice` (whose entries are [k0, b1))
+    size_t slice;
+    int t;
+    long long k, k0, b1;
+    bool valid;
+  };
+  struct Words {
+    double a[PK ? 1 : CH];
+    unsigned c[CH];
+  };
+  struct Step {  // what a step has in flight: its gathered row pieces, the own rows of its unit, its matrix values
+    double gv[CH][2];
+    double x[2], v[2], y[2];
+    Words w;
+  };
+  size_t cand = first + NW;
+  long long q0 = 0, q1 = 0;
+  if (cand < end) { q0 = slice_bound(A.slice_ptr, cand); q1 = slice_bound(A.slice_ptr, cand + 1); }
+  // the step after p; past the last one: the same position again, marked invalid (its loads re-read valid addresses)
+  auto advance = [&](const Pos &p) {
+    Pos n = p;
+    if (!p.valid) return n;
+    if (p.k + CH < p.b1) { n.k = p.k + CH; return n; }
+    if (p.t < 3) { n.t = p.t + 1; n.k = p.k0; return n; }
+    if (cand < end) {
+      n.slice = cand; n.t = 0; n.k0 = n.k = q0; n.b1 = q1;
+      cand += NW;  // (the bounds of the slice after it: requested a whole slice ahead)
+      if (cand < end) { q0 = slice_bound(A.slice_ptr, cand); q1 = slice_bound(A.slice_ptr, cand + 1); }
+      return n;
+    }
+    n.valid = false;
+    return n;
+  };
+  // (entries beyond the slice width re-read the chunk's first entry -- or entry 0 of the matrix for an empty slice --
+  // and are zeroed when the chunk is consumed: sell_stream)
+  auto load_words = [&](Words &o, const Pos &p) {
+    const unsigned r4 = (unsigned)(16 * p.t + g) * 4u, r8 = (unsigned)(16 * p.t + g) * 8u;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const long long kj = (p.k + j < p.b1) ? p.k + j : ((p.k < p.b1) ? p.k : 0);
+      if (PK) {
+        const char *pb = reinterpret_cast<const char *>(A.pk + (size_t)kj * 64);
+        o.c[j] = *reinterpret_cast<const unsigned *>(pb + r4);
+      } else {
+        const char *vb = reinterpret_cast<const char *>(A.val + (size_t)kj * 64);
+        const char *cb = reinterpret_cast<const char *>(A.col + (size_t)kj * 64);
+        o.a[j] = *reinterpret_cast<const double *>(vb + r8);
+        o.c[j] = *reinterpret_cast<const unsigned *>(cb + r4);
+      }
+    }
+  };
+  // the words of step p have arrived in `wd`: issue its gathers and the own rows of its unit into `s`
+  auto issue = [&](Step &s, const Words &wd, const Pos &p) {
+    s.w = wd;
+    const unsigned row = (unsigned)(p.slice * 64) + (unsigned)(16 * p.t + g);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const unsigned ci = PK ? row + (unsigned)((int)wd.c[j] >> 8) : wd.c[j];
+      const char *base = reinterpret_cast<const char *>(V);
+      unsigned boff = ci * (unsigned)(P * 8);
+      if (HALO && ci >= nloc) {
+        base = reinterpret_cast<const char *>(A.halo);
+        boff = (ci - nloc) * (unsigned)(P * 8);
+      }
+      QuadCols<P>::load(base, boff, o0, o1, s.gv[j][0], s.gv[j][1]);
+    }
+    epi.begin(p.slice, p.t, s.x, s.v, s.y);
+  };
+  double acc[2] = {0, 0};
+  auto consume = [&](Step &s, const Pos &p) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const double av = PK ? vt[s.w.c[j] & 255u] : s.w.a[j];
+      const double aj = (p.k + j < p.b1) ? av : 0.0;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma clang fp contract(off)
+        const double pr = aj * s.gv[j][c];
+        acc[c] = acc[c] + pr;
+      }
+    }
+    if (p.k + CH >= p.b1) {  // the unit's last chunk
+      epi.end(p.slice, p.t, acc, s.x, s.v, s.y);
+      acc[0] = acc[1] = 0;
+    }
+  };
+  Pos pc;
+  pc.slice = first; pc.t = 0; pc.valid = true;
+  pc.k0 = pc.k = slice_bound(A.slice_ptr, first);
+  pc.b1 = slice_bound(A.slice_ptr, first + 1);
+  Words wd;
+  Step sa, sb;
+  load_words(wd, pc);
+  issue(sa, wd, pc);
+  Pos pn = advance(pc);
+  load_words(wd, pn);
+  for (;;) {
+    {  // consume sa (step pc) while sb (step pn) and the words of the step after it are in flight
+      issue(sb, wd, pn);
+      const Pos pw = advance(pn);
+      load_words(wd, pw);
+      consume(sa, pc);
+      if (!pn.valid) break;
+      pc = pn; pn = pw;
+    }
+    {
+      issue(sa, wd, pn);
+      const Pos pw = advance(pn);
+      load_words(wd, pw);
+      consume(sb, pc);
+      if (!pn.valid) break;
+      pc = pn; pn = pw;
+    }
   }
 }
 

@@ -42,6 +42,12 @@ enum { POST_SYM = 1, POST_INVSQRT = 2 };
 #ifndef MI_WIDE_CHUNK_FROM
 #define MI_WIDE_CHUNK_FROM 7   // rows of >= this many doubles gather in chunks of MI_WIDE_CHUNK entries
 #endif
+#ifndef MI_WIDE_QUAD_CHUNK
+#define MI_WIDE_QUAD_CHUNK 8   // entries per chunk step of the quad-layout pass (16 bytes per entry and lane)
+#endif
+#ifndef MI_WIDE_QUAD_WAVES
+#define MI_WIDE_QUAD_WAVES 2   // waves per SIMD of the quad-layout pass (<= 168 registers: 3 would fit)
+#endif
 #ifndef MI_WIDE_WAVES
 #define MI_WIDE_WAVES 2        // waves per SIMD the kernel is held to (measured: 3 -- 168 registers, p <= 7 -- is 3-6 % slower)
 #endif
@@ -497,7 +503,9 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
   __shared__ double lds[KC * kWideWaves];
   __shared__ double vt[PK ? 256 : 1];
   __shared__ double Sm[P * P], Mm[P * P];
+#ifndef MI_WIDE_ABLATE_MATH  // (the timing experiments produce wrong iterates: their launches must not turn into no-ops)
   if (st && st->mode != CG_RUN) return;
+#endif
   if constexpr (HALO) halo_wait(hwait.w);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (PK) vt[threadIdx.x] = A.vtab[threadIdx.x];
@@ -530,7 +538,11 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off), *vs = row_of(V, slice, off), *ys = row_of(Y, slice, off);
 #pragma unroll
+#ifdef MI_WIDE_ABLATE_OWN  // (timing experiment only: X and Y rows not read -- wrong results)
+      for (int c = 0; c < P; ++c) { v[c] = vs[c]; x[c] = v[c] + 1.0; y[c] = v[c] - 1.0; }
+#else
       for (int c = 0; c < P; ++c) { x[c] = xs[c]; v[c] = vs[c]; y[c] = ys[c]; }
+#endif
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P]) {
       if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
@@ -557,7 +569,11 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
         for (int aa = 0; aa < P; ++aa) t += x[aa] * Mm[aa * P + b];
 #endif
         o[b] = acc[b] - t;  // Z - X M
+#ifdef MI_WIDE_ABLATE_STORE  // (timing experiment only: one double of the row stored)
+        if (b == 0) os[b] = acc[0] + acc[P - 1];
+#else
         os[b] = o[b];
+#endif
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
         MI_WIDE_SCHED();
       }
@@ -589,6 +605,180 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
   const int wu = __builtin_amdgcn_readfirstlane(w);
   sell_stream<P, HALO, PK, Epi, kWideWaves, (P >= MI_WIDE_CHUNK_FROM ? MI_WIDE_CHUNK : MI_SPMM_CHUNK)>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
+}
+
+// The same pass in the QUAD layout of spmm_core.h (sell_stream_quad): lane (g, q) holds columns 2q, 2q + 1 of the rows
+// 16 t + g of its wave's slice, every load and store of a row is 64 contiguous bytes per quad.  A row's full width --
+// the left operands of the three products and of the Gram -- comes from the quad's four lanes by DPP broadcasts; S and M
+// sit in LDS padded to 8 x 8 with zero columns (a lane reads its two columns of a row of the matrix as one 16-byte
+// read); the Gram of the output is accumulated RAW (y_a o_b - x_a (o S)_b for the lane's two b: 2 P accumulators instead
+// of P (P + 1) / 2) and symmetrised once, at the end, through LDS.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// full[2 i + c] = the value of column 2 i + c held by lane i of the quad
+template <int P>
+__device__ __forceinline__ void quad_row(const double (&own)[2], double (&full)[8]) {
+  full[0] = dpp_quad_f64<0x00>(own[0]); full[1] = dpp_quad_f64<0x00>(own[1]);
+  full[2] = dpp_quad_f64<0x55>(own[0]); full[3] = dpp_quad_f64<0x55>(own[1]);
+  full[4] = dpp_quad_f64<0xAA>(own[0]);
+  if constexpr (P > 5) full[5] = dpp_quad_f64<0xAA>(own[1]);
+  if constexpr (P > 6) full[6] = dpp_quad_f64<0xFF>(own[0]);
+  if constexpr (P > 7) full[7] = dpp_quad_f64<0xFF>(own[1]);
+}
+template <int P, bool HALO, bool PK>
+__global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(MI_WIDE_QUAD_WAVES, MI_WIDE_QUAD_WAVES))) void k_st_hess_wideq(SellView A, const CgState *__restrict__ st,
+                                                             const double *__restrict__ V, const double *__restrict__ X,
+                                                             const double *__restrict__ Y, const double *__restrict__ S,
+                                                             const double *__restrict__ gdir, double *__restrict__ out,
+                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
+  constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
+  __shared__ double lds[3 * kWideWaves];
+  __shared__ double graw[kWideWaves][P][8];
+  __shared__ double vt[PK ? 256 : 1];
+  __shared__ __attribute__((aligned(16))) double Sm[P * 8], Mm[P * 8];
+#ifndef MI_WIDEQ_ABLATE_EPI
+  if (st && st->mode != CG_RUN) return;
+#endif
+  if constexpr (HALO) halo_wait(hwait.w);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (PK) vt[threadIdx.x] = A.vtab[threadIdx.x];
+  if (threadIdx.x < P * 8) {
+    const int aa = threadIdx.x >> 3, b = threadIdx.x & 7;
+    Sm[threadIdx.x] = b < P ? S[aa * P + b] : 0.0;
+    Mm[threadIdx.x] = b < P ? gdir[SLOT_GDIR_P + (aa <= b ? SymIdx<P>::at(aa, b) : SymIdx<P>::at(b, aa))] : 0.0;
+  }
+  __syncthreads();
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  double a[3] = {0, 0, 0};
+  double G[P][2];
+#pragma unroll
+  for (int i = 0; i < P; ++i) G[i][0] = G[i][1] = 0;
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ X, *__restrict__ Y, *__restrict__ V;
+    double *__restrict__ out;
+    const double *Sm, *Mm;
+    double (&a)[3];
+    double (&G)[P][2];
+    int q, g;
+    unsigned o0, o1;
+    __device__ __forceinline__ unsigned row_off(size_t slice, int t) const {  // (rows past the end re-read the slice's first)
+      const unsigned r = (unsigned)slice * 64u + (unsigned)(16 * t + g);
+      return (r < (unsigned)A.n ? r : (unsigned)slice * 64u) * (unsigned)(P * 8);
+    }
+    __device__ __forceinline__ void begin(size_t slice, int t, double (&x)[2], double (&v)[2], double (&y)[2]) const {
+      const unsigned off = row_off(slice, t);
+      QuadCols<P>::load(reinterpret_cast<const char *>(X), off, o0, o1, x[0], x[1]);
+      QuadCols<P>::load(reinterpret_cast<const char *>(V), off, o0, o1, v[0], v[1]);
+      QuadCols<P>::load(reinterpret_cast<const char *>(Y), off, o0, o1, y[0], y[1]);
+    }
+    __device__ __forceinline__ void end(size_t slice, int t, double (&acc)[2], const double (&x)[2], const double (&v)[2],
+                                        const double (&y)[2]) {
+      const bool c0 = 2 * q < P, c1 = 2 * q + 1 < P;
+      const double2 *S2 = reinterpret_cast<const double2 *>(Sm) + q, *M2 = reinterpret_cast<const double2 *>(Mm) + q;
+      // (S and M are re-read from LDS for every row: loop-invariant code motion must not park them in registers)
+      asm volatile("" ::: "memory");
+      const bool live = (unsigned)slice * 64u + (unsigned)(16 * t + g) < (unsigned)A.n;
+      const bool u0 = live && c0, u1 = live && c1;
+      const double vv[2] = {u0 ? v[0] : 0.0, u1 ? v[1] : 0.0};
+      const double xx[2] = {u0 ? x[0] : 0.0, u1 ? x[1] : 0.0};
+      const double yy[2] = {u0 ? y[0] : 0.0, u1 ? y[1] : 0.0};
+      double z[2] = {u0 ? acc[0] : 0.0, u1 ? acc[1] : 0.0};
+#ifdef MI_WIDEQ_ABLATE_EPI  // (timing experiment only: the row epilogue reduced to the store -- wrong results)
+      {
+        char *ob = reinterpret_cast<char *>(out);
+        const unsigned ro = row_off(slice, t);
+        if (u0) *reinterpret_cast<double2 *>(ob + (ro + o0)) = make_double2(z[0] + xx[0] + yy[0] + vv[0], z[1] + xx[1] + yy[1] + vv[1]);
+        a[0] += z[0];
+        return;
+      }
+#endif
+      double vf[8], xf[8], yf[8], of[8];
+      quad_row<P>(vv, vf);
+      quad_row<P>(xx, xf);
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa) {  // Z = A V - V S, then out = Z - X M (the lane's two columns)
+        const double2 sc = S2[aa * 4];
+        z[0] -= vf[aa] * sc.x; z[1] -= vf[aa] * sc.y;
+      }
+      MI_WIDE_SCHED();
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa) {
+        const double2 mc = M2[aa * 4];
+        z[0] -= xf[aa] * mc.x; z[1] -= xf[aa] * mc.y;
+      }
+      MI_WIDE_SCHED();
+      {
+        char *ob = reinterpret_cast<char *>(out);
+        const unsigned ro = row_off(slice, t);
+        if constexpr (P % 2 == 0) {
+          if (u0) *reinterpret_cast<double2 *>(ob + (ro + o0)) = make_double2(z[0], z[1]);
+        } else {
+          if (u0) *reinterpret_cast<double *>(ob + (ro + o0)) = z[0];
+          if (u1) *reinterpret_cast<double *>(ob + (ro + o1)) = z[1];
+        }
+      }
+      a[0] += vv[0] * z[0]; a[0] += vv[1] * z[1];
+      a[1] += z[0] * z[0]; a[1] += z[1] * z[1];
+      a[2] += vv[0] * vv[0]; a[2] += vv[1] * vv[1];
+      quad_row<P>(z, of);
+      double os_[2] = {0, 0};  // (o S), the lane's two columns
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa) {
+        const double2 sc = S2[aa * 4];
+        os_[0] += of[aa] * sc.x; os_[1] += of[aa] * sc.y;
+      }
+      MI_WIDE_SCHED();
+      quad_row<P>(yy, yf);
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa) {  // raw Gram of this output row: y_a o_b - x_a (o S)_b
+        G[aa][0] += yf[aa] * z[0] - xf[aa] * os_[0];
+        G[aa][1] += yf[aa] * z[1] - xf[aa] * os_[1];
+      }
+    }
+  } epi{A, X, Y, V, out, Sm, Mm, a, G, lane & 3, lane >> 2, QuadCols<P>::off0(lane & 3), QuadCols<P>::off1(lane & 3)};
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  sell_stream_quad<P, HALO, PK, Epi, kWideWaves, MI_WIDE_QUAD_CHUNK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
+  // the wave's raw Gram: sum over the 16 quads (lane bits 2..5), lanes 0..3 hold columns 2q, 2q + 1
+#pragma unroll
+  for (int aa = 0; aa < P; ++aa)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      double t = G[aa][c];
+#pragma unroll
+      for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m, 64);
+      if (lane < 4) graw[w][aa][2 * lane + c] = t;
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double t = wave_reduce_sum(a[k]);
+    if (lane == 0) lds[k * kWideWaves + w] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < KC) {
+    double t[kWideWaves];
+    if (threadIdx.x < 3) {
+#pragma unroll
+      for (int i = 0; i < kWideWaves; ++i) t[i] = lds[threadIdx.x * kWideWaves + i];
+    } else {
+      int aa = 0, idx = (int)threadIdx.x - 3;  // packed index -> (aa, b), aa <= b
+      while (idx >= P - aa) { idx -= P - aa; ++aa; }
+      const int b = aa + idx;
+#pragma unroll
+      for (int i = 0; i < kWideWaves; ++i) t[i] = aa == b ? graw[i][aa][aa] : .5 * (graw[i][aa][b] + graw[i][b][aa]);
+    }
+#pragma unroll
+    for (int span = 1; span < kWideWaves; span *= 2)
+#pragma unroll
+      for (int i = 0; i + span < kWideWaves; i += 2 * span) t[i] = t[i] + t[i + span];
+    partials[(size_t)threadIdx.x * kMaxRows + blockIdx.x] = t[0];
+  }
 }
 
 // Gram partial rows of two dense n x P fields.
@@ -943,7 +1133,10 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   // 256-thread workgroups, as many per CU as the kernel is held to (WideWaves<P>: one wave per SIMD each): one resident
   // round, at most kMaxRows partial rows; several ranks in rows mode need exactly kMaxGrid of them
   const size_t wgs = (A->nslices + kWideWaves - 1) / kWideWaves;
-  const int resident = ctx->num_cu * (p <= 7 ? MI_WIDE_WAVES : 2);
+  // the quad layout where it measured faster (St(1e6,p), profiles/r05_wide_quad_ab.txt: p = 8: 82 vs 98 us; p = 5, 6, 7:
+  // 80 / 73 / 93 vs 59 / 69 / 83 us for one lane per row); MI355OPT_WIDE_QUAD=0 / 1 forces either form
+  const bool quad = ctx->cfg.wide_quad < 0 ? p == 8 : ctx->cfg.wide_quad != 0;
+  const int resident = ctx->num_cu * (quad ? MI_WIDE_QUAD_WAVES : p <= 7 ? MI_WIDE_WAVES : 2);
   int grid = ctx->uniform_grid ? kMaxGrid : (int)std::max<size_t>(1, std::min<size_t>(wgs, std::min(resident, kMaxRows)));
   if (!ctx->uniform_grid && ctx->max_grid < kMaxGrid) grid = std::min(grid, ctx->max_grid);
   HaloWaitArg<true> hw_halo;
@@ -953,11 +1146,13 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   hw_halo.halo_hi = (unsigned)A->halo_hi;
   SellView view = sell_view(A);  // after the exchange: it selects the halo buffer the rows landed in
   KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
-#define HWIDE(PV, HL, PKV, HWARG)                                                                                       \
-  hipLaunchKernelGGL((k_st_hess_wide<PV, HL, PKV>), dim3(grid), dim3(kWideBlock), 0, ctx->stream, view,              \
-                     (const CgState *)ctx->cg_live, (const double *)in->d, (const double *)q->X->d,                   \
-                     (const double *)q->Y->d, (const double *)q->S_dev, (const double *)(ctx->scalars + SLOT_GDIR),   \
-                     out->d, ctx->partials, HWARG)
+#define HWIDE_ARGS(HWARG)                                                                                               \
+  dim3(grid), dim3(kWideBlock), 0, ctx->stream, view, (const CgState *)ctx->cg_live, (const double *)in->d,             \
+      (const double *)q->X->d, (const double *)q->Y->d, (const double *)q->S_dev,                                       \
+      (const double *)(ctx->scalars + SLOT_GDIR), out->d, ctx->partials, HWARG
+#define HWIDE(PV, HL, PKV, HWARG)                                                                   \
+  if (quad) hipLaunchKernelGGL((k_st_hess_wideq<PV, HL, PKV>), HWIDE_ARGS(HWARG));                     \
+  else hipLaunchKernelGGL((k_st_hess_wide<PV, HL, PKV>), HWIDE_ARGS(HWARG))
 #define HWIDE_P(PV)                                                                                  \
   if (A->halo) { if (A->pk) { HWIDE(PV, true, true, hw_halo); } else { HWIDE(PV, true, false, hw_halo); } } \
   else { if (A->pk) { HWIDE(PV, false, true, hw_none); } else { HWIDE(PV, false, false, hw_none); } }
@@ -969,6 +1164,7 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   }
 #undef HWIDE_P
 #undef HWIDE
+#undef HWIDE_ARGS
   *nparts = grid;
   MI_HIP(hipGetLastError());
   return MI_OK;
@@ -1255,7 +1451,7 @@ int mi_stiefel_rq_model(mi_stiefel_rq *q, const mi_vec *X, mi_vec *grad, mi_op *
   // (the opt-in two-kernel step: p = 3, window form with computed far columns, one rank)
   q->dg.twok = q->p == 3 && !q->A->halo && q->A->wk && q->A->win_chunks > 0 && q->A->win_far_pure > 0 &&
                q->A->win_far_pure < ((size_t)1 << 31) && !q->ctx->cfg.no_window && !q->ctx->cfg.no_far_computed &&
-               !q->ctx->uniform_grid;
+               !q->ctx->uniform_grid && !(q->A->wk16 && q->ctx->cfg.words16);
   // the one-pass kernel uses 32-bit byte offsets: fields of 4 GiB or more keep the two-pass operator -- and so does
   // a matrix that is not symmetric (checked at creation): the one-pass form replaces X'(A p) by (A X)'p
   q->hess.dirgram = (sell_stream_ok(q->A, q->p) && q->A->symmetric) ? &q->dg : nullptr;

@@ -244,6 +244,39 @@ def test_stpcg_run_ahead_invariance(ctx):
             assert cur[0] == base[0] and cur[1] == base[1] and np.array_equal(cur[2], base[2])
 
 
+def test_polled_read_back_equals_stream_synchronize():
+    """r05: a scalar read-back is a one-wave kernel that stores the slots and then a sequence number into coherent pinned
+    words the host polls (`stream_wait` / `read_slots_sync`, context.hip / blas1.hip: 14.4 instead of 18.8 us per dot
+    product and read, tools/sync_latency.py); MI355OPT_NO_POLLED_SYNC=1 is the copy + hipStreamSynchronize it replaces.
+    Same values, same number of counted synchronisations, and a long queue behind the poll (its 2 ms bound, then the
+    blocking wait) changes nothing."""
+    from optimization_amd import capi
+    n = 200_000
+    rng = np.random.default_rng(5)
+    a, b = rng.normal(size=n), rng.normal(size=n)
+    g, D, M = _diag_problem(n, seed=3, lo=1.0, hi=900.0)
+    long_queue = rng.normal(size=4_000_000)
+    out = {}
+    for tag, opt in (("polled", 0), ("sync", 1)):
+        c = capi.Context(0)
+        try:
+            c.set_option("NO_POLLED_SYNC", opt)
+            A, B = c.upload(a), c.upload(b)
+            s0 = c.sync_count()
+            dots = [A.dot(B), A.dot(A), B.dot(B)]
+            syncs = c.sync_count() - s0
+            big = c.upload(long_queue)   # ~100 queued passes: the read-back waits longer than the poll's bound
+            for _ in range(100):
+                big.scale(1.0000001)
+            dots.append(big.dot(big))
+            r = c.stpcg(c.upload(g), c.op_diag(c.upload(D)), Delta=1e9, max_iterations=60, kappa_fgr=1e-9, theta=1.0)
+            out[tag] = (dots, syncs, r["iterations"], r["M_norm"], r["s"].numpy().copy())
+        finally:
+            c.close()
+    assert out["polled"][0] == out["sync"][0] and out["polled"][1] == out["sync"][1] == 3
+    assert out["polled"][2:4] == out["sync"][2:4] and np.array_equal(out["polled"][4], out["sync"][4])
+
+
 def test_profiler_ranges_nest_around_a_solve(ctx):
     """mi_range_push/pop (roctx markers, SURVEY 8(b) group 9) are callable around and inside a solve; the solve
     itself opens a range named mi_stpcg (checked with rocprofv3 --marker-trace in profiles/)."""

@@ -765,9 +765,14 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
     oracle.free(oprob)
     monkeypatch.setenv("MI355OPT_NO_PACKED", "1" if fmt == "plain" else "0")
     res = {}
-    for mode, (no_dirgram, direct) in {"recurrence": ("0", "0"), "direct": ("0", "1"), "two-pass": ("1", "0")}.items():
+    # (the one-pass form in both of its layouts at every width: one lane per row, and a quad of lanes per row --
+    # MI355OPT_WIDE_QUAD; the default picks by width)
+    modes = {"recurrence": ("0", "0", "-1"), "recurrence-quad": ("0", "0", "1"), "recurrence-lanes": ("0", "0", "0"),
+             "direct": ("0", "1", "-1"), "two-pass": ("1", "0", "-1")}
+    for mode, (no_dirgram, direct, quad) in modes.items():
         monkeypatch.setenv("MI355OPT_NO_DIRGRAM", no_dirgram)
         monkeypatch.setenv("MI355OPT_DIRGRAM_DIRECT", direct)
+        monkeypatch.setenv("MI355OPT_WIDE_QUAD", quad)
         c = capi.Context(0)
         try:
             A = c.csr(n, rowptr, col, val)
@@ -783,7 +788,8 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
             res[mode] = dict(r, s=r["s"].numpy().copy(), launches=launches, b=dict(rb, s=rb["s"].numpy().copy()))
         finally:
             c.close()
-    assert res["recurrence"]["launches"] == {"stiefel_hess_fused": res["recurrence"]["hvp_calls"], "stiefel_finish_dots": 0}
+    for mode in ("recurrence", "recurrence-quad", "recurrence-lanes"):
+        assert res[mode]["launches"] == {"stiefel_hess_fused": res[mode]["hvp_calls"], "stiefel_finish_dots": 0}, mode
     for mode in ("direct", "two-pass"):
         assert res[mode]["launches"]["stiefel_hess_fused"] == 0 and res[mode]["launches"]["stiefel_finish_dots"] > 0
     for mode, r in res.items():
@@ -794,6 +800,9 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
         assert (r["b"]["iterations"], r["b"]["exit_reason"]) == (ob["iterations"], ob["exit_reason"]), mode
         assert rel_err(r["b"]["s"], ob["s"]) < 1e-10 and abs(r["b"]["M_norm"] - ob["M_norm"]) <= 1e-12 * ob["M_norm"], mode
     assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
+    assert rel_err(res["recurrence-quad"]["s"], res["recurrence-lanes"]["s"]) < 1e-11
+    # (the default is one of the two, bit for bit)
+    assert any(np.array_equal(res["recurrence"]["s"], res[m]["s"]) for m in ("recurrence-quad", "recurrence-lanes"))
 
 
 @pytest.mark.parametrize("p", [6, 8])
