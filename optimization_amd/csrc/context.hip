@@ -63,7 +63,7 @@ int poll_finish(mi_ctx *ctx, unsigned long long seq, const char *what) {
   if (seq && hipGetLastError() == hipSuccess) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
-      if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) == seq) return MI_OK;
+      if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) >= seq) return MI_OK;  // (the sequence only grows, in stream order)
       if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
   }
@@ -374,7 +374,7 @@ static int ctx_init(mi_ctx *ctx, int device) {
   }
   MI_HIP(hipHostMalloc((void **)&ctx->host_scalars, sizeof(double) * kScalarSlots,
                        hipHostMallocMapped | hipHostMallocCoherent));  // (written by k_slots_to_host, blas1.hip)
-  MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState) + 16, hipHostMallocDefault)  /* + a preconditioner's failure word */);
+  MI_HIP(hipHostMalloc((void **)&ctx->cg_host, sizeof(CgState) + 16, hipHostMallocMapped | hipHostMallocCoherent)  /* + a preconditioner's failure word; written by k_cg_result_to_host */);
   MI_HIP(hipHostMalloc((void **)&ctx->status, sizeof(HostStatus),
                        hipHostMallocMapped | hipHostMallocCoherent));
   MI_HIP(hipHostMalloc((void **)&ctx->poll_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));

@@ -165,6 +165,7 @@ struct mi_ctx {
   hipEvent_t cg_deferred_ev = nullptr;
   bool cg_deferred = false;
   size_t cg_deferred_hvp = 0;
+  unsigned long long cg_deferred_seq = 0;  // polled form of the deferred result (0: the event form)
   mi::HostStatus *status = nullptr;      // pinned, device-visible
   mi::HostStatus *status_dev = nullptr;  // device pointer of the same memory
   double *trace_dev = nullptr;           // 4 x trace_cap doubles

@@ -626,16 +626,53 @@ static int precon_fail_check(mi_ctx *ctx) {
   return MI_ERR_INTERNAL;
 }
 
+// The final state of a solve lands in the pinned words by a kernel store, the polled sequence number behind it
+// (context.hip: stream_wait): no copy engine and no wake-up between a solve and its caller.
+__global__ void k_cg_result_to_host(unsigned long long *host, const unsigned long long *__restrict__ st,
+                                    const double *__restrict__ fail_dev, unsigned long long *flag,
+                                    unsigned long long seq) {
+  constexpr int kWords = (int)(sizeof(CgState) / 8);
+  static_assert(sizeof(CgState) % 8 == 0, "CgState is copied in 8-byte words");
+  if (threadIdx.x < kWords) host[threadIdx.x] = st[threadIdx.x];
+  if (threadIdx.x == kWords) reinterpret_cast<double *>(host)[kWords] = fail_dev ? *fail_dev : 0.0;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// enqueue that kernel; returns the sequence number to poll for, 0 when polling is off (the caller copies instead)
+static unsigned long long result_to_host(mi_ctx *ctx, const CgState *st_final, const mi_precon *P) {
+  unsigned long long *flag = nullptr, *hdev = nullptr;
+  unsigned long long seq = poll_begin(ctx, &flag);
+  if (!seq) return 0;
+  if (hipHostGetDevicePointer((void **)&hdev, ctx->cg_host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;  // (the sequence number stays unused: the next one is larger)
+  }
+  hipLaunchKernelGGL(k_cg_result_to_host, dim3(1), dim3(64), 0, ctx->stream, hdev,
+                     reinterpret_cast<const unsigned long long *>(st_final),
+                     (const double *)(P ? P->fail_word : nullptr), flag, seq);
+  return seq;
+}
+
 int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result) {
   MI_REQUIRE(ctx && result, "null argument");
   MI_REQUIRE(ctx->cg_deferred, "mi_stpcg_collect: no deferred solve is pending on this context");
   ctx->cg_deferred = false;
-  hipError_t e = hipEventQuery(ctx->cg_deferred_ev);
-  if (e == hipErrorNotReady) {
-    e = hipEventSynchronize(ctx->cg_deferred_ev);
-    ctx->host_syncs++;
+  if (ctx->cg_deferred_seq) {
+    const unsigned long long seq = ctx->cg_deferred_seq;
+    ctx->cg_deferred_seq = 0;
+    if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) < seq) {
+      ctx->host_syncs++;
+      MI_TRY(poll_finish(ctx, seq, "stpcg deferred read-back"));
+    }
+  } else {
+    hipError_t e = hipEventQuery(ctx->cg_deferred_ev);
+    if (e == hipErrorNotReady) {
+      e = hipEventSynchronize(ctx->cg_deferred_ev);
+      ctx->host_syncs++;
+    }
+    if (e != hipSuccess) return hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__);
   }
-  if (e != hipSuccess) return hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__);
   int ipc_err = 0;
   (void)mi_comm_ipc_error(ctx, &ipc_err);
   if (ipc_err) {
@@ -717,6 +754,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   }
 
   ctx->cg_deferred = false;  // (a result nobody collected is superseded)
+  ctx->cg_deferred_seq = 0;
   ctx->epoch++;
   ctx->status->word = 0;
   ctx->status->epoch = ctx->epoch;
@@ -1015,12 +1053,17 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   if (prm->defer_result && !(trace && trace->cap)) {
     // the copy travels behind the solve; whoever waits for the stream next (or mi_stpcg_collect) completes it
     hipError_t e = hipSuccess;
-    if (!ctx->cg_deferred_ev) e = hipEventCreateWithFlags(&ctx->cg_deferred_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
     *precon_fail_host(ctx) = 0.0;
-    if (e == hipSuccess && P && P->fail_word)
-      e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipEventRecord(ctx->cg_deferred_ev, st);
+    ctx->cg_deferred_seq = result_to_host(ctx, st_final, P);
+    if (!ctx->cg_deferred_seq) {
+      if (!ctx->cg_deferred_ev) e = hipEventCreateWithFlags(&ctx->cg_deferred_ev, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess && P && P->fail_word)
+        e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipEventRecord(ctx->cg_deferred_ev, st);
+    } else {
+      e = hipGetLastError();
+    }
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__));
     ctx->cg_deferred = true;
     ctx->cg_deferred_hvp = result->hvp_calls;
@@ -1029,13 +1072,18 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     result->exit_reason = -1;
     result->rv_final = 0;
   } else {
-    hipError_t e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipSuccess;
     *precon_fail_host(ctx) = 0.0;
-    if (e == hipSuccess && P && P->fail_word)
-      e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
     ctx->host_syncs++;
-    if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
+    if (const unsigned long long seq = result_to_host(ctx, st_final, P)) {
+      CG_CHECK(poll_finish(ctx, seq, "stpcg read-back"));
+    } else {
+      e = hipMemcpyAsync(ctx->cg_host, st_final, sizeof(CgState), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess && P && P->fail_word)
+        e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
+    }
     CG_CHECK(precon_fail_check(ctx));
     {
       int ipc_err = 0;
