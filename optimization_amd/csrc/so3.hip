@@ -109,8 +109,20 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
     if (live && we != 0) {
       const size_t j = (size_t)inc.nbr[e0];
       double S[9], Rj[9];
+#if defined(MI_SO3_ABLATE_GATHER4)  // (timing experiment only: a 32-byte record per neighbour -- wrong results)
+      {
+        const double2 q0 = *reinterpret_cast<const double2 *>(R + 8 * (j & ~(size_t)1)), q1 = *reinterpret_cast<const double2 *>(R + 8 * (j & ~(size_t)1) + 2);
+        Rj[0] = q0.x; Rj[1] = q0.y; Rj[2] = q1.x; Rj[3] = q1.y;
+#pragma unroll
+        for (int c = 4; c < 9; ++c) Rj[c] = Rj[c - 4] + 1.0;
+      }
+#elif defined(MI_SO3_ABLATE_GATHER0)  // (no neighbour gather at all)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) Rj[c] = Ri[c] + we;
+#else
 #pragma unroll
       for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
+#endif
       // head: term R_i - R_j Rt (j = tail); tail: R_i - R_j Rt'  (the transposition is in Sinc)
       if (SQ) {
         const double *sq = Sinc + (size_t)k * 4 * 64 + lane;
