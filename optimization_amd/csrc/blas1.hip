@@ -181,6 +181,9 @@ int read_slots_sync(mi_ctx *ctx, int slot0, int k, double *out) {
   if (seq) {
     hipLaunchKernelGGL(k_slots_to_host, dim3(1), dim3(64), 0, ctx->stream, hdev, (const double *)(ctx->scalars + slot0),
                        k, flag, seq);
+    if (hipGetLastError() != hipSuccess) seq = 0;  // (nothing was enqueued: the copy below does the work)
+  }
+  if (seq) {
     MI_TRY(poll_finish(ctx, seq, "scalar read-back"));
   } else {
     MI_HIP(hipMemcpyAsync(ctx->host_scalars, ctx->scalars + slot0, sizeof(double) * k,

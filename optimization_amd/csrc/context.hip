@@ -56,11 +56,11 @@ unsigned long long poll_begin(mi_ctx *ctx, unsigned long long **flag_dev) {
   }
   return ++ctx->poll_seq;
 }
-// Poll for `seq` (stored by a kernel the caller enqueued behind the work).  Bounded: a kernel that faulted never
-// stores the flag -- the synchronisation below then reports the error -- and a long queue is better slept on than
-// spun on.
+// Poll for `seq` (stored by a kernel the caller enqueued behind the work -- and whose LAUNCH the caller has checked:
+// seq = 0 means "no flag will come").  Bounded: a kernel that faulted never stores the flag -- the synchronisation
+// below then reports the error -- and a long queue is better slept on than spun on.
 int poll_finish(mi_ctx *ctx, unsigned long long seq, const char *what) {
-  if (seq && hipGetLastError() == hipSuccess) {
+  if (seq) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
       if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) >= seq) return MI_OK;  // (the sequence only grows, in stream order)
@@ -75,7 +75,10 @@ int stream_wait(mi_ctx *ctx, const char *what) {
   ctx->host_syncs++;
   unsigned long long *dev = nullptr;
   const unsigned long long seq = poll_begin(ctx, &dev);
-  if (seq) hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, ctx->stream, dev, seq);
+  if (seq) {
+    hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, ctx->stream, dev, seq);
+    if (hipGetLastError() != hipSuccess) return poll_finish(ctx, 0, what);  // (no flag will come: the blocking wait)
+  }
   return poll_finish(ctx, seq, what);
 }
 int readback_sync(mi_ctx *ctx, int n, const void *const *dev, const size_t *bytes, void *const *host) {

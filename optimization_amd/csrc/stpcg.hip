@@ -651,6 +651,7 @@ static unsigned long long result_to_host(mi_ctx *ctx, const CgState *st_final, c
   hipLaunchKernelGGL(k_cg_result_to_host, dim3(1), dim3(64), 0, ctx->stream, hdev,
                      reinterpret_cast<const unsigned long long *>(st_final),
                      (const double *)(P ? P->fail_word : nullptr), flag, seq);
+  if (hipGetLastError() != hipSuccess) return 0;  // (nothing was enqueued: the caller copies)
   return seq;
 }
 
@@ -1061,8 +1062,6 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       if (e == hipSuccess && P && P->fail_word)
         e = hipMemcpyAsync(precon_fail_host(ctx), P->fail_word, sizeof(double), hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipEventRecord(ctx->cg_deferred_ev, st);
-    } else {
-      e = hipGetLastError();
     }
     if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg deferred read-back", __FILE__, __LINE__));
     ctx->cg_deferred = true;
