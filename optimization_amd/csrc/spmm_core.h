@@ -156,7 +156,8 @@ __device__ __forceinline__ void sell_stream(const SellView &A, size_t first, siz
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         a[j] = vt[cur.c[j] & 255u];
-        ci[j] = row + (unsigned)((int)cur.c[j] >> 8);
+        // (an EMPTY slice parks its loads on entry 0 of the matrix, whose column offsets belong to other rows: the own row)
+        ci[j] = k < b1 ? row + (unsigned)((int)cur.c[j] >> 8) : (row < nloc ? row : nloc - 1u);
       }
     } else {
 #pragma unroll
@@ -310,7 +311,8 @@ __device__ __forceinline__ void sell_stream_quad(const SellView &A, size_t first
     const unsigned row = (unsigned)(p.slice * 64) + (unsigned)(16 * p.t + g);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const unsigned ci = PK ? row + (unsigned)((int)wd.c[j] >> 8) : wd.c[j];
+      // (an EMPTY slice parks its loads on entry 0 of the matrix, whose column offsets belong to other rows: the own row)
+      const unsigned ci = PK ? (p.k < p.b1 ? row + (unsigned)((int)wd.c[j] >> 8) : (row < nloc ? row : nloc - 1u)) : wd.c[j];
       const char *base = reinterpret_cast<const char *>(V);
       unsigned boff = ci * (unsigned)(P * 8);
       if (HALO && ci >= nloc) {
