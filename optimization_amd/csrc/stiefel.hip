@@ -489,6 +489,16 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
 // registers a 1024-thread workgroup leaves a wave), S and M in LDS (every lane reads the same address: broadcast reads,
 // no bank conflicts) instead of 2 x 64 replicated registers, up to kMaxRows partial rows.
 constexpr int kWideBlock = 256, kWideWaves = kWideBlock / 64;
+// first slice of workgroup lb's range: the planned runs of whole 4-slice tiles (sparse.hip window_bounds: cut so that
+// the far stride of the matrix -- the plane stride of a 3-D stencil -- is a whole number of runs, a far row then is
+// some other workgroup's own row at the same moment of the kernel) or equal shares
+__device__ __forceinline__ size_t wide_first_slice(size_t nslices, unsigned lb, unsigned nb, const int *bounds) {
+  if (bounds) {
+    const size_t s = (size_t)bounds[lb] * kWideWaves;
+    return s < nslices ? s : nslices;
+  }
+  return (nslices * lb) / nb;
+}
 template <int P>
 struct WideWaves {
   static constexpr int value = P <= 7 ? MI_WIDE_WAVES : 2;
@@ -498,7 +508,8 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
                                                              const double *__restrict__ V, const double *__restrict__ X,
                                                              const double *__restrict__ Y, const double *__restrict__ S,
                                                              const double *__restrict__ gdir, double *__restrict__ out,
-                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
+                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait,
+                                                             const int *__restrict__ bounds) {
   constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
   __shared__ double lds[KC * kWideWaves];
   __shared__ double vt[PK ? 256 : 1];
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
   }
   __syncthreads();
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
-  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  const size_t s0 = wide_first_slice(A.nslices, lb, nb, bounds), s1 = wide_first_slice(A.nslices, lb + 1, nb, bounds);
   double a[KC];
 #pragma unroll
   for (int i = 0; i < KC; ++i) a[i] = 0;
@@ -635,7 +646,8 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(MI_W
                                                              const double *__restrict__ V, const double *__restrict__ X,
                                                              const double *__restrict__ Y, const double *__restrict__ S,
                                                              const double *__restrict__ gdir, double *__restrict__ out,
-                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait) {
+                                                             double *__restrict__ partials, HaloWaitArg<HALO> hwait,
+                                                             const int *__restrict__ bounds) {
   constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
   __shared__ double lds[3 * kWideWaves];
   __shared__ double graw[kWideWaves][P][8];
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(MI_W
   }
   __syncthreads();
   const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
-  const size_t s0 = (A.nslices * lb) / nb, s1 = (A.nslices * (lb + 1)) / nb;
+  const size_t s0 = wide_first_slice(A.nslices, lb, nb, bounds), s1 = wide_first_slice(A.nslices, lb + 1, nb, bounds);
   double a[3] = {0, 0, 0};
   double G[P][2];
 #pragma unroll
@@ -1139,6 +1151,9 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   const int resident = ctx->num_cu * (quad ? MI_WIDE_QUAD_WAVES : p <= 7 ? MI_WIDE_WAVES : 2);
   int grid = ctx->uniform_grid ? kMaxGrid : (int)std::max<size_t>(1, std::min<size_t>(wgs, std::min(resident, kMaxRows)));
   if (!ctx->uniform_grid && ctx->max_grid < kMaxGrid) grid = std::min(grid, ctx->max_grid);
+  const int *bounds = nullptr;
+  if (!ctx->uniform_grid && A->win_far_stride && !ctx->cfg.no_win_bounds && kWideWaves == kWinWaves)
+    MI_TRY(window_bounds(ctx, A, grid, (int)wgs, &grid, &bounds));  // (runs cut to the far stride; tiles = 4 slices)
   HaloWaitArg<true> hw_halo;
   HaloWaitArg<false> hw_none;
   MI_TRY(comm_halo_exchange_or_wait(ctx, A, p, in->d, &hw_halo.w));
@@ -1149,7 +1164,7 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
 #define HWIDE_ARGS(HWARG)                                                                                               \
   dim3(grid), dim3(kWideBlock), 0, ctx->stream, view, (const CgState *)ctx->cg_live, (const double *)in->d,             \
       (const double *)q->X->d, (const double *)q->Y->d, (const double *)q->S_dev,                                       \
-      (const double *)(ctx->scalars + SLOT_GDIR), out->d, ctx->partials, HWARG
+      (const double *)(ctx->scalars + SLOT_GDIR), out->d, ctx->partials, HWARG, bounds
 #define HWIDE(PV, HL, PKV, HWARG)                                                                   \
   if (quad) hipLaunchKernelGGL((k_st_hess_wideq<PV, HL, PKV>), HWIDE_ARGS(HWARG));                     \
   else hipLaunchKernelGGL((k_st_hess_wide<PV, HL, PKV>), HWIDE_ARGS(HWARG))
