@@ -190,8 +190,9 @@ def generic_leg_in_its_own_process(n, p, packed, label):
             "kernels": {k: v for k, v in (rf.get("kernels") or {}).items() if v.get("launches")}}
 
 
-def run_steps(ctx, g, H, s_out, steps):
-    """Execute exactly `steps` completed STPCG inner iterations; returns number of solves."""
+def run_steps(ctx, g, H, s_out, steps, last=None):
+    """Execute exactly `steps` completed STPCG inner iterations; returns number of solves (last: a dict that receives
+    the result record of the last solve)."""
     done, solves = 0, 0
     while done < steps:
         r = ctx.stpcg(g, H, Delta=1e3, max_iterations=min(TPCG, steps - done), kappa_fgr=1e-12,
@@ -200,6 +201,8 @@ def run_steps(ctx, g, H, s_out, steps):
         if r["iterations"] == 0:
             raise RuntimeError("STPCG made no progress (exit %d)" % r["exit_reason"])
         done += r["iterations"]
+    if last is not None:
+        last.update({k: v for k, v in r.items() if k != "s"})
     return solves
 
 
@@ -347,13 +350,19 @@ def cpu_model():
     return "?"
 
 
-def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
+def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d, keep=None, timed_iterations=None):
     """(a) The reference's own CPU path (oracle/_ref/libref.so = the reference templates compiled from
     /root/reference, single-threaded like the reference; the plain-C oracle, "port", if that build is absent) and
     (b) the oracle's OpenMP build (its vector and row loops as `omp parallel for`) on all the host CPUs this
     process may use -- both on a bounded sample of the same workload, same iteration counts asserted.
     `value` prices a CPU step with the same bytes as the GPU's `value` (so the ratio of the two is the ratio of
-    steps per second)."""
+    steps per second).
+    keep: a dict that receives what the `parity` block of the line is made of -- the step, traces and counts of the
+    reference's last timed solve ("ref"), one traced solve of the plain-C port ("port": the reference's observer sees
+    alpha only, the port also records beta, kappa, <r,v>, and its step must equal the reference's bit for bit), the
+    re-associated reference ("omp": the same statements with per-thread partial sums = the conditioning floor of the
+    comparison) and, when the timed GPU solve had another iteration count (`timed_iterations`), the same three at
+    that count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py
     n = nx * ny * nz
@@ -374,11 +383,27 @@ def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
         t0 = time.perf_counter()
         for _ in range(solves):
             r = O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=TPCG, kappa_fgr=1e-12, theta=1.0,
-                                lib=lib)
+                                lib=lib, trace_cap=TPCG + 2)
             if r["iterations"] != TPCG:
                 raise RuntimeError("CPU baseline: %d iterations instead of %d" % (r["iterations"], TPCG))
             iters += r["iterations"]
         dt = time.perf_counter() - t0
+        if keep is not None:
+            # (outside the timed sample) what the parity block needs
+            def solve(lib_, k):
+                return O.stpcg_problem(prob, Xb.ravel(), g, 1e3, max_iterations=k, kappa_fgr=1e-12, theta=1.0,
+                                       lib=lib_, trace_cap=k + 2)
+            if omp:
+                keep["omp"] = {TPCG: r}
+                if timed_iterations and timed_iterations != TPCG:
+                    keep["omp"][timed_iterations] = solve(lib, timed_iterations)
+            else:
+                keep["ref"], keep["ref_kind"], keep["g"] = {TPCG: r}, kind, g
+                keep["port"] = {TPCG: solve(O, TPCG)} if kind == "reference" else {TPCG: r}
+                if timed_iterations and timed_iterations != TPCG:
+                    keep["ref"][timed_iterations] = solve(lib, timed_iterations)
+                    keep["port"][timed_iterations] = solve(O, timed_iterations) if kind == "reference" \
+                        else keep["ref"][timed_iterations]
         O.free(prob)
         out.append({"value": iters * bytes_per_step / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": kind,
                     "sample": f"{solves} STPCG solves x {TPCG} inner iterations of the same St({n},{p}) workload "
@@ -387,6 +412,233 @@ def cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, bytes_per_step, bytes_8d):
                     "reference_schedule_bytes_per_second_not_a_bandwidth": iters * bytes_8d / dt,
                     "cpu": cpu_model(), "host_cores_visible": os.cpu_count(), "host_cores_usable": ncpu})
     return out[0], out[1]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _trace_rel(a, b):
+    k = min(len(a), len(b))
+    return float(np.max(np.abs(np.asarray(a[:k]) / np.asarray(b[:k]) - 1))) if k else 0.0
+
+
+def parity_block(keep, gpu):
+    """CHECKER (outside every timed region): the GPU's solves against the reference's, in numbers, in the line the driver
+    records.  gpu: {iterations: dict(s=ndarray, M_norm, iterations, exit_reason, trace)} of (a) the LAST TIMED solve's
+    step (copied off the device right behind the timed region, before anything else ran) and (b) one more solve of
+    max_TPCG_iterations with traces.  Reference: the `cpu_baseline` leg's own solves (oracle/_ref/libref.so = the
+    reference's templates; "port" = oracle/liboracle.so when that build is absent).  floor_*: how far the SAME reference
+    algorithm moves when only the association of its sums changes (oracle/liboracle_omp.so) -- no implementation with
+    another reduction order can be held to less."""
+    BAR = 1e-10   # BASELINE.json north_star: "iterate match to the CPU reference within 1e-10 relative"
+    out = {"bar": BAR, "reference": ("oracle/_ref/libref.so: the reference's own templates compiled from its headers, "
+                                     "1 thread") if keep["ref_kind"] == "reference"
+           else "oracle/liboracle.so: the plain-C restatement (no reference build on this box)",
+           "floor": "oracle/liboracle_omp.so: the same statements, per-thread partial sums (re-associated reference)"}
+    port_is_ref = True
+    for k, gr in gpu.items():
+        ref, port, omp = keep["ref"][k], keep["port"][k], keep["omp"].get(k)
+        same = bool(np.array_equal(ref["s"], port["s"]) and ref["M_norm"] == port["M_norm"] and
+                    list(ref["trace"]["alpha"]) == list(port["trace"]["alpha"]))
+        port_is_ref = port_is_ref and same
+        rec = {"iterations_gpu": int(gr["iterations"]), "iterations_reference": int(ref["iterations"]),
+               "iterations_equal": bool(gr["iterations"] == ref["iterations"]),
+               "exit_reason_equal": bool(gr["exit_reason"] == port["exit_reason"]),
+               "s_rel": _rel(gr["s"], ref["s"]),
+               "M_norm_rel": abs(gr["M_norm"] / ref["M_norm"] - 1.0)}
+        if gr.get("trace"):
+            rec["alpha_rel"] = _trace_rel(gr["trace"]["alpha"], ref["trace"]["alpha"])
+            rec["beta_rel"] = _trace_rel(gr["trace"]["beta"], port["trace"]["beta"])
+            rec["kappa_rel"] = _trace_rel(gr["trace"]["kappa"], port["trace"]["kappa"])
+        if omp is not None:
+            rec["floor_s"] = _rel(omp["s"], ref["s"])
+            rec["floor_alpha"] = _trace_rel(omp["trace"]["alpha"], ref["trace"]["alpha"])
+            rec["floor_beta"] = _trace_rel(omp["trace"]["beta"], port["trace"]["beta"])
+        rec["s_within_bar"] = bool(rec["s_rel"] <= BAR)
+        out[gr["label"]] = rec
+    out["port_equals_reference_bitwise"] = port_is_ref
+    return out
+
+
+# ---- cfg3 / cfg5 legs: the other two single-GPU configurations of BASELINE.json in the driver's own line --------------
+def _bench_client():
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "libbench_client.so")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path + " (run __graft_entry__.build())")
+    L = C.CDLL(path)
+    L.bc_last_error.restype = C.c_char_p
+    return L, C
+
+
+def cfg3_leg(ctx, N=500_000, steps=500):
+    """BASELINE cfg3: SO(3)^N pose graph, N = 5e5, ring + 2 chords per node, TNT with 3x3 block-Jacobi preconditioned
+    STPCG.  (a) one fused inner iteration (reference IterativeSolvers.h:285-422) = block HVP + 3x3 block-Jacobi CG, priced
+    by SURVEY.md 8(d): 120 Nt for the CG part (Nt = 3 N tangent doubles) + the HVP's matrix (72 B per stored 3x3 block,
+    4 B per block index), xi read, h written; (b) a whole TNT outer iteration through the drop-in templates
+    (tools/bench_client.cpp: Optimization::Riemannian::TNT on DeviceVector), wall time / outer iterations."""
+    t_leg = time.perf_counter()
+    # near the optimum (where TNT spends its inner iterations): PSD Hessians, full inner solves
+    ei, ej, Rt, w, _Rtrue, Rinit = wl.pose_graph(N, seed=7, init_sigma=0.02)
+    prob = ctx.so3n(N, ei, ej, Rt, w)
+    R = ctx.upload(Rinit)
+    g, H, P = prob.model(R)
+    inc = 2 * ei.size                       # incidences = off-diagonal 3x3 blocks of the connection Laplacian
+    Nt = 3 * N
+    hvp_bytes = 72 * (inc + N) + 4 * inc + 8 * 2 * Nt
+    step_bytes = 120 * Nt + hvp_bytes
+    s_out = ctx.vec(Nt)
+    kw = dict(Delta=1e6, kappa_fgr=1e-14, theta=1.0, s_out=s_out)
+    first = ctx.stpcg(g, H, P, max_iterations=50, **kw)
+    k_solve = first["iterations"]
+    if k_solve == 0:
+        raise RuntimeError("cfg3: STPCG made no progress")
+    # solves with the result DEFERRED (what TNT's fused outer loop does): the device's pipeline, no host turnaround
+    nsolves = max(1, steps // k_solve)
+    for _ in range(max(1, nsolves // 4)):
+        ctx.stpcg(g, H, P, max_iterations=50, defer=True, **kw)
+    ctx.stpcg_collect()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(nsolves):
+        ctx.stpcg(g, H, P, max_iterations=50, defer=True, **kw)
+    last = ctx.stpcg_collect()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    if last["iterations"] != k_solve:
+        raise RuntimeError("cfg3: solves differ in length")
+    names = ("bsr3_spmv_dots", "cg_update", "cg_pupdate")
+    for k in names:
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    for _ in range(5):   # capped at the length they converge at: no speculative no-op launch is averaged in
+        ctx.stpcg(g, H, P, max_iterations=k_solve, **kw)
+    per = {}
+    for k in names:
+        cnt, ms = ctx.ktime_read(k)
+        ctx.ktime_enable(k, False)
+        per[k] = {"launches": cnt, "avg_us_event_pairs": 1e3 * ms / max(cnt, 1)}
+    hv = per["bsr3_spmv_dots"]
+    us_step = 1e6 * dt / (nsolves * k_solve)
+    out = {"workload": f"cfg3 SO(3)^N, N = {N}, ring + 2 chords per node ({ei.size} edges), chordal cost, "
+                       "3x3 block-Jacobi preconditioned STPCG at a near-optimal iterate",
+           "inner_step": {"us": us_step, "steps": nsolves * k_solve, "iterations_per_solve": k_solve,
+                          "algorithmic_bytes": step_bytes,
+                          "bytes_basis": "SURVEY 8(d): 120 Nt (block-Jacobi CG) + 72 (blocks + N) + 4 blocks + 16 Nt (HVP)",
+                          "GBps": step_bytes / us_step / 1e3, "frac": step_bytes / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "timing": "wall clock over solves whose results are deferred (set-up kernels and the "
+                                    "speculative launches behind a solve's exit included)",
+                          "roofline": {"bound": "hbm", "kernel": "bsr3_spmv_dots", "algorithmic_bytes_per_launch": hvp_bytes,
+                                       "avg_launch_us_event_pairs": hv["avg_us_event_pairs"],
+                                       "achieved": hvp_bytes / hv["avg_us_event_pairs"] / 1e3, "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": hvp_bytes / hv["avg_us_event_pairs"] / 1e3 / HBM_PEAK_GBS,
+                                       "traffic": None},
+                          "kernels": per}}
+    del g, H, P, s_out
+    # (b) the outer iteration through the drop-in templates
+    L, C = _bench_client()
+
+    class Rep(C.Structure):
+        _fields_ = [("seconds", C.c_double), ("f", C.c_double), ("gradfx_norm", C.c_double), ("outer", C.c_size_t),
+                    ("inner", C.c_size_t), ("syncs", C.c_size_t), ("status", C.c_int)]
+    rep = Rep()
+    i32, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.bc_tnt_so3n.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, i32, i32, dp, dp, dp, C.c_size_t, C.c_size_t,
+                              C.c_int, C.POINTER(Rep)]
+    R0 = np.ascontiguousarray(Rinit, dtype=np.float64).ravel()
+    rc = L.bc_tnt_so3n(ctx.h, N, ei.size, ei.ctypes.data_as(i32), ej.ctypes.data_as(i32),
+                       Rt.ctypes.data_as(dp), w.ctypes.data_as(dp), R0.ctypes.data_as(dp), 12, 50, 2, C.byref(rep))
+    if rc:
+        raise RuntimeError("cfg3 TNT: " + L.bc_last_error().decode())
+    ipo = rep.inner / max(rep.outer, 1)
+    # an outer iteration's compulsory bytes: the fused trial step (dm product = one HVP; retraction R, h -> R+: 168 N;
+    # model assembly at R+: R own 72 N, per incidence 32 (quaternion measurement) + 8 (weight) + 8 (indices) + 72 (R_j)
+    # read and 72 (block) written, D, D^-1 72 N each and grad 24 N written; 7 tangent vectors through the step's dots and
+    # D^-1 grad: 168 N) + its inner iterations
+    trial_bytes = hvp_bytes + 168 * N + (240 * N + 192 * inc) + 168 * N
+    outer_bytes = trial_bytes + ipo * step_bytes
+    us_outer = 1e6 * rep.seconds / max(rep.outer, 1)
+    out["outer_iteration"] = {"us": us_outer, "outer_iterations": int(rep.outer), "inner_iterations": int(rep.inner),
+                              "inner_per_outer": ipo, "host_syncs_per_outer": rep.syncs / max(rep.outer, 1),
+                              "status": int(rep.status), "f": rep.f,
+                              "algorithmic_bytes": outer_bytes, "trial_step_bytes": trial_bytes,
+                              "GBps": outer_bytes / us_outer / 1e3,
+                              "frac": outer_bytes / (us_outer * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                              "through": "Optimization::Riemannian::TNT<DeviceVector, DeviceVector> (tools/bench_client.cpp), "
+                                         "second run in its context, wall time / outer iterations"}
+    out["leg_seconds"] = time.perf_counter() - t_leg
+    return out
+
+
+def cfg5_leg(ctx, grid=126, nx=24, nev=20, iters=22):
+    """BASELINE cfg5: LOBPCG, k = 20 eigenpairs of the 7-point Laplacian on grid^3 (m = 2 000 376), nx = 24, no
+    preconditioner, through the drop-in template (tools/bench_client.cpp: Optimization::LinearAlgebra::LOBPCG on
+    DeviceMatrix, random-X0 overload): `iters` iterations with tau so small that nothing converges or locks, i.e. every
+    timed iteration runs at the full basis width ns = 3 nx.  Bytes by SURVEY.md 8(d):
+    2 A_bytes + 8 m (2 ns [A S] + 2 ns [Gram] + ns + 2 nx [X, P update] + 2 nx [A X] + 3 nx [residual])."""
+    t_leg = time.perf_counter()
+    m = grid ** 3
+    rowptr, col, val = wl.laplacian_3d(grid, grid, grid)
+    A = ctx.csr(m, rowptr, col, val)
+    nnz = int(rowptr[-1])
+    del rowptr, col, val
+    L, C = _bench_client()
+
+    class Rep(C.Structure):
+        _fields_ = [("spi", C.c_double), ("total", C.c_double), ("theta0", C.c_double), ("rmax", C.c_double),
+                    ("iterations", C.c_size_t), ("timed", C.c_size_t), ("nc", C.c_size_t)]
+    rep = Rep()
+    L.bc_lobpcg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double,
+                            C.POINTER(Rep)]
+    names = ("lobpcg_gram", "lobpcg_update", "lobpcg_residual", "csr_spmm")
+    rc = L.bc_lobpcg(ctx.h, A.h, m, nx, nev, 4, 1e-300, C.byref(rep))     # pool and kernels warm
+    if rc:
+        raise RuntimeError("cfg5 LOBPCG: " + L.bc_last_error().decode())
+    rc = L.bc_lobpcg(ctx.h, A.h, m, nx, nev, iters, 1e-300, C.byref(rep))
+    if rc:
+        raise RuntimeError("cfg5 LOBPCG: " + L.bc_last_error().decode())
+    spi, timed = rep.spi, int(rep.timed)
+    ns = 3 * nx
+    a_bytes = 12 * nnz + 4 * (m + 1)
+    it_bytes = 2 * a_bytes + 8 * m * (2 * ns + 2 * ns + ns + 2 * nx + 2 * nx + 3 * nx)
+    # the same iterations once more with an event pair around every library call of the four kernel families
+    for k in names:
+        ctx.ktime_enable(k, True)
+    ctx.ktime_reset()
+    rc = L.bc_lobpcg(ctx.h, A.h, m, nx, nev, iters, 1e-300, C.byref(rep))
+    per = {}
+    for k in names:
+        cnt, ms = ctx.ktime_read(k)
+        ctx.ktime_enable(k, False)
+        per[k] = {"calls": cnt, "avg_us_event_pairs": 1e3 * ms / max(cnt, 1)}
+    if rc:
+        raise RuntimeError("cfg5 LOBPCG: " + L.bc_last_error().decode())
+    # Gram pair S'A(S), S'S at ns = 72: 25 tiles of 16 x 16 (upper block triangles of both, the half-empty last tile
+    # column shared), 2 m flops per tile entry; the first two calls of a run are on narrower bases, so the average over
+    # the run slightly flatters the time per call -- the TF/s figure is therefore computed from full-width calls only if
+    # the run is long enough for them to dominate (iters >= 20)
+    tiles = 25 if ns == 72 else None
+    gram = dict(per["lobpcg_gram"])
+    if tiles and gram["calls"]:
+        gf = tiles * 256 * 2 * m / 1e9
+        gram.update(tiles_16x16=tiles, executed_GF=gf, TFLOPs=gf / gram["avg_us_event_pairs"] * 1e3,
+                    fp64_matrix_peak_TFLOPs=78.6, frac_of_fp64_matrix_peak=gf / gram["avg_us_event_pairs"] * 1e3 / 78.6,
+                    operand_bytes=8 * m * 2 * ns, GBps=8 * m * 2 * ns / gram["avg_us_event_pairs"] / 1e3)
+    out = {"workload": f"cfg5 LOBPCG, 7-pt Laplacian {grid}^3 (m = {m}), nx = {nx}, nev = {nev}, ns = {ns}, no "
+                       "preconditioner, B = I",
+           "us": 1e6 * spi, "iterations_timed": timed, "iterations": int(rep.iterations), "converged_pairs": int(rep.nc),
+           "algorithmic_bytes": it_bytes, "bytes_basis": "SURVEY 8(d) cfg5 formula",
+           "GBps": it_bytes / (1e6 * spi) / 1e3 if spi > 0 else None,
+           "frac": it_bytes / spi / 1e9 / HBM_PEAK_GBS if spi > 0 else None,
+           "ritz_0": rep.theta0, "max_residual_norm": rep.rmax,
+           "gram_pair": gram, "kernel_families": per,
+           "through": "Optimization::LinearAlgebra::LOBPCG<HostVectorD, DeviceMatrix> (tools/bench_client.cpp), user "
+                      "function to user function, the first two iterations (basis not yet at full width) dropped",
+           "leg_seconds": time.perf_counter() - t_leg}
+    del A
+    return out
 
 
 def self_launch(args, argv):
@@ -614,7 +866,9 @@ def main():
                          "state (reported as device_wakeup_steps; 0 switches it off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the plain-matrix and beyond-cache legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the plain-matrix, beyond-cache, cfg3 and cfg5 legs")
+    ap.add_argument("--leg-budget", type=float, default=float(os.environ.get("MI355OPT_BENCH_LEG_BUDGET", "45")),
+                    help="seconds the cfg3 + cfg5 legs may use together (a leg that would start later is skipped)")
     ap.add_argument("--comm", default=os.environ.get("MI355OPT_COMM", "auto"),
                     choices=["auto", "peer", "peer-separate", "peer-separate-rprime", "rccl", "rccl2"],
                     help="exchange layer of the headline at N > 1 (auto: the fastest layer that verifies)")
@@ -712,7 +966,8 @@ def main():
     packed = os.environ.get("MI355OPT_NO_PACKED", "0") != "1"
     peer_up = peer_memory
 
-    def make_line(m, layer, choice, legs, plain_leg=None, big_leg=None, cpu=None, cpu_all=None):
+    def make_line(m, layer, choice, legs, plain_leg=None, big_leg=None, cpu=None, cpu_all=None, parity=None,
+                  leg3=None, leg5=None):
         """the JSON line for one measurement `m` of measure()"""
         dt, value, moved_bytes = m["dt"], m["value"], m["moved_bytes"]
         return {
@@ -751,6 +1006,10 @@ def main():
             # (12-byte entries, streaming one-pass kernel; no value table, no window form, no computed far columns)
             "generic_csr_leg": plain_leg, "beyond_cache_leg": big_leg,
             "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all,
+            # N = 1: the timed GPU solve against the reference leg's own solve of the same problem, in numbers
+            "parity": parity,
+            # N = 1: the other two single-GPU configurations of BASELINE.json, time-boxed (--leg-budget)
+            "cfg3_leg": leg3, "cfg5_leg": leg5,
         }
 
     def measure(layer):
@@ -779,11 +1038,17 @@ def main():
         if args.warmup > 0:
             run_steps(ctx, g, H, s_out, args.warmup)
         barrier()
+        last = {}
         t0 = time.perf_counter()
-        solves = run_steps(ctx, g, H, s_out, args.steps)
+        solves = run_steps(ctx, g, H, s_out, args.steps, last)
         ctx.sync()
         dt = time.perf_counter() - t0
         barrier()
+        # the step the LAST TIMED solve left behind, for the parity block (a device-to-host copy after the clock stopped)
+        timed_solve = None
+        if world == 1 and not use_comm and not args.no_cpu_baseline:
+            timed_solve = dict(last, s=s_out.numpy().copy(), trace=None,
+                               label="timed_solve_last_of_the_timed_region")
         if dist is not None:
             import torch
             t = torch.tensor([dt], dtype=torch.float64)
@@ -865,7 +1130,7 @@ def main():
                 roofline = None
         value = world * args.steps * moved_bytes / dt / 1e9
         return dict(dt=dt, solves=solves, roofline=roofline, moved_bytes=moved_bytes, value=value,
-                    wakeup_steps=wakeup_steps)
+                    wakeup_steps=wakeup_steps, timed_solve=timed_solve, model=(g, H))
 
     # ---- N > 1: every exchange layer that is up is verified and timed; the headline takes the fastest --------------
     # The first cross-device run of this code happens inside the driver's scaling bench, where a layer that HANGS (an
@@ -933,8 +1198,23 @@ def main():
                                                                                "value", "wakeup_steps"))
 
     # ---- extra legs and CPU baselines: rank 0 of a single-GPU run -------------------------------------------
-    plain_leg = big_leg = cpu = cpu_all = None
+    plain_leg = big_leg = cpu = cpu_all = parity = leg3 = leg5 = None
     if rank == 0 and world == 1 and not use_comm:
+        gpu_solves, m_g_host = None, None
+        if not args.no_cpu_baseline and m["timed_solve"] is not None:
+            # (b) of the parity block: one more solve of max_TPCG_iterations with its alpha / beta / kappa traces
+            g_, H_ = m["model"]
+            m_g_host = g_.numpy()
+            rt = ctx.stpcg(g_, H_, Delta=1e3, max_iterations=TPCG, kappa_fgr=1e-12, theta=1.0, trace_cap=TPCG + 2)
+            full = dict({k: v for k, v in rt.items() if k != "s"}, s=rt["s"].numpy(),
+                        label=f"full_solve_{TPCG}_iterations")
+            gpu_solves = {TPCG: full}
+            ts = m["timed_solve"]
+            if ts["iterations"] != TPCG:
+                gpu_solves[ts["iterations"]] = ts
+            else:   # the last timed solve IS a full solve: its step must be the traced solve's, bit for bit
+                full["equals_last_timed_solve_bitwise"] = bool(np.array_equal(ts["s"], full["s"]))
+        m.pop("model", None)
         if not args.no_legs:
             try:
                 plain_label = (f"cfg2 St({n},{p}), generic CSR path: the matrix in " +
@@ -949,8 +1229,35 @@ def main():
                                     label=f"St(8000000,{p}), 200^3 grid, one GPU: beyond the Infinity Cache")
             except capi.MiError as e:  # an extra leg must never take the headline down with it
                 print("bench.py: extra leg failed: %s" % e, file=sys.stderr)
+        if not args.no_legs:
+            # cfg3 / cfg5: each leg is skipped once the legs together have used up --leg-budget seconds; a leg that
+            # fails costs itself, never the line
+            t_legs = time.perf_counter()
+            for name, fn in (("cfg3", cfg3_leg), ("cfg5", cfg5_leg)):
+                used = time.perf_counter() - t_legs
+                if used > args.leg_budget:
+                    rec = {"skipped": f"--leg-budget {args.leg_budget:.0f} s used up ({used:.0f} s)"}
+                else:
+                    try:
+                        rec = fn(ctx)
+                    except Exception as e:  # noqa: BLE001
+                        print(f"bench.py: {name} leg failed: {e}", file=sys.stderr)
+                        rec = {"failed": str(e)[:300]}
+                if name == "cfg3":
+                    leg3 = rec
+                else:
+                    leg5 = rec
         if not args.no_cpu_baseline:
-            cpu, cpu_all = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, moved_bytes, bytes_per_step)
+            keep = {} if gpu_solves else None
+            cpu, cpu_all = cpu_baseline(nx, ny, nz, p, rowptr, col, val, Xb, moved_bytes, bytes_per_step, keep=keep,
+                                        timed_iterations=(m["timed_solve"] or {}).get("iterations"))
+            if keep:
+                try:
+                    parity = parity_block(keep, gpu_solves)
+                    parity["g_rel"] = _rel(m_g_host, keep["g"]) if m_g_host is not None else None
+                except Exception as e:  # noqa: BLE001  (the checker must never take the headline down with it)
+                    print("bench.py: parity block failed: %r" % (e,), file=sys.stderr)
+                    parity = {"failed": str(e)[:300]}
 
     if rank == 0 and use_comm and not args.no_cpu_baseline:
         # N > 1 (r04 verdict): the reference's CPU path "in the same run" here too.  Rank 0 times it AFTER the timed region
@@ -969,7 +1276,7 @@ def main():
         except Exception as e:  # noqa: BLE001  (the baseline must never take the headline down with it)
             print("bench.py: CPU baseline at N > 1 failed: %s" % e, file=sys.stderr)
     if rank == 0:
-        out = make_line(m, comm_layer, comm_choice, comm_legs, plain_leg, big_leg, cpu, cpu_all)
+        out = make_line(m, comm_layer, comm_choice, comm_legs, plain_leg, big_leg, cpu, cpu_all, parity, leg3, leg5)
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

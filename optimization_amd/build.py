@@ -117,6 +117,21 @@ def build(force=False, jobs=None, verbose=False):
     return LIB
 
 
+WLGEN_SRC = os.path.join(HERE, "wlgen.c")
+WLGEN_LIB = os.path.join(HERE, "libmi355wl.so")
+
+
+def build_wlgen(force=False):
+    """optimization_amd/libmi355wl.so: the machine-independent input generators of workloads.py (mt19937_64, own sin,
+    own thin QR; wlgen.c).  Plain gcc, SSE2 baseline, contraction off: the same bytes on any x86-64 host."""
+    if force or _newer(WLGEN_SRC, WLGEN_LIB, []):
+        r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra", WLGEN_SRC,
+                            "-o", WLGEN_LIB, "-lm"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("wlgen build failed:\n" + r.stderr[-4000:])
+    return WLGEN_LIB
+
+
 def build_harness(force=False):
     """C++ test harnesses on top of the drop-in template layer (g++; plus a clang syntax check so
     the headers stay compilable by hipcc's front end):
@@ -153,6 +168,16 @@ def build_harness(force=False):
             if r.returncode != 0:
                 raise RuntimeError("clang front-end check of the template layer failed:\n" + r.stderr[-6000:])
     out.append(dev_so)
+    # tools/bench_client.cpp: the client of the drop-in headers behind bench.py's cfg3 / cfg5 legs (no oracle includes)
+    bc_src = os.path.join(ROOT, "tools", "bench_client.cpp")
+    bc_so = os.path.join(ROOT, "tools", "libbench_client.so")
+    if force or _newer(bc_src, bc_so, hdrs + [LIB]):
+        cmd = common + ["-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include"), bc_src, "-o", bc_so,
+                        "-L", HERE, "-lmi355opt", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("bench client build failed:\n" + r.stderr[-6000:])
+    out.append(bc_so)
     # examples/*.cpp: stand-alone client programs of the drop-in headers (binaries under examples/bin/)
     exdir = os.path.join(ROOT, "examples")
     os.makedirs(os.path.join(exdir, "bin"), exist_ok=True)
@@ -244,5 +269,6 @@ def build_sanitize(force=False, run=True):
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build(force=force, verbose=True))
+    print(build_wlgen(force=force))
     print(build_harness(force=force))
     print(build_sanitize(force=force))

@@ -52,33 +52,102 @@ def laplacian_3d_eigvec(nx, ny, nz, kx, ky, kz):
     return v, lam
 
 
+_WL = None
+
+
+def _wl():
+    """optimization_amd/libmi355wl.so (wlgen.c): mt19937_64, an own sin and an own thin QR -- integer arithmetic and
+    IEEE +,-,*,/,sqrt in a fixed order, so that the arrays below are the same BYTES on every host (SURVEY.md 8(d):
+    "mt19937_64(seed) U(-1,1), host-generated"; r01-r05 used numpy's PCG64, libm's sin and LAPACK's QR, whose last bits
+    follow the CPU model).  Built on demand with gcc when it is not there."""
+    global _WL
+    if _WL is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi355wl.so")
+        src = os.path.join(os.path.dirname(path), "wlgen.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            from optimization_amd import build as _b
+            _b.build_wlgen()
+        L = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        L.wl_uniform_pm1.argtypes = [C.c_uint64, C.c_size_t, dp]
+        L.wl_uniform_pm1.restype = None
+        L.wl_add_uniform_pm1.argtypes = [C.c_uint64, C.c_size_t, C.c_double, dp]
+        L.wl_add_uniform_pm1.restype = None
+        L.wl_mt19937_64_raw.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.wl_mt19937_64_raw.restype = None
+        L.wl_thin_qr.argtypes = [C.c_size_t, C.c_size_t, dp]
+        L.wl_thin_qr.restype = C.c_int
+        L.wl_grid_mode.argtypes = [C.c_int64] * 6 + [dp, C.c_size_t]
+        L.wl_grid_mode.restype = C.c_int
+        L.wl_sin_pi_ratio.argtypes = [C.c_int64, C.c_int64]
+        L.wl_sin_pi_ratio.restype = C.c_double
+        _WL = (L, dp)
+    return _WL
+
+
+def mt19937_64_raw(seed, count):
+    L, _ = _wl()
+    import ctypes as C
+    out = np.zeros(count, dtype=np.uint64)
+    L.wl_mt19937_64_raw(seed, count, out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
+
+
+def uniform_pm1(seed, count):
+    """count doubles U(-1,1) from mt19937_64(seed): 2 ((x >> 11) 2^-53) - 1"""
+    L, dp = _wl()
+    out = np.zeros(count)
+    L.wl_uniform_pm1(seed, count, out.ctypes.data_as(dp))
+    return out
+
+
+def thin_qr(M):
+    """Q factor (positive diagonal of R) of the n x p matrix M, own arithmetic (Gram-Schmidt twice, wlgen.c)"""
+    L, dp = _wl()
+    Q = np.array(M, dtype=np.float64, order="C")
+    if L.wl_thin_qr(Q.shape[0], Q.shape[1], Q.ctypes.data_as(dp)):
+        raise ValueError("thin_qr: dependent columns")
+    return Q
+
+
 def random_stiefel(n, p, seed=20260928):
-    """X0 = Q factor of a seeded U(-1,1) n x p matrix (row-major n x p, X0' X0 = I)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    M = rng.uniform(-1.0, 1.0, size=(n, p))
-    Q, R = np.linalg.qr(M)
-    Q = Q * np.sign(np.diag(R))[None, :]
-    return np.ascontiguousarray(Q)
+    """X0 = Q factor of an n x p matrix of mt19937_64(seed) U(-1,1) entries (row-major n x p, X0' X0 = I): SURVEY.md
+    8(d)'s cfg2 start, the same bytes on every host."""
+    return thin_qr(uniform_pm1(seed, n * p).reshape(n, p))
 
 
 def polar(Y):
-    """polar factor Y (Y'Y)^-1/2 (host helper for building near-optimal bench iterates)."""
+    """polar factor Y (Y'Y)^-1/2 (host helper)."""
     G = Y.T @ Y
     w, Q = np.linalg.eigh(G)
     return Y @ (Q @ np.diag(w ** -0.5) @ Q.T)
 
 
+def lowest_modes(nx, ny, nz, p):
+    """the p lowest modes (kx, ky, kz) of the grid Laplacian; eigenvalues that agree to 1e-12 (the degenerate triples
+    of a cubic grid) are ordered by the index tuple, so the choice does not hang on libm's last bits"""
+    def lam(m):
+        return 4 * sum(np.sin(np.pi * k / (2 * (n + 1))) ** 2 for k, n in zip(m, (nx, ny, nz)))
+    return sorted(((kx, ky, kz) for kx in (1, 2, 3) for ky in (1, 2, 3) for kz in (1, 2, 3)),
+                  key=lambda m: (round(lam(m), 12), m))[:p]
+
+
 def stiefel_bench_iterate(nx, ny, nz, p=3, eps=1e-3, seed=7):
     """A point near the minimiser of f(X) = .5 tr(X'AX) on the grid Laplacian: the p lowest exact
-    eigenvectors, perturbed by eps * U(-1,1) and re-orthonormalised.  There the Riemannian Hessian is
-    (numerically) positive semi-definite, so STPCG runs its full iteration budget -- the regime in
-    which a TNT solve spends nearly all of its inner iterations."""
-    modes = sorted(((kx, ky, kz) for kx in (1, 2, 3) for ky in (1, 2, 3) for kz in (1, 2, 3)),
-                   key=lambda m: (laplacian_3d_eigvec(nx, ny, nz, *m)[1], m))[:p]
-    X = np.stack([laplacian_3d_eigvec(nx, ny, nz, *m)[0] for m in modes], axis=1)
-    rng = np.random.Generator(np.random.PCG64(seed))
-    X = X + eps * rng.uniform(-1, 1, size=X.shape) / np.sqrt(X.shape[0])
-    return np.ascontiguousarray(polar(X)), modes
+    eigenvectors, perturbed by eps * U(-1,1) / sqrt(n) (mt19937_64(seed)) and re-orthonormalised (thin QR).  There the
+    Riemannian Hessian is (numerically) positive semi-definite, so STPCG runs its full iteration budget -- the regime in
+    which a TNT solve spends nearly all of its inner iterations.  Machine-independent bytes (wlgen.c)."""
+    L, dp = _wl()
+    modes = lowest_modes(nx, ny, nz, p)
+    n = nx * ny * nz
+    X = np.zeros((n, p))
+    for j, m in enumerate(modes):
+        if L.wl_grid_mode(nx, ny, nz, *m, X[:, j:].ctypes.data_as(dp), p):
+            raise MemoryError
+    L.wl_add_uniform_pm1(seed, n * p, eps / np.sqrt(float(n)), X.ctypes.data_as(dp))
+    return thin_qr(X), modes
 
 
 def hat(x):

@@ -95,3 +95,35 @@ def test_template_layer_is_clean_under_asan_and_ubsan():
         pytest.skip(str(e))
     import os
     assert os.path.exists(exe)
+
+
+def test_workload_generators_are_machine_independent():
+    """the synthetic inputs come from mt19937_64 + own arithmetic (optimization_amd/wlgen.c), not from
+    numpy's generators, libm's sin or LAPACK's QR -- so the SAME BYTES on every host.  Known answers: the published
+    first and 10000th outputs of mt19937_64 seeded with 5489 (ISO C++ [rand.predef]: the 10000th consecutive invocation
+    of a default-constructed std::mt19937_64 produces 9981545732273789042); SHA-256 of the generated arrays as made on
+    the build machine (a host that generates other bytes fails here, not in a parity test)."""
+    import hashlib
+    from optimization_amd import workloads as wl
+    raw = wl.mt19937_64_raw(5489, 10000)
+    assert int(raw[0]) == 14514284786278117030 and int(raw[9999]) == 9981545732273789042
+    u = wl.uniform_pm1(20260928, 3000)
+    assert np.all(u >= -1.0) and np.all(u < 1.0)
+    assert np.allclose(u[:3], [0.63845261, 0.88333058, -0.03266483], atol=1e-8)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()  # noqa: E731
+    assert sha(u) == "f562f724a203acaab36c01d4cc998338651843b643e57d4a465690b7b4f407f6"
+    X = wl.random_stiefel(1000, 3)
+    assert sha(X) == "49df7c05a398148b5d0838971d9c3f00efd8884d4f04bae229adfa13a5e9d72b"
+    assert np.abs(X.T @ X - np.eye(3)).max() < 1e-14
+    Xb, modes = wl.stiefel_bench_iterate(24, 20, 16, 3, eps=1e-2, seed=5)      # (smoke()'s iterate)
+    assert sha(Xb) == "1bb470fab32a91499f5689bdb6329c142a53827d6bdb2ec1142333093faf4832"
+    assert np.abs(Xb.T @ Xb - np.eye(3)).max() < 1e-14
+    # the own sin against libm, over every argument the grids of the test-suite use
+    L = wl._wl()[0]
+    for den in (17, 21, 25, 101, 127, 201):
+        for num in range(0, 4 * den + 1):
+            assert abs(L.wl_sin_pi_ratio(num, den) - np.sin(np.pi * num / den)) < 2e-15   # (libm gets a rounded argument)
+    # the eigenvector generator against the numpy one the other tests use
+    v, _ = wl.laplacian_3d_eigvec(24, 20, 16, 1, 2, 1)
+    Xe, _ = wl.stiefel_bench_iterate(24, 20, 16, 3, eps=0.0, seed=5)
+    assert min(np.abs(Xe[:, j] - v).max() for j in range(3)) < 1e-14
