@@ -65,6 +65,30 @@ MI_API int mi_ctx_sync(mi_ctx *ctx);                   /* sync: hipStreamSynchro
  * syncs; uploads/downloads of whole vectors not counted): how often the host sits on the critical path of e.g. one
  * TNT outer iteration (tools/bench_tnt.py) */
 MI_API int mi_ctx_sync_count(mi_ctx *ctx, size_t *count);
+/* Which side of the fusion boundary the work of this context ran on (r06).  The template layer selects the fused
+ * entry points by probing its std::function arguments with target<>() (Riemannian/TNT.h, LinearAlgebra/
+ * IterativeSolvers.h of this repository): a client that wraps a tagged callable in a lambda of its own -- a logger, a
+ * penalty term, the adapter style of the reference's own TNT.h:400-426 -- silently gets the generic loop (one host
+ * synchronisation per inner product).  These counters make that visible: the fused_* fields count calls of the fused
+ * entry points (mi_stpcg, mi_lsqr, mi_*_trial), generic_inner_products counts host-synchronising inner products
+ * (mi_vec_dot, mi_vec_dot_batch), and the generic_* solver fields are reported by the template layer through
+ * mi_ctx_note_generic when a solve on MI355::DeviceVector falls to its generic loop.  With MI355OPT_WARN_GENERIC=1 in the
+ * environment the first such fall of each kind also prints one line on stderr saying which probe failed. */
+typedef struct mi_fusion_counters {
+  unsigned long long fused_stpcg_solves;
+  unsigned long long generic_stpcg_solves;
+  unsigned long long fused_lsqr_solves;
+  unsigned long long generic_lsqr_solves;
+  unsigned long long fused_trial_steps;      /* TNT / GradientDescent trial points evaluated by one fused chain */
+  unsigned long long generic_trial_steps;    /* ... by the reference's statement sequence on DeviceVector */
+  unsigned long long generic_inner_products; /* host-synchronising inner products */
+} mi_fusion_counters;
+enum { MI_GENERIC_STPCG = 0, MI_GENERIC_LSQR = 1, MI_GENERIC_TRIAL = 2 };
+MI_API int mi_ctx_fusion_counters(mi_ctx *ctx, mi_fusion_counters *out);
+MI_API int mi_ctx_fusion_counters_reset(mi_ctx *ctx);
+/* template layer -> library: a solve / trial step of kind `what` (MI_GENERIC_*) on device vectors ran the generic loop;
+ * `why` (may be NULL) names the probe that failed */
+MI_API int mi_ctx_note_generic(mi_ctx *ctx, int what, const char *why);
 MI_API int mi_ctx_stream(mi_ctx *ctx, void **stream);  /* the hipStream_t all work is enqueued on */
 MI_API int mi_ctx_device_name(mi_ctx *ctx, char *buf, size_t buflen);
 MI_API int mi_ctx_pool_bytes(mi_ctx *ctx, size_t *bytes_reserved);
@@ -192,6 +216,10 @@ MI_API int mi_op_create_callback_fused(mi_ctx *ctx, size_t n, mi_apply_fn fn, mi
                                        mi_op **out);
 MI_API int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out);           /* Hp = d .* p */
 MI_API int mi_op_create_csr(mi_ctx *ctx, const mi_csr *A, int p, mi_op **out);     /* Hp = A p    */
+/* out = outer(inner(in)): e.g. TNLS's right-preconditioned LSQR operators A = dF o M, A' = M' o dF^* (reference
+ * TNLS.h:60-63,432-447) as ONE device operator each, so that the inner solve stays in mi_lsqr.  Borrows both operands
+ * (they must outlive the composition); owns one pooled intermediate vector. */
+MI_API int mi_op_create_compose(mi_ctx *ctx, mi_op *outer, mi_op *inner, mi_op **out);
 MI_API int mi_op_apply(mi_op *op, const mi_vec *in, mi_vec *out);
 MI_API int mi_op_dims(const mi_op *op, size_t *n_in, size_t *n_out); /* either pointer may be null */
 MI_API int mi_op_destroy(mi_op *op);

@@ -168,6 +168,17 @@ def build_harness(force=False):
             if r.returncode != 0:
                 raise RuntimeError("clang front-end check of the template layer failed:\n" + r.stderr[-6000:])
     out.append(dev_so)
+    # tests/cpp/harness_sinfit.hip: the reference's TNLS sin-fit problem with HIP kernels of its own (hipcc)
+    sf_src = os.path.join(tdir, "harness_sinfit.hip")
+    sf_so = os.path.join(tdir, "libharness_sinfit.so")
+    if force or _newer(sf_src, sf_so, hdrs + [LIB]):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall",
+               "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include"), sf_src, "-o", sf_so,
+               "-L", HERE, "-lmi355opt", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("sin-fit harness build failed:\n" + r.stderr[-6000:])
+    out.append(sf_so)
     # tools/bench_client.cpp: the client of the drop-in headers behind bench.py's cfg3 / cfg5 legs (no oracle includes)
     bc_src = os.path.join(ROOT, "tools", "bench_client.cpp")
     bc_so = os.path.join(ROOT, "tools", "libbench_client.so")

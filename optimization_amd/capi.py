@@ -116,6 +116,10 @@ def load():
         "mi_ctx_sync": [vp],
         "mi_ctx_set_option": [vp, C.c_char_p, C.c_long],
         "mi_ctx_sync_count": [vp, c_size_p],
+        "mi_ctx_fusion_counters": [vp, C.POINTER(FusionCounters)],
+        "mi_ctx_fusion_counters_reset": [vp],
+        "mi_ctx_note_generic": [vp, C.c_int, C.c_char_p],
+        "mi_op_create_compose": [vp, vp, vp, C.POINTER(vp)],
         "mi_ctx_stream": [vp, C.POINTER(vp)],
         "mi_ctx_device_name": [vp, C.c_char_p, C.c_size_t],
         "mi_ctx_pool_bytes": [vp, c_size_p],
@@ -236,6 +240,12 @@ def load():
     return L
 
 
+class FusionCounters(C.Structure):
+    _fields_ = [(k, C.c_ulonglong) for k in ("fused_stpcg_solves", "generic_stpcg_solves", "fused_lsqr_solves",
+                                             "generic_lsqr_solves", "fused_trial_steps", "generic_trial_steps",
+                                             "generic_inner_products")]
+
+
 def check(status):
     if status != MI_OK:
         raise MiError(status, load().mi_last_error().decode())
@@ -306,6 +316,14 @@ class Context:
         n = C.c_size_t(0)
         check(self.L.mi_ctx_sync_count(self.h, C.byref(n)))
         return n.value
+
+    def fusion_counters(self, reset=False):
+        """mi_ctx_fusion_counters: which side of the fusion boundary the work of this context ran on"""
+        fc = FusionCounters()
+        check(self.L.mi_ctx_fusion_counters(self.h, C.byref(fc)))
+        if reset:
+            check(self.L.mi_ctx_fusion_counters_reset(self.h))
+        return {k: int(getattr(fc, k)) for k, _ in FusionCounters._fields_}
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -350,6 +350,7 @@ int mi_vec_dot_batch(mi_ctx *ctx, int k, const mi_vec *const *x, const mi_vec *c
     ys[i] = y[i]->d;
   }
   MI_TRY(dot_batch_to_slots(ctx, k, xs, ys, x[0]->n, 0));
+  ctx->fusion.generic_inner_products += (unsigned long long)k;
   return read_slots_sync(ctx, 0, k, out);
 }
 

@@ -227,6 +227,7 @@ OPT_BOOL(opt_no_gram_half, cfg.no_gram_half)
 OPT_BOOL(opt_so3_no_quat, cfg.so3_no_quat)
 OPT_BOOL(opt_no_update_pair, cfg.no_update_pair)
 OPT_BOOL(opt_two_kernel_step, cfg.two_kernel_step)
+OPT_BOOL(opt_warn_generic, warn_generic)
 #undef OPT_BOOL
 int opt_max_grid(mi_ctx *c, long v) {
   c->max_grid = (int)std::min<long>(kMaxGrid, std::max<long>(1, v));
@@ -253,6 +254,7 @@ const OptionDesc kOptions[] = {
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
     {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
+    {"WARN_GENERIC", opt_warn_generic},
 };
 // value of a switch: an integer; anything else that is not empty ("yes", "true", "on" -- and the presence-only
 // `MI355OPT_X=` of the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off
@@ -449,6 +451,33 @@ int mi_ctx_sync(mi_ctx *ctx) {
 int mi_ctx_sync_count(mi_ctx *ctx, size_t *count) {
   MI_REQUIRE(ctx && count, "null argument");
   *count = ctx->host_syncs;
+  return MI_OK;
+}
+
+int mi_ctx_fusion_counters(mi_ctx *ctx, mi_fusion_counters *out) {
+  MI_REQUIRE(ctx && out, "null argument");
+  *out = ctx->fusion;
+  return MI_OK;
+}
+
+int mi_ctx_fusion_counters_reset(mi_ctx *ctx) {
+  MI_REQUIRE(ctx, "ctx is null");
+  ctx->fusion = mi_fusion_counters{0, 0, 0, 0, 0, 0, 0};
+  return MI_OK;
+}
+
+int mi_ctx_note_generic(mi_ctx *ctx, int what, const char *why) {
+  MI_REQUIRE(ctx, "ctx is null");
+  MI_REQUIRE(what >= 0 && what <= 2, "bad kind %d", what);
+  static const char *const kKind[3] = {"STPCG", "LSQR", "TNT / GradientDescent trial step"};
+  if (what == MI_GENERIC_STPCG) ctx->fusion.generic_stpcg_solves++;
+  if (what == MI_GENERIC_LSQR) ctx->fusion.generic_lsqr_solves++;
+  if (what == MI_GENERIC_TRIAL) ctx->fusion.generic_trial_steps++;
+  if (ctx->warn_generic && !ctx->warned_generic[what]) {
+    ctx->warned_generic[what] = true;
+    fprintf(stderr, "[mi355opt] note (MI355OPT_WARN_GENERIC): %s on MI355::DeviceVector runs the GENERIC loop (every inner "
+                    "product waits for the device): %s\n", kKind[what], why ? why : "a target<>() probe failed");
+  }
   return MI_OK;
 }
 

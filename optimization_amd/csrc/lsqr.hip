@@ -405,6 +405,7 @@ int mi_lsqr(mi_ctx *ctx, mi_op *A, mi_op *At, const mi_vec *b, const mi_lsqr_par
             mi_lsqr_result *result) {
   MI_REQUIRE(ctx && A && At && b && prm && x_out && result, "null argument");
   touch(x_out);
+  ctx->fusion.fused_lsqr_solves++;
   RangeScope range("mi_lsqr");
   // the reference's own argument checks (:573-590), same messages
   MI_REQUIRE(!(prm->lambda < 0), "Tikhonov regularization parameter (lambda) must be a nonnegative real value");

@@ -173,6 +173,9 @@ struct mi_ctx {
   unsigned int epoch = 0;
   uint64_t vec_serial = 0;  // mi_vec::serial source
   size_t host_syncs = 0;  // stream synchronisations the library made on this context (mi_ctx_sync_count)
+  mi_fusion_counters fusion = {0, 0, 0, 0, 0, 0, 0};  // mi_ctx_fusion_counters
+  bool warn_generic = false;      // env MI355OPT_WARN_GENERIC=1: one stderr line per kind of generic fall
+  bool warned_generic[3] = {false, false, false};
   // pinned staging ring for small host -> device uploads that must not stall the host (stage_upload, context.hip)
   static constexpr int kStageSlots = 4;
   static constexpr size_t kStageBytes = 96 * 96 * sizeof(double);

@@ -191,6 +191,44 @@ int mi_op_create_callback_rect(mi_ctx *ctx, size_t n_in, size_t n_out, mi_apply_
   return MI_OK;
 }
 
+// out = outer(inner(in)) through one pooled intermediate vector, which lives as long as the operator (stream order makes
+// its reuse across applications safe).  Neither operand is owned.
+namespace {
+struct ComposeImpl {
+  mi_op *outer, *inner;
+  mi_vec *mid;
+};
+int op_compose_apply(mi_op *self, const mi_vec *in, mi_vec *out) {
+  ComposeImpl *c = static_cast<ComposeImpl *>(self->impl);
+  MI_TRY(mi_op_apply(c->inner, in, c->mid));
+  return mi_op_apply(c->outer, c->mid, out);
+}
+void op_compose_destroy(mi_op *self) {
+  ComposeImpl *c = static_cast<ComposeImpl *>(self->impl);
+  mi_vec_destroy(c->mid);
+  delete c;
+}
+}  // namespace
+
+int mi_op_create_compose(mi_ctx *ctx, mi_op *outer, mi_op *inner, mi_op **out) {
+  MI_REQUIRE(ctx && outer && inner && out, "null argument");
+  MI_REQUIRE(outer->ctx == ctx && inner->ctx == ctx, "operators belong to another context");
+  const size_t mid_n = inner->n_out ? inner->n_out : inner->n;
+  MI_REQUIRE(outer->n == mid_n, "compose: inner produces %zu values, outer takes %zu", mid_n, outer->n);
+  mi_vec *mid = nullptr;
+  MI_TRY(mi_vec_create(ctx, mid_n, &mid));
+  mi_op *op = new mi_op();
+  op->ctx = ctx;
+  op->n = inner->n;
+  const size_t n_out = outer->n_out ? outer->n_out : outer->n;
+  op->n_out = n_out == op->n ? 0 : n_out;
+  op->apply = op_compose_apply;
+  op->destroy = op_compose_destroy;
+  op->impl = new ComposeImpl{outer, inner, mid};
+  *out = op;
+  return MI_OK;
+}
+
 int mi_op_create_diag(mi_ctx *ctx, const mi_vec *d, mi_op **out) {
   MI_REQUIRE(ctx && d && out, "null argument");
   MI_REQUIRE(d->ctx == ctx, "vector belongs to another context");

@@ -645,6 +645,7 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
   MI_REQUIRE(R->n == 9 * q->N && R_trial->n == 9 * q->N && h->n == 3 * q->N && g->n == 3 * q->N, "dimension mismatch");
   MI_REQUIRE(R_trial->d != R->d, "the trial point must not alias the current one");
   mi_ctx *ctx = q->ctx;
+  ctx->fusion.fused_trial_steps++;
   const size_t N3 = 3 * q->N;
   if (!q->grad_next) {
     MI_TRY(mi_vec_create(ctx, 9 * q->N, &q->Dinv_next));

@@ -1493,6 +1493,7 @@ int mi_stiefel_rq_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *h, cons
   MI_TRY(check_np(q->ctx, q->n, q->p, X, h, g));
   MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;
+  ctx->fusion.fused_trial_steps++;
   const size_t N = q->n * (size_t)q->p;
   if (!q->Y_next) {
     MI_TRY(mi_vec_create(ctx, N, &q->Y_next));
@@ -1551,6 +1552,7 @@ int mi_stiefel_rq_armijo_trial(mi_stiefel_rq *q, const mi_vec *X, const mi_vec *
   MI_TRY(check_np(q->ctx, q->n, q->p, X, g, h_out));
   MI_TRY(check_np(q->ctx, q->n, q->p, X_trial, nullptr, nullptr));
   mi_ctx *ctx = q->ctx;
+  ctx->fusion.fused_trial_steps++;
   const size_t N = q->n * (size_t)q->p;
   if (!q->Y_next) {
     MI_TRY(mi_vec_create(ctx, N, &q->Y_next));

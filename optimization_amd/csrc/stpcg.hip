@@ -697,6 +697,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
              s_out->n, H->n);
   MI_REQUIRE(g->d != s_out->d, "g and s_out must not alias");
   touch(s_out);
+  ctx->fusion.fused_stpcg_solves++;
   MI_REQUIRE(!P || (P->ctx == ctx && P->n == g->n), "preconditioner dimension/context mismatch");
   MI_REQUIRE(!prm->constraint_At || (P && P->apply_project),
              "constraint_At needs a constraint preconditioner (mi_precon_create_constraint)");

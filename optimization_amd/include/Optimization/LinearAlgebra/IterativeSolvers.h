@@ -68,36 +68,49 @@ bool stpcg_on_device(const Vector &g, const SymmetricLinearOperator<Vector, Args
                      const std::optional<STPCGPreconditioner<Vector, Multiplier, Args...>> &P,
                      const std::optional<LinearOperator<Multiplier, Vector, Args...>> &At,
                      Scalar Delta, size_t max_iterations, Scalar kappa_fgr, Scalar theta, Scalar epsilon,
-                     Vector &s_out, Scalar &update_step_M_norm, size_t &num_iterations) {
+                     Vector &s_out, Scalar &update_step_M_norm, size_t &num_iterations, const char *&why) {
+  // `why`: which probe sent the solve to the generic loop (reported through mi_ctx_note_generic by the caller)
   if constexpr (!MI355::is_device_vector<Vector>::value || !std::is_same<Scalar, double>::value) {
+    why = "Scalar is not double";
     return false;
   } else {
     using namespace MI355;
-    if (g.empty()) return false;
-    if (!inner_product.template target<FrobeniusInnerProduct>()) return false;
+    auto no = [&why](const char *w) {
+      why = w;
+      return false;
+    };
+    if (g.empty()) return no("the gradient is an empty vector");
+    if (!inner_product.template target<FrobeniusInnerProduct>())
+      return no("the inner product is not MI355::FrobeniusInnerProduct (a plain callable, or a tagged one wrapped in a "
+                "lambda)");
     const DeviceOperator *dop = H.template target<DeviceOperator>();
-    if (!dop || !dop->op) return false;
+    if (!dop || !dop->op)
+      return no("the operator H is not a MI355::DeviceOperator (a plain callable, or a tagged one wrapped in a lambda)");
     mi_precon *prec = nullptr;
     bool constraint_At = false;
     if (P) {
       if (const auto *dp = P->template target<DeviceSTPCGPreconditioner<Multiplier>>()) {
-        if (!dp->P || At) return false;  // (an ordinary preconditioner has no multipliers for `At` to act on)
+        // (an ordinary preconditioner has no multipliers for `At` to act on)
+        if (!dp->P || At) return no("an ordinary device preconditioner was passed together with At");
         prec = dp->P;
       } else if constexpr (is_device_vector<Multiplier>::value) {
         // projected solve (:229-253,381-405): constraint preconditioner and A' of ONE device KKT object
         const auto *cp = P->template target<DeviceConstraintPreconditioner>();
-        if (!cp || !cp->P) return false;
+        if (!cp || !cp->P)
+          return no("the preconditioner is neither a MI355::DeviceSTPCGPreconditioner nor a "
+                    "MI355::DeviceConstraintPreconditioner");
         if (At) {
           const auto *ct = At->template target<DeviceConstraintTranspose>();
-          if (!ct || ct->P != cp->P) return false;
+          if (!ct || ct->P != cp->P)
+            return no("At is not the MI355::DeviceConstraintTranspose of the constraint preconditioner's KKT object");
           constraint_At = true;
         }
         prec = cp->P;
       } else {
-        return false;
+        return no("the preconditioner is not a MI355::DeviceSTPCGPreconditioner");
       }
     } else if (At) {
-      return false;
+      return no("At was passed without a constraint preconditioner");
     }
     mi_stpcg_params prm;
     mi_stpcg_default_params(&prm);
@@ -127,17 +140,25 @@ bool lsqr_on_device(const LinearOperator<VectorX, VectorY, Args...> &A,
                     const InnerProduct<VectorX, Scalar, Args...> &ipx,
                     const InnerProduct<VectorY, Scalar, Args...> &ipy, size_t max_iterations, Scalar lambda,
                     Scalar btol, Scalar Atol, Scalar Abar_cond_limit, Scalar Delta, VectorX &x_out, Scalar &xnorm,
-                    size_t &num_iterations) {
+                    size_t &num_iterations, const char *&why) {
   if constexpr (!MI355::is_device_vector<VectorX>::value || !MI355::is_device_vector<VectorY>::value ||
                 !std::is_same<Scalar, double>::value || sizeof...(Args) != 0) {
+    why = "extra arguments (Args...), a Scalar other than double, or a host vector type";
     return false;
   } else {
     using namespace MI355;
-    if (b.empty()) return false;
-    if (!ipx.template target<FrobeniusInnerProduct>() || !ipy.template target<FrobeniusInnerProduct>()) return false;
+    auto no = [&why](const char *w) {
+      why = w;
+      return false;
+    };
+    if (b.empty()) return no("b is an empty vector");
+    if (!ipx.template target<FrobeniusInnerProduct>() || !ipy.template target<FrobeniusInnerProduct>())
+      return no("an inner product is not MI355::FrobeniusInnerProduct (a plain callable, or a tagged one wrapped in a "
+                "lambda)");
     const DeviceOperator *da = A.template target<DeviceOperator>();
     const DeviceOperator *dat = At.template target<DeviceOperator>();
-    if (!da || !da->op || !dat || !dat->op) return false;
+    if (!da || !da->op || !dat || !dat->op)
+      return no("A or At is not a MI355::DeviceOperator (a plain callable, or a tagged one wrapped in a lambda)");
     size_t nx = 0;
     check(mi_op_dims(dat->op, nullptr, &nx));
     mi_lsqr_params prm;
@@ -193,14 +214,21 @@ Vector STPCG(const Vector &g, const SymmetricLinearOperator<Vector, Args...> &H,
                                 "of H (epsilon) should be a small positive number in the range (0,1)");
 
 #if OPTIMIZATION_HAVE_MI355
-  if constexpr (sizeof...(Args) == 0) {
-    if (!user_function) {
-      Vector s_dev;
-      if (detail::stpcg_on_device<Vector, Multiplier, Scalar>(g, H, inner_product, P, At, Delta, max_iterations,
-                                                              kappa_fgr, theta, epsilon, s_dev,
-                                                              update_step_M_norm, num_iterations))
-        return s_dev;
+  if constexpr (MI355::is_device_vector<Vector>::value) {
+    const char *why = "extra arguments (Args...) are passed to the callables";
+    if constexpr (sizeof...(Args) == 0) {
+      if (!user_function) {
+        Vector s_dev;
+        if (detail::stpcg_on_device<Vector, Multiplier, Scalar>(g, H, inner_product, P, At, Delta, max_iterations,
+                                                                kappa_fgr, theta, epsilon, s_dev,
+                                                                update_step_M_norm, num_iterations, why))
+          return s_dev;
+      } else {
+        why = "a user function is supplied (it observes every iteration's vectors)";
+      }
     }
+    // the generic loop below on device vectors: make the fall observable (mi_ctx_fusion_counters, MI355OPT_WARN_GENERIC)
+    if (!g.empty()) (void)mi_ctx_note_generic(g.context(), MI_GENERIC_STPCG, why);
   }
 #endif
 
@@ -320,12 +348,17 @@ VectorX LSQR(const LinearOperator<VectorX, VectorY, Args...> &A,
     throw std::invalid_argument("Trust-region radius (Delta) must be a positive real value");
 
 #if OPTIMIZATION_HAVE_MI355
-  if (!user_function) {
-    VectorX x_dev;
-    if (detail::lsqr_on_device<VectorX, VectorY, Scalar, Args...>(A, At, b, inner_product_x, inner_product_y,
-                                                                  max_iterations, lambda, btol, Atol, Abar_cond_limit,
-                                                                  Delta, x_dev, xnorm, num_iterations))
-      return x_dev;
+  {
+    const char *why = "a user function is supplied (it observes every iteration's vectors)";
+    if (!user_function) {
+      VectorX x_dev;
+      if (detail::lsqr_on_device<VectorX, VectorY, Scalar, Args...>(A, At, b, inner_product_x, inner_product_y,
+                                                                    max_iterations, lambda, btol, Atol, Abar_cond_limit,
+                                                                    Delta, x_dev, xnorm, num_iterations, why))
+        return x_dev;
+    }
+    if constexpr (MI355::is_device_vector<VectorY>::value)
+      if (!b.empty()) (void)mi_ctx_note_generic(b.context(), MI_GENERIC_LSQR, why);
   }
 #endif
 

@@ -291,13 +291,19 @@ struct FrobeniusInnerProduct {
 };
 
 // LinearAlgebra::SymmetricLinearOperator<DeviceVector, ...> backed by an mi_op
+// (a rectangular operator -- a Jacobian, n_in -> n_out -- returns a vector of ITS output length)
+inline DeviceVector apply_device_operator(mi_op *op, const DeviceVector &v) {
+  size_t n_out = 0;
+  check(mi_op_dims(op, nullptr, &n_out));
+  DeviceVector out = n_out == v.size() ? DeviceVector::like(v) : DeviceVector::on(v.context(), n_out);
+  check(mi_op_apply(op, v.handle(), out.handle()));
+  return out;
+}
 struct DeviceOperator {
   mi_op *op = nullptr;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &v, A &...) const {
-    DeviceVector out = DeviceVector::like(v);
-    check(mi_op_apply(op, v.handle(), out.handle()));
-    return out;
+    return apply_device_operator(op, v);
   }
 };
 // Callables handed out by a problem object (MI355/Stiefel.h, MI355/SO3.h) carry the address of that object as
@@ -357,9 +363,7 @@ struct DeviceHessian {
   const void *owner = nullptr;
   template <typename... A>
   DeviceVector operator()(const DeviceVector &, const DeviceVector &v, A &...) const {
-    DeviceVector out = DeviceVector::like(v);
-    check(mi_op_apply(op, v.handle(), out.handle()));
-    return out;
+    return apply_device_operator(op, v);
   }
 };
 // Riemannian::LinearOperator used as TNT's `precon`, backed by an mi_precon bound to X

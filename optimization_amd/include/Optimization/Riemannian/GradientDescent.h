@@ -171,6 +171,13 @@ GradientDescentResult<Variable, Scalar> GradientDescent(
       }
 #endif
       if (!fused_trial) {
+#if OPTIMIZATION_GD_HAVE_MI355
+        if constexpr (MI355::is_device_vector<Tangent>::value && MI355::is_device_vector<Variable>::value)
+          if (!g.empty())  // the statement sequence on device vectors: observable (mi_ctx_fusion_counters)
+            (void)mi_ctx_note_generic(g.context(), MI_GENERIC_TRIAL,
+                                      "GradientDescent: metric, objective, gradient field and retraction are not the "
+                                      "tagged callables of ONE device problem (plain callables, or wrapped in lambdas)");
+#endif
         h = -t * g;
         x_trial = retract(x, h, args...);
         fx_trial = f(x_trial, args...);

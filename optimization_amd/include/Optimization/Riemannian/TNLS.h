@@ -19,6 +19,7 @@
 #include <functional>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <tuple>
@@ -179,6 +180,9 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
   // every linearisation because J may hand back new operators.
   constexpr bool device_types = MI355::is_device_vector<TangentX>::value &&
                                 MI355::is_device_vector<VectorY>::value && sizeof...(Args) == 0;
+  // (with a right preconditioner whose two halves are tagged device operators as well, A = dF o M and A' = M' o dF^*
+  // (:432-447) are composed on the device -- mi_op_create_compose -- so that the preconditioned solve stays fused too)
+  std::shared_ptr<mi_op> composed_A, composed_At;
   auto retag_for_device = [&]() {
     if constexpr (device_types) {
       // back to the generic views first (J may hand back tagged device operators at one iterate and plain callables
@@ -186,12 +190,26 @@ TNLS(const Mapping<VariableX, VectorY, Args...> &F, const JacobianPairFunction<V
       A = A_generic;
       At = At_generic;
       inner_product_X = inner_product_X_generic;
-      if (precon) return;
+      composed_A.reset();
+      composed_At.reset();
       const auto *a = dF.template target<MI355::DeviceHessian>();
       const auto *at = dFt.template target<MI355::DeviceHessian>();
-      if (!a || !at || !metric_X.template target<MI355::FrobeniusMetric>()) return;
-      A = MI355::DeviceOperator{a->op};
-      At = MI355::DeviceOperator{at->op};
+      if (!a || !at || !a->op || !at->op || !metric_X.template target<MI355::FrobeniusMetric>()) return;
+      if (precon) {
+        const auto *m = precon->first.template target<MI355::DeviceHessian>();
+        const auto *mt = precon->second.template target<MI355::DeviceHessian>();
+        if (!m || !mt || !m->op || !mt->op) return;
+        mi_op *ca = nullptr, *cat = nullptr;
+        MI355::check(mi_op_create_compose(x.context(), a->op, m->op, &ca));
+        composed_A.reset(ca, [](mi_op *o) { mi_op_destroy(o); });
+        MI355::check(mi_op_create_compose(x.context(), mt->op, at->op, &cat));
+        composed_At.reset(cat, [](mi_op *o) { mi_op_destroy(o); });
+        A = MI355::DeviceOperator{ca};
+        At = MI355::DeviceOperator{cat};
+      } else {
+        A = MI355::DeviceOperator{a->op};
+        At = MI355::DeviceOperator{at->op};
+      }
       inner_product_X = MI355::FrobeniusInnerProduct{};
     }
   };

@@ -264,6 +264,14 @@ TNT(const Objective<Variable, Scalar, Args...> &f, const QuadraticModel<Variable
       if (fused_trial && precon)
         if (const auto *dp = precon->template target<MI355::DevicePreconditioner>())
           owners_precon = dp->owner == fused_trial->owner;
+      if (!fused_trial && !grad.empty())  // the statement sequence below on device vectors: make it observable
+        (void)mi_ctx_note_generic(
+            grad.context(), MI_GENERIC_TRIAL,
+            !tr ? "the retraction is not a MI355::DeviceTrialRetraction (a plain callable, or a tagged one wrapped in a lambda)"
+            : !fo ? "the objective is not the MI355::DeviceObjective of the retraction's problem (a plain callable, or wrapped)"
+            : !dh ? "the Hessian the quadratic model returned is not a MI355::DeviceHessian (a plain callable, or wrapped)"
+                  : "objective, Hessian and retraction belong to different problems, or the metric is not "
+                    "MI355::FrobeniusMetric");
     }
     // with a fused trial step right behind it, the fused inner solve does not wait for the device either: one
     // read-back serves both (MI355::DeferScope)

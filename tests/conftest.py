@@ -79,3 +79,23 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.linalg.norm(b), 1e-300)
     return np.linalg.norm(a - b) / den
+
+
+def trace_close(a, ref, floor_trace, tol, factor=3.0):
+    """Per-iteration scalars (alpha_k, beta_k) against the reference's: |a_k / ref_k - 1| <= tol, or -- where the SAME
+    reference algorithm with re-associated sums (floor_trace, conftest.oracle_omp) has itself moved further than that --
+    `factor` x the running maximum of its deviation up to k.  Returns (ok, message with the measured pair)."""
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    k = min(a.size, ref.size)
+    e = np.abs(a[:k] / ref[:k] - 1)
+    bar = np.full(k, tol)
+    fl = np.zeros(k)
+    if floor_trace is not None:
+        fm = np.abs(np.asarray(floor_trace, dtype=np.float64)[:k] / ref[:k] - 1)
+        fl[:fm.size] = np.maximum.accumulate(fm)
+        bar = np.maximum(bar, factor * fl)
+    bad = np.nonzero(e > bar)[0]
+    msg = (f"max deviation {e.max():.2e} at k = {int(e.argmax())} (re-associated reference there: {fl[int(e.argmax())]:.2e}; "
+           f"bar {tol:.0e} or {factor:g} x floor)" + (f"; first violation at k = {int(bad[0])}: {e[bad[0]]:.2e} > {bar[bad[0]]:.2e}"
+                                                      if bad.size else ""))
+    return bad.size == 0 and a.size == ref.size, msg

@@ -63,6 +63,15 @@ static void fill_params(RM::TNTParams<double> &tp, const orc_tnt_params *p) {
   tp.Delta_tolerance = p->Delta_tolerance;
 }
 
+// mi_ctx_fusion_counters of the context of the last harness call that took a snapshot (FusionSnap below)
+static mi_fusion_counters g_last_fusion = {0, 0, 0, 0, 0, 0, 0};
+extern "C" void hd_last_fusion_counters(mi_fusion_counters *out) { *out = g_last_fusion; }
+struct FusionSnap {  // declared right behind the Context: its destructor runs before the context is destroyed
+  mi_ctx *c;
+  explicit FusionSnap(const Context &ctx) : c(ctx.get()) {}
+  ~FusionSnap() { (void)mi_ctx_fusion_counters(c, &g_last_fusion); }
+};
+
 static double g_last_tnt_seconds = 0.0;
 static double g_last_tnt_wall_seconds = 0.0;
 static size_t g_last_tnt_syncs = 0;
@@ -116,6 +125,7 @@ extern "C" int hd_stpcg_diag(size_t n, const double *g, const double *D, const d
                              double *M_norm, size_t *iterations) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   DeviceVector gd(ctx, g, n), Dd(ctx, D, n);
   mi_op *op = nullptr;
   MI355::check(mi_op_create_diag(ctx.get(), Dd.handle(), &op));
@@ -310,6 +320,7 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
                               const double *X0, const orc_tnt_params *params, int mode, orc_tnt_result *res) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   MI355::StiefelRayleighQuotient prob(ctx, n, p, rowptr, col, val);
   DeviceVector x0(ctx, X0, n * (size_t)p);
   RM::TNTParams<double> tp;
@@ -332,6 +343,18 @@ extern "C" int hd_tnt_stiefel(size_t n, int p, const int32_t *rowptr, const int3
     // TNT must call THIS f (the reference always calls the supplied f), i.e. keep the statement sequence
     auto ft = prob.objective();
     f = [ft](const DeviceVector &X) { return ft(X) + 1.0; };
+  }
+  if (mode == 4) {
+    // r06: ONLY the Hessian the model returns is wrapped in a lambda of the client's -- what a
+    // logger or a penalty term does, and what the reference's own adapter lambdas (TNT.h:400-426) look like.  Metric,
+    // objective and retraction stay tagged.  The run must give the same answers; the fusion counters must say that it
+    // ran on the generic side of the boundary.
+    auto QMt = prob.quadratic_model();
+    QM = [QMt](const DeviceVector &X, DeviceVector &g, RM::LinearOperator<DeviceVector, DeviceVector> &Hs) {
+      RM::LinearOperator<DeviceVector, DeviceVector> tagged;
+      QMt(X, g, tagged);
+      Hs = [tagged](const DeviceVector &Y, const DeviceVector &V) { return tagged(Y, V); };
+    };
   }
   if (mode == 1) {  // hide the tags
     auto QMt = prob.quadratic_model();
@@ -368,6 +391,7 @@ extern "C" int hd_tnt_so3n(size_t N, size_t E, const int32_t *ei, const int32_t 
                            orc_tnt_result *res) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   MI355::RotationAveraging prob(ctx, N, E, ei, ej, Rt, w);
   DeviceVector x0(ctx, R0, 9 * N);
   RM::TNTParams<double> tp;
@@ -763,6 +787,7 @@ extern "C" int hd_gd_stiefel(size_t n, int p, const int32_t *rowptr, const int32
                              double *objective_values, size_t *linesearch_iterations, size_t *syncs_out) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   MI355::StiefelRayleighQuotient prob(ctx, n, p, rowptr, col, val);
   DeviceVector x0(ctx, X0, n * (size_t)p);
   RM::GradientDescentParams<double> gp;
@@ -829,6 +854,7 @@ extern "C" int hd_lsqr_csr(size_t n, const int32_t *rp, const int32_t *cl, const
                            double *x_out, double *xnorm_out, size_t *iterations_out) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
   LA::LinearOperator<DeviceVector, DeviceVector> Aop, Atop;
   LA::InnerProduct<DeviceVector, double> ip;
@@ -871,6 +897,7 @@ extern "C" int hd_tnls_affine(size_t n, const int32_t *rp, const int32_t *cl, co
                               double *gradnorm_out, int *status_out, size_t *outer_out, size_t *inner_total_out) {
   HD_GUARD_BEGIN
   Context ctx(0);
+  FusionSnap fusion_snap(ctx);
   CsrPair M(ctx, n, rp, cl, vl, rpt, clt, vlt);
   DeviceVector bv(ctx, b, n);
   mi_op *opA = nullptr, *opAt = nullptr;

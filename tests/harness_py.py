@@ -45,6 +45,15 @@ class DeviceHarness:
     def err(self):
         return self.L.hd_last_error().decode()
 
+    def fusion_counters(self):
+        """mi_ctx_fusion_counters of the context of the last harness call (hd_last_fusion_counters)"""
+        from optimization_amd import capi
+        fc = capi.FusionCounters()
+        self.L.hd_last_fusion_counters.restype = None
+        self.L.hd_last_fusion_counters.argtypes = [C.POINTER(capi.FusionCounters)]
+        self.L.hd_last_fusion_counters(C.byref(fc))
+        return {k: int(getattr(fc, k)) for k, _ in capi.FusionCounters._fields_}
+
     def stpcg_diag(self, g, D, Minv, Delta, max_iterations, kappa, theta, mode):
         g = np.ascontiguousarray(g, dtype=np.float64)
         D = np.ascontiguousarray(D, dtype=np.float64)
@@ -289,3 +298,36 @@ class DeviceHarness:
         return dict(rc=rc, err=self.err() if rc else "", x=x.reshape(n, p), f=f.value, gradfx_norm=gn.value,
                     status=st.value, iterations=it.value, objective_values=fv[:k].copy(),
                     linesearch_iterations=ls[:k].astype(np.int64), syncs=sy.value)
+
+
+class SinfitHarness:
+    """tests/cpp/libharness_sinfit.so (hipcc): the reference's TNLS sin-fit problem with HIP kernels of its own; the
+    Jacobian pair handed back by J(x) is a pair of FRESH device operators at every linearisation."""
+    PATH = os.path.join(HERE, "cpp", "libharness_sinfit.so")
+
+    def __init__(self):
+        from optimization_amd import capi
+        if not os.path.exists(self.PATH):
+            raise FileNotFoundError(self.PATH + " (run __graft_entry__.build())")
+        self.L = C.CDLL(self.PATH)
+        self.L.hs_last_error.restype = C.c_char_p
+        self.FC = capi.FusionCounters
+        self.L.hs_tnls_sinfit.restype = C.c_int
+        self.L.hs_tnls_sinfit.argtypes = [C.c_size_t, dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                          C.c_size_t, dp, dp, dp, C.POINTER(C.c_int), sp, sp, sp, C.POINTER(self.FC)]
+
+    def tnls_sinfit(self, t, y, beta0, with_precon=False, mode=0, root_tolerance=1e-6, gradient_tolerance=0.0,
+                    Delta_tolerance=0.0, max_iterations=100):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        b0 = np.ascontiguousarray(beta0, dtype=np.float64)
+        beta = np.zeros(2)
+        f, gn = C.c_double(0), C.c_double(0)
+        st, outer, inner, jac = C.c_int(-1), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        fc = self.FC()
+        rc = self.L.hs_tnls_sinfit(t.size, _dp(t), _dp(y), _dp(b0), int(with_precon), mode, root_tolerance,
+                                   gradient_tolerance, Delta_tolerance, max_iterations, _dp(beta), C.byref(f),
+                                   C.byref(gn), C.byref(st), C.byref(outer), C.byref(inner), C.byref(jac), C.byref(fc))
+        return dict(rc=rc, err=self.L.hs_last_error().decode() if rc else "", beta=beta, f=f.value,
+                    gradfx_norm=gn.value, status=st.value, outer=outer.value, inner_total=inner.value,
+                    jacobians=jac.value, counters={k: int(getattr(fc, k)) for k, _ in self.FC._fields_})

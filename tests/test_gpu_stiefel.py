@@ -231,7 +231,7 @@ def test_full_size_fused_stpcg_vs_oracle(ctx, oracle, full_rq):
 
 
 @pytest.mark.parametrize("p", [1, 2, 3, 4])
-def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
+def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, oracle_omp, monkeypatch, p):
     """STPCG's one-pass Stiefel Hessian (mi_op::dirgram) in both forms -- Gram of the direction carried by
     scalar recurrences (default without a preconditioner) and Gram rows formed by the direction kernel
     (MI355OPT_DIRGRAM_DIRECT=1) -- against the two-pass operator (MI355OPT_NO_DIRGRAM=1) and the oracle, for
@@ -246,6 +246,16 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
     o = oracle.stpcg_problem(oprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
                              trace_cap=64)
     oracle.free(oprob)
+    # the conditioning floor of the late scalars: on this 504-row problem the Hessian is nearly singular at the iterate
+    # (the residual RISES again after ~30 iterations), and the reference algorithm itself, sums re-associated, moves
+    # beta_40 by 3e-8 at p = 4
+    fl = None
+    if oracle_omp is not None:
+        mprob = oracle_omp.stiefel_rq(n, p, rowptr, col, val)
+        gm = oracle_omp.eval_grad(mprob, Xb.ravel())
+        fl = oracle_omp.stpcg_problem(mprob, Xb.ravel(), gm, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
+                                      trace_cap=64)["trace"]
+        oracle_omp.free(mprob)
     env = {"recurrence": ("0", "0"), "direct": ("0", "1"), "two-pass": ("1", "0")}
     res = {}
     for mode, (no_dirgram, direct) in env.items():
@@ -271,10 +281,12 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypatch, p):
         assert res[mode]["launches"]["stiefel_finish_dots"] == 0
     assert res["two-pass"]["launches"]["stiefel_hess_fused"] == 0
     assert res["two-pass"]["launches"]["stiefel_finish_dots"] > 0
+    from conftest import trace_close
     for mode, r in res.items():
         assert r["iterations"] == o["iterations"] and r["exit_reason"] == o["exit_reason"], mode
-        assert np.allclose(r["trace"]["alpha"], o["trace"]["alpha"], rtol=1e-9), mode
-        assert np.allclose(r["trace"]["beta"], o["trace"]["beta"], rtol=1e-8), mode
+        for key, tol in (("alpha", 1e-9), ("beta", 1e-8)):
+            ok, msg = trace_close(r["trace"][key], o["trace"][key], fl[key] if fl else None, tol)
+            assert ok, f"{mode} {key}: {msg}"
         assert rel_err(r["s"], o["s"]) < 1e-10, mode
     assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
     assert rel_err(res["direct"]["s"], res["two-pass"]["s"]) < 1e-11

@@ -573,3 +573,82 @@ def test_tnt_supplied_objective_is_the_one_called(harness, oracle):
     # same decisions while df is far above the rounding of (f + 1)
     k = 5
     assert list(c["inner_iterations"][:k]) == list(a["inner_iterations"][:k])
+
+
+# ---- r06: TNLS with a Jacobian that CHANGES, on the device ------------------------------------
+@pytest.fixture(scope="module")
+def sinfit():
+    import harness_py
+    return harness_py.SinfitHarness()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["fused_lsqr", "generic"])
+@pytest.mark.parametrize("case", ["root", "least_squares", "least_squares_preconditioned"])
+def test_tnls_sinfit_with_a_changing_jacobian_on_the_device(sinfit, golden, case, mode):
+    """The reference's own TNLS problem (tests/TNLS_unit_test.cpp:151-260: y = sin(b0 t + b1), m = 100; root finding,
+    least squares without and with the right preconditioner R^-1 of J'J = R'R) through Riemannian::TNLS on DeviceVector
+    with HIP kernels of the client's own (tests/cpp/harness_sinfit.hip): J(x) hands back FRESH tagged operators at every
+    linearisation, so TNLS must re-tag its LSQR operators every outer iteration (TNLS.h:414-462) -- and with the
+    preconditioner compose them on the device (mi_op_create_compose).  Against the REAL reference's result on the same
+    input bytes (tests/golden/tnls_sinfit.json): status, outer and inner counts, beta and |F| to 1e-10.  mode 0: every
+    inner solve ran in the fused mi_lsqr (mi_ctx_fusion_counters); mode 1: the same kernels behind plain lambdas."""
+    fx = golden("tnls_sinfit.json")
+    c = [c_ for c_ in fx["cases"] if c_["name"] == case][0]
+    r = sinfit.tnls_sinfit(fx["t"], c["y"], fx["beta0"], mode=mode, **c["kw"])
+    assert r["rc"] == 0, r["err"]
+    eb = float(np.abs(r["beta"] - np.array(c["beta"])).max() / np.abs(c["beta"]).max())
+    ef = abs(r["f"] - c["f"]) / max(abs(c["f"]), 1e-3)   # (the root case ends at |F| ~ 4e-10: absolute there)
+    print(f"tnls sinfit {case} mode {mode}: status {r['status']}, outer {r['outer']} (ref {c['outer']}), inner "
+          f"{r['inner_total']} (ref {c['inner_total']}), beta {eb:.2e}, f {ef:.2e}, jacobians {r['jacobians']}, {r['counters']}")
+    assert r["status"] == c["status"]
+    assert (r["outer"], r["inner_total"]) == (c["outer"], c["inner_total"])
+    assert eb <= 1e-10 and ef <= 1e-10
+    assert r["jacobians"] >= 3          # the Jacobian really changed hands several times
+    k = r["counters"]
+    if mode == 0:
+        assert k["fused_lsqr_solves"] == r["outer"] and k["generic_lsqr_solves"] == 0, k
+    else:
+        assert k["generic_lsqr_solves"] == r["outer"] and k["fused_lsqr_solves"] == 0, k
+
+
+# ---- r06 (VERDICT r05 item 7): the fusion boundary is observable -----------------------------------------------------
+def test_wrapping_the_hessian_in_a_lambda_flips_the_fusion_counters_and_nothing_else(harness, oracle, golden, capfd,
+                                                                                    monkeypatch):
+    """The template layer picks the fused entry points by std::function::target<>() probes; a client that wraps the
+    Hessian the quadratic model returns in a lambda of its own (mode 4 of hd_tnt_stiefel: what a logger does, and what
+    the reference's own adapter lambdas TNT.h:400-426 look like) gets the generic loop.  That used to be silent.  Now:
+    mi_ctx_fusion_counters says which side every solve and trial step ran on, MI355OPT_WARN_GENERIC=1 prints one line
+    per kind naming the probe that failed -- and the run itself is unchanged (same counts, f to 1e-12)."""
+    g = golden("tnt_stiefel_8x7x6.json")
+    nx, ny, nz = g["grid"]
+    p, n = g["p"], nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    X0 = np.array(g["x0"]).reshape(n, p)
+    prm = oracle.default_params(gradient_tolerance=1e-8, relative_decrease_tolerance=0, stepsize_tolerance=0,
+                                preconditioned_gradient_tolerance=0, Delta_tolerance=0, max_iterations=200,
+                                max_TPCG_iterations=50)
+    monkeypatch.setenv("MI355OPT_WARN_GENERIC", "1")
+    capfd.readouterr()
+    a = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 0)
+    ka = harness.fusion_counters()
+    err_a = capfd.readouterr().err
+    b = harness.tnt_stiefel(n, p, rowptr, col, val, X0, prm, 4)
+    kb = harness.fusion_counters()
+    err_b = capfd.readouterr().err
+    assert a["rc"] == 0 and b["rc"] == 0, (a.get("err"), b.get("err"))
+    print("tagged :", ka, "\nwrapped:", kb, "\n", err_b.strip())
+    outer = a["outer_iterations"]
+    # nothing else changes
+    assert (b["status"], b["outer_iterations"], b["accepted"]) == (a["status"], outer, a["accepted"])
+    assert list(b["inner_iterations"]) == list(a["inner_iterations"])
+    assert abs(a["f"] - b["f"]) < 1e-12 and abs(a["f"] - g["f"]) < 1e-12
+    # the tagged run: every inner solve in mi_stpcg, every trial point by the fused chain, no generic work at all
+    assert ka["fused_stpcg_solves"] == outer and ka["generic_stpcg_solves"] == 0
+    assert ka["fused_trial_steps"] == outer and ka["generic_trial_steps"] == 0
+    assert "runs the GENERIC loop" not in err_a
+    # the wrapped run: the other side of the boundary, visibly
+    assert kb["generic_stpcg_solves"] == outer and kb["fused_stpcg_solves"] == 0
+    assert kb["generic_trial_steps"] == outer and kb["fused_trial_steps"] == 0
+    assert kb["generic_inner_products"] > 10 * ka["generic_inner_products"]
+    assert err_b.count("STPCG on MI355::DeviceVector runs the GENERIC loop") == 1      # once, not once per solve
+    assert "MI355::DeviceOperator" in err_b and "trial step" in err_b
