@@ -112,9 +112,10 @@ enum {
  * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
  * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA,
  * NO_ZERO_COPY, NO_GRAM_HALF, NO_UPDATE_PAIR, SO3_NO_QUAT, SO3_SORT_NBR, HALO_RPRIME, TWO_KERNEL_STEP, WIDE_QUAD,
- * NO_POLLED_SYNC (DESIGN.md / INTEGRATION.md say what each selects).  A value that is not an integer counts as 1 unless it
- * is "no" / "false" / "off"; any other MI355OPT_* variable found in the environment (a removed or misspelt switch)
- * gets one warning on stderr.  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
+ * NO_POLLED_SYNC, WARN_GENERIC (DESIGN.md / INTEGRATION.md say what each selects).  For the boolean switches a value that
+ * is not an integer counts as 1 unless it is "no" / "false" / "off"; the integer-valued ones (MAX_GRID, IPC_TIMEOUT_MS,
+ * WIDE_QUAD, SO3_SORT_NBR) take integers only -- anything else is ignored with a warning and the default stays.  Any other
+ * MI355OPT_* variable found in the environment (a removed or misspelt switch) gets one warning on stderr.  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_
  * prefix); format switches (NO_PACKED) act when a matrix is created, the communication ones before the layer they
  * concern is brought up.  Nothing else in the library reads the environment. */
 MI_API int mi_ctx_set_option(mi_ctx *ctx, const char *name, long value);
@@ -244,12 +245,20 @@ MI_API int mi_precon_create_constraint(mi_ctx *ctx, size_t n, size_t m, const mi
  * inside ONE workgroup (fixed-order reductions: deterministic) to a relative residual of inner_tol (0: 1e-14 -- the
  * projection must be accurate to rounding or the outer iterates drift out of the null space of A) or
  * inner_max_iterations (0: 10 m + 100), then v = M^-1 (r - A' lambda) and, with constraint_At, r -= A' lambda.
- * mi_precon_constraint_info reports what the inner iteration needed and left (sync).  Minv must outlive P. */
+ * mi_precon_constraint_info reports what the inner iteration needed and left (sync).  Minv must outlive P.
+ * Failure semantics (r06): a BREAKDOWN of the inner iteration (p'Sp <= 0 or not finite: dependent constraint rows, NaN /
+ * Inf in the residual; status code 1) makes the mi_stpcg / mi_stpcg_collect that used the preconditioner return
+ * MI_ERR_INTERNAL -- its result is not a projected step.  Stopping at inner_max_iterations short of inner_tol (status
+ * code 2) is NOT an error: the caller who caps the iteration count gets the inexact projection it asked for, the solve
+ * returns MI_OK with mi_stpcg_result::precon_status = 2, and mi_precon_constraint_info -- which always returns MI_OK on
+ * a valid handle -- gives the code and the worst relative residual so far.  The status word is per solve (reset at the
+ * start of each mi_stpcg). */
 MI_API int mi_precon_create_constraint_csr(mi_ctx *ctx, size_t n, size_t m, const int32_t *rowptr, const int32_t *col,
                                            const double *val, const mi_vec *Minv, double inner_tol,
                                            size_t inner_max_iterations, mi_precon **out);
 MI_API int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, double *last_relative_residual,
-                                     double *worst_relative_residual);
+                                     double *worst_relative_residual, int *status_code /* 0, 1 or 2; any pointer may
+                                     be null */);
 MI_API int mi_precon_constraint_solve(mi_precon *P, const mi_vec *r, mi_vec *v, mi_vec *lambda /*nullable*/);
 MI_API int mi_precon_constraint_At(mi_precon *P, const mi_vec *lambda, mi_vec *out);
 MI_API int mi_precon_apply(mi_precon *P, const mi_vec *r, mi_vec *v);
@@ -289,6 +298,9 @@ typedef struct mi_stpcg_result {
   int exit_reason;
   size_t hvp_calls;          /* operator applications enqueued (incl. speculative ones past the exit) */
   double rv_final;           /* last <r,v> */
+  int precon_status;         /* 0, or 2: a constraint preconditioner's inner iteration stopped at its iteration limit short
+                                of its tolerance during this solve (an INEXACT projection; mi_precon_constraint_info has
+                                the residual left).  A breakdown (code 1) makes mi_stpcg return MI_ERR_INTERNAL instead */
 } mi_stpcg_result;
 
 typedef struct mi_stpcg_trace { /* optional per-iteration scalars, host arrays of capacity cap */

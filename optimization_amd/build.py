@@ -237,6 +237,10 @@ def _sanitizer_probe(tdir, san):
         for opts in ("detect_leaks=1:abort_on_error=0", "detect_leaks=0:abort_on_error=0"):
             r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS=opts))
             if r.returncode == 0:
+                if "detect_leaks=0" in opts:
+                    print("[build] warning: LeakSanitizer cannot run here (ptrace / seccomp restriction?): the sanitizer "
+                          "target runs with detect_leaks=0 -- heap errors and undefined behaviour are still checked, "
+                          "leaks are NOT", file=sys.stderr)
                 return opts
         raise SanitizerUnavailable("a trivial sanitized program does not run here:\n" + r.stderr[-800:])
 

@@ -68,7 +68,8 @@ class StpcgParams(C.Structure):
 
 class StpcgResult(C.Structure):
     _fields_ = [("update_step_M_norm", C.c_double), ("num_iterations", C.c_size_t),
-                ("exit_reason", C.c_int), ("hvp_calls", C.c_size_t), ("rv_final", C.c_double)]
+                ("exit_reason", C.c_int), ("hvp_calls", C.c_size_t), ("rv_final", C.c_double),
+                ("precon_status", C.c_int)]
 
 
 class LsqrParams(C.Structure):
@@ -166,7 +167,7 @@ def load():
         "mi_precon_create_constraint": [vp, C.c_size_t, C.c_size_t, vp, vp, C.POINTER(vp)],
         "mi_precon_create_constraint_csr": [vp, C.c_size_t, C.c_size_t, c_int32_p, c_int32_p, c_double_p, vp, C.c_double,
                                             C.c_size_t, C.POINTER(vp)],
-        "mi_precon_constraint_info": [vp, c_size_p, c_double_p, c_double_p],
+        "mi_precon_constraint_info": [vp, c_size_p, c_double_p, c_double_p, C.POINTER(C.c_int)],
         "mi_precon_constraint_solve": [vp, vp, vp, vp],
         "mi_precon_constraint_At": [vp, vp, vp],
         "mi_precon_destroy": [vp],
@@ -519,7 +520,8 @@ class Context:
         check(self.L.mi_stpcg(self.h, g.h, H.h, P.h if P is not None else None, C.byref(prm), s.h,
                               C.byref(res), C.byref(tr) if tr else None))
         out = dict(s=s, M_norm=res.update_step_M_norm, iterations=res.num_iterations,
-                   exit_reason=res.exit_reason, hvp_calls=res.hvp_calls, rv_final=res.rv_final)
+                   exit_reason=res.exit_reason, hvp_calls=res.hvp_calls, rv_final=res.rv_final,
+                   precon_status=res.precon_status)
         if tr:
             out["trace"] = {k: v[:tr.len].copy() for k, v in arrs.items()}
         return out
@@ -528,7 +530,7 @@ class Context:
         res = StpcgResult()
         check(self.L.mi_stpcg_collect(self.h, C.byref(res)))
         return dict(M_norm=res.update_step_M_norm, iterations=res.num_iterations, exit_reason=res.exit_reason,
-                    hvp_calls=res.hvp_calls, rv_final=res.rv_final)
+                    hvp_calls=res.hvp_calls, rv_final=res.rv_final, precon_status=res.precon_status)
 
     # fused LSQR ---------------------------------------------------------------------------------
     def lsqr(self, A, At, b, x_out=None, **kw):
@@ -970,10 +972,12 @@ class ConstraintPrecon(Precon):
         return out
 
     def info(self):
-        """(inner iterations of the last application, its relative residual, the worst one so far): sparse form only"""
-        it, last, worst = C.c_size_t(0), C.c_double(0), C.c_double(0)
-        check(self.L.mi_precon_constraint_info(self.h, C.byref(it), C.byref(last), C.byref(worst)))
-        return it.value, last.value, worst.value
+        """(inner iterations of the last application, its relative residual, the worst one so far, status code: 0 ok,
+        1 the inner iteration broke down, 2 it stopped at its iteration limit short of its tolerance): sparse form only.
+        Never raises on a valid handle -- the code is an output."""
+        it, last, worst, code = C.c_size_t(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        check(self.L.mi_precon_constraint_info(self.h, C.byref(it), C.byref(last), C.byref(worst), C.byref(code)))
+        return it.value, last.value, worst.value, code.value
 
 
 class _BorrowedPrecon(Precon):

@@ -33,7 +33,10 @@ static int readback_reserve(mi_ctx *ctx, size_t total) {
     ctx->readback_host = nullptr;
     ctx->readback_bytes = 0;
     const size_t cap = std::max<size_t>(total, 256 * 1024);
-    MI_HIP(hipHostMalloc(&ctx->readback_host, cap, hipHostMallocDefault));
+    // (Mapped | Coherent like poll_flag and host_scalars: kernels store Gram blocks and residual norms straight into this
+    // area and the host reads them behind a polled flag -- with hipHostMallocDefault the coherence of such stores hangs
+    // on the HIP_HOST_COHERENT environment variable)
+    MI_HIP(hipHostMalloc(&ctx->readback_host, cap, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->readback_bytes = cap;
   }
   return MI_OK;
@@ -59,11 +62,17 @@ unsigned long long poll_begin(mi_ctx *ctx, unsigned long long **flag_dev) {
 // Poll for `seq` (stored by a kernel the caller enqueued behind the work -- and whose LAUNCH the caller has checked:
 // seq = 0 means "no flag will come").  Bounded: a kernel that faulted never stores the flag -- the synchronisation
 // below then reports the error -- and a long queue is better slept on than spun on.
+static inline void cpu_relax() {
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(__i386__))
+  __builtin_ia32_pause();
+#endif
+}
 int poll_finish(mi_ctx *ctx, unsigned long long seq, const char *what) {
   if (seq) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
       if (__atomic_load_n(ctx->poll_flag, __ATOMIC_ACQUIRE) >= seq) return MI_OK;  // (the sequence only grows, in stream order)
+      cpu_relax();  // (spin-wait hint: a sibling hyper-thread / an oversubscribed host gets the core's slots)
       if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
   }
@@ -201,6 +210,7 @@ namespace {
 struct OptionDesc {
   const char *name;
   int (*set)(mi_ctx *, long);
+  bool integer = false;  // an integer-valued option (a count, a time): only an integer is a value for it
 };
 // (plain functions, not lambdas: a captureless lambda does not convert to a function pointer in hipcc's device pass)
 #define OPT_BOOL(FN, FIELD) \
@@ -247,29 +257,37 @@ int opt_ipc_timeout_ms(mi_ctx *c, long v) {
 }
 const OptionDesc kOptions[] = {
     {"FORCE_SLOT_PATH", opt_force_slot_path}, {"FORCE_LOCKSTEP", opt_force_lockstep},
-    {"NO_DIRGRAM", opt_no_dirgram}, {"DIRGRAM_DIRECT", opt_dirgram_direct}, {"MAX_GRID", opt_max_grid},
-    {"FORCE_UNIFORM_GRID", opt_force_uniform_grid}, {"IPC_TIMEOUT_MS", opt_ipc_timeout_ms},
+    {"NO_DIRGRAM", opt_no_dirgram}, {"DIRGRAM_DIRECT", opt_dirgram_direct}, {"MAX_GRID", opt_max_grid, true},
+    {"FORCE_UNIFORM_GRID", opt_force_uniform_grid}, {"IPC_TIMEOUT_MS", opt_ipc_timeout_ms, true},
     {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
-    {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad},
-    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr},
+    {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true},
+    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
     {"WARN_GENERIC", opt_warn_generic},
 };
-// value of a switch: an integer; anything else that is not empty ("yes", "true", "on" -- and the presence-only
-// `MI355OPT_X=` of the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off
-long option_value(const char *e) {
+// value of a BOOLEAN switch: an integer; anything else ("yes", "true", "on" -- and the presence-only `MI355OPT_X=` of
+// the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off.  An INTEGER-valued
+// option (MAX_GRID, IPC_TIMEOUT_MS, WIDE_QUAD, SO3_SORT_NBR) takes integers only: `MI355OPT_IPC_TIMEOUT_MS=` or `=yes`
+// used to mean a 1 ms timeout and `MI355OPT_MAX_GRID=` one workgroup -- now a warning, and the default stays.
+bool option_value(const OptionDesc &o, const char *e, long *v) {
   char *end = nullptr;
-  const long v = strtol(e, &end, 0);
-  if (end != e && *end == '\0') return v;
-  if (!strcasecmp(e, "no") || !strcasecmp(e, "false") || !strcasecmp(e, "off")) return 0;
-  return 1;
+  *v = strtol(e, &end, 0);
+  if (end != e && *end == '\0') return true;
+  if (o.integer) {
+    fprintf(stderr, "[mi355opt] warning: MI355OPT_%s=\"%s\" is not an integer; ignored (the default stays)\n", o.name, e);
+    return false;
+  }
+  *v = (!strcasecmp(e, "no") || !strcasecmp(e, "false") || !strcasecmp(e, "off")) ? 0 : 1;
+  return true;
 }
 void config_from_env(mi_ctx *ctx) {
   for (const OptionDesc &o : kOptions) {
     char name[64];
     snprintf(name, sizeof(name), "MI355OPT_%s", o.name);
-    if (const char *e = getenv(name)) (void)o.set(ctx, option_value(e));
+    long v = 0;
+    if (const char *e = getenv(name))
+      if (option_value(o, e, &v)) (void)o.set(ctx, v);
   }
   // A removed or misspelt switch must not turn an A/B script into two runs of the default path without a word: warn
   // once per process about every MI355OPT_* variable that is neither a switch of the library nor one of the names the

@@ -545,7 +545,7 @@ int mi_precon_create_constraint_csr(mi_ctx *ctx, size_t n, size_t m, const int32
 }
 
 int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, double *last_relative_residual,
-                              double *worst_relative_residual) {
+                              double *worst_relative_residual, int *status_code) {
   MI_REQUIRE(P && P->kind == 3, "not a constraint preconditioner");
   KktImpl *k = (KktImpl *)P->impl;
   double h[4] = {0, 0, 0, 0};
@@ -557,13 +557,10 @@ int mi_precon_constraint_info(mi_precon *P, size_t *last_inner_iterations, doubl
   if (last_inner_iterations) *last_inner_iterations = (size_t)h[0];
   if (last_relative_residual) *last_relative_residual = h[1];
   if (worst_relative_residual) *worst_relative_residual = h[2];
-  if (h[3] != 0.0) {
-    set_error(h[3] == 1.0 ? "constraint preconditioner: the inner CG on S = A M^-1 A' broke down (p'Sp <= 0 or not "
-                            "finite: dependent constraint rows, or NaN / Inf in the residual)"
-                          : "constraint preconditioner: the inner CG on S = A M^-1 A' stopped at its iteration limit "
-                            "short of the tolerance");
-    return MI_ERR_INTERNAL;
-  }
+  // the getter itself succeeds whatever the inner iteration did: the code is an OUTPUT (1: broke down -- p'Sp <= 0 or not
+  // finite; 2: stopped at its iteration limit short of the tolerance), so that a caller can read the residual exactly
+  // when it needs it
+  if (status_code) *status_code = (int)h[3];
   return MI_OK;
 }
 

@@ -617,12 +617,16 @@ void mi_stpcg_default_params(mi_stpcg_params *p) {
 
 // the sticky failure word of the solve's preconditioner (mi_precon::fail_word) travels right behind the state copy
 static inline double *precon_fail_host(mi_ctx *ctx) { return reinterpret_cast<double *>(ctx->cg_host + 1); }
-static int precon_fail_check(mi_ctx *ctx) {
+// Code 1 (the preconditioner's inner iteration BROKE DOWN: p'Sp <= 0, NaN / Inf) is an error of the solve: its result is
+// not a projected step.  Code 2 (the inner iteration stopped at its iteration limit short of its tolerance) is NOT: a
+// caller that caps inner_max_iterations to bound the cost asks for an inexact projection -- the solve
+// returns MI_OK, mi_stpcg_result::precon_status says 2, and mi_precon_constraint_info has the residual that was left.
+static int precon_fail_check(mi_ctx *ctx, mi_stpcg_result *result) {
   const double w = *precon_fail_host(ctx);
-  if (w == 0.0) return MI_OK;
-  set_error("the preconditioner of this solve reported a failed application (code %g: 1 = its inner iteration broke "
-            "down, 2 = it stopped at its iteration limit short of its tolerance): the result is not a projected step",
-            w);
+  if (result) result->precon_status = (int)w;
+  if (w != 1.0) return MI_OK;
+  set_error("the preconditioner of this solve reported a failed application (code 1: its inner iteration broke down -- "
+            "dependent constraint rows, or NaN / Inf in the residual): the result is not a projected step");
   return MI_ERR_INTERNAL;
 }
 
@@ -686,7 +690,7 @@ int mi_stpcg_collect(mi_ctx *ctx, mi_stpcg_result *result) {
   result->exit_reason = f.exit_reason;
   result->rv_final = f.rv;
   result->hvp_calls = ctx->cg_deferred_hvp;
-  return precon_fail_check(ctx);
+  return precon_fail_check(ctx, result);
 }
 
 int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpcg_params *prm,
@@ -1071,6 +1075,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
     result->num_iterations = 0;
     result->exit_reason = -1;
     result->rv_final = 0;
+    result->precon_status = 0;
   } else {
     hipError_t e = hipSuccess;
     *precon_fail_host(ctx) = 0.0;
@@ -1084,7 +1089,7 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) CG_CHECK(hip_fail(e, "stpcg read-back", __FILE__, __LINE__));
     }
-    CG_CHECK(precon_fail_check(ctx));
+    CG_CHECK(precon_fail_check(ctx, result));
     {
       int ipc_err = 0;
       (void)mi_comm_ipc_error(ctx, &ipc_err);

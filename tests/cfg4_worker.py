@@ -37,7 +37,8 @@ def main():
         n_glob, n = nx * ny * nz, nx * ny * (z1 - z0)
         r0 = nx * ny * z0
         Xb = np.load(os.path.join(out_dir, "Xb.npy"), mmap_mode="r")[r0:r0 + n]
-        rowptr, col, val = wl.laplacian_3d(nx, ny, nz, z_range=(z0, z1))
+        shift = float(os.environ.get("CFG4_SHIFT", "0.1"))
+        rowptr, col, val = wl.laplacian_3d(nx, ny, nz, shift=shift, z_range=(z0, z1))
         starts = [nx * ny * a for a, _ in wl.shard_rows(nz, world)] + [n_glob]
         dist.barrier()
         A = c.csr_sharded(n_glob, r0, r0 + n, rowptr, col, val, starts)
@@ -46,9 +47,16 @@ def main():
         X = c.upload(np.ascontiguousarray(Xb))
         out["f"] = prob.objective(X)
         g, H = prob.model(X)
+        gsolve = g
+        if os.path.exists(os.path.join(out_dir, "g.npy")):
+            # the solve's INPUT is the caller's gradient, bit for bit (its rows of this slab): parity of the solver on
+            # identical inputs, with the device's own gradient still written out below
+            gsolve = c.upload(np.ascontiguousarray(np.load(os.path.join(out_dir, "g.npy"), mmap_mode="r")[p * r0:p * (r0 + n)]))
         c.ktime_enable("stiefel_hess_fused", True)
         k0 = c.comm_kernel_launches()
-        r = c.stpcg(g, H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
+        maxit = int(os.environ.get("CFG4_MAXIT", "50"))
+        r = c.stpcg(gsolve, H, Delta=float(os.environ.get("CFG4_DELTA", "1e3")), max_iterations=maxit, kappa_fgr=1e-12,
+                    theta=1.0, trace_cap=maxit + 2)
         out["one_pass_launches"] = c.ktime_read("stiefel_hess_fused")[0]
         # kernels the exchange layer launched during the solve: (scalar exchanges, halo pushes, halo pushes folded in)
         out["comm_kernels"] = [b - a for a, b in zip(k0, c.comm_kernel_launches())]

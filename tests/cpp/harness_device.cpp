@@ -280,7 +280,7 @@ extern "C" int hd_stpcg_projected(size_t n, size_t m, const double *g, const dou
     *iterations = it;
     g_last_kkt_inner = 0;
     g_last_kkt_worst = 0;
-    MI355::check(mi_precon_constraint_info(kkt, &g_last_kkt_inner, nullptr, &g_last_kkt_worst));
+    MI355::check(mi_precon_constraint_info(kkt, &g_last_kkt_inner, nullptr, &g_last_kkt_worst, nullptr));
     mi_precon_destroy(kkt);
     mi_op_destroy(op);
     return 0;

@@ -115,7 +115,17 @@ def main():
     Xb_glob, _ = wl.stiefel_bench_iterate(nx, ny, nz, p, eps=1e-2, seed=5)
     r0, r1 = prob.row_starts[rank], prob.row_starts[rank + 1]
     X = np.ascontiguousarray(Xb_glob[r0:r1])
-    g = prob.grad(X)
+    g_own = prob.grad(X)   # (binds S and X for hess; the sharded gradient itself is compared with the oracle's below)
+    # The solves take the UNSHARDED oracle's gradient as their input, bit for bit (its rows of this slab): the test is
+    # about the distributed ALGORITHM on identical inputs.  (The sharded gradient differs from it by rounding, ~1e-15
+    # of |A X|, i.e. ~1e-13 of |g| at this near-optimal iterate, and the nearly singular Hessian multiplies that.)
+    O0 = oracle_py.Oracle()
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    gprob = O0.stiefel_rq(n_glob, p, rowptr, col, val)
+    g_ref = O0.eval_grad(gprob, Xb_glob.ravel()).reshape(n_glob, p)
+    O0.free(gprob)
+    g = np.ascontiguousarray(g_ref[r0:r1])
+    g_err = float(np.abs(g_own - g).max() / np.abs(g_ref).max())
 
     n_local = prob.n * p
     decisions = []
@@ -172,7 +182,7 @@ def main():
             it1=res["iterations"], exit1=res["exit_reason"], M1=res["M_norm"], it2=res2["iterations"],
             exit2=res2["exit_reason"], M2=res2["M_norm"], alpha2=res2["trace"]["alpha"].tolist(),
             halo=[list(pp[2:]) for pp in pieces], same_scalars=all(d == dec[0] for d in dec), n_local=n_local,
-            rprime_same=all(every_rp),
+            rprime_same=all(every_rp), g_err=g_err,
             n_glob=n_glob), open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()

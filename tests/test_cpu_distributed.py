@@ -64,9 +64,9 @@ def test_sharded_stpcg_matches_unsharded(oracle, oracle_omp, tmp_path, world):
     f1 = f2 = fa = fM = None
     if oracle_omp is not None:
         pm = oracle_omp.stiefel_rq(n, p, rowptr, col, val)
-        gm = oracle_omp.eval_grad(pm, Xb.ravel())
-        m1 = oracle_omp.stpcg_problem(pm, Xb.ravel(), gm, 0.05, max_iterations=40, kappa_fgr=1e-6, theta=.5)
-        m2 = oracle_omp.stpcg_problem(pm, Xb.ravel(), gm, 1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0,
+        oracle_omp.eval_grad(pm, Xb.ravel())   # (binds the model; the floor solves take the oracle's g, like the workers)
+        m1 = oracle_omp.stpcg_problem(pm, Xb.ravel(), g, 0.05, max_iterations=40, kappa_fgr=1e-6, theta=.5)
+        m2 = oracle_omp.stpcg_problem(pm, Xb.ravel(), g, 1e3, max_iterations=25, kappa_fgr=1e-10, theta=1.0,
                                       trace_cap=64)
         oracle_omp.free(pm)
         f1, f2 = rel_err(m1["s"], o1["s"]), rel_err(m2["s"], o2["s"])
@@ -74,11 +74,15 @@ def test_sharded_stpcg_matches_unsharded(oracle, oracle_omp, tmp_path, world):
         fa = float(np.max(np.abs(m2["trace"]["alpha"] / o2["trace"]["alpha"] - 1)))
     e1, e2 = rel_err(d["s1"], o1["s"]), rel_err(d["s2"], o2["s"])
     ea = float(np.max(np.abs(np.array(d["alpha2"]) / o2["trace"]["alpha"] - 1)))
-    print(f"sharded x{world}: s1 {e1:.2e} (floor {f1}), s2 {e2:.2e} (floor {f2}), alpha {ea:.2e} (floor {fa})")
-    assert abs(d["M1"] - o1["M_norm"]) <= floor_or(1e-10, fM, 10) * o1["M_norm"]
-    assert e1 <= floor_or(1e-10, f1, 10)
-    assert e2 <= floor_or(1e-10, f2, 10)
-    assert ea <= floor_or(1e-10, fa, 10)
+    print(f"sharded x{world}: s1 {e1:.2e} (floor {f1}), s2 {e2:.2e} (floor {f2}), alpha {ea:.2e} (floor {fa}); the sharded "
+          f"gradient vs the oracle's: {d['g_err']:.2e} of max|g|")
+    # r06: the workers' solves take the oracle's gradient bits as their input (identical inputs), which is what lets
+    # the bars below be the plain 1e-10 -- or 3 x the measured floor, no longer 10 x
+    assert d["g_err"] < 1e-11
+    assert abs(d["M1"] - o1["M_norm"]) <= floor_or(1e-10, fM) * o1["M_norm"], (d["M1"], o1["M_norm"], fM)
+    assert e1 <= floor_or(1e-10, f1), (e1, f1)
+    assert e2 <= floor_or(1e-10, f2), (e2, f2)
+    assert ea <= floor_or(1e-10, fa), (ea, fa)
     # halo = one grid plane from each neighbour, symmetric send/receive counts
     plane = nx * ny
     for r, (need_lo, need_hi, send_lo, send_hi) in enumerate(d["halo"]):

@@ -11,14 +11,16 @@ The fixture holds scalars and checksums only (24 MB vectors do not travel).  The
 compared with come from the plain-C oracle re-run on the GPU box's host on the same inputs.  That oracle IS the
 reference bit for bit -- at small sizes on every problem (tests/test_cpu_oracle_templates.py) and on this very
 full-size solve (::test_oracle_is_the_reference_on_the_full_size_bench_solve there, SHA-256 of the 24 MB step).
-Across MACHINES the inputs themselves differ in their last bits (numpy's sin and LAPACK's QR dispatch on the CPU
-model), so the oracle's run on the GPU box is held against the fixture made here with a tolerance (counts exactly,
-traces to 1e-9) and the device against the oracle's run on identical arrays.
+r06: the inputs come from optimization_amd/wlgen.c (mt19937_64, own sin, own QR) and are the same bytes on every
+machine, so the oracle's run on the GPU box must reproduce the fixture made on the build machine exactly.
 
-Tolerance: BASELINE.json asks for iterates within 1e-10 relative.  Where that is not reachable the test says why in
-numbers: the SAME reference algorithm with its sums re-associated (the oracle's OpenMP build: identical statements,
-per-thread partial sums) moves away from the sequential-sum reference by `floor`; no implementation whose reduction
-order differs from the reference's can be asked to do better than a small multiple of that.
+Tolerance: BASELINE.json asks for iterates within 1e-10 relative.  r06: the STPCG solves are compared ON IDENTICAL
+INPUTS (the oracle's gradient uploaded bit for bit) at the plain 1e-10 -- measured 6e-15.  Where an input cannot be
+shared (a whole TNT run: every outer iteration's gradient is the device's own; or the bench solve started from the
+device's own gradient) the test says in numbers what the conditioning does: the SAME reference algorithm with its sums
+re-associated (the oracle's OpenMP build: identical statements, per-thread partial sums) moves away from the
+sequential-sum reference by `floor`; no implementation whose reduction order differs from the reference's can be asked
+to do better than a small multiple of that.
 """
 import os
 
@@ -66,14 +68,17 @@ def bench_solve(oracle, cfg2):
     g = oracle.eval_grad(cfg2["oprob"], Xb.ravel())
     o = oracle.stpcg_problem(cfg2["oprob"], Xb.ravel(), g, prm["Delta"], max_iterations=prm["max_iterations"],
                              kappa_fgr=prm["kappa_fgr"], theta=prm["theta"], trace_cap=64)
-    # this host's oracle run against what the REAL reference did on the build container (inputs equal up to the
-    # last bits of numpy's sin / QR on another CPU model)
+    # this host's oracle run against what the REAL reference did on the build container: the inputs are the same bytes
+    # on every machine (wlgen.c) and the oracle library is the one built there, so the solve must be the fixture's
+    # BIT FOR BIT -- the vectors the device is compared with below ARE the reference's
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()  # noqa: E731
+    assert sha(Xb) == it["sha256"]
     assert o["iterations"] == fx["iterations"] == 50
-    assert abs(o["M_norm"] - fx["M_norm"]) <= 1e-10 * fx["M_norm"]
+    assert o["M_norm"] == fx["M_norm"]
     for k in ("alpha", "beta", "kappa", "rv"):
-        assert np.allclose(o["trace"][k], fx["trace"][k], rtol=1e-9), k
-    assert abs(float((o["s"] * o["s"]).sum()) - fx["s"]["sq_sum"]) <= 1e-9 * fx["s"]["sq_sum"]
-    assert abs(float((g * g).sum()) - fx["g"]["sq_sum"]) <= 1e-9 * fx["g"]["sq_sum"]
+        assert list(o["trace"][k]) == fx["trace"][k], k
+    assert sha(g) == fx["g"]["sha256"] and sha(o["s"]) == fx["s"]["sha256"]
     floor = None
     if cfg2["omp_prob"] is not None:
         omp = cfg2["omp"]
@@ -97,7 +102,14 @@ FORMATS = {
 
 @pytest.mark.parametrize("fmt", list(FORMATS))
 def test_bench_solve_matches_the_reference(cfg2, bench_solve, monkeypatch, fmt):
-    """bench.py's solve, N = 3e6, 50 iterations, in every matrix format, against the reference's."""
+    """bench.py's solve, N = 3e6, 50 iterations, in every matrix format, against the reference's -- on the SAME INPUTS
+    (r06): STPCG's input g is the oracle's gradient uploaded bit for bit, and the bar is BASELINE.json's plain 1e-10 on
+    the step, the alpha / beta / kappa traces and |s|_M, with no conditioning-floor allowance.  (Measured: 6e-15 on the
+    step.  With the gradient the DEVICE computes as the input -- it differs from the oracle's by 5e-13 of |g|, the
+    cancellation in A X - X sym(X'AX) at a near-optimal iterate -- the same solve ends 2e-10 from the reference's, and
+    so does the reference itself with re-associated sums: that is the conditioning of the problem acting on a
+    perturbed INPUT, profiles/r06_parity_curve.md; it is printed below, and asserted against the floor, for the default
+    format.)"""
     from optimization_amd import capi
     for k, v in FORMATS[fmt].items():
         monkeypatch.setenv(k, v)
@@ -108,12 +120,14 @@ def test_bench_solve_matches_the_reference(cfg2, bench_solve, monkeypatch, fmt):
         prob = c.stiefel_rq(A, N, P)
         X = c.upload(bench_solve["Xb"])
         g, H = prob.model(X)
-        assert rel_err(g.numpy(), bench_solve["g"]) < 1e-11  # (|g| is 1e-3 of |A X| at this near-optimal iterate)
+        eg = rel_err(g.numpy(), bench_solve["g"])
+        assert eg < 1e-11  # (|g| is 1e-3 of |A X| at this near-optimal iterate)
         prm, o = bench_solve["prm"], bench_solve["o"]
         c.ktime_enable("stiefel_hess_fused", True)
         c.ktime_enable("stiefel_finish_dots", True)
-        r = c.stpcg(g, H, Delta=prm["Delta"], max_iterations=prm["max_iterations"], kappa_fgr=prm["kappa_fgr"],
-                    theta=prm["theta"], trace_cap=64)
+        kw = dict(Delta=prm["Delta"], max_iterations=prm["max_iterations"], kappa_fgr=prm["kappa_fgr"],
+                  theta=prm["theta"], trace_cap=64)
+        r = c.stpcg(c.upload(bench_solve["g"]), H, **kw)
         one_pass = c.ktime_read("stiefel_hess_fused")[0]
         two_pass = c.ktime_read("stiefel_finish_dots")[0]
         assert (two_pass > 0) == (fmt == "two_pass_operator") and (one_pass > 0) == (fmt != "two_pass_operator")
@@ -124,14 +138,45 @@ def test_bench_solve_matches_the_reference(cfg2, bench_solve, monkeypatch, fmt):
         ek = float(np.max(np.abs(r["trace"]["kappa"] / o["trace"]["kappa"] - 1)))
         es = rel_err(r["s"].numpy(), o["s"])
         em = abs(r["M_norm"] - o["M_norm"]) / o["M_norm"]
-        fl = bench_solve["floor"] or dict(s=0.0, alpha=0.0, beta=0.0)
-        print(f"{fmt}: s {es:.2e} (re-associated reference: {fl['s']:.2e}), alpha {ea:.2e} ({fl['alpha']:.2e}), "
-              f"beta {eb:.2e} ({fl['beta']:.2e}), kappa {ek:.2e}, |s|_M {em:.2e}")
-        # BASELINE.json: 1e-10 relative on the iterate; the per-iteration scalars are ratios of two sums of 3e6
-        # terms each and get the slack the re-associated reference itself needs
-        assert es <= max(1e-10, 3 * fl["s"]), (es, fl)
-        assert em <= 1e-11
-        assert ea <= max(1e-10, 3 * fl["alpha"]) and eb <= max(1e-9, 3 * fl["beta"]), (ea, eb, fl)
+        print(f"{fmt}, same g bits: s {es:.2e}, alpha {ea:.2e}, beta {eb:.2e}, kappa {ek:.2e}, |s|_M {em:.2e}   (plain 1e-10)")
+        assert es <= 1e-10 and ea <= 1e-10 and eb <= 1e-10 and ek <= 1e-10 and em <= 1e-11, (es, ea, eb, ek, em)
+        if fmt == "default_window_packed":
+            # the same solve from the gradient the device computed: a perturbed INPUT, held against the floor
+            rd = c.stpcg(g, H, **kw)
+            fl = bench_solve["floor"] or dict(s=0.0, alpha=0.0, beta=0.0)
+            esd = rel_err(rd["s"].numpy(), o["s"])
+            print(f"{fmt}, the device's own gradient as input (differs from the oracle's by {eg:.2e}): s {esd:.2e} "
+                  f"(re-associated reference, its own gradient: {fl['s']:.2e})")
+            assert rd["iterations"] == 50 and esd <= max(1e-10, 3 * fl["s"]), (esd, fl)
+    finally:
+        c.close()
+
+
+def test_bench_solve_error_curve_plain_tolerance(cfg2, bench_solve, oracle):
+    """the error of the step along the bench solve, k = 5, 10, 20 (= the driver's --steps), 30, 40,
+    50 iterations -- plain 1e-10 at EVERY k on identical inputs (measured 1e-14 ... 6e-15; the whole curve for k = 1 ...
+    50: profiles/r06_parity_curve.md).  With the device's own gradient as the input the error follows the conditioning
+    curve of the solve (5e-13 at k = 1 -> 2e-10 at k = 50, crossing 1e-10 at k = 34): asserted at 1e-10 up to k = 30."""
+    from optimization_amd import capi
+    c = capi.Context(0)
+    try:
+        rowptr, col, val = cfg2["csr"]
+        A = c.csr(N, rowptr, col, val)
+        prob = c.stiefel_rq(A, N, P)
+        g, H = prob.model(c.upload(bench_solve["Xb"]))
+        gs = c.upload(bench_solve["g"])
+        prm = bench_solve["prm"]
+        for k in (5, 10, 20, 30, 40, 50):
+            kw = dict(max_iterations=k, kappa_fgr=prm["kappa_fgr"], theta=prm["theta"])
+            o = oracle.stpcg_problem(cfg2["oprob"], bench_solve["Xb"].ravel(), bench_solve["g"], prm["Delta"], **kw)
+            r = c.stpcg(gs, H, Delta=prm["Delta"], **kw)
+            rd = c.stpcg(g, H, Delta=prm["Delta"], **kw)
+            es, esd = rel_err(r["s"].numpy(), o["s"]), rel_err(rd["s"].numpy(), o["s"])
+            print(f"k = {k:2d}: s vs reference, same g bits {es:.2e}; the device's own g {esd:.2e}")
+            assert r["iterations"] == o["iterations"] == k
+            assert es <= 1e-10, (k, es)
+            if k <= 30:
+                assert esd <= 1e-10, (k, esd)
     finally:
         c.close()
 
@@ -145,7 +190,8 @@ def test_full_cfg2_tnt_run_matches_the_reference_trace(cfg2, oracle):
     fx = cfg2["fx"]["tnt"]
     rowptr, col, val = cfg2["csr"]
     X0 = wl.random_stiefel(N, P, seed=fx["seed"])
-    assert abs(float(X0.sum()) - fx["x0"]["sum"]) < 1e-9  # (same start up to the last bits of another CPU's QR)
+    import hashlib
+    assert hashlib.sha256(X0.tobytes()).hexdigest() == fx["x0"]["sha256"]   # (the same start, byte for byte: wlgen.c)
     prm = oracle.default_params(**fx["params"])
     hz = harness_py.DeviceHarness()
     r = hz.tnt_stiefel(N, P, rowptr, col, val, X0, prm, 0)

@@ -308,12 +308,15 @@ def test_peer_memory_wait_is_bounded_and_fails_loudly():
     assert o["stpcg"].startswith("MiError"), o
 
 
-def _run_cfg4_workers(world, grid, Xb, extra_env=None, port=29580):
-    """W processes of tests/cfg4_worker.py on GPU 0 -> (per-rank records, concatenated step, concatenated gradient)"""
+def _run_cfg4_workers(world, grid, Xb, extra_env=None, port=29580, g_input=None):
+    """W processes of tests/cfg4_worker.py on GPU 0 -> (per-rank records, concatenated step, concatenated gradient).
+    g_input: the gradient the solves take as their input (its rows per slab) instead of the one the device computes."""
     import tempfile
     nx, ny, nz = grid
     with tempfile.TemporaryDirectory() as tmp:
         np.save(os.path.join(tmp, "Xb.npy"), Xb)
+        if g_input is not None:
+            np.save(os.path.join(tmp, "g.npy"), np.ascontiguousarray(g_input).ravel())
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(port + world),
                os.path.join(ROOT, "tests", "cfg4_worker.py")]
@@ -429,7 +432,8 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world, extra, 
     p, n = 3, nx * ny * nz
     Xb = cfg4_oracle["Xb"]
     env = {"MI355OPT_NO_FOLD": "1", "MI355OPT_HALO_RPRIME": "1"} if extra == "rprime" else None
-    outs, s_sh, g_sh = _run_cfg4_workers(world, (nx, ny, nz), Xb, extra_env=env)
+    # (r06) every rank's solve takes its rows of the ORACLE's gradient as the input: parity on identical inputs, plain 1e-10
+    outs, s_sh, g_sh = _run_cfg4_workers(world, (nx, ny, nz), Xb, extra_env=env, g_input=cfg4_oracle["g"])
     # (i) the oracle
     oc, fl = cfg4_oracle["o"], cfg4_oracle["floor"] or dict(s=0.0, alpha=0.0, beta=0.0)
     assert (outs[0]["iters"], outs[0]["exit"]) == (oc["iterations"], oc["exit_reason"]) and oc["iterations"] == 50
@@ -441,9 +445,9 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world, extra, 
     om = abs(float.fromhex(outs[0]["M"]) - oc["M_norm"]) / oc["M_norm"]
     print(f"cfg4 on one GPU, {world} ranks{' (r-prime halo)' if extra else ''} vs the CPU oracle: s {os_:.2e} (floor "
           f"{fl['s']:.2e}), alpha {oa:.2e} ({fl['alpha']:.2e}), beta {ob:.2e} ({fl['beta']:.2e}), |s|_M {om:.2e}")
-    assert rel_err(g_sh, cfg4_oracle["g"]) < 1e-11
-    assert os_ <= floor_or(1e-10, fl["s"]) and om <= 1e-11
-    assert oa <= floor_or(1e-10, fl["alpha"]) and ob <= floor_or(1e-9, fl["beta"])
+    assert rel_err(g_sh, cfg4_oracle["g"]) < 1e-11     # (the gradient the devices computed, which the solve did not use)
+    assert os_ <= 1e-10 and om <= 1e-11, (os_, om)
+    assert oa <= 1e-10 and ob <= 1e-10, (oa, ob)
     if extra == "rprime":   # one ordinary halo push (first pass), then the rows of r' once per iteration
         assert all(o["comm_kernels"][1] >= 50 and o["comm_kernels"][2] == 0 for o in outs), [o["comm_kernels"] for o in outs]
     assert all(o["enabled"] and o["ipc_error"] == 0 for o in outs), outs
@@ -462,7 +466,7 @@ def test_cfg4_sharded_on_one_gpu_matches_the_single_context_solve(world, extra, 
         del rowptr, col, val
         prob = c.stiefel_rq(A, n, p)
         g, H = prob.model(c.upload(Xb))
-        one = c.stpcg(g, H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
+        one = c.stpcg(c.upload(cfg4_oracle["g"]), H, Delta=1e3, max_iterations=50, kappa_fgr=1e-12, theta=1.0, trace_cap=64)
         f1 = prob.objective(c.upload(Xb))
         s1, g1 = one["s"].numpy(), g.numpy()
     finally:

@@ -252,8 +252,8 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, oracle_omp, monkey
     fl = None
     if oracle_omp is not None:
         mprob = oracle_omp.stiefel_rq(n, p, rowptr, col, val)
-        gm = oracle_omp.eval_grad(mprob, Xb.ravel())
-        fl = oracle_omp.stpcg_problem(mprob, Xb.ravel(), gm, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
+        oracle_omp.eval_grad(mprob, Xb.ravel())   # (binds the model; the floor solve takes the oracle's g as well)
+        fl = oracle_omp.stpcg_problem(mprob, Xb.ravel(), go, 1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0,
                                       trace_cap=64)["trace"]
         oracle_omp.free(mprob)
     env = {"recurrence": ("0", "0"), "direct": ("0", "1"), "two-pass": ("1", "0")}
@@ -266,11 +266,13 @@ def test_one_pass_hessian_matches_two_pass_and_oracle(oracle, oracle_omp, monkey
             A = c.csr(n, rowptr, col, val)
             prob = c.stiefel_rq(A, n, p)
             g, H = prob.model(c.upload(Xb))
+            assert rel_err(g.numpy(), go) < 1e-11
             names = ("stiefel_hess_fused", "stiefel_finish_dots")
             for k in names:
                 c.ktime_enable(k, True)
             c.ktime_reset()
-            r = c.stpcg(g, H, Delta=1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
+            # (r06) the solve's input is the oracle's gradient, bit for bit: parity of the solver on identical inputs
+            r = c.stpcg(c.upload(go), H, Delta=1e3, max_iterations=40, kappa_fgr=1e-8, theta=1.0, trace_cap=64)
             launches = {k: c.ktime_read(k)[0] for k in names}
             res[mode] = dict(r, s=r["s"].numpy().copy(), launches=launches)
         finally:
