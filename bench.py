@@ -782,6 +782,59 @@ class Watchdog:
             os._exit(0 if (kept is not None or self.rank != 0) else 3)
 
 
+def dry_run_layers(world, comm_arg, ndev):
+    """`--dry-run-layers N` (at N = 1, on any box -- no GPU work): what a `--gpus N` run WOULD do, so that the one shot on
+    an 8-GPU node has no first-time code path besides the cross-device transport itself: the launch line, the probe
+    order, the exchange layers in the order they are verified and timed, the rule that picks the headline's, the slab
+    partition with every rank's halo plan (the host-side planning code of mi_csr_create_sharded really runs here:
+    mi_csr_shard_plan per rank, extents checked for symmetry) and the bytes per exchange."""
+    nx, ny, nz = wl.cfg2_grid(world)
+    slabs = wl.shard_rows(nz, world)
+    n_glob, plane = nx * ny * nz, nx * ny
+    starts = [plane * a for a, _ in slabs] + [n_glob]
+    ranks = []
+    for r, (z0, z1) in enumerate(slabs):
+        # the plan only looks at the column indices of the slab's boundary planes: build those two planes' rows
+        rec = {"rank": r, "z_planes": [z0, z1], "rows": plane * (z1 - z0)}
+        need = [0, 0]
+        for side, zz in ((0, z0), (1, z1 - 1)):
+            _, colg, _ = wl.laplacian_3d(nx, ny, nz, z_range=(zz, zz + 1))
+            _, lo, hi = capi.csr_shard_plan(n_glob, world, r, starts, colg)
+            need[0] += lo if side == 0 else 0
+            need[1] += hi if side == 1 else 0
+        rec["halo_rows_needed"] = {"from_rank_below": need[0], "from_rank_above": need[1]}
+        ranks.append(rec)
+    sym = all(ranks[r]["halo_rows_needed"]["from_rank_above"] == ranks[r + 1]["halo_rows_needed"]["from_rank_below"]
+              for r in range(world - 1))
+    want_peer = comm_arg not in ("rccl", "rccl2")
+    layers = (["peer", "peer-separate", "peer-separate-rprime"] if want_peer else []) + ["rccl", "rccl2"]
+    return {
+        "world": world, "gpus_visible_here": ndev,
+        "launch": f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {world} --master-addr 127.0.0.1 "
+                  f"--master-port P bench.py --gpus {world} --steps K --warmup W   (or bare: python bench.py --gpus {world})",
+        "control_plane": "torch.distributed / gloo: rendezvous, barriers, max-over-ranks time, object broadcasts of the "
+                         "oracle check; never on the data path",
+        "bring_up_order": ["RCCL probe in throwaway processes (ncclCommInitRank + two all-reduces of known values)",
+                           "ncclCommInitRank in the bench processes (only if every rank's probe came back clean)",
+                           "peer-memory probe in throwaway processes (hipIpc export / map / self-test incl. the folded "
+                           "exchange and all three forms of the halo push)",
+                           "peer-memory layer mapped in the bench processes (only if every probe came back clean)"],
+        "layers_in_order": [{"layer": L, "what": LAYER_TEXT[L]} for L in layers],
+        "per_layer": "verify (sharded SpMM of exact eigenvectors, all-reduced <E,E>, a replicated 10-iteration solve "
+                     "against the CPU oracle at 1e-10, folded == separate bits) -> 100 warm-up + --ab-steps timed steps -> "
+                     "event-paired pass; a layer that raises or fails verification costs itself, not the line; a layer "
+                     "that never returns is cut by the watchdog (--leg-timeout) and the line measured before it is printed",
+        "headline": "measured at once on the FIRST layer that verifies (kept for the watchdog), measured again on the "
+                    "fastest verified layer if that is another one (--comm forces one)",
+        "workload": f"cfg4-style weak scaling: Stiefel({n_glob},3) on {nx}x{ny}x{nz}, z-slabs",
+        "ranks": ranks, "halo_plan_symmetric": bool(sym),
+        "exchange_bytes_per_iteration_per_rank": {
+            "scalar_exchanges": "2 (recurrence form): 9 doubles (3 curvature dots + 6 Gram entries) and 1 double",
+            "halo_rows": f"{plane} rows x 3 doubles = {plane * 24} bytes to each neighbour"},
+        "cpu_baseline": "rank 0, after the timed region, on the PER-GPU problem",
+    }
+
+
 def comm_set_layer(ctx, layer, peer_up=True):
     """switch the exchange layer of a context (the same call on every rank); peer_up: the peer-memory layer is mapped"""
     ctx.set_option("HALO_RPRIME", 1 if layer in ("rccl2", "peer-separate-rprime") else 0)
@@ -878,6 +931,9 @@ def main():
     ap.add_argument("--leg-timeout", type=float, default=float(os.environ.get("MI355OPT_BENCH_LEG_TIMEOUT", "240")),
                     help="N > 1: seconds an exchange layer's leg (or a headline measurement) may take before the "
                          "watchdog prints the line already measured on an earlier layer and ends the run")
+    ap.add_argument("--dry-run-layers", type=int, default=0, metavar="N",
+                    help="N = 1 runs only: add a `dry_run_layers` block saying what a --gpus N run would try, in which "
+                         "order, with every rank's halo plan computed by the real planning code (no GPU work)")
     ap.add_argument("--peer-probe", choices=["peer", "rccl"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-peer-probe", action="store_true",
                     help="N > 1: map peer memory in the bench processes without trying it in throwaway ones first")
@@ -1293,6 +1349,11 @@ def main():
             print("bench.py: CPU baseline at N > 1 failed: %s" % e, file=sys.stderr)
     if rank == 0:
         out = make_line(m, comm_layer, comm_choice, comm_legs, plain_leg, big_leg, cpu, cpu_all, parity, leg3, leg5)
+        if args.dry_run_layers > 1 and world == 1:
+            try:
+                out["dry_run_layers"] = dry_run_layers(args.dry_run_layers, args.comm, capi.device_count())
+            except Exception as e:  # noqa: BLE001
+                out["dry_run_layers"] = {"failed": str(e)[:300]}
         os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -436,15 +436,29 @@ static int rprime_alloc(mi_ctx *ctx, const mi_csr *A) {
   return comm_halo_alloc(ctx, 2 * A->halo_stride * sizeof(double), &A->halo_r, &A->halo_r_in_arena, &A->halo_r_off);
 }
 
-bool comm_rprime_enabled(const mi_ctx *ctx, const mi_csr *A) {
-  if (!ctx->cfg.halo_rprime || ctx->world_size <= 1 || !ctx->comm || !A || !A->halo) return false;
-  if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return false;
+// Whether this solve takes the r'-halo form.  The decision is made from replicated facts only (the switch, the layer in
+// use, the halo extents' non-emptiness -- all the same on every rank), and the buffer pair is allocated HERE with the
+// return code propagated (it used to be a side effect of a const query that answered "no" on a rank whose
+// allocation failed -- that rank then enqueued the 3-collective form while its peers enqueued the r'-halo group, and the
+// run hung instead of reporting anything).  *enabled is only meaningful when MI_OK is returned.
+int comm_rprime_prepare(mi_ctx *ctx, const mi_csr *A, bool *enabled) {
+  *enabled = false;
+  if (!ctx->cfg.halo_rprime || ctx->world_size <= 1 || !ctx->comm || !A || !A->halo) return MI_OK;
+  // (a rank without halo rows of its own still takes part in its neighbours' exchanges: every rank of a slab partition
+  // with more than one slab sends or receives something, so this test is the same everywhere)
+  if (A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0) return MI_OK;
   // the r' rows need a buffer pair of their own where the layer in use can reach it: inside the arena for peer stores
   // (the same decision on every rank: same sizes, same allocation order), anywhere for RCCL
   const Comm *c = (const Comm *)ctx->comm;
-  if (rprime_alloc(const_cast<mi_ctx *>(ctx), A) != MI_OK) return false;
-  if (c->ipc_enabled && A->halo_in_arena) return A->halo_r_in_arena;
-  return c->nccl != nullptr;
+  const int st = rprime_alloc(ctx, A);
+  if (st != MI_OK) {
+    set_error("r'-halo form: this rank could not allocate its residual-halo buffers (%zu bytes); refusing to continue "
+              "with a collective sequence that would differ from its peers'", 2 * A->halo_stride * sizeof(double));
+    return MI_ERR_OOM;
+  }
+  if (c->ipc_enabled && A->halo_in_arena) *enabled = A->halo_r_in_arena;
+  else *enabled = c->nccl != nullptr;
+  return MI_OK;
 }
 
 void comm_rprime_buffers(const mi_ctx *, const mi_csr *A, int p, const double **halo_r, double **halo_p, size_t *count) {

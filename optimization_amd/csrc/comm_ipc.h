@@ -272,7 +272,7 @@ void comm_halo_fold_drop(mi_ctx *ctx);
 // halo(p') = -halo(r') + beta halo(p) from the halo rows of p it already holds -- the SAME expression, on the same bits,
 // as the owner of those rows evaluates for them (k_cg_pupdate), so the result is bit-identical to exchanging p'.
 // usable for this matrix on this context right now? (several ranks, a halo, the switch on)
-bool comm_rprime_enabled(const mi_ctx *ctx, const struct mi_csr *A);
+int comm_rprime_prepare(mi_ctx *ctx, const struct mi_csr *A, bool *enabled);
 // all-reduce of the k component rows of `partials` (rows mode) AND the boundary rows of the n x p field R into A's r'-halo
 // buffer: one RCCL group; with the peer-memory layer's separate kernels, the scalar exchange is the caller's and this
 // only pushes the rows (partials == null)

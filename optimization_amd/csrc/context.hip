@@ -251,6 +251,10 @@ int opt_so3_sort_nbr(mi_ctx *c, long v) {
   c->cfg.so3_sort_nbr = (int)v;
   return MI_OK;
 }
+int opt_reanchor(mi_ctx *c, long v) {
+  c->cfg.reanchor = (int)std::max<long>(0, std::min<long>(v, 1 << 20));
+  return MI_OK;
+}
 int opt_ipc_timeout_ms(mi_ctx *c, long v) {
   c->cfg.ipc_timeout_ms = std::max<long>(0, v);
   return MI_OK;
@@ -264,7 +268,7 @@ const OptionDesc kOptions[] = {
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
     {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
-    {"WARN_GENERIC", opt_warn_generic},
+    {"WARN_GENERIC", opt_warn_generic}, {"REANCHOR", opt_reanchor, true},
 };
 // value of a BOOLEAN switch: an integer; anything else ("yes", "true", "on" -- and the presence-only `MI355OPT_X=` of
 // the r01-r03 scripts) means 1, so that no spelling that used to switch something on is silently off.  An INTEGER-valued

@@ -929,11 +929,24 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
       for (int j = 0; j < kFarCap; ++j) f[j] = pinned_load(reinterpret_cast<const unsigned *>(fb + j * 256));
     }
   };
+  // (MI_SPMM_ABLATE_FAR: timing-only experiment builds, WRONG results -- what the two far gathers of a row cost.
+  //  1: they read rows next to the wave's own chunk instead (same instructions, lines that are in L1 / L2 anyway: the
+  //     time of the pass if the far rows cost no traffic beyond the L2); 2: no far loads at all.  r06, EXPERIMENTS.md)
   auto far_rows = [&](const unsigned (&f)[kFarCap], double (&g)[kFarCap][KC]) {
 #pragma unroll
     for (int s_ = 0; s_ < kFarCap; ++s_)
 #pragma unroll
-      for (int c = 0; c < KC; ++c) g[s_][c] = pinned_load(xc[c] + f[s_]);
+      for (int c = 0; c < KC; ++c) {
+#if defined(MI_SPMM_ABLATE_FAR) && MI_SPMM_ABLATE_FAR == 2
+        g[s_][c] = (double)f[s_];
+#elif defined(MI_SPMM_ABLATE_FAR) && MI_SPMM_ABLATE_FAR == 1
+        // f[0] = row + D, f[1] = row - D (load_far): back to the row itself, one / two chunks further on
+        const unsigned near_ = (s_ == 0 ? f[0] - W.far_d : f[1] + W.far_d) + 64u * (unsigned)(s_ + 1);
+        g[s_][c] = pinned_load(xc[c] + (near_ < (unsigned)m ? near_ : 0u));
+#else
+        g[s_][c] = pinned_load(xc[c] + f[s_]);
+#endif
+      }
   };
 
   int slice = t0 * NW + w;

@@ -115,6 +115,11 @@ struct Config {
   bool no_polled_sync = false;      // NO_POLLED_SYNC: stream_wait is hipStreamSynchronize (no flag kernel + host poll)
   bool two_kernel_step = false;     // TWO_KERNEL_STEP: opt-in experiment (r05): <r+,r+> by recurrence, the two CG kernels of an
                                     // unpreconditioned Stiefel(n,3) iteration merged (changes the rounding of IterativeSolvers.h:408)
+  // REANCHOR: every this many iterations the recurrence form of the Stiefel Hessian's projection matrix (stpcg.hip) is
+  // re-anchored -- G(p) and G(r) recomputed by the direct form (two passes over X, Y and the vector) -- so that the
+  // absolute error the recurrences carry stays at the scale of the CURRENT residual instead of the initial one
+  // (r06, tests/test_gpu_long_solves.py).  0: never (the r03-r05 behaviour).
+  int reanchor = 50;
   bool no_update_pair = false;      // NO_UPDATE_PAIR: the matrix-pipe panel update in 16-row blocks, 8 bytes per lane (r04 form)
   bool no_gram_half = false;        // NO_GRAM_HALF: the fused Gram pair with a tile column of its own per Gram (r04 form)
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe

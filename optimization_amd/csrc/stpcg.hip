@@ -272,6 +272,26 @@ __device__ __forceinline__ void gdir_from_rows(const double *__restrict__ partia
   }
 }
 
+// the same fixed-order reduction into ONE destination (re-anchoring, r06)
+__device__ __forceinline__ void gdir_rows_to(const double *__restrict__ partials, int count, int gns,
+                                             double *__restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  for (int w = threadIdx.x >> 6; w < gns; w += kWaves) {
+    const double *src = partials + (size_t)w * kMaxRows;
+    double t[kMaxRows / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) {
+      const int r = lane + 64 * j;
+      t[j] = (r < count) ? src[r] : 0.0;
+    }
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxRows / 64; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+    if (lane == 0) dst[w] = v;
+  }
+}
+
 struct CgSetup {
   double Delta, kappa_fgr, theta, epsilon;
   unsigned long long max_iterations;
@@ -586,6 +606,23 @@ __global__ __launch_bounds__(kBlock) void k_cg_gdir_init(const double *__restric
   }
 }
 
+// Re-anchoring of the recurrence form (r06): dst = G(vector) from the rows k_cg_dirgram just left (or the all-reduced
+// slots).  The recurrences G(r') = G(r) + alpha G(Hp), G(p') = -G(r') + beta G(p) carry an ABSOLUTE error of the size
+// rounding had at the scale of the residual they started from; on identical inputs a 200-iteration solve ends 2.6e-13
+// from the reference with them and 8e-15 with the two-pass operator, and follows the reference's alpha trace for 354
+// instead of 395 iterations (tests/test_gpu_long_solves.py).  Every mi_ctx::cfg.reanchor iterations both are replaced
+// by their direct values.  A solve that has left CG_RUN keeps what it has (its kernels do nothing any more).
+__global__ __launch_bounds__(kBlock) void k_cg_gdir_anchor(const double *__restrict__ partials, int count, int ns,
+                                                           const double *__restrict__ slots, int from_slots,
+                                                           const CgState *__restrict__ st, double *__restrict__ dst) {
+  if (st->mode != CG_RUN) return;
+  if (!from_slots) {
+    gdir_rows_to(partials, count, ns, dst);
+    return;
+  }
+  if (threadIdx.x < ns) dst[threadIdx.x] = slots[threadIdx.x];
+}
+
 inline void cpu_relax() { __builtin_ia32_pause(); }
 
 }  // namespace
@@ -792,7 +829,19 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
   // (the folded exchange carries at most kIpcVals = 16 values: p <= 4)
   const bool folded = sharded && recur && kc <= kIpcVals && comm_fold_enabled(ctx) && !ctx->force_slot_path;
   // r'-halo form (Config::halo_rprime): the halo rows of r' travel with the <r,v> all-reduce, halo(p') is formed locally
-  const bool rprime = recur && !folded && dgp->halo_A && comm_rprime_enabled(ctx, dgp->halo_A);
+  bool rprime = false;
+  if (recur && !folded && dgp->halo_A) {
+    // (allocates the residual-halo buffers on first use; a rank that cannot must fail HERE, loudly, rather than take
+    // another collective sequence than its peers -- ADVICE r05)
+    const int st_rp = comm_rprime_prepare(ctx, dgp->halo_A, &rprime);
+    if (st_rp != MI_OK) {
+      mi_vec_destroy(r);
+      mi_vec_destroy(p);
+      mi_vec_destroy(Hp);
+      if (v) mi_vec_destroy(v);
+      return st_rp;
+    }
+  }
   // unpreconditioned recurrence form: initialisation and the first direction's Gram rows in one pass
   // (k_cg_init_dirgram); one rank, nothing to exchange: G(p0), G(r0) set by k_cg_scalar_init itself
   const bool init_fused = recur && n == dgp->n * (size_t)dgp->p;
@@ -909,6 +958,30 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         // a function of the replicated device state only, not of when this host happened to look.  (No
         // rank can get past that count unknowingly: the throttle holds it until the exit is published.)
         if (!lockstep || k >= (w >> 1) + (uint64_t)run_ahead) break;
+      }
+
+      // r06: re-anchor the recurrence form's G(p), G(r) by the direct form every cfg.reanchor iterations (the count is
+      // the loop index: the same on every rank, so the exchanges it carries stay matched across ranks)
+      if (recur && !twok && ctx->cfg.reanchor > 0 && k > 0 && k % (size_t)ctx->cfg.reanchor == 0) {
+        const size_t nrows = dgp->n;
+        for (int which = 0; which < 2; ++which) {
+          const double *vec = which == 0 ? p->d : r->d;
+          switch (dgp->p) {
+            case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
+            case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
+            case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
+            case 4: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
+            case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(StBlk<5>::threads), 0, st, nrows, vec, dga); break;
+            case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(StBlk<6>::threads), 0, st, nrows, vec, dga); break;
+            case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(StBlk<7>::threads), 0, st, nrows, vec, dga); break;
+            default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(StBlk<8>::threads), 0, st, nrows, vec, dga); break;
+          }
+          if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, gns, slots_g));
+          else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, gns));
+          hipLaunchKernelGGL(k_cg_gdir_anchor, dim3(1), dim3(kBlock), 0, st, (const double *)ctx->partials2, grid, gns,
+                             (const double *)slots_g, sharded ? 1 : 0, (const CgState *)st0,
+                             dga.gdir + (which == 0 ? SLOT_GDIR_P : 0));
+        }
       }
 
       // Hp = H(p) (:294) + partial rows of <p,Hp>, <Hp,Hp>, <p,p> in ctx->partials

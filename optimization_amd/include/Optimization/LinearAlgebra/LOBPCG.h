@@ -169,6 +169,9 @@ lobpcg_device(const SymmetricLinearOperator<Matrix, Args...> &A,
       // panel -- and the Grams are formed from the blocks of S, A(S) (and B(S)): upper block triangles on the matrix
       // pipe, one read-back (:271-275).  Column for column the same operator results as A(S), B(S) on the assembled
       // basis, which is never formed (r05: also without B; r04 copied the blocks together for a plain callable).
+      // NOTE for clients: the reference calls each operator ONCE per iteration on the assembled S
+      // (:267-268); here a plain callable is called once on [R | P] or once per block, on views of nx - nc columns, and
+      // A(X) is carried over -- same columns out, but another call count and other panel widths than under the reference.
       MI355::PanelBlocks ASb, BSb;
       if (reuse_x) {
         ASb.add(AX.leftCols(nx));

@@ -15,6 +15,12 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-roofline --no-legs"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- $BENCH --steps 500 --warmup 50 \
   > "$OUT/${TAG}_trace.log" 2>&1
+# r06: the driver's own command WITH the cfg3 / cfg5 legs (no CPU legs: they are not kernels) under the kernel trace: the
+# per-kernel averages its legs' dominant kernels must agree with (k_bsr3_spmv*, k_so3_model, k_spmm_colmajor_win,
+# k_gram_pair_sym, k_lobpcg_update*)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace_legs" -- \
+  python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/${TAG}_trace_legs.json" 2> "$OUT/${TAG}_trace_legs.log"
+cp $(ls -t "$OUT/${TAG}_trace_legs"/*/*kernel_stats.csv | head -1) "$OUT/${TAG}_bench_legs_kernel_stats.csv" 2>/dev/null
 cd "$REPO"
 # exact L2<->fabric bytes per launch (read requests by size + WRITE_SIZE, separate passes) and their calibration
 bash tools/pmc_bytes.sh "gpurun_out/${TAG}_pmc" > "$OUT/${TAG}_pmc.log" 2>&1

@@ -3,7 +3,7 @@
 #   bash tools/round_profiles.sh r04     then, in the build container:   python tools/profile_summary.py r04
 # and copy gpurun_out/<tag>_keep/* into profiles/.  One artifact set per round (no per-experiment refreshes).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$(pwd)
 K=$REPO/gpurun_out/${TAG}_keep
 mkdir -p "$K"
@@ -45,5 +45,11 @@ examples/bin/stpcg_user_stencil > "$K/${TAG}_user_operator.txt" 2>&1
 [ -f optimization_amd/libmi355opt_fstamp.so ] && MI355OPT_LIB=$PWD/optimization_amd/libmi355opt_fstamp.so \
   python tools/fold_stamps.py single > "$K/${TAG}_cg_update_stamps.txt" 2>&1
 cp gpurun_out/${TAG}_bench.json gpurun_out/${TAG}_tnt.json gpurun_out/${TAG}_lsqr.json "$K/" 2>/dev/null
+cp gpurun_out/${TAG}_bench_legs_kernel_stats.csv gpurun_out/${TAG}_trace_legs.json "$K/" 2>/dev/null
+# r06: the driver's own command, the parity curve, the long solves, what re-anchoring costs
+(time python bench.py --steps 20 --warmup 5 --dry-run-layers 8) > "$K/${TAG}_bench_default.json" 2> "$K/${TAG}_bench_default.err"
+python tools/parity_curve.py > "$K/${TAG}_parity_curve.json" 2> "$K/${TAG}_parity_curve_table.md"
+python tools/reanchor_cost.py > "$K/${TAG}_reanchor_cost.json" 2>/dev/null
+python -m pytest tests/test_gpu_long_solves.py -m gpu -q -s 2>&1 | grep -v "^$" | cut -c1-300 > "$K/${TAG}_long_solves.log"
 cp gpurun_out/${TAG}_pmc/bytes.json "$K/${TAG}_pmc_traffic_cfg2.json" 2>/dev/null
 ls -la "$K"; cat "$K/${TAG}_gputest_full_suite.log" | tail -3
