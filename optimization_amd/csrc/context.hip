@@ -229,6 +229,7 @@ OPT_BOOL(opt_no_far_computed, cfg.no_far_computed)
 OPT_BOOL(opt_words16, cfg.words16)
 OPT_BOOL(opt_no_spmm_stream, cfg.no_spmm_stream)
 OPT_BOOL(opt_no_spmm_win, cfg.no_spmm_win)
+OPT_BOOL(opt_no_spmm_sweep, cfg.no_spmm_sweep)
 OPT_BOOL(opt_no_zero_copy, cfg.no_zero_copy)
 OPT_BOOL(opt_no_polled_sync, cfg.no_polled_sync)
 OPT_BOOL(opt_no_update_mfma, cfg.no_update_mfma)
@@ -251,6 +252,10 @@ int opt_so3_sort_nbr(mi_ctx *c, long v) {
   c->cfg.so3_sort_nbr = (int)v;
   return MI_OK;
 }
+int opt_sweep_zsegs(mi_ctx *c, long v) {
+  c->cfg.sweep_zsegs = (int)std::max<long>(0, std::min<long>(v, 1024));
+  return MI_OK;
+}
 int opt_reanchor(mi_ctx *c, long v) {
   c->cfg.reanchor = (int)std::max<long>(0, std::min<long>(v, 1 << 20));
   return MI_OK;
@@ -266,6 +271,7 @@ const OptionDesc kOptions[] = {
     {"NO_FOLD", opt_no_fold}, {"HALO_PUSH_LATE", opt_halo_push_late}, {"NO_PACKED", opt_no_packed},
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
+    {"NO_SPMM_SWEEP", opt_no_spmm_sweep}, {"SWEEP_ZSEGS", opt_sweep_zsegs, true},
     {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
     {"WARN_GENERIC", opt_warn_generic}, {"REANCHOR", opt_reanchor, true},

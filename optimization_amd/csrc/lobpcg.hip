@@ -1091,6 +1091,240 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
   }
 }
 
+// ---- the panel product in PLANE-SWEEP form (r06) ---------------------------------------------------
+// For matrices whose far structure is pure (mi_csr::win_far_pure = D: every entry is within +-128 rows of its row, or at
+// exactly row + D / row - D -- a 3-D stencil on an x-fastest grid, D = one grid plane).  The window form above walks a
+// workgroup through CONSECUTIVE tiles, keeps the near rows in an LDS ring and gathers the two far rows of every row from
+// global memory: 3.25 loads per output element, and the far rows miss the XCD's L2 in 40 % of the cases (1713 MB read at
+// the fabric for 1104 algorithmic on cfg5's 48-column product; with the far rows read from lines that are in the L2
+// anyway the same kernel takes 408 us instead of 450, without them 350: profiles/r06_spmm_far_ablation.txt).
+// Here a workgroup of 4 waves owns a TILE of kSwRows = 512 consecutive rows and walks it through the rows
+// base + j D, j = j0 ... j1 - 1: the rows at +D of step j ARE the tile's own rows of step j + 1 and the rows at -D those of
+// step j - 1, so every row of X is loaded ONCE as "the next plane's rows" (two steps ahead, into registers), serves as
+// the far operand, then as the own rows (written to LDS from the registers), then as the -D operand (read back from
+// LDS): no far gather exists.  What is re-read is the near HALO, 128 rows either side of the tile per step (one row per
+// thread, prefetched a step ahead; the neighbouring tiles' workgroups are in the same z-range on the same XCD).
+// 1.5 loads per output element.  Entries are decoded from the packed words (mi_csr::pk: (col - row) << 8 | value index)
+// in storage order with the same fused multiply-adds as k_spmm_colmajor_pk: the same bits.
+constexpr int kSwRows = 512, kSwHalo = 128, kSwWin = kSwRows + 2 * kSwHalo, kSwGroups = kSwRows / 64 / kWinWaves;
+template <int KC, int HW, bool RES>
+__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_spmm_colmajor_sweep(SellView A, unsigned D, int tiles, int zs, int k,
+                                                                   int c_first, ColBlocks X, double *__restrict__ Y,
+                                                                   ThetaArg theta, double *__restrict__ R,
+                                                                   double *__restrict__ partials_all) {
+  static_assert(kWinBlock == 256 && kSwGroups == 2 && 2 * kSwHalo == kWinBlock, "thread <-> halo row, wave <-> groups");
+  const int c0 = c_first + (int)blockIdx.y * KC;
+  double *const partials = RES ? partials_all + (size_t)blockIdx.y * (2 * KC) * kMaxRows : nullptr;
+  extern __shared__ __attribute__((aligned(16))) double ring_dyn[];  // KC x (kSwWin + 1)
+  __shared__ double vt[256];
+  __shared__ double red[RES ? 2 * KC * kWinWaves : 1];
+  constexpr unsigned RR = (unsigned)kSwWin + 1u;
+  LdsDouble *const L = (LdsDouble *)ring_dyn;
+  vt[threadIdx.x] = A.vtab[threadIdx.x];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int zseg = (int)lb / tiles, tile = (int)lb % tiles;
+  const long long m = (long long)A.n;
+  const int nst = (int)((m + (long long)D - 1) / (long long)D);
+  const int j0 = zseg * zs, j1 = j0 + zs < nst ? j0 + zs : nst;
+  double nr[RES ? KC : 1], nxs[RES ? KC : 1], th[RES ? KC : 1];
+  if (RES) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      nr[c] = 0;
+      nxs[c] = 0;
+      th[c] = (c0 + c < k) ? theta.v[c0 + c] : 0.0;
+    }
+  }
+  const double *xc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) xc[c] = X.col(std::min(c0 + c, k - 1), (size_t)m);
+  // in-plane offset of this lane's row of group i, and whether it is a row of THIS tile (the last tile of a plane is cut)
+  unsigned loc[kSwGroups];
+  bool mine[kSwGroups];
+#pragma unroll
+  for (int i = 0; i < kSwGroups; ++i) {
+    loc[i] = (unsigned)(64 * (w + kWinWaves * i) + lane);
+    mine[i] = (unsigned)tile * (unsigned)kSwRows + loc[i] < D;
+  }
+  const long long base = (long long)tile * kSwRows;
+  auto rows_load = [&](int j, double (&buf)[kSwGroups][KC]) {   // the tile's rows of step j (clamped: unused when outside)
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+      const long long r = base + (long long)j * (long long)D + (long long)loc[i];
+      const size_t rr = (r >= 0 && r < m) ? (size_t)r : 0;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) buf[i][c] = pinned_load(xc[c] + rr);
+    }
+  };
+  auto halo_load = [&](int j, double (&buf)[KC]) {  // one halo row per thread: 128 below the tile, 128 above
+    const long long r = base + (long long)j * (long long)D +
+                        ((int)threadIdx.x < kSwHalo ? (long long)threadIdx.x - kSwHalo : (long long)kSwRows + (threadIdx.x - kSwHalo));
+    const size_t rr = (r >= 0 && r < m) ? (size_t)r : 0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) buf[c] = pinned_load(xc[c] + rr);
+  };
+  struct Words {
+    unsigned wv[HW];
+    int width;
+  };
+  // The words of a step in TWO stages a step apart, so that no load of a step waits for another load of the same step
+  // (loads return in order: a dependent pair at the top of a step drains everything issued before it, i.e. exposes the
+  // whole memory latency once per step -- measured: 755 -> 540 us with two workgroups per CU, still 11 us per step):
+  // stage 1 the slice bounds of the rows, stage 2 -- a step later -- the packed words themselves.
+  struct Where {
+    unsigned b0, lane_in_slice;
+    int width;
+  };
+  auto where_load = [&](int j, Where (&wh)[kSwGroups]) {
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+      const long long r = base + (long long)j * (long long)D + (long long)loc[i];
+      const bool ok = mine[i] && r < m && j < j1;
+      const size_t rr = ok ? (size_t)r : 0, sl = rr >> 6;
+      const long long b0 = pinned_load(A.slice_ptr + sl), b1 = pinned_load(A.slice_ptr + sl + 1);
+      wh[i].b0 = (unsigned)b0;
+      wh[i].width = ok ? (int)(b1 - b0) : 0;
+      wh[i].lane_in_slice = (unsigned)(rr & 63);
+    }
+  };
+  auto words_load = [&](const Where (&wh)[kSwGroups], Words (&wd)[kSwGroups]) {
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+      wd[i].width = wh[i].width;
+#pragma unroll
+      for (int e = 0; e < HW; ++e)
+        wd[i].wv[e] = (e < wh[i].width) ? pinned_load(A.pk + ((size_t)(wh[i].b0 + (unsigned)e) * 64 + wh[i].lane_in_slice)) : 0u;
+    }
+  };
+  if (j0 >= j1) {
+    if constexpr (RES) {
+      double z[2 * KC];
+#pragma unroll
+      for (int c = 0; c < 2 * KC; ++c) z[c] = 0;
+      block_partials_store_nw<2 * KC, kWinWaves>(z, red, partials);
+    }
+    return;
+  }
+  // registers: xprev = the tile's rows of step j - 1, xcur = of step j (only until they are in the window), xnext = of
+  // step j + 1; the rows of step j + 2 are in flight during the step
+  double xprev[kSwGroups][KC], xcur[kSwGroups][KC], xnext[kSwGroups][KC], hal[KC];
+  Words wd[kSwGroups];
+  Where wh[kSwGroups];
+  where_load(j0, wh);
+  rows_load(j0 - 1, xprev);
+  rows_load(j0, xcur);
+  rows_load(j0 + 1, xnext);
+  halo_load(j0, hal);
+  words_load(wh, wd);
+  where_load(j0 + 1, wh);
+  for (int j = j0; j < j1; ++j) {
+    // the tile's own rows and its halo into the window (the previous step's readers are past their barrier)
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+      LdsDouble *dst = L + (unsigned)kSwHalo + loc[i];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) dst[(unsigned)c * RR] = xcur[i][c];
+    }
+    {
+      LdsDouble *dst = L + ((int)threadIdx.x < kSwHalo ? threadIdx.x : (unsigned)kSwRows + threadIdx.x);
+#pragma unroll
+      for (int c = 0; c < KC; ++c) dst[(unsigned)c * RR] = hal[c];
+    }
+    // two steps ahead: the rows that are this step's +2D (into the registers the own rows just left); next step's halo
+    // and words
+    const bool more = j + 1 < j1;
+    Words wn[kSwGroups];
+    words_load(wh, wn);          // step j + 1's words (their bounds came in during the previous step)
+    where_load(j + 2, wh);
+    rows_load(j + 2, xcur);
+    halo_load(more ? j + 1 : j, hal);
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+      double acc[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) acc[c] = 0;
+      const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+      for (int e = 0; e < HW; ++e) {
+        const unsigned word = wd[i].wv[e];
+        const bool live = e < wd[i].width;
+        const double a = vt[word & 255u];
+        const int d = (int)word >> 8;
+        const bool up = d == (int)D, dn = d == -(int)D;
+        const unsigned long long mup = __builtin_amdgcn_ballot_w64(up), mdn = __builtin_amdgcn_ballot_w64(dn),
+                                 mlv = __builtin_amdgcn_ballot_w64(live);
+        if (mlv == 0) continue;
+        if (mup == 0 && mdn == 0 && mlv == all) {
+          const LdsDouble *l = L + (unsigned)((int)kSwHalo + (int)loc[i] + d);
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, l[(unsigned)c * RR], acc[c]);
+        } else if (mup == all && mlv == all) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, xnext[i][c], acc[c]);
+        } else if (mdn == all && mlv == all) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc[c] = __builtin_fma(a, xprev[i][c], acc[c]);
+        } else {
+          const LdsDouble *l = L + (unsigned)((int)kSwHalo + (int)loc[i] + ((up || dn || !live) ? 0 : d));
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {
+            double v = l[(unsigned)c * RR];
+            v = up ? xnext[i][c] : (dn ? xprev[i][c] : v);
+            const double t = __builtin_fma(a, v, acc[c]);
+            acc[c] = live ? t : acc[c];
+          }
+        }
+      }
+      // the own rows come back from the window: they are the next step's -D operand (and the residual's X)
+      {
+        const LdsDouble *own = L + (unsigned)kSwHalo + loc[i];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) xprev[i][c] = own[(unsigned)c * RR];
+      }
+      const long long r = base + (long long)j * (long long)D + (long long)loc[i];
+      if (mine[i] && r < m) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+          if (c0 + c < k) __builtin_nontemporal_store(acc[c], Y + (size_t)(c0 + c) * (size_t)m + (size_t)r);
+        if constexpr (RES) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c)
+            if (c0 + c < k) {
+              const double xv = xprev[i][c];
+              const double res = __builtin_fma(-xv, th[c], acc[c]);
+              R[(size_t)(c0 + c) * (size_t)m + (size_t)r] = res;
+              nr[c] = __builtin_fma(res, res, nr[c]);
+              nxs[c] = __builtin_fma(xv, xv, nxs[c]);
+            }
+        }
+      }
+    }
+    // rotate: (own -> prev happened above) next -> cur, the rows loaded at the top of this step -> next
+#pragma unroll
+    for (int i = 0; i < kSwGroups; ++i) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const double t = xnext[i][c];
+        xnext[i][c] = xcur[i][c];
+        xcur[i][c] = t;
+      }
+      wd[i] = wn[i];
+    }
+    if (more) lds_barrier();
+  }
+  if constexpr (RES) {
+    double a[2 * KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      a[c] = nr[c];
+      a[KC + c] = nxs[c];
+    }
+    block_partials_store_nw<2 * KC, kWinWaves>(a, red, partials);
+  }
+}
+
 // Y[r, c] = d[r] X[r, c]  (diagonal operators of the reference's LOBPCG tests, tests/LOBPCG_unit_test.cpp:56-74)
 __global__ __launch_bounds__(256) void k_rowscale(size_t m, size_t k, const double *__restrict__ d,
                                                   const double *__restrict__ X, double *__restrict__ Y) {
@@ -1844,9 +2078,13 @@ bool spmm_win_ok(const mi_csr *A) {
 
 // Y = A X in window form, 8 columns per pass.  theta_host != nullptr: the fused residual form (k_spmm_colmajor_win<..,
 // RES>): R = Y - X diag(theta) and, per pass, the 16 column sums |R_j|^2, |X_j|^2 reduced into sums_dev + 16 * pass.
+bool spmm_sweep_ok(const mi_csr *A);
+int spmm_sweep_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const double *theta_host, double *Rd,
+                      double *sums_dev);
 int spmm_win_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const double *theta_host, double *Rd,
                     double *sums_dev) {
   mi_ctx *ctx = A->ctx;
+  if (spmm_sweep_ok(A)) return spmm_sweep_launch(A, k, Xd, Yd, theta_host, Rd, sums_dev);
   // 49 KB of ring at a half-width of two chunks, two workgroups per CU at 212-231 VGPRs (4 columns per pass: 313 us
   // per 24 columns, 8: 251 -> 224-236 with the later changes; r04: 12 columns per pass -- 74 KB of ring, 241-244 VGPRs,
   // still two waves per SIMD -- 234-242 us in the same call: the per-pass costs are not the bound, not kept)
@@ -1906,6 +2144,53 @@ int spmm_win_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const doub
       MI_TRY(reduce_rows_allreduce(ctx, ctx->partials2, wgrid, 16, sums_dev + 16 * (c0 / kSpmmWinCols)));
     }
   }
+  MI_HIP(hipGetLastError());
+  return MI_OK;
+}
+
+// the plane-sweep form applies: packed matrix with a pure far structure, one context, no halo; opt-out NO_SPMM_SWEEP
+bool spmm_sweep_ok(const mi_csr *A) {
+  return A->pk && A->win_far_pure >= (size_t)(2 * kSwRows) && A->win_far_pure < ((size_t)1 << 22) && A->win_chunks > 0 &&
+         A->win_chunks <= 2 && A->win_head <= 8 && !A->ctx->cfg.no_spmm_sweep && !A->ctx->uniform_grid &&
+         A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0 && A->n < ((size_t)1 << 31) && !A->ctx->comm;
+}
+
+int spmm_sweep_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const double *theta_host, double *Rd,
+                      double *sums_dev) {
+  mi_ctx *ctx = A->ctx;
+  constexpr int KC = 8;
+  const size_t lds = (size_t)KC * ((size_t)kSwWin + 1) * sizeof(double);
+  const bool hw7 = A->win_head <= 7, res = theta_host != nullptr;
+  const void *fn = nullptr;
+  if (res) fn = hw7 ? (const void *)k_spmm_colmajor_sweep<KC, 7, true> : (const void *)k_spmm_colmajor_sweep<KC, 8, true>;
+  else fn = hw7 ? (const void *)k_spmm_colmajor_sweep<KC, 7, false> : (const void *)k_spmm_colmajor_sweep<KC, 8, false>;
+  const unsigned D = (unsigned)A->win_far_pure;
+  const int tiles = (int)((D + kSwRows - 1) / kSwRows);
+  const int nst = (int)((A->n + D - 1) / D);
+  const int npass = (k + KC - 1) / KC;
+  // z-segments: enough workgroups to fill the chip twice over in one launch, at most kMaxRows partial rows, and not so
+  // short that a segment's start-up (three plane-tiles loaded for zs computed) weighs more than ~20 %
+  int zsegs = ctx->cfg.sweep_zsegs > 0 ? ctx->cfg.sweep_zsegs : (4 * ctx->num_cu + tiles * npass - 1) / (tiles * npass);
+  zsegs = std::max(1, std::min(zsegs, std::min(nst / 12 > 0 ? nst / 12 : 1, kMaxRows / tiles)));
+  const int zs = (nst + zsegs - 1) / zsegs;
+  zsegs = (nst + zs - 1) / zs;
+  const int xgrid = tiles * zsegs;
+  MI_REQUIRE(xgrid <= kMaxRows, "plane-sweep product: %d workgroups per pass", xgrid);
+  SellView view = sell_view(A);
+  ThetaArg theta_arg{};
+  if (res) std::copy(theta_host, theta_host + k, theta_arg.v);
+  void *pr = nullptr;
+  if (res) MI_TRY(pool_alloc(ctx, (size_t)npass * 2 * KC * kMaxRows * sizeof(double), &pr));
+  double *partials = (double *)pr;
+  unsigned Darg = D;
+  int tiles_a = tiles, zs_a = zs, c0 = 0;
+  void *args[] = {&view, &Darg, &tiles_a, &zs_a, &k, &c0, &Xd, &Yd, &theta_arg, &Rd, &partials};
+  hipError_t e = hipLaunchKernel(fn, dim3(xgrid, npass), dim3(kWinBlock), args, lds, ctx->stream);
+  int st = e == hipSuccess ? MI_OK : hip_fail(e, "plane-sweep panel product launch", __FILE__, __LINE__);
+  if (st == MI_OK && res)
+    st = launch_reduce_rows_to_slots(ctx, partials, xgrid, 2 * KC, sums_dev, npass, (size_t)2 * KC * kMaxRows);
+  if (pr) pool_free(ctx, pr);
+  MI_TRY(st);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }

@@ -108,6 +108,9 @@ struct Config {
   bool no_far_computed = false;     // NO_FAR_COMPUTED: far columns loaded from wfar
   bool words16 = false;             // WORDS16: 16-bit window words (opt-in)
   bool no_spmm_stream = false;      // NO_SPMM_STREAM: the straight sparse core instead of the pipelined one
+  bool no_spmm_sweep = true;        // NO_SPMM_SWEEP: the LOBPCG panel product of a pure-far-structure matrix keeps the window
+                                    // form (r06: the plane-sweep form is opt-in until it measures faster: NO_SPMM_SWEEP=0)
+  int sweep_zsegs = 0;              // SWEEP_ZSEGS: z-segments of the plane-sweep product (0: chosen by the launcher)
   bool no_spmm_win = false;         // NO_SPMM_WIN: the LOBPCG panel product in gather form
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
   int wide_quad = -1;               // WIDE_QUAD: the one-pass Hessian of rows of 5 ... 8 doubles in the quad layout (4 lanes per

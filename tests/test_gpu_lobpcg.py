@@ -85,6 +85,49 @@ def test_panel_spmm_window_form_has_the_bits_of_the_gather_form(ctx, grid, k, mo
     assert np.abs(Yw - ref).max() <= 1e-14 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("grid,k", [((40, 40, 40), 24), ((64, 48, 30), 9), ((126, 30, 30), 48), ((50, 50, 7), 17),
+                                    ((33, 32, 29), 12)])
+def test_panel_spmm_plane_sweep_form_has_the_bits_of_the_window_form(ctx, grid, k):
+    """r06, an OPT-IN experiment (MI355OPT_NO_SPMM_SWEEP=0): the panel product of a matrix with a
+    pure far structure in plane-sweep form (k_spmm_colmajor_sweep: a workgroup walks a 512-row tile through the planes,
+    the rows at +-D are the tile's own rows of the neighbouring steps held in registers, no far gather; entries decoded
+    from the packed words) against the window form: the same fused multiply-adds in the same order, bit for bit -- the
+    plain product and the fused residual form (R = A X - X diag(theta) and the column norms) -- on grids whose planes
+    are and are not multiples of the tile, whose last tile is cut, and whose z-extent is shorter than a z-segment.
+    Measured at cfg5 (m = 126^3, 48 columns): 1349 MB read at the fabric instead of 1713 (the far gathers are gone:
+    over-fetch 1.33x -> 1.15x) but 500 us instead of 444: two barriers per 512-row step at 8 waves per CU; not the
+    default (EXPERIMENTS.md, profiles/r06_spmm_far_ablation.txt)."""
+    import scipy.sparse as sps
+    nx, ny, nz = grid
+    n = nx * ny * nz
+    rowptr, col, val = wl.laplacian_3d(nx, ny, nz)
+    A = ctx.csr(n, rowptr, col, val)
+    rng = np.random.default_rng(n + k)
+    X = rng.normal(size=(n, k))
+    theta = rng.uniform(0.5, 2.0, size=k)
+    Xd = ctx.upload(np.asfortranarray(X).ravel(order="F"))
+    nres = min(k, 24)
+    try:
+        ctx.set_option("NO_SPMM_SWEEP", 1)
+        Yw = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+        rw = A.spmm_colmajor_residual(nres, Xd, theta[:nres])
+        rw = [np.array(v.numpy() if hasattr(v, "numpy") else v, copy=True) for v in rw]
+        ctx.set_option("NO_SPMM_SWEEP", 0)
+        ctx.ktime_enable("csr_spmm", True)
+        Ys = A.spmm_colmajor(k, Xd).numpy().reshape(k, n).T
+        rs = A.spmm_colmajor_residual(nres, Xd, theta[:nres])
+        rs = [np.array(v.numpy() if hasattr(v, "numpy") else v, copy=True) for v in rs]
+    finally:
+        ctx.set_option("NO_SPMM_SWEEP", 1)
+    assert np.array_equal(Yw, Ys)
+    # AX and R bit for bit; the column norms group their sums by other workgroups: to rounding
+    assert np.array_equal(rw[0], rs[0]) and np.array_equal(rw[1], rs[1])
+    for a, b in zip(rw[2:], rs[2:]):
+        assert np.allclose(a, b, rtol=1e-13)
+    ref = sps.csr_matrix((val, col, rowptr), shape=(n, n)) @ X
+    assert np.abs(Ys - ref).max() <= 1e-14 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("m,ks", [(100_008, 72), (65_536, 48), (4099, 72), (1000, 72), (40, 48), (7, 72)])
 def test_panel_update_on_the_matrix_pipe_has_the_bits_of_the_vector_kernel(ctx, m, ks, monkeypatch):
     """The 48-column update of a LOBPCG iteration (mi_lobpcg_update, ks = 48 or 72): k_panel_update_mfma (coefficients
