@@ -122,7 +122,9 @@ struct Config {
   // re-anchored -- G(p) and G(r) recomputed by the direct form (two passes over X, Y and the vector) -- so that the
   // absolute error the recurrences carry stays at the scale of the CURRENT residual instead of the initial one
   // (r06, tests/test_gpu_long_solves.py).  0: never (the r03-r05 behaviour).
-  int reanchor = 50;
+  int reanchor = 25;  // (25: the alpha trace of a 1000-iteration-budget solve is followed as long as with the direct form --
+                      //  p = 8: 305 iterations, 50: 261, never: 256, two-pass 303; tools/anchor_probe.py; +2.1 % per iteration
+                      //  in long solves, nothing in solves of <= 25 iterations)
   bool no_update_pair = false;      // NO_UPDATE_PAIR: the matrix-pipe panel update in 16-row blocks, 8 bytes per lane (r04 form)
   bool no_gram_half = false;        // NO_GRAM_HALF: the fused Gram pair with a tile column of its own per Gram (r04 form)
   bool no_update_mfma = false;      // NO_UPDATE_MFMA: the 48-column panel update on the vector pipe

@@ -539,6 +539,42 @@ __global__ __launch_bounds__(StBlk<SP>::threads) void k_cg_dirgram(size_t nrows,
   store_sym_partials<SP>(G, lds, dg.gpartials);
 }
 
+// the same for TWO vectors in one pass (re-anchoring, r06; rows of <= 4 doubles): partial rows of G(a) as components
+// [0, NS) and of G(b) as [NS, 2 NS); X and Y are read once.  Row for row and thread for thread the sums of k_cg_dirgram.
+template <int SP>
+__global__ __launch_bounds__(kBlock) void k_cg_dirgram2(size_t nrows, const CgState *__restrict__ st,
+                                                        const double *__restrict__ va, const double *__restrict__ vb,
+                                                        DirGramArgs dg) {
+  static_assert(SP >= 1 && SP <= 4, "narrow rows");
+  __shared__ double lds[SymIdx<SP>::NS * kWaves];
+  if (st->mode != CG_RUN) return;
+  double Sm[SP * SP], Ga[SP * SP], Gb[SP * SP];
+#pragma unroll
+  for (int i = 0; i < SP * SP; ++i) { Ga[i] = 0; Gb[i] = 0; Sm[i] = dg.S[i]; }
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < nrows; row += stride) {
+    double x[SP], y[SP], a[SP], b[SP];
+#pragma unroll
+    for (int c = 0; c < SP; ++c) {
+      x[c] = dg.X[row * SP + c]; y[c] = dg.Y[row * SP + c]; a[c] = va[row * SP + c]; b[c] = vb[row * SP + c];
+    }
+#pragma unroll
+    for (int j = 0; j < SP; ++j) {
+      double ta = 0, tb = 0;
+#pragma unroll
+      for (int i = 0; i < SP; ++i) { ta += a[i] * Sm[i * SP + j]; tb += b[i] * Sm[i * SP + j]; }
+#pragma unroll
+      for (int i = 0; i < SP; ++i) {
+        Ga[i * SP + j] += y[i] * a[j] - x[i] * ta;
+        Gb[i * SP + j] += y[i] * b[j] - x[i] * tb;
+      }
+    }
+  }
+  store_sym_partials<SP>(Ga, lds, dg.gpartials);
+  __syncthreads();
+  store_sym_partials<SP>(Gb, lds, dg.gpartials + (size_t)SymIdx<SP>::NS * kMaxRows);
+}
+
 // k_cg_init<PRE_NONE> and k_cg_dirgram in one pass for the unpreconditioned solve over rows of SP doubles (the cfg2 /
 // cfg4 hot path: v = r, p = -g): g is read once, p is not read back, one launch fewer per solve (16.4 + 14.3 us as two
 // kernels at cfg2).  Row r of every field belongs to the thread k_cg_dirgram gives it, so the Gram rows have its bits;
@@ -612,15 +648,19 @@ __global__ __launch_bounds__(kBlock) void k_cg_gdir_init(const double *__restric
 // from the reference with them and 8e-15 with the two-pass operator, and follows the reference's alpha trace for 354
 // instead of 395 iterations (tests/test_gpu_long_solves.py).  Every mi_ctx::cfg.reanchor iterations both are replaced
 // by their direct values.  A solve that has left CG_RUN keeps what it has (its kernels do nothing any more).
+// dst2 != nullptr: components [ns, 2 ns) go there (the two-vector pass k_cg_dirgram2)
 __global__ __launch_bounds__(kBlock) void k_cg_gdir_anchor(const double *__restrict__ partials, int count, int ns,
                                                            const double *__restrict__ slots, int from_slots,
-                                                           const CgState *__restrict__ st, double *__restrict__ dst) {
+                                                           const CgState *__restrict__ st, double *__restrict__ dst,
+                                                           double *__restrict__ dst2) {
   if (st->mode != CG_RUN) return;
   if (!from_slots) {
     gdir_rows_to(partials, count, ns, dst);
+    if (dst2) gdir_rows_to(partials + (size_t)ns * kMaxRows, count, ns, dst2);
     return;
   }
   if (threadIdx.x < ns) dst[threadIdx.x] = slots[threadIdx.x];
+  if (dst2 && threadIdx.x < ns) dst2[threadIdx.x] = slots[ns + threadIdx.x];
 }
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
@@ -964,23 +1004,34 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
       // the loop index: the same on every rank, so the exchanges it carries stay matched across ranks)
       if (recur && !twok && ctx->cfg.reanchor > 0 && k > 0 && k % (size_t)ctx->cfg.reanchor == 0) {
         const size_t nrows = dgp->n;
-        for (int which = 0; which < 2; ++which) {
-          const double *vec = which == 0 ? p->d : r->d;
+        if (dgp->p <= 4) {
+          // rows of <= 4 doubles: both Grams from ONE pass over X, Y, p, r and one (all-)reduction of 2 gns components
           switch (dgp->p) {
-            case 1: hipLaunchKernelGGL(k_cg_dirgram<1>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
-            case 2: hipLaunchKernelGGL(k_cg_dirgram<2>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
-            case 3: hipLaunchKernelGGL(k_cg_dirgram<3>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
-            case 4: hipLaunchKernelGGL(k_cg_dirgram<4>, dim3(grid), dim3(kBlock), 0, st, nrows, vec, dga); break;
-            case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(StBlk<5>::threads), 0, st, nrows, vec, dga); break;
-            case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(StBlk<6>::threads), 0, st, nrows, vec, dga); break;
-            case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(StBlk<7>::threads), 0, st, nrows, vec, dga); break;
-            default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(StBlk<8>::threads), 0, st, nrows, vec, dga); break;
+            case 1: hipLaunchKernelGGL(k_cg_dirgram2<1>, dim3(grid), dim3(kBlock), 0, st, nrows, (const CgState *)st0, (const double *)p->d, (const double *)r->d, dga); break;
+            case 2: hipLaunchKernelGGL(k_cg_dirgram2<2>, dim3(grid), dim3(kBlock), 0, st, nrows, (const CgState *)st0, (const double *)p->d, (const double *)r->d, dga); break;
+            case 3: hipLaunchKernelGGL(k_cg_dirgram2<3>, dim3(grid), dim3(kBlock), 0, st, nrows, (const CgState *)st0, (const double *)p->d, (const double *)r->d, dga); break;
+            default: hipLaunchKernelGGL(k_cg_dirgram2<4>, dim3(grid), dim3(kBlock), 0, st, nrows, (const CgState *)st0, (const double *)p->d, (const double *)r->d, dga); break;
           }
-          if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, gns, slots_g));
-          else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, gns));
+          if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, 2 * gns, slots_g));
+          else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, 2 * gns));
           hipLaunchKernelGGL(k_cg_gdir_anchor, dim3(1), dim3(kBlock), 0, st, (const double *)ctx->partials2, grid, gns,
-                             (const double *)slots_g, sharded ? 1 : 0, (const CgState *)st0,
-                             dga.gdir + (which == 0 ? SLOT_GDIR_P : 0));
+                             (const double *)slots_g, sharded ? 1 : 0, (const CgState *)st0, dga.gdir + SLOT_GDIR_P,
+                             dga.gdir);
+        } else {
+          for (int which = 0; which < 2; ++which) {
+            const double *vec = which == 0 ? p->d : r->d;
+            switch (dgp->p) {
+              case 5: hipLaunchKernelGGL(k_cg_dirgram<5>, dim3(grid), dim3(StBlk<5>::threads), 0, st, nrows, vec, dga); break;
+              case 6: hipLaunchKernelGGL(k_cg_dirgram<6>, dim3(grid), dim3(StBlk<6>::threads), 0, st, nrows, vec, dga); break;
+              case 7: hipLaunchKernelGGL(k_cg_dirgram<7>, dim3(grid), dim3(StBlk<7>::threads), 0, st, nrows, vec, dga); break;
+              default: hipLaunchKernelGGL(k_cg_dirgram<8>, dim3(grid), dim3(StBlk<8>::threads), 0, st, nrows, vec, dga); break;
+            }
+            if (sharded) CG_CHECK(reduce_rows_allreduce(ctx, ctx->partials2, grid, gns, slots_g));
+            else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials2, gns));
+            hipLaunchKernelGGL(k_cg_gdir_anchor, dim3(1), dim3(kBlock), 0, st, (const double *)ctx->partials2, grid, gns,
+                               (const double *)slots_g, sharded ? 1 : 0, (const CgState *)st0,
+                               dga.gdir + (which == 0 ? SLOT_GDIR_P : 0), (double *)nullptr);
+          }
         }
       }
 
