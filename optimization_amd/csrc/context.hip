@@ -248,6 +248,10 @@ int opt_wide_quad(mi_ctx *c, long v) {
   c->cfg.wide_quad = v < 0 ? -1 : v != 0;
   return MI_OK;
 }
+int opt_wide_window(mi_ctx *c, long v) {
+  c->cfg.wide_window = v < 0 ? -1 : v != 0;
+  return MI_OK;
+}
 int opt_so3_sort_nbr(mi_ctx *c, long v) {
   c->cfg.so3_sort_nbr = (int)v;
   return MI_OK;
@@ -272,7 +276,7 @@ const OptionDesc kOptions[] = {
     {"NO_WINDOW", opt_no_window}, {"NO_WIN_BOUNDS", opt_no_win_bounds}, {"NO_FAR_COMPUTED", opt_no_far_computed},
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
     {"NO_SPMM_SWEEP", opt_no_spmm_sweep}, {"SWEEP_ZSEGS", opt_sweep_zsegs, true},
-    {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true},
+    {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true}, {"WIDE_WINDOW", opt_wide_window, true},
     {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
     {"WARN_GENERIC", opt_warn_generic}, {"REANCHOR", opt_reanchor, true},
 };

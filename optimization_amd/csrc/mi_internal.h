@@ -115,6 +115,8 @@ struct Config {
   bool no_zero_copy = false;        // NO_ZERO_COPY: LOBPCG Gram / residual results through a device buffer + read-back
   int wide_quad = -1;               // WIDE_QUAD: the one-pass Hessian of rows of 5 ... 8 doubles in the quad layout (4 lanes per
                                     // row): -1 = where it measured faster (p = 8), 0 = never (one lane per row), 1 = always
+  int wide_window = -1;             // WIDE_WINDOW: the one-pass Hessian of rows of 5 ... 8 doubles in WINDOW form (r06): -1 = p <= 7
+                                    // when the matrix has a window, 0 = never, 1 = every width
   bool no_polled_sync = false;      // NO_POLLED_SYNC: stream_wait is hipStreamSynchronize (no flag kernel + host poll)
   bool two_kernel_step = false;     // TWO_KERNEL_STEP: opt-in experiment (r05): <r+,r+> by recurrence, the two CG kernels of an
                                     // unpreconditioned Stiefel(n,3) iteration merged (changes the rounding of IterativeSolvers.h:408)

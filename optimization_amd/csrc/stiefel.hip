@@ -618,6 +618,117 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
   block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
 }
 
+// The wide-row pass in WINDOW form (r06): the same epilogue as k_st_hess_wide (S and M in LDS, 3 + P (P +
+// 1) / 2 partial components), but the product A V through spmm_core.h's sell_window instead of sell_stream -- the near
+// rows of V come out of an LDS ring that is filled by coalesced 512-byte loads of whole 64-row chunks (a chunk of a
+// row-major field is 64 P contiguous doubles), only the two far rows of a row are gathered lane by lane, and the far
+// columns are computed (pure far structure).  What the lane-per-row form pays for -- seven neighbour gathers of P
+// strided 8-byte loads each, every wave instruction touching 64 half-lines (profiles/r05_wide_ablation.txt) -- is gone;
+// the own X and Y rows remain lane-per-row loads.  One context, packed matrix with a window (sparse.hip build_window),
+// no halo.  The ring is dynamic LDS sized for the matrix's own window: (nc 64 + 1 + far slots) P doubles.
+template <int P, int HW, bool FARD>
+__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_hess_widewin(
+    SellView A, WinView Wv, const CgState *__restrict__ st, const double *__restrict__ V, const double *__restrict__ X,
+    const double *__restrict__ Y, const double *__restrict__ S, const double *__restrict__ gdir, double *__restrict__ out,
+    double *__restrict__ partials) {
+  static_assert(kWideWaves == kWinWaves, "one workgroup shape");
+  constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
+  __shared__ double lds[KC * kWideWaves];
+  __shared__ double vt[256];
+  __shared__ double Sm[P * P], Mm[P * P];
+  extern __shared__ __attribute__((aligned(16))) double ring_dyn[];
+  if (st && st->mode != CG_RUN) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  vt[threadIdx.x] = A.vtab[threadIdx.x];
+  if (threadIdx.x < P * P) {
+    const int aa = threadIdx.x / P, b = threadIdx.x % P;
+    Sm[threadIdx.x] = S[threadIdx.x];
+    Mm[threadIdx.x] = gdir[SLOT_GDIR_P + (aa <= b ? SymIdx<P>::at(aa, b) : SymIdx<P>::at(b, aa))];
+  }
+  // (sell_window's barrier behind the ring fill publishes vt, Sm and Mm too)
+  const unsigned nb = gridDim.x, lb = xcd_remap(blockIdx.x, nb);
+  double a[KC];
+#pragma unroll
+  for (int i = 0; i < KC; ++i) a[i] = 0;
+  struct Epi {
+    const SellView &A;
+    const double *__restrict__ X, *__restrict__ Y;
+    double *__restrict__ out;
+    const double *Sm, *Mm;
+    double (&a)[KC];
+    int lane;
+    double xn[P], yn[P];
+    __device__ __forceinline__ unsigned lane_off(size_t slice) const {
+      return ((unsigned)slice * 64u + (unsigned)lane < (unsigned)A.n) ? (unsigned)lane * (unsigned)(P * 8) : 0u;
+    }
+    __device__ __forceinline__ const double *row_of(const double *F, size_t slice, unsigned off) const {
+      return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F) + (unsigned)slice * (unsigned)(64 * P * 8) + off);
+    }
+    __device__ __forceinline__ void request(size_t slice) {
+      const unsigned off = lane_off(slice);
+      const double *xs = row_of(X, slice, off), *ys = row_of(Y, slice, off);
+#pragma unroll
+      for (int c = 0; c < P; ++c) xn[c] = pinned_load(xs + c);
+#pragma unroll
+      for (int c = 0; c < P; ++c) yn[c] = pinned_load(ys + c);
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&v)[P]) {
+      if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
+      // (S and M are re-read from LDS for every row: loop-invariant code motion must not park 128 doubles in registers)
+      asm volatile("" ::: "memory");
+      double *os = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (unsigned)slice * (unsigned)(64 * P * 8) +
+                                              lane_off(slice));
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
+        acc[b] -= t;  // Z = A V - V S
+        MI_WIDE_SCHED();
+      }
+      double o[P];
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += xn[aa] * Mm[aa * P + b];
+        o[b] = acc[b] - t;  // Z - X M
+        os[b] = o[b];
+        a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
+        MI_WIDE_SCHED();
+      }
+      double os_[P];  // packed sym(y o' - x (o S)'): the Gram of this output row
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
+        os_[b] = t;
+        MI_WIDE_SCHED();
+      }
+#pragma unroll
+      for (int aa = 0; aa < P; ++aa)
+#pragma unroll
+        for (int b = aa; b < P; ++b) {
+          const double gab = yn[aa] * o[b] - xn[aa] * os_[b];
+          const double gba = yn[b] * o[aa] - xn[b] * os_[aa];
+          a[3 + SymIdx<P>::at(aa, b)] += (aa == b) ? gab : .5 * (gab + gba);
+        }
+    }
+  } epi{A, X, Y, out, Sm, Mm, a, lane, {}, {}};
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int ntiles = (int)((A.nslices + kWinWaves - 1) / kWinWaves), per = (ntiles + (int)nb - 1) / (int)nb;
+  int t0 = (int)lb * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  if (Wv.bounds) {
+    t0 = scalar_int(Wv.bounds, lb);
+    t1 = scalar_int(Wv.bounds, lb + 1);
+  }
+  if (t0 >= t1) __syncthreads();  // (sell_window returns at once: the tables above still need their barrier)
+  sell_window<P, HW, false, FARD, false>(A, Wv, t0, t1, wu, lane, V, vt, ring_dyn, epi);
+  __syncthreads();
+  block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
+}
+
 // The same pass in the QUAD layout of spmm_core.h (sell_stream_quad): lane (g, q) holds columns 2q, 2q + 1 of the rows
 // 16 t + g of its wave's slice, every load and store of a row is 64 contiguous bytes per quad.  A row's full width --
 // the left operands of the three products and of the Gram -- comes from the quad's four lanes by DPP broadcasts; S and M
@@ -1154,6 +1265,54 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   const int *bounds = nullptr;
   if (!ctx->uniform_grid && A->win_far_stride && !ctx->cfg.no_win_bounds && kWideWaves == kWinWaves)
     MI_TRY(window_bounds(ctx, A, grid, (int)wgs, &grid, &bounds));  // (runs cut to the far stride; tiles = 4 slices)
+  // r06: the window form where the matrix has one (packed, window of <= 2 chunks, no halo, one context) -- p = 5, 6, 7 by
+  // default (at p = 8 the ring's rows are 64 bytes apart: 16-way LDS bank conflicts, and the quad layout is there);
+  // MI355OPT_WIDE_WINDOW = 0 / 1 forces it off / on for every width
+  const bool winform = (ctx->cfg.wide_window < 0 ? p <= 7 && !(ctx->cfg.wide_quad > 0) : ctx->cfg.wide_window != 0) &&
+                       A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !A->halo && !ctx->uniform_grid &&
+                       !ctx->cfg.no_window && A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0;
+  if (winform) {
+    const int wc = A->win_chunks, nc = 2 * kWinWaves + 2 * wc;
+    const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
+    const size_t lds_bytes = (size_t)(nc * 64 + 1 + kWinFarRows) * (size_t)p * sizeof(double);
+    const void *fn = nullptr;
+#define WW(PV, HWV) fn = fard ? (const void *)k_st_hess_widewin<PV, HWV, true> : (const void *)k_st_hess_widewin<PV, HWV, false>
+#define WW_P(PV) if (A->win_head <= 7) { WW(PV, 7); } else { WW(PV, 8); }
+    switch (p) {
+      case 5: WW_P(5); break;
+      case 6: WW_P(6); break;
+      case 7: WW_P(7); break;
+      default: WW_P(8); break;
+    }
+#undef WW_P
+#undef WW
+    static bool attr_set[4][2][2] = {};
+    bool &done = attr_set[p - 5][A->win_head <= 7 ? 0 : 1][fard ? 1 : 0];
+    if (!done) {  // (more than 64 KB of dynamic LDS needs the attribute)
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 8 * 1024));
+      (void)hipGetLastError();
+      done = true;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kWinBlock, lds_bytes) != hipSuccess || occ < 1) occ = 1;
+    (void)hipGetLastError();
+    const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
+    int wgs = std::min(std::min(occ, 2) * ctx->num_cu, kMaxRows);
+    if (ctx->max_grid < kMaxGrid) wgs = std::min(wgs, ctx->max_grid);
+    int wgrid = 0;
+    const int *wbounds = nullptr;
+    MI_TRY(window_bounds(ctx, A, wgs, ntiles, &wgrid, &wbounds));
+    WinView wv{A->wk, A->wfar, wc, nc, A->win_zero, wbounds, fard ? (unsigned)A->win_far_pure : 0u, nullptr};
+    SellView view = sell_view(A);
+    const CgState *live = ctx->cg_live;
+    const double *inp = in->d, *Xp = q->X->d, *Yp = q->Y->d, *Sp = q->S_dev, *gd = ctx->scalars + SLOT_GDIR;
+    double *outp = out->d, *parts = ctx->partials;
+    void *args[] = {&view, &wv, &live, &inp, &Xp, &Yp, &Sp, &gd, &outp, &parts};
+    KScope ks(ctx, MI_K_STIEFEL_HESS_FUSED);
+    MI_HIP(hipLaunchKernel(fn, dim3(wgrid), dim3(kWinBlock), args, lds_bytes, ctx->stream));
+    *nparts = wgrid;
+    return MI_OK;
+  }
   HaloWaitArg<true> hw_halo;
   HaloWaitArg<false> hw_none;
   MI_TRY(comm_halo_exchange_or_wait(ctx, A, p, in->d, &hw_halo.w));

@@ -781,12 +781,16 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
     res = {}
     # (the one-pass form in both of its layouts at every width: one lane per row, and a quad of lanes per row --
     # MI355OPT_WIDE_QUAD; the default picks by width)
-    modes = {"recurrence": ("0", "0", "-1"), "recurrence-quad": ("0", "0", "1"), "recurrence-lanes": ("0", "0", "0"),
-             "direct": ("0", "1", "-1"), "two-pass": ("1", "0", "-1")}
-    for mode, (no_dirgram, direct, quad) in modes.items():
+    # r06: and in WINDOW form (k_st_hess_widewin: near rows from an LDS ring, the default for p <= 7 on matrices that have a
+    # window -- this grid's does)
+    modes = {"recurrence": ("0", "0", "-1", "-1"), "recurrence-quad": ("0", "0", "1", "0"),
+             "recurrence-lanes": ("0", "0", "0", "0"), "recurrence-window": ("0", "0", "-1", "1"),
+             "direct": ("0", "1", "-1", "-1"), "two-pass": ("1", "0", "-1", "-1")}
+    for mode, (no_dirgram, direct, quad, window) in modes.items():
         monkeypatch.setenv("MI355OPT_NO_DIRGRAM", no_dirgram)
         monkeypatch.setenv("MI355OPT_DIRGRAM_DIRECT", direct)
         monkeypatch.setenv("MI355OPT_WIDE_QUAD", quad)
+        monkeypatch.setenv("MI355OPT_WIDE_WINDOW", window)
         c = capi.Context(0)
         try:
             A = c.csr(n, rowptr, col, val)
@@ -802,7 +806,7 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
             res[mode] = dict(r, s=r["s"].numpy().copy(), launches=launches, b=dict(rb, s=rb["s"].numpy().copy()))
         finally:
             c.close()
-    for mode in ("recurrence", "recurrence-quad", "recurrence-lanes"):
+    for mode in ("recurrence", "recurrence-quad", "recurrence-lanes", "recurrence-window"):
         assert res[mode]["launches"] == {"stiefel_hess_fused": res[mode]["hvp_calls"], "stiefel_finish_dots": 0}, mode
     for mode in ("direct", "two-pass"):
         assert res[mode]["launches"]["stiefel_hess_fused"] == 0 and res[mode]["launches"]["stiefel_finish_dots"] > 0
@@ -815,8 +819,12 @@ def test_wide_rows_one_pass_hessian_matches_two_pass_and_oracle(oracle, monkeypa
         assert rel_err(r["b"]["s"], ob["s"]) < 1e-10 and abs(r["b"]["M_norm"] - ob["M_norm"]) <= 1e-12 * ob["M_norm"], mode
     assert rel_err(res["recurrence"]["s"], res["two-pass"]["s"]) < 1e-11
     assert rel_err(res["recurrence-quad"]["s"], res["recurrence-lanes"]["s"]) < 1e-11
-    # (the default is one of the two, bit for bit)
-    assert any(np.array_equal(res["recurrence"]["s"], res[m]["s"]) for m in ("recurrence-quad", "recurrence-lanes"))
+    assert rel_err(res["recurrence-window"]["s"], res["recurrence-lanes"]["s"]) < 1e-11
+    if fmt == "plain":   # (no packed copy: no window; the window switch then leaves the default choice of the other two)
+        assert any(np.array_equal(res["recurrence-window"]["s"], res[m]["s"]) for m in ("recurrence-quad", "recurrence-lanes"))
+    # (the default is one of the three, bit for bit)
+    assert any(np.array_equal(res["recurrence"]["s"], res[m]["s"])
+               for m in ("recurrence-quad", "recurrence-lanes", "recurrence-window"))
 
 
 @pytest.mark.parametrize("p", [6, 8])
