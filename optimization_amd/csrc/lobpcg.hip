@@ -1106,21 +1106,29 @@ __global__ __launch_bounds__(kWinBlock) void k_spmm_colmajor_win(SellView A, Win
 // thread, prefetched a step ahead; the neighbouring tiles' workgroups are in the same z-range on the same XCD).
 // 1.5 loads per output element.  Entries are decoded from the packed words (mi_csr::pk: (col - row) << 8 | value index)
 // in storage order with the same fused multiply-adds as k_spmm_colmajor_pk: the same bits.
-constexpr int kSwRows = 512, kSwHalo = 128, kSwWin = kSwRows + 2 * kSwHalo, kSwGroups = kSwRows / 64 / kWinWaves;
+// (waves x row groups per wave: 4 x 2 -- 230-245 VGPRs, two workgroups = 8 waves per CU, 496-514 us at cfg5 -- or, with
+// -DMI_SWEEP_WAVES=8, 8 x 1: the same tile and window, 128 VGPRs, 16 waves per CU: 518-521 us.  Twice the occupancy
+// changes nothing: with every workgroup's step requested in one burst the pass is paced by the memory system serving
+// 512 workgroups x 96 KB per round, at 4.3-4.5 TB/s)
+constexpr int kSwRows = 512, kSwHalo = 128, kSwWin = kSwRows + 2 * kSwHalo;
+#ifndef MI_SWEEP_WAVES
+#define MI_SWEEP_WAVES 4
+#endif
+constexpr int kSwWaves = MI_SWEEP_WAVES, kSwBlock = 64 * kSwWaves, kSwGroups = kSwRows / 64 / kSwWaves;
 template <int KC, int HW, bool RES>
-__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_spmm_colmajor_sweep(SellView A, unsigned D, int tiles, int zs, int k,
+__global__ __launch_bounds__(kSwBlock) __attribute__((amdgpu_waves_per_eu(kSwWaves == 8 ? 4 : 2, kSwWaves == 8 ? 4 : 2))) void k_spmm_colmajor_sweep(SellView A, unsigned D, int tiles, int zs, int k,
                                                                    int c_first, ColBlocks X, double *__restrict__ Y,
                                                                    ThetaArg theta, double *__restrict__ R,
                                                                    double *__restrict__ partials_all) {
-  static_assert(kWinBlock == 256 && kSwGroups == 2 && 2 * kSwHalo == kWinBlock, "thread <-> halo row, wave <-> groups");
+  static_assert(kSwGroups >= 1 && kSwGroups * kSwWaves * 64 == kSwRows && 2 * kSwHalo == 256, "thread <-> halo row, wave <-> groups");
   const int c0 = c_first + (int)blockIdx.y * KC;
   double *const partials = RES ? partials_all + (size_t)blockIdx.y * (2 * KC) * kMaxRows : nullptr;
   extern __shared__ __attribute__((aligned(16))) double ring_dyn[];  // KC x (kSwWin + 1)
   __shared__ double vt[256];
-  __shared__ double red[RES ? 2 * KC * kWinWaves : 1];
+  __shared__ double red[RES ? 2 * KC * kSwWaves : 1];
   constexpr unsigned RR = (unsigned)kSwWin + 1u;
   LdsDouble *const L = (LdsDouble *)ring_dyn;
-  vt[threadIdx.x] = A.vtab[threadIdx.x];
+  if (threadIdx.x < 256) vt[threadIdx.x] = A.vtab[threadIdx.x];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
   const int zseg = (int)lb / tiles, tile = (int)lb % tiles;
@@ -1144,7 +1152,7 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
   bool mine[kSwGroups];
 #pragma unroll
   for (int i = 0; i < kSwGroups; ++i) {
-    loc[i] = (unsigned)(64 * (w + kWinWaves * i) + lane);
+    loc[i] = (unsigned)(64 * (w + kSwWaves * i) + lane);
     mine[i] = (unsigned)tile * (unsigned)kSwRows + loc[i] < D;
   }
   const long long base = (long long)tile * kSwRows;
@@ -1157,12 +1165,22 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
       for (int c = 0; c < KC; ++c) buf[i][c] = pinned_load(xc[c] + rr);
     }
   };
-  auto halo_load = [&](int j, double (&buf)[KC]) {  // one halo row per thread: 128 below the tile, 128 above
+  // one halo row per thread (128 below the tile, 128 above); 512 threads: the two halves of the workgroup take half the
+  // columns of a row each
+  constexpr int HP = kSwBlock / 256, HC = KC / HP;
+  static_assert(KC % HP == 0, "halo columns per thread");
+  const int hrow = (int)(threadIdx.x & 255), hc0 = (int)(threadIdx.x >> 8) * HC;
+  auto halo_load = [&](int j, double (&buf)[HC]) {
     const long long r = base + (long long)j * (long long)D +
-                        ((int)threadIdx.x < kSwHalo ? (long long)threadIdx.x - kSwHalo : (long long)kSwRows + (threadIdx.x - kSwHalo));
+                        (hrow < kSwHalo ? (long long)hrow - kSwHalo : (long long)kSwRows + (hrow - kSwHalo));
     const size_t rr = (r >= 0 && r < m) ? (size_t)r : 0;
 #pragma unroll
-    for (int c = 0; c < KC; ++c) buf[c] = pinned_load(xc[c] + rr);
+    for (int c = 0; c < HC; ++c) {
+      const double *col = xc[0];   // (xc[hc0 + c] with a runtime hc0: selected below, the array stays in registers)
+#pragma unroll
+      for (int cc = 0; cc < KC; ++cc) col = (cc == hc0 + c) ? xc[cc] : col;
+      buf[c] = pinned_load(col + rr);
+    }
   };
   struct Words {
     unsigned wv[HW];
@@ -1202,13 +1220,13 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
       double z[2 * KC];
 #pragma unroll
       for (int c = 0; c < 2 * KC; ++c) z[c] = 0;
-      block_partials_store_nw<2 * KC, kWinWaves>(z, red, partials);
+      block_partials_store_nw<2 * KC, kSwWaves>(z, red, partials);
     }
     return;
   }
   // registers: xprev = the tile's rows of step j - 1, xcur = of step j (only until they are in the window), xnext = of
   // step j + 1; the rows of step j + 2 are in flight during the step
-  double xprev[kSwGroups][KC], xcur[kSwGroups][KC], xnext[kSwGroups][KC], hal[KC];
+  double xprev[kSwGroups][KC], xcur[kSwGroups][KC], xnext[kSwGroups][KC], hal[HC];
   Words wd[kSwGroups];
   Where wh[kSwGroups];
   where_load(j0, wh);
@@ -1227,9 +1245,9 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
       for (int c = 0; c < KC; ++c) dst[(unsigned)c * RR] = xcur[i][c];
     }
     {
-      LdsDouble *dst = L + ((int)threadIdx.x < kSwHalo ? threadIdx.x : (unsigned)kSwRows + threadIdx.x);
+      LdsDouble *dst = L + (hrow < kSwHalo ? (unsigned)hrow : (unsigned)kSwRows + (unsigned)hrow) + (unsigned)hc0 * RR;
 #pragma unroll
-      for (int c = 0; c < KC; ++c) dst[(unsigned)c * RR] = hal[c];
+      for (int c = 0; c < HC; ++c) dst[(unsigned)c * RR] = hal[c];
     }
     // two steps ahead: the rows that are this step's +2D (into the registers the own rows just left); next step's halo
     // and words
@@ -1321,7 +1339,7 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
       a[c] = nr[c];
       a[KC + c] = nxs[c];
     }
-    block_partials_store_nw<2 * KC, kWinWaves>(a, red, partials);
+    block_partials_store_nw<2 * KC, kSwWaves>(a, red, partials);
   }
 }
 
@@ -2185,7 +2203,7 @@ int spmm_sweep_launch(const mi_csr *A, int k, ColBlocks Xd, double *Yd, const do
   unsigned Darg = D;
   int tiles_a = tiles, zs_a = zs, c0 = 0;
   void *args[] = {&view, &Darg, &tiles_a, &zs_a, &k, &c0, &Xd, &Yd, &theta_arg, &Rd, &partials};
-  hipError_t e = hipLaunchKernel(fn, dim3(xgrid, npass), dim3(kWinBlock), args, lds, ctx->stream);
+  hipError_t e = hipLaunchKernel(fn, dim3(xgrid, npass), dim3(kSwBlock), args, lds, ctx->stream);
   int st = e == hipSuccess ? MI_OK : hip_fail(e, "plane-sweep panel product launch", __FILE__, __LINE__);
   if (st == MI_OK && res)
     st = launch_reduce_rows_to_slots(ctx, partials, xgrid, 2 * KC, sums_dev, npass, (size_t)2 * KC * kMaxRows);
