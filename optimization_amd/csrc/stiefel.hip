@@ -668,15 +668,9 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off), *ys = row_of(Y, slice, off);
 #pragma unroll
-#if defined(MI_WIDEWIN_NT) && (MI_WIDEWIN_NT & 1)   // (experiment: X and Y rows are read once per pass)
-      for (int c = 0; c < P; ++c) xn[c] = __builtin_nontemporal_load(xs + c);
-#pragma unroll
-      for (int c = 0; c < P; ++c) yn[c] = __builtin_nontemporal_load(ys + c);
-#else
       for (int c = 0; c < P; ++c) xn[c] = pinned_load(xs + c);
 #pragma unroll
       for (int c = 0; c < P; ++c) yn[c] = pinned_load(ys + c);
-#endif
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&v)[P]) {
       if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
@@ -699,11 +693,7 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += xn[aa] * Mm[aa * P + b];
         o[b] = acc[b] - t;  // Z - X M
-#if defined(MI_WIDEWIN_NT) && (MI_WIDEWIN_NT & 2)
-        __builtin_nontemporal_store(o[b], os + b);
-#else
-        os[b] = o[b];
-#endif
+        os[b] = o[b];  // (non-temporal stores / loads of the own rows: 58 -> 63-74 us at p = 6, EXPERIMENTS.md r06)
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
         MI_WIDE_SCHED();
       }
