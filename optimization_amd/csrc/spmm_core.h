@@ -481,7 +481,10 @@ struct WinView {
 // halo_lo / halo_hi (HALO && FARD): rows of rank - 1 / rank + 1 in the halo buffer; a computed far column that leaves
 // the local rows is the halo column of that row (mi_csr: column n + h, h < halo_lo: row h - halo_lo of the slab below,
 // else row h - halo_lo of the slab above)
-template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi>
+// RS (r06): doubles between consecutive rows of the ring -- P (the ring is the memory image of its chunks) or, for the
+// wide rows, P padded to an odd number: with RS = P = 6 or 8 the row-by-row reads of 64 lanes fall on half / a sixteenth
+// of the LDS banks (k_st_hess_widewin).  RS > P scatters a staged chunk's doubles to (row, column) addresses.
+template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi, int RS = P>
 __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
                                             const double *__restrict__ V, const double *vt, double *lds_rows,
                                             Epi &epi, unsigned halo_lo = 0, unsigned halo_hi = 0) {
@@ -517,9 +520,18 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     }
   };
   auto chunk_store = [&](int slot, const double (&buf)[P]) {
-    LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * P) + lane;
+    if constexpr (RS == P) {
+      LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * P) + lane;
 #pragma unroll
-    for (int c = 0; c < P; ++c) dst[c * 64] = buf[c];
+      for (int c = 0; c < P; ++c) dst[c * 64] = buf[c];
+    } else {
+      LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * RS);
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const unsigned e = (unsigned)lane + 64u * (unsigned)c;  // element of the chunk: row e / P, column e % P
+        dst[(e / (unsigned)P) * (unsigned)RS + e % (unsigned)P] = buf[c];
+      }
+    }
   };
   // raw operands of a slice: its words (ONE scalar base + immediate offsets j * 256: the words behind a narrower
   // slice belong to the next slice or to the padding mi_csr keeps behind the array, and are replaced by zw when
@@ -581,7 +593,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   };
 
   const int zrow = nc * 64;
-  const unsigned far_base = (unsigned)(zrow + 1 + w * (kFarCap * 64) + lane) * (unsigned)P;  // this lane's slot 0
+  const unsigned far_base = (unsigned)(zrow + 1 + w * (kFarCap * 64) + lane) * (unsigned)RS;  // this lane's slot 0
   int slice = t0 * NW + w;               // (tiles are aligned: slice % NW == w)
   bool have = slice < nchunks;
   int k = 0, b1 = 0;
@@ -619,7 +631,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       const int q = lo + w + i * NW;
       if (q >= 0 && q < hi) chunk_store(q % nc, b[i]);
     }
-    if (threadIdx.x < P) L[zrow * P + threadIdx.x] = 0.0;
+    if (threadIdx.x < P) L[zrow * RS + threadIdx.x] = 0.0;
     slot_own = (t0 * NW + w) % nc;
   }
   int slot_job = (t0 * NW + NW + wc + w) % nc;  // slot of the chunk this wave stages during the first tile
@@ -676,7 +688,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
 #pragma unroll
       for (int s = 0; s < kFarCap; ++s)
 #pragma unroll
-        for (int c = 0; c < P; ++c) L[far_base + (unsigned)(s * 64 * P + c)] = gf[s][c];
+        for (int c = 0; c < P; ++c) L[far_base + (unsigned)(s * 64 * RS + c)] = gf[s][c];
       MI_STAMP(2 + 8 * (t - t0) + 2, gf[kFarCap - 1][P - 1]);
       // ---- entries in storage order ----------------------------------------------------------------------------
       double acc[P];
@@ -685,7 +697,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
 #pragma unroll
       for (int j = 0; j < HW; ++j) {
         const double aj = vt[wd[j] & 255u];
-        const LdsDouble *l = L + (wd[j] >> 8) * (unsigned)P;
+        const LdsDouble *l = L + (wd[j] >> 8) * (unsigned)RS;
 #pragma unroll
         for (int c = 0; c < P; ++c) {
 #pragma clang fp contract(off)
@@ -698,7 +710,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       if (job) chunk_store(slot_job, pre);
       {
         double vrow[P];
-        const LdsDouble *l = L + (unsigned)(slot_own * 64 + lane) * (unsigned)P;
+        const LdsDouble *l = L + (unsigned)(slot_own * 64 + lane) * (unsigned)RS;
 #pragma unroll
         for (int c = 0; c < P; ++c) vrow[c] = l[c];
         if (!(dbg & 4)) epi.end(slice, acc, vrow);

@@ -626,8 +626,16 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 // strided 8-byte loads each, every wave instruction touching 64 half-lines (profiles/r05_wide_ablation.txt) -- is gone;
 // the own X and Y rows remain lane-per-row loads.  One context, packed matrix with a window (sparse.hip build_window),
 // no halo.  The ring is dynamic LDS sized for the matrix's own window: (nc 64 + 1 + far slots) P doubles.
+// ring rows of the wide window form (spmm_core.h sell_window RS): at P = 8 rows 64 bytes apart put the row-by-row reads
+// of a wave on a sixteenth of the LDS banks (218 us; 9 doubles apart: 102 us -- still behind the quad layout's 80, so
+// p = 8 does not take this form by default); at P = 6 the padding changes nothing (57.7 us either way) and costs
+// 11-14 registers: not applied
+template <int P>
+struct WideRing {
+  static constexpr int stride = (P == 8) ? 9 : P;
+};
 template <int P, int HW, bool FARD>
-__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_st_hess_widewin(
+__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 7 ? 2 : 1, P <= 7 ? 2 : 1))) void k_st_hess_widewin(
     SellView A, WinView Wv, const CgState *__restrict__ st, const double *__restrict__ V, const double *__restrict__ X,
     const double *__restrict__ Y, const double *__restrict__ S, const double *__restrict__ gdir, double *__restrict__ out,
     double *__restrict__ partials) {
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(2, 2)
     t1 = scalar_int(Wv.bounds, lb + 1);
   }
   if (t0 >= t1) __syncthreads();  // (sell_window returns at once: the tables above still need their barrier)
-  sell_window<P, HW, false, FARD, false>(A, Wv, t0, t1, wu, lane, V, vt, ring_dyn, epi);
+  sell_window<P, HW, false, FARD, false, Epi, WideRing<P>::stride>(A, Wv, t0, t1, wu, lane, V, vt, ring_dyn, epi);
   __syncthreads();
   block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
 }
@@ -1274,7 +1282,7 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   if (winform) {
     const int wc = A->win_chunks, nc = 2 * kWinWaves + 2 * wc;
     const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
-    const size_t lds_bytes = (size_t)(nc * 64 + 1 + kWinFarRows) * (size_t)p * sizeof(double);
+    const size_t lds_bytes = (size_t)(nc * 64 + 1 + kWinFarRows) * (size_t)(p == 8 ? 9 : p) * sizeof(double);
     const void *fn = nullptr;
 #define WW(PV, HWV) fn = fard ? (const void *)k_st_hess_widewin<PV, HWV, true> : (const void *)k_st_hess_widewin<PV, HWV, false>
 #define WW_P(PV) if (A->win_head <= 7) { WW(PV, 7); } else { WW(PV, 8); }
