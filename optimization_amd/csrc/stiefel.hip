@@ -645,7 +645,9 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
   __shared__ double vt[256];
   __shared__ double Sm[P * P], Mm[P * P];
   extern __shared__ __attribute__((aligned(16))) double ring_dyn[];
-  if (st && st->mode != CG_RUN) return;
+#if !defined(MI_WIDE_ABLATE_MATH) && !defined(MI_WIDE_ABLATE_OWN) && !defined(MI_WIDE_ABLATE_STORE)
+  if (st && st->mode != CG_RUN) return;   // (the timing experiments produce wrong iterates: their launches must not turn into no-ops)
+#endif
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   vt[threadIdx.x] = A.vtab[threadIdx.x];
   if (threadIdx.x < P * P) {
@@ -676,9 +678,14 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off), *ys = row_of(Y, slice, off);
 #pragma unroll
+#ifdef MI_WIDE_ABLATE_OWN   // (timing experiment only: X and Y rows not read -- wrong results)
+      for (int c = 0; c < P; ++c) { xn[c] = (double)(off + c); yn[c] = xn[c] - 1.0; }
+      (void)xs; (void)ys;
+#else
       for (int c = 0; c < P; ++c) xn[c] = pinned_load(xs + c);
 #pragma unroll
       for (int c = 0; c < P; ++c) yn[c] = pinned_load(ys + c);
+#endif
     }
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&v)[P]) {
       if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
@@ -689,8 +696,10 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
+#ifndef MI_WIDE_ABLATE_MATH
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += v[aa] * Sm[aa * P + b];
+#endif
         acc[b] -= t;  // Z = A V - V S
         MI_WIDE_SCHED();
       }
@@ -698,10 +707,16 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
+#ifndef MI_WIDE_ABLATE_MATH
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += xn[aa] * Mm[aa * P + b];
+#endif
         o[b] = acc[b] - t;  // Z - X M
+#ifdef MI_WIDE_ABLATE_STORE  // (timing experiment only: one double of the row stored)
+        if (b == 0) os[b] = acc[0] + acc[P - 1];
+#else
         os[b] = o[b];  // (non-temporal stores / loads of the own rows: 58 -> 63-74 us at p = 6, EXPERIMENTS.md r06)
+#endif
         a[0] += v[b] * o[b]; a[1] += o[b] * o[b]; a[2] += v[b] * v[b];
         MI_WIDE_SCHED();
       }
@@ -709,8 +724,10 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         double t = 0;
+#ifndef MI_WIDE_ABLATE_MATH
 #pragma unroll
         for (int aa = 0; aa < P; ++aa) t += o[aa] * Sm[aa * P + b];
+#endif
         os_[b] = t;
         MI_WIDE_SCHED();
       }
