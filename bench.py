@@ -572,11 +572,12 @@ def cfg3_leg(ctx, N=500_000, steps=500):
     if rc:
         raise RuntimeError("cfg3 TNT: " + L.bc_last_error().decode())
     ipo = rep.inner / max(rep.outer, 1)
-    # an outer iteration's compulsory bytes: the fused trial step (dm product = one HVP; retraction R, h -> R+: 168 N;
-    # model assembly at R+: R own 72 N, per incidence 32 (quaternion measurement) + 8 (weight) + 8 (indices) + 72 (R_j)
-    # read and 72 (block) written, D, D^-1 72 N each and grad 24 N written; 7 tangent vectors through the step's dots and
-    # D^-1 grad: 168 N) + its inner iterations
-    trial_bytes = hvp_bytes + 168 * N + (240 * N + 192 * inc) + 168 * N
+    # an outer iteration's compulsory bytes: the fused trial step (dm product = one HVP; retraction R, h -> R+ and, r06,
+    # its quaternions: 168 N + 32 N; model assembly at R+: R own 72 N, per incidence 32 (quaternion measurement) + 8
+    # (weight) + 8 (indices) + 32 (the neighbour's quaternion; 72 as a matrix until r05) read and 72 (block) written,
+    # D, D^-1 72 N each and grad 24 N written; 7 tangent vectors through the step's dots and D^-1 grad: 168 N) + its
+    # inner iterations
+    trial_bytes = hvp_bytes + 200 * N + (240 * N + 152 * inc) + 168 * N
     outer_bytes = trial_bytes + ipo * step_bytes
     us_outer = 1e6 * rep.seconds / max(rep.outer, 1)
     out["outer_iteration"] = {"us": us_outer, "outer_iterations": int(rep.outer), "inner_iterations": int(rep.inner),

@@ -111,7 +111,7 @@ enum {
  * environment ONCE per context, in mi_ctx_create: MI355OPT_<NAME>=<integer> for NAME in FORCE_SLOT_PATH,
  * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
  * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA,
- * NO_ZERO_COPY, NO_GRAM_HALF, NO_UPDATE_PAIR, SO3_NO_QUAT, SO3_SORT_NBR, HALO_RPRIME, TWO_KERNEL_STEP, WIDE_QUAD,
+ * NO_ZERO_COPY, NO_GRAM_HALF, NO_UPDATE_PAIR, SO3_NO_QUAT, SO3_NO_RQUAT, SO3_SORT_NBR, HALO_RPRIME, TWO_KERNEL_STEP, WIDE_QUAD,
  * NO_POLLED_SYNC, WARN_GENERIC, REANCHOR, NO_SPMM_SWEEP, SWEEP_ZSEGS, WIDE_WINDOW (DESIGN.md / INTEGRATION.md say what each selects).  For the boolean switches a value that
  * is not an integer counts as 1 unless it is "no" / "false" / "off"; the integer-valued ones (MAX_GRID, IPC_TIMEOUT_MS,
  * WIDE_QUAD, WIDE_WINDOW, SO3_SORT_NBR, REANCHOR, SWEEP_ZSEGS) take integers only -- anything else is ignored with a warning and the default stays.  Any other

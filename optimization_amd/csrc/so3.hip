@@ -86,8 +86,48 @@ __device__ __forceinline__ void quat_to_mat(double w, double x, double y, double
   S[3] = 2 * (xy + wz);     S[4] = 1 - 2 * (xx + zz); S[5] = 2 * (yz - wx);
   S[6] = 2 * (xz - wy);     S[7] = 2 * (yz + wx);     S[8] = 1 - 2 * (xx + yy);
 }
-template <bool MODEL, bool SQ>
+// Rotation -> unit quaternion (w, x, y, z), Shepperd's branch on the largest of trace, R00, R11, R22 (no cancellation in
+// the pivot), contraction off: the retraction's fused form and the conversion pass below must give the same bits for
+// the same matrix whatever kernel they are inlined into.
+__device__ __forceinline__ void mat_to_quat(const double *R, double *q) {
+#pragma clang fp contract(off)
+  const double tr = R[0] + R[4] + R[8];
+  double w, x, y, z;
+  if (tr > 0) {
+    const double s = sqrt(tr + 1.0) * 2;  // 4 w
+    w = .25 * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2;  // 4 x
+    w = (R[7] - R[5]) / s; x = .25 * s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2;  // 4 y
+    w = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; y = .25 * s; z = (R[5] + R[7]) / s;
+  } else {
+    const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2;  // 4 z
+    w = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; z = .25 * s;
+  }
+  const double nrm = sqrt(w * w + x * x + y * y + z * z);
+  q[0] = w / nrm; q[1] = x / nrm; q[2] = y / nrm; q[3] = z / nrm;
+}
+// Rq[4 i ...] = quaternion of R_i (r06): the 32-byte gather record of the model assembly
+__global__ __launch_bounds__(256) void k_so3_quat(size_t N, const double *__restrict__ R, double *__restrict__ Rq) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += stride) {
+    double Ri[9], q[4];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Ri[c] = R[9 * i + c];
+    mat_to_quat(Ri, q);
+    *reinterpret_cast<double2 *>(Rq + 4 * i) = make_double2(q[0], q[1]);
+    *reinterpret_cast<double2 *>(Rq + 4 * i + 2) = make_double2(q[2], q[3]);
+  }
+}
+// GQ (r06): the neighbour's rotation R_j is gathered as its unit quaternion from Rq (32 bytes, never
+// across a 128-byte line; two 16-byte loads) and expanded, instead of as nine doubles at a 72-byte stride (1.56 lines on
+// average).  Rq is written by the retraction of the trial step (k_so3_retract<true>) or, for a point the library did not
+// produce, by k_so3_quat right before the assembly.  The own rotation R_i is read from R itself.
+template <bool MODEL, bool SQ, bool GQ>
 __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double *__restrict__ R,
+                                                const double *__restrict__ Rq,
                                                 const double *__restrict__ Sinc, const double *__restrict__ winc,
                                                 double *__restrict__ grad, double *__restrict__ Dinv,
                                                 double *__restrict__ Bblk, double *__restrict__ Dsl, size_t slice,
@@ -120,8 +160,13 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
 #pragma unroll
       for (int c = 0; c < 9; ++c) Rj[c] = Ri[c] + we;
 #else
+      if (GQ) {
+        const double2 qa = *reinterpret_cast<const double2 *>(Rq + 4 * j), qb = *reinterpret_cast<const double2 *>(Rq + 4 * j + 2);
+        quat_to_mat(qa.x, qa.y, qb.x, qb.y, Rj);
+      } else {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
+        for (int c = 0; c < 9; ++c) Rj[c] = R[9 * j + c];
+      }
 #endif
       // head: term R_i - R_j Rt (j = tail); tail: R_i - R_j Rt'  (the transposition is in Sinc)
       if (SQ) {
@@ -192,8 +237,8 @@ __device__ __forceinline__ void so3_model_slice(const IncView &inc, const double
   Di[6] = c02 / det; Di[7] = c12 / det; Di[8] = c22 / det;
 }
 
-template <bool MODEL, bool SQ>
-__global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R,
+template <bool MODEL, bool SQ, bool GQ>
+__global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__restrict__ R, const double *__restrict__ Rq,
                                                    const double *__restrict__ Sinc, const double *__restrict__ winc,
                                                    double *__restrict__ grad,
                                                    double *__restrict__ Dinv, double *__restrict__ Bblk,
@@ -203,7 +248,7 @@ __global__ __launch_bounds__(256) void k_so3_model(IncView inc, const double *__
   double facc = 0;
   const size_t ngroups = (inc.nslices + 3) / 4;
   for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
-    so3_model_slice<MODEL, SQ>(inc, R, Sinc, winc, grad, Dinv, Bblk, Dsl, grp * 4 + w, lane, facc);
+    so3_model_slice<MODEL, SQ, GQ>(inc, R, Rq, Sinc, winc, grad, Dinv, Bblk, Dsl, grp * 4 + w, lane, facc);
   // the workgroup's partial of the objective: workgroup b -> row b % kMaxRows of component b / kMaxRows (one workgroup
   // per group of slices keeps the dynamic balance of ~2000 short workgroups: a grid capped at kMaxRows rows cost the
   // assembly 30 us at N = 5e5); the components are added in fixed order by k_sum_slots
@@ -282,8 +327,11 @@ __global__ __launch_bounds__(kBlock) void k_bsr3_spmv(IncView inc, const CgState
 
 // Y_i = R_i exp(hat(xi_i))  (Rodrigues; same series switch as oracle/problems.c: orc_so3_exp)
 // (80 scalar registers: see stpcg.hip, k_cg_update_s80)
+// WQ (r06): also the quaternion of every Y_i into Yq (the model assembly's gather record at the trial point)
+template <bool WQ>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k_so3_retract(size_t N, const double *__restrict__ R,
-                                                        const double *__restrict__ xi, double *__restrict__ Y) {
+                                                        const double *__restrict__ xi, double *__restrict__ Y,
+                                                        double *__restrict__ Yq) {
   const size_t stride = (size_t)gridDim.x * kBlock;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
     const double x0 = xi[3 * i], x1 = xi[3 * i + 1], x2 = xi[3 * i + 2];
@@ -307,6 +355,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void k
     mat3_mul(Ri, Ex, Yi);
 #pragma unroll
     for (int c = 0; c < 9; ++c) Y[9 * i + c] = Yi[c];
+    if (WQ) {
+      double q[4];
+      mat_to_quat(Yi, q);
+      *reinterpret_cast<double2 *>(Yq + 4 * i) = make_double2(q[0], q[1]);
+      *reinterpret_cast<double2 *>(Yq + 4 * i + 2) = make_double2(q[2], q[3]);
+    }
   }
 }
 
@@ -328,6 +382,8 @@ struct mi_so3n {
   double *Sinc = nullptr, *winc = nullptr;  // padded * 9 (or * 4: sinc_quat), padded: per-incidence measurement and weight
   bool sinc_quat = false;                   // Sinc holds unit quaternions (all measurements are rotations to rounding)
   double *Dsl = nullptr;                    // nslices * 9 * 64: diagonal blocks in slice order
+  double *Rq = nullptr;                     // 4 N: unit quaternions of the point the NEXT assembly gathers from (r06; null:
+                                            // SO3_NO_RQUAT -- the assembly gathers R itself)
   mi_op hess;
   mi_precon bj;
   const mi_vec *R = nullptr;                // the point the model is bound to (mi_so3n_model) ...
@@ -355,13 +411,22 @@ IncView view(const mi_so3n *q) {
   return IncView{q->N, q->nslices, q->slice_ptr, q->perm, q->nbr};
 }
 // the assembly (model = true) or its objective alone, objective partials into ctx->partials2
-void launch_model(mi_so3n *q, bool model, int grid, const double *R, double *grad, double *Dinv, double *Bblk, double *Dsl) {
+// have_quat: q->Rq already holds the quaternions of R (the trial step's retraction wrote them); otherwise they are formed
+// here first (one pass over R: a point the library did not produce -- the start, or the statement sequence's calls)
+void launch_model(mi_so3n *q, bool model, int grid, const double *R, double *grad, double *Dinv, double *Bblk, double *Dsl,
+                  bool have_quat = false) {
   mi_ctx *ctx = q->ctx;
-#define SO3M(MV, SQV)                                                                                           \
-  hipLaunchKernelGGL((k_so3_model<MV, SQV>), dim3(grid), dim3(256), 0, ctx->stream, view(q), R,                  \
-                     (const double *)q->Sinc, (const double *)q->winc, grad, Dinv, Bblk, Dsl, ctx->partials2)
-  if (model) { if (q->sinc_quat) SO3M(true, true); else SO3M(true, false); }
-  else { if (q->sinc_quat) SO3M(false, true); else SO3M(false, false); }
+  const bool gq = q->Rq != nullptr;
+  if (gq && !have_quat)
+    hipLaunchKernelGGL(k_so3_quat, dim3(grid_for(ctx, q->N, 1)), dim3(256), 0, ctx->stream, q->N, R, q->Rq);
+#define SO3M(MV, SQV, GQV)                                                                                      \
+  hipLaunchKernelGGL((k_so3_model<MV, SQV, GQV>), dim3(grid), dim3(256), 0, ctx->stream, view(q), R,             \
+                     (const double *)q->Rq, (const double *)q->Sinc, (const double *)q->winc, grad, Dinv, Bblk, Dsl, \
+                     ctx->partials2)
+#define SO3M_G(MV, SQV) if (gq) SO3M(MV, SQV, true); else SO3M(MV, SQV, false)
+  if (model) { if (q->sinc_quat) { SO3M_G(true, true); } else { SO3M_G(true, false); } }
+  else { if (q->sinc_quat) { SO3M_G(false, true); } else { SO3M_G(false, false); } }
+#undef SO3M_G
 #undef SO3M
 }
 // the objective partials the assembly left in ctx->partials2 -> one (all-reduced) sum in slots[0]
@@ -542,6 +607,7 @@ int mi_so3n_create(mi_ctx *ctx, size_t N, size_t E, const int32_t *ei, const int
   MI_TRY(upload((void **)&q->slice_ptr, sp.data(), sp.size() * sizeof(long long)));
   MI_TRY(upload((void **)&q->perm, perm.data(), perm.size() * sizeof(int)));
   MI_HIP(hipMalloc((void **)&q->Dsl, nslices * 9 * 64 * sizeof(double)));
+  if (!ctx->cfg.so3_no_rquat) MI_HIP(hipMalloc((void **)&q->Rq, std::max<size_t>(1, N) * 4 * sizeof(double)));
   MI_TRY(upload((void **)&q->nbr, nbr.data(), padded * sizeof(int)));
   MI_HIP(hipMalloc((void **)&q->Bblk, std::max<size_t>(1, padded * 9) * sizeof(double)));
   MI_TRY(upload((void **)&q->Sinc, sinc.data(), sinc.size() * sizeof(double)));
@@ -569,6 +635,7 @@ int mi_so3n_destroy(mi_so3n *q) {
   (void)hipStreamSynchronize(q->ctx->stream);
   (void)hipFree(q->slice_ptr); (void)hipFree(q->nbr);
   (void)hipFree(q->Bblk); (void)hipFree(q->perm); (void)hipFree(q->Dsl);
+  if (q->Rq) (void)hipFree(q->Rq);
   (void)hipFree(q->Sinc); (void)hipFree(q->winc);
   (void)hipFree(q->Bblk_next); (void)hipFree(q->Dsl_next);
   mi_vec_destroy(q->Dinv);
@@ -625,8 +692,8 @@ int mi_so3n_retract(mi_so3n *q, const mi_vec *R, const mi_vec *xi, mi_vec *Y) {
   MI_REQUIRE(q && R && xi && Y, "null argument");
   MI_REQUIRE(R->n == 9 * q->N && Y->n == 9 * q->N && xi->n == 3 * q->N, "dimension mismatch");
   touch(Y);
-  hipLaunchKernelGGL(k_so3_retract, dim3(grid_for(q->ctx, q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
-                     (const double *)R->d, (const double *)xi->d, Y->d);
+  hipLaunchKernelGGL(k_so3_retract<false>, dim3(grid_for(q->ctx, q->N, 1)), dim3(kBlock), 0, q->ctx->stream, q->N,
+                     (const double *)R->d, (const double *)xi->d, Y->d, (double *)nullptr);
   MI_HIP(hipGetLastError());
   return MI_OK;
 }
@@ -662,13 +729,20 @@ int mi_so3n_trial(mi_so3n *q, const mi_vec *R, const mi_vec *h, const mi_vec *g,
     const double *xs[3] = {h->d, g->d, h->d}, *ys[3] = {h->d, h->d, q->Hh->d};
     MI_TRY(dot_batch_to_slots(ctx, 3, xs, ys, N3, SLOT_MISC));
   }
-  // (b) R+ = R exp(hat h)
-  MI_TRY(mi_so3n_retract(q, R, h, R_trial));
+  // (b) R+ = R exp(hat h) (+ the quaternions of R+, the assembly's gather records: the bits k_so3_quat would give)
+  if (q->Rq) {
+    touch(R_trial);
+    hipLaunchKernelGGL(k_so3_retract<true>, dim3(grid_for(ctx, q->N, 1)), dim3(kBlock), 0, ctx->stream, q->N,
+                       (const double *)R->d, (const double *)h->d, R_trial->d, q->Rq);
+    MI_HIP(hipGetLastError());
+  } else {
+    MI_TRY(mi_so3n_retract(q, R, h, R_trial));
+  }
   // (c) + (d) the model at R+ into the second set of arrays, with f(R+) from the same pass (r05: the objective was an
   // edge pass of its own, 61 us and 416 MB at the fabric) -- reduced exactly as mi_so3n_objective does
   {
     const int grid = model_grid(q);
-    launch_model(q, true, grid, R_trial->d, q->grad_next->d, q->Dinv_next->d, q->Bblk_next, q->Dsl_next);
+    launch_model(q, true, grid, R_trial->d, q->grad_next->d, q->Dinv_next->d, q->Bblk_next, q->Dsl_next, q->Rq != nullptr);
     MI_HIP(hipGetLastError());
     MI_TRY(model_objective_to_slot(q, grid, ctx->scalars + SLOT_MISC + 3));
   }
