@@ -127,3 +127,32 @@ def test_workload_generators_are_machine_independent():
     v, _ = wl.laplacian_3d_eigvec(24, 20, 16, 1, 2, 1)
     Xe, _ = wl.stiefel_bench_iterate(24, 20, 16, 3, eps=0.0, seed=5)
     assert min(np.abs(Xe[:, j] - v).max() for j in range(3)) < 1e-14
+
+
+def test_bench_dry_run_layers_plans_every_rank_with_the_real_planning_code():
+    """bench.py --dry-run-layers N (r06): at N = 1 the line says what a --gpus N run would launch, probe, verify and time,
+    in order, and every rank's halo plan comes from mi_csr_shard_plan (the host-side planning code of
+    mi_csr_create_sharded) -- no GPU needed.  Slab partition of cfg4's 200^3 grid over 8 ranks: 25 planes and 1e6 rows per
+    rank, one 200 x 200 plane of halo rows from each neighbour, symmetric."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    saved = os.dup(1)   # (bench.py points descriptor 1 at stderr when imported: put it back afterwards)
+    try:
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        d = b.dry_run_layers(8, "auto", 0)
+    finally:
+        import sys
+        os.dup2(saved, 1)
+        os.close(saved)
+        sys.stdout = sys.__stdout__
+    assert d["world"] == 8 and d["halo_plan_symmetric"]
+    assert [l["layer"] for l in d["layers_in_order"]] == ["peer", "peer-separate", "peer-separate-rprime", "rccl", "rccl2"]
+    for r, rec in enumerate(d["ranks"]):
+        assert rec["rows"] == 1_000_000 and rec["z_planes"] == [25 * r, 25 * r + 25]
+        assert rec["halo_rows_needed"]["from_rank_below"] == (40_000 if r > 0 else 0)
+        assert rec["halo_rows_needed"]["from_rank_above"] == (40_000 if r < 7 else 0)
+    d2 = b.dry_run_layers(2, "rccl", 0)
+    assert [l["layer"] for l in d2["layers_in_order"]] == ["rccl", "rccl2"] and d2["ranks"][0]["rows"] == 1_000_000
