@@ -626,6 +626,9 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 // strided 8-byte loads each, every wave instruction touching 64 half-lines (profiles/r05_wide_ablation.txt) -- is gone;
 // the own X and Y rows remain lane-per-row loads.  One context, packed matrix with a window (sparse.hip build_window),
 // no halo.  The ring is dynamic LDS sized for the matrix's own window: (nc 64 + 1 + far slots) P doubles.
+#ifndef MI_WIDEWIN_2WAVES_UPTO
+#define MI_WIDEWIN_2WAVES_UPTO 7   // widths held to 256 VGPRs (two workgroups per CU); wider: one workgroup per CU
+#endif
 // ring rows of the wide window form (spmm_core.h sell_window RS): at P = 8 rows 64 bytes apart put the row-by-row reads
 // of a wave on a sixteenth of the LDS banks (218 us; 9 doubles apart: 102 us -- still behind the quad layout's 80, so
 // p = 8 does not take this form by default); at P = 6 the padding changes nothing (57.7 us either way) and costs
@@ -635,7 +638,7 @@ struct WideRing {
   static constexpr int stride = (P == 8) ? 9 : P;
 };
 template <int P, int HW, bool FARD>
-__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 7 ? 2 : 1, P <= 7 ? 2 : 1))) void k_st_hess_widewin(
+__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1, P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1))) void k_st_hess_widewin(
     SellView A, WinView Wv, const CgState *__restrict__ st, const double *__restrict__ V, const double *__restrict__ X,
     const double *__restrict__ Y, const double *__restrict__ S, const double *__restrict__ gdir, double *__restrict__ out,
     double *__restrict__ partials) {
