@@ -2,6 +2,7 @@
 // plain SpMM kernel (sparse.hip) and the fused Stiefel Hessian kernel (stiefel.hip).
 #pragma once
 #include "mi_internal.h"
+#include <type_traits>
 
 namespace mi {
 
@@ -462,6 +463,38 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// 64 consecutive rows of a row-major field as the wave holds them after P coalesced 512-byte loads (lane l: the
+// doubles l, 64 + l, ... of the 64 P): stored as rows RS doubles apart / one lane's row read back
+template <int P, int RS>
+__device__ __forceinline__ void image_store(LdsDouble *rows, int lane, const double (&buf)[P]) {
+  if constexpr (RS == P) {
+#pragma unroll
+    for (int c = 0; c < P; ++c) rows[c * 64 + lane] = buf[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const unsigned e = (unsigned)lane + 64u * (unsigned)c;  // element of the chunk: row e / P, column e % P
+      rows[(e / (unsigned)P) * (unsigned)RS + e % (unsigned)P] = buf[c];
+    }
+  }
+}
+template <int P, int RS>
+__device__ __forceinline__ void image_row(const LdsDouble *rows, int lane, double (&out)[P]) {
+  const LdsDouble *l = rows + (unsigned)lane * (unsigned)RS;
+#pragma unroll
+  for (int c = 0; c < P; ++c) out[c] = l[c];
+}
+// An epilogue that declares `using wants_scratch = void;` is handed the wave's far slots (2 x 64 rows, RS doubles apart) as
+// scratch space: end(slice, acc, vrow, scratch) -- free once the slice's entries are done.
+template <class E, class = void>
+struct EpiScratch : std::false_type {};
+template <class E>
+struct EpiScratch<E, std::void_t<typename E::wants_scratch>> : std::true_type {};
+
+#ifndef MI_WIN_FARC
+#define MI_WIN_FARC 1   // pure far structure, one context: far rows as coalesced images (sell_window FARC) -- 1: the wide rows
+                        // (p = 5 / 6 / 7: 46.7 / 57.3 / 78.0 -> 46.3 / 56.1 / 74.8 us), 2: also p <= 4 (no change there)
+#endif
 // the window-form matrix arrays (mi_csr::wk, wfar) and constants
 struct WinView {
   const uint32_t *__restrict__ wk;
@@ -484,11 +517,16 @@ struct WinView {
 // RS (r06): doubles between consecutive rows of the ring -- P (the ring is the memory image of its chunks) or, for the
 // wide rows, P padded to an odd number: with RS = P = 6 or 8 the row-by-row reads of 64 lanes fall on half / a sixteenth
 // of the LDS banks (k_st_hess_widewin).  RS > P scatters a staged chunk's doubles to (row, column) addresses.
-template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi, int RS = P>
+// FARC (r06): FARD without a halo -- the far rows of a slice are the 64 CONSECUTIVE rows at slice 64 +- D: loaded as P
+// coalesced 512-byte loads per slot (a memory image, like a ring chunk) instead of P strided 8-byte loads per lane (at 6
+// doubles a row a wave instruction of those touches 24 lines).  A row without that neighbour has no word for the slot, so
+// whatever lies at the clamped address is never referenced.
+template <int P, int HW, bool HALO, bool FARD, bool W16, class Epi, int RS = P, bool FARC = false>
 __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W, int t0, int t1, int w, int lane,
                                             const double *__restrict__ V, const double *vt, double *lds_rows,
                                             Epi &epi, unsigned halo_lo = 0, unsigned halo_hi = 0) {
   static_assert(HW <= kWinHead, "head width");
+  static_assert(!FARC || (FARD && !HALO), "coalesced far rows: pure far structure, one context");
   constexpr int NW = kWinWaves;
   const int nchunks = (int)A.nslices;
 #ifdef MI_WIN_DEBUG  // timing experiments only (wrong results): flags in the high bits of wc
@@ -520,18 +558,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     }
   };
   auto chunk_store = [&](int slot, const double (&buf)[P]) {
-    if constexpr (RS == P) {
-      LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * P) + lane;
-#pragma unroll
-      for (int c = 0; c < P; ++c) dst[c * 64] = buf[c];
-    } else {
-      LdsDouble *dst = L + (unsigned)slot * (unsigned)(64 * RS);
-#pragma unroll
-      for (int c = 0; c < P; ++c) {
-        const unsigned e = (unsigned)lane + 64u * (unsigned)c;  // element of the chunk: row e / P, column e % P
-        dst[(e / (unsigned)P) * (unsigned)RS + e % (unsigned)P] = buf[c];
-      }
-    }
+    image_store<P, RS>(L + (unsigned)slot * (unsigned)(64 * RS), lane, buf);
   };
   // raw operands of a slice: its words (ONE scalar base + immediate offsets j * 256: the words behind a narrower
   // slice belong to the next slice or to the padding mi_csr keeps behind the array, and are replaced by zw when
@@ -592,7 +619,21 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
     for (int cc = 0; cc < P; ++cc) out[cc] = pinned_load(src + cc);
   };
 
+  // FARC: slot s of slice sl as a memory image (32-bit wrap-around below row 0 lands past the field or on a valid
+  // address: clamped or unreferenced either way)
+  auto far_chunk = [&](int sl, int s, double (&out)[P]) {
+    const unsigned r0 = (unsigned)sl * 64u + (s == 0 ? W.far_d : 0u - W.far_d);
+    const unsigned b0 = r0 * (unsigned)(P * 8) + lane8;
+#pragma unroll
+    for (int cc = 0; cc < P; ++cc) {
+      const unsigned b = b0 + (unsigned)cc * 512u;
+      const unsigned bs = b < nPbytes ? b : 0u;
+      out[cc] = pinned_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(V) + bs));
+    }
+  };
+
   const int zrow = nc * 64;
+  const unsigned far_rows0 = (unsigned)(zrow + 1 + w * (kFarCap * 64)) * (unsigned)RS;          // the wave's slot 0, row 0
   const unsigned far_base = (unsigned)(zrow + 1 + w * (kFarCap * 64) + lane) * (unsigned)RS;  // this lane's slot 0
   int slice = t0 * NW + w;               // (tiles are aligned: slice % NW == w)
   bool have = slice < nchunks;
@@ -607,7 +648,7 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   // the previous tile ran), h.c its words and h.f the far columns of the NEXT slice.  The entry loop then waits for
   // no memory at all; the tile's only waits are for the staged chunk and for the X/Y rows at its end.
   unsigned f0[kFarCap];
-  load_far(f0, have ? slice : 0);
+  if constexpr (!FARC) load_far(f0, have ? slice : 0);
   load_words(h, k, have ? slice : 0);
 #else
   load_head(h, k, have ? slice : 0);
@@ -639,9 +680,14 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
   double gf[kFarCap][P];
   {
     const bool more0 = have && t0 + 1 < t1 && slice + NW < nchunks;
-    load_far(h.f, more0 ? slice + NW : (have ? slice : 0));
+    if constexpr (FARC) {
 #pragma unroll
-    for (int s = 0; s < kFarCap; ++s) far_row(f0[s], gf[s]);
+      for (int s = 0; s < kFarCap; ++s) far_chunk(have ? slice : 0, s, gf[s]);
+    } else {
+      load_far(h.f, more0 ? slice + NW : (have ? slice : 0));
+#pragma unroll
+      for (int s = 0; s < kFarCap; ++s) far_row(f0[s], gf[s]);
+    }
   }
 #endif
   lds_barrier();
@@ -665,10 +711,15 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
       for (int j = 0; j < HW; ++j) wd[j] = entry_word(h, j, k, b1);
       MI_STAMP(2 + 8 * (t - t0) + 1, (double)wd[0]);  // this slice's matrix words were there
       double gn[kFarCap][P];  // the NEXT slice's far rows (h.f: its far columns, loaded a tile ago)
+      if constexpr (FARC) {
 #pragma unroll
-      for (int s = 0; s < kFarCap; ++s) far_row(h.f[s], gn[s]);
+        for (int s = 0; s < kFarCap; ++s) far_chunk(more ? nslice : slice, s, gn[s]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < kFarCap; ++s) far_row(h.f[s], gn[s]);
+      }
       load_words(h, q0, more ? nslice : slice);
-      {
+      if constexpr (!FARC) {
         const int nslice2 = nslice + NW;
         const bool more2 = more && t + 2 < t1 && nslice2 < nchunks;
         load_far(h.f, more2 ? nslice2 : (more ? nslice : slice));
@@ -685,10 +736,15 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
 #endif
       if (!(dbg & 2)) epi.request(slice);  // the epilogue rows of THIS slice: the entries' work lies between here and their use
       // the gathers (and only they: 2 P + HW + 2 + 2 P pinned loads were issued behind them) -> far slots
+      if constexpr (FARC) {
 #pragma unroll
-      for (int s = 0; s < kFarCap; ++s)
+        for (int s = 0; s < kFarCap; ++s) image_store<P, RS>(L + far_rows0 + (unsigned)(s * 64 * RS), lane, gf[s]);
+      } else {
 #pragma unroll
-        for (int c = 0; c < P; ++c) L[far_base + (unsigned)(s * 64 * RS + c)] = gf[s][c];
+        for (int s = 0; s < kFarCap; ++s)
+#pragma unroll
+          for (int c = 0; c < P; ++c) L[far_base + (unsigned)(s * 64 * RS + c)] = gf[s][c];
+      }
       MI_STAMP(2 + 8 * (t - t0) + 2, gf[kFarCap - 1][P - 1]);
       // ---- entries in storage order ----------------------------------------------------------------------------
       double acc[P];
@@ -713,7 +769,11 @@ __device__ __forceinline__ void sell_window(const SellView &A, const WinView &W,
         const LdsDouble *l = L + (unsigned)(slot_own * 64 + lane) * (unsigned)RS;
 #pragma unroll
         for (int c = 0; c < P; ++c) vrow[c] = l[c];
-        if (!(dbg & 4)) epi.end(slice, acc, vrow);
+        if constexpr (EpiScratch<Epi>::value) {
+          if (!(dbg & 4)) epi.end(slice, acc, vrow, L + far_rows0);
+        } else {
+          if (!(dbg & 4)) epi.end(slice, acc, vrow);
+        }
         MI_STAMP(2 + 8 * (t - t0) + 5, acc[0]);  // epilogue done, stores issued
       }
 #ifndef MI_WIN_NO_FARAHEAD

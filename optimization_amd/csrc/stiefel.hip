@@ -461,7 +461,8 @@ __global__ __launch_bounds__(HW > 0 ? kWinBlock : kBlock) void k_st_hess_fused(S
     if constexpr (HALO)
       sell_window<P, HW, true, (FAR >= 1), false>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi, hwait.halo_lo, hwait.halo_hi);
     else
-      sell_window<P, HW, false, (FAR >= 1), (FAR == 2)>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
+      // (far rows as coalesced images, sell_window FARC: 26.7-26.9 us either way at p = 3 -- the gathers stay)
+      sell_window<P, HW, false, (FAR >= 1), (FAR == 2), Epi, P, (FAR >= 1) && (MI_WIN_FARC >= 2)>(A, Wv, t0, t1, wu, lane, V, vt, ring, epi);
   } else {
     sell_stream<P, HALO, PK>(A, s0 + (size_t)wu, s1, lane, V, vt, epi);
   }
@@ -626,6 +627,12 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 // strided 8-byte loads each, every wave instruction touching 64 half-lines (profiles/r05_wide_ablation.txt) -- is gone;
 // the own X and Y rows remain lane-per-row loads.  One context, packed matrix with a window (sparse.hip build_window),
 // no halo.  The ring is dynamic LDS sized for the matrix's own window: (nc 64 + 1 + far slots) P doubles.
+#ifndef MI_WIDEWIN_COAL
+#define MI_WIDEWIN_COAL 0   // 1: own X / Y rows as coalesced memory images, transposed through the wave's far slots (measured slower)
+#endif
+#ifndef MI_WIDEWIN_X16
+#define MI_WIDEWIN_X16 1    // P = 6: own X / Y rows by 16-byte asm loads (k_st_hess_widewin Epi::request)
+#endif
 #ifndef MI_WIDEWIN_2WAVES_UPTO
 #define MI_WIDEWIN_2WAVES_UPTO 7   // widths held to 256 VGPRs (two workgroups per CU); wider: one workgroup per CU
 #endif
@@ -677,6 +684,70 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
     __device__ __forceinline__ const double *row_of(const double *F, size_t slice, unsigned off) const {
       return reinterpret_cast<const double *>(reinterpret_cast<const char *>(F) + (unsigned)slice * (unsigned)(64 * P * 8) + off);
     }
+#if MI_WIDEWIN_COAL && !defined(MI_WIDE_ABLATE_OWN)
+    // The slice's rows of X and Y are 64 P consecutive doubles each: P coalesced 512-byte loads per field (lane l: the
+    // doubles l, 64 + l, ...) instead of P strided 8-byte loads per lane -- at 6 doubles a row a wave instruction of
+    // those touches 24 lines, and the texture path, not the bytes, then paces the pass (profiles/r06_widewin_ablation.txt:
+    // -7 us without them).  The images become rows again through the wave's far slots, free once the entries are done.
+    // MEASURED (r06, same box, alternating): p = 5 / 6 / 7: 46.3 / 56.1 / 74.8 us without -> 47.5 / 57.0 / 82.3 us with:
+    // the 4 P extra LDS operations per row cost more than the lines save.  Not the default.
+    using wants_scratch = void;
+    __device__ __forceinline__ void request(size_t slice) {
+      const unsigned nPbytes = (unsigned)(A.n * P * 8);
+      const unsigned b0 = (unsigned)slice * (unsigned)(64 * P * 8) + (unsigned)lane * 8u;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const unsigned b = b0 + (unsigned)c * 512u;
+        xn[c] = pinned_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(X) + (b < nPbytes ? b : 0u)));
+      }
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const unsigned b = b0 + (unsigned)c * 512u;
+        yn[c] = pinned_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(Y) + (b < nPbytes ? b : 0u)));
+      }
+    }
+    __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&v)[P], LdsDouble *scratch) {
+      constexpr int RS = WideRing<P>::stride;
+      image_store<P, RS>(scratch, lane, xn);
+      image_store<P, RS>(scratch + 64 * RS, lane, yn);
+      image_row<P, RS>(scratch, lane, xn);   // (one wave: its LDS operations complete in order)
+      image_row<P, RS>(scratch + 64 * RS, lane, yn);
+      end(slice, acc, v);
+    }
+#elif MI_WIDEWIN_X16 && !defined(MI_WIDE_ABLATE_OWN)
+    // P = 6: a row is three 16-byte pieces -- three global_load_dwordx4 per field instead of six 8-byte loads (half the
+    // texture-path instructions, half the hits on lines still pending: 57.5 -> 55.8 us, same box, alternating; at P = 8
+    // in this form 100 -> 105 us, not used).  There is no ordered (pinned) 16-byte load to be had from the compiler, so
+    // these are asm statements: absent from hipcc's s_waitcnt bookkeeping, waited for by the explicit vmcnt(0) in
+    // arrive() (they are the newest loads of the tile: a wait hipcc computes for an older load only gets longer).
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d xq[3], yq[3];
+    __device__ __forceinline__ void request(size_t slice) {
+      if constexpr (P == 6) {
+        const unsigned off = (unsigned)slice * (unsigned)(64 * P * 8) + lane_off(slice);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xq[c]) : "v"(off), "s"(X), "n"(16 * c) : "memory");
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(yq[c]) : "v"(off), "s"(Y), "n"(16 * c) : "memory");
+      } else {
+        const unsigned off = lane_off(slice);
+        const double *xs = row_of(X, slice, off), *ys = row_of(Y, slice, off);
+#pragma unroll
+        for (int c = 0; c < P; ++c) xn[c] = pinned_load(xs + c);
+#pragma unroll
+        for (int c = 0; c < P; ++c) yn[c] = pinned_load(ys + c);
+      }
+    }
+    __device__ __forceinline__ void arrive() {
+      if constexpr (P == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(yq[0]), "+v"(yq[1]), "+v"(yq[2])::"memory");
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xn[2 * c] = xq[c].x; xn[2 * c + 1] = xq[c].y; yn[2 * c] = yq[c].x; yn[2 * c + 1] = yq[c].y; }
+      }
+    }
+#else
     __device__ __forceinline__ void request(size_t slice) {
       const unsigned off = lane_off(slice);
       const double *xs = row_of(X, slice, off), *ys = row_of(Y, slice, off);
@@ -690,7 +761,11 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
       for (int c = 0; c < P; ++c) yn[c] = pinned_load(ys + c);
 #endif
     }
+#endif
     __device__ __forceinline__ void end(size_t slice, double (&acc)[P], const double (&v)[P]) {
+#if MI_WIDEWIN_X16 && !MI_WIDEWIN_COAL && !defined(MI_WIDE_ABLATE_OWN)
+      arrive();  // (every lane: the wait is not a matter of the lane's row)
+#endif
       if ((unsigned)slice * 64u + (unsigned)lane >= (unsigned)A.n) return;
       // (S and M are re-read from LDS for every row: loop-invariant code motion must not park 128 doubles in registers)
       asm volatile("" ::: "memory");
@@ -752,7 +827,7 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
     t1 = scalar_int(Wv.bounds, lb + 1);
   }
   if (t0 >= t1) __syncthreads();  // (sell_window returns at once: the tables above still need their barrier)
-  sell_window<P, HW, false, FARD, false, Epi, WideRing<P>::stride>(A, Wv, t0, t1, wu, lane, V, vt, ring_dyn, epi);
+  sell_window<P, HW, false, FARD, false, Epi, WideRing<P>::stride, FARD && MI_WIN_FARC>(A, Wv, t0, t1, wu, lane, V, vt, ring_dyn, epi);
   __syncthreads();
   block_partials_store_nw<KC, kWideWaves>(a, lds, partials);
 }

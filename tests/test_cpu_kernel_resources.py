@@ -60,3 +60,42 @@ def test_streaming_kernels_that_need_eight_waves_per_simd_stay_within_80_sgprs()
     for n, (sg, vg, _, scratch) in ls.items():
         if n.startswith(("k_lsqr_xw<", "k_lsqr_unorm<", "k_lsqr_vnorm<")):
             assert sg <= 80 and vg <= 64 and scratch == 0, (n, sg, vg, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_asm_loads_of_the_wide_window_pass_are_left_alone_until_their_wait(tmp_path):
+    """k_st_hess_widewin<6, ...> loads its own X / Y rows by six `global_load_dwordx4` ASM statements (stiefel.hip
+    Epi::request: there is no ordered 16-byte load to be had from the compiler) and waits for them by an ASM
+    `s_waitcnt vmcnt(0)` (Epi::arrive).  hipcc does not know that the registers of an asm load are filled later: a copy or
+    a spill of one of them between the load and the wait would move garbage.  This test reads the generated code of every
+    P = 6 instantiation: 6 asm loads each, no scratch memory, and no instruction between the loads and the wait that
+    names one of their destination registers."""
+    asm = tmp_path / "stiefel.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-I", os.path.join(ROOT, "optimization_amd", "include"), "-S", "--cuda-device-only",
+           os.path.join(CSRC, "stiefel.hip"), "-o", str(asm)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = asm.read_text().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*k_st_hess_widewinILi6.*:\s*; @", l)]
+    assert len(starts) == 4, len(starts)   # head widths 7 / 8 x computed / loaded far columns
+    for st in starts:
+        regs, waiting, nload, nwait, touched = set(), False, 0, 0, []
+        i = st + 1
+        while i < len(lines) and not re.match(r"^_ZN.*:\s*; @", lines[i]):
+            l, in_asm = lines[i], "ASMSTART" in lines[i - 1]
+            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", l)
+            if m and in_asm:
+                regs |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                waiting, nload = True, nload + 1
+            elif waiting and in_asm and "s_waitcnt vmcnt(0)" in l:
+                waiting, regs, nwait = False, set(), nwait + 1
+            elif waiting and not l.strip().startswith(";"):
+                assert "scratch_" not in l, l
+                for m2 in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", l):
+                    r_ = {int(m2.group(3))} if m2.group(3) else set(range(int(m2.group(1)), int(m2.group(2)) + 1))
+                    if r_ & regs:
+                        touched.append(l.strip())
+            i += 1
+        assert nload == 6 and nwait == 1, (lines[st][:80], nload, nwait)
+        assert not touched, (lines[st][:80], touched[:4])
