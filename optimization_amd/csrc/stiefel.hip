@@ -633,6 +633,9 @@ __global__ __launch_bounds__(kWideBlock) __attribute__((amdgpu_waves_per_eu(Wide
 #ifndef MI_WIDEWIN_X16
 #define MI_WIDEWIN_X16 1    // P = 6: own X / Y rows by 16-byte asm loads (k_st_hess_widewin Epi::request)
 #endif
+#ifndef MI_WIDEWIN_3WAVES_UPTO
+#define MI_WIDEWIN_3WAVES_UPTO 3   // (experiment: 4 = three workgroups per CU at p = 4)
+#endif
 #ifndef MI_WIDEWIN_2WAVES_UPTO
 #define MI_WIDEWIN_2WAVES_UPTO 7   // widths held to 256 VGPRs (two workgroups per CU); wider: one workgroup per CU
 #endif
@@ -645,12 +648,12 @@ struct WideRing {
   static constexpr int stride = (P == 8) ? 9 : P;
 };
 template <int P, int HW, bool FARD>
-__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1, P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1))) void k_st_hess_widewin(
+__global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= MI_WIDEWIN_3WAVES_UPTO ? 3 : P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1, P <= MI_WIDEWIN_3WAVES_UPTO ? 3 : P <= MI_WIDEWIN_2WAVES_UPTO ? 2 : 1))) void k_st_hess_widewin(
     SellView A, WinView Wv, const CgState *__restrict__ st, const double *__restrict__ V, const double *__restrict__ X,
     const double *__restrict__ Y, const double *__restrict__ S, const double *__restrict__ gdir, double *__restrict__ out,
     double *__restrict__ partials) {
   static_assert(kWideWaves == kWinWaves, "one workgroup shape");
-  constexpr int NS = SymIdx<P>::NS, KC = 3 + NS;
+  constexpr int KC = DirComps<P>::value;  // 3 + P (P + 1) / 2 (P = 4: padded to 16, the pads stay zero)
   __shared__ double lds[KC * kWideWaves];
   __shared__ double vt[256];
   __shared__ double Sm[P * P], Mm[P * P];
@@ -715,21 +718,21 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
       end(slice, acc, v);
     }
 #elif MI_WIDEWIN_X16 && !defined(MI_WIDE_ABLATE_OWN)
-    // P = 6: a row is three 16-byte pieces -- three global_load_dwordx4 per field instead of six 8-byte loads (half the
-    // texture-path instructions, half the hits on lines still pending: 57.5 -> 55.8 us, same box, alternating; at P = 8
-    // in this form 100 -> 105 us, not used).  There is no ordered (pinned) 16-byte load to be had from the compiler, so
-    // these are asm statements: absent from hipcc's s_waitcnt bookkeeping, waited for by the explicit vmcnt(0) in
-    // arrive() (they are the newest loads of the tile: a wait hipcc computes for an older load only gets longer).
+    // P = 4, 6: a row is two / three 16-byte pieces -- P / 2 global_load_dwordx4 per field instead of P 8-byte loads (half
+    // the texture-path instructions, half the hits on lines still pending: p = 6 57.5 -> 55.8 us, same box, alternating;
+    // at P = 8 in this form 100 -> 105 us, not used).  There is no ordered (pinned) 16-byte load to be had from the
+    // compiler, so these are asm statements: absent from hipcc's s_waitcnt bookkeeping, waited for by the explicit
+    // vmcnt(0) in arrive() (they are the newest loads of the tile: a wait hipcc computes for an older load only gets longer).
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d xq[3], yq[3];
     __device__ __forceinline__ void request(size_t slice) {
-      if constexpr (P == 6) {
+      if constexpr (P == 4 || P == 6) {
         const unsigned off = (unsigned)slice * (unsigned)(64 * P * 8) + lane_off(slice);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < P / 2; ++c)
           asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(xq[c]) : "v"(off), "s"(X), "n"(16 * c) : "memory");
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < P / 2; ++c)
           asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(yq[c]) : "v"(off), "s"(Y), "n"(16 * c) : "memory");
       } else {
         const unsigned off = lane_off(slice);
@@ -741,10 +744,13 @@ __global__ __launch_bounds__(kWinBlock) __attribute__((amdgpu_waves_per_eu(P <= 
       }
     }
     __device__ __forceinline__ void arrive() {
-      if constexpr (P == 6) {
+      if constexpr (P == 6)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(xq[2]), "+v"(yq[0]), "+v"(yq[1]), "+v"(yq[2])::"memory");
+      else if constexpr (P == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq[0]), "+v"(xq[1]), "+v"(yq[0]), "+v"(yq[1])::"memory");
+      if constexpr (P == 4 || P == 6) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { xn[2 * c] = xq[c].x; xn[2 * c + 1] = xq[c].y; yn[2 * c] = yq[c].x; yn[2 * c + 1] = yq[c].y; }
+        for (int c = 0; c < P / 2; ++c) { xn[2 * c] = xq[c].x; xn[2 * c + 1] = xq[c].y; yn[2 * c] = yq[c].x; yn[2 * c + 1] = yq[c].y; }
       }
     }
 #else
@@ -1350,7 +1356,16 @@ int window_occupancy(int p, bool halo, int hw, bool fard) {
   return slot;
 }
 
-// p = 5 ... 8: the recurrence form through k_st_hess_wide (stpcg.hip asks for nothing else at these widths)
+// r06: the window form where the matrix has one (packed, window of <= 2 chunks, no halo, one context) -- p = 4 ... 7 by
+// default (at p = 8 the ring's rows are 64 bytes apart: 16-way LDS bank conflicts, and the quad layout is there);
+// MI355OPT_WIDE_WINDOW = 0 / 1 forces it off / on for every width
+static bool wide_window_form(const mi_ctx *ctx, const mi_csr *A, int p) {
+  return (ctx->cfg.wide_window < 0 ? p <= 7 && !(ctx->cfg.wide_quad > 0) : ctx->cfg.wide_window != 0) && A->pk && A->wk &&
+         A->win_chunks > 0 && A->win_chunks <= 2 && !A->halo && !ctx->uniform_grid && !ctx->cfg.no_window &&
+         A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0;
+}
+
+// p = 5 ... 8 (and p = 4 in window form): the recurrence form through k_st_hess_wide / k_st_hess_widewin
 int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_count, int *nparts) {
   mi_ctx *ctx = q->ctx;
   const mi_csr *A = q->A;
@@ -1368,12 +1383,8 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
   const int *bounds = nullptr;
   if (!ctx->uniform_grid && A->win_far_stride && !ctx->cfg.no_win_bounds && kWideWaves == kWinWaves)
     MI_TRY(window_bounds(ctx, A, grid, (int)wgs, &grid, &bounds));  // (runs cut to the far stride; tiles = 4 slices)
-  // r06: the window form where the matrix has one (packed, window of <= 2 chunks, no halo, one context) -- p = 5, 6, 7 by
-  // default (at p = 8 the ring's rows are 64 bytes apart: 16-way LDS bank conflicts, and the quad layout is there);
-  // MI355OPT_WIDE_WINDOW = 0 / 1 forces it off / on for every width
-  const bool winform = (ctx->cfg.wide_window < 0 ? p <= 7 && !(ctx->cfg.wide_quad > 0) : ctx->cfg.wide_window != 0) &&
-                       A->pk && A->wk && A->win_chunks > 0 && A->win_chunks <= 2 && !A->halo && !ctx->uniform_grid &&
-                       !ctx->cfg.no_window && A->halo_lo + A->halo_hi + A->send_lo + A->send_hi == 0;
+  const bool winform = wide_window_form(ctx, A, p);
+  MI_REQUIRE(p > 4 || winform, "internal: p = 4 takes the wide rows' kernel in its window form only");
   if (winform) {
     const int wc = A->win_chunks, nc = 2 * kWinWaves + 2 * wc;
     const bool fard = A->win_far_pure > 0 && A->win_far_pure < ((size_t)1 << 31) && !ctx->cfg.no_far_computed;
@@ -1382,6 +1393,7 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
 #define WW(PV, HWV) fn = fard ? (const void *)k_st_hess_widewin<PV, HWV, true> : (const void *)k_st_hess_widewin<PV, HWV, false>
 #define WW_P(PV) if (A->win_head <= 7) { WW(PV, 7); } else { WW(PV, 8); }
     switch (p) {
+      case 4: WW_P(4); break;
       case 5: WW_P(5); break;
       case 6: WW_P(6); break;
       case 7: WW_P(7); break;
@@ -1389,8 +1401,8 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
     }
 #undef WW_P
 #undef WW
-    static bool attr_set[4][2][2] = {};
-    bool &done = attr_set[p - 5][A->win_head <= 7 ? 0 : 1][fard ? 1 : 0];
+    static bool attr_set[5][2][2] = {};
+    bool &done = attr_set[p - 4][A->win_head <= 7 ? 0 : 1][fard ? 1 : 0];
     if (!done) {  // (more than 64 KB of dynamic LDS needs the attribute)
       (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 8 * 1024));
       (void)hipGetLastError();
@@ -1400,7 +1412,7 @@ int rq_apply_dir_wide(mi_stiefel_rq *q, const mi_vec *in, mi_vec *out, int gram_
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kWinBlock, lds_bytes) != hipSuccess || occ < 1) occ = 1;
     (void)hipGetLastError();
     const int ntiles = (int)((A->nslices + kWinWaves - 1) / kWinWaves);
-    int wgs = std::min(std::min(occ, 2) * ctx->num_cu, kMaxRows);
+    int wgs = std::min(std::min(occ, p <= MI_WIDEWIN_3WAVES_UPTO ? 3 : 2) * ctx->num_cu, kMaxRows);
     if (ctx->max_grid < kMaxGrid) wgs = std::min(wgs, ctx->max_grid);
     int wgrid = 0;
     const int *wbounds = nullptr;
@@ -1453,6 +1465,9 @@ int rq_apply_dir(mi_op *self, const mi_vec *in, mi_vec *out, int gram_count, int
   mi_ctx *ctx = q->ctx;
   const mi_csr *A = q->A;
   const int p = q->p;
+  // p = 4 has no window form of its own (ring + far slots of 4 x 4 workgroups: see WIN below); in the recurrence form it
+  // takes the wide rows' (k_st_hess_widewin<4>, dynamic LDS sized for the matrix's own window) where that one applies
+  if (p == 4 && gram_count == -1 && wide_window_form(ctx, A, p)) return rq_apply_dir_wide(q, in, out, gram_count, nparts);
   // one workgroup per CU and one round (the kernel needs > 64 VGPRs: a second round would only repeat the
   // prologue); the rows mode of several ranks needs the uniform 512-row partial layout instead
   constexpr int cap = 256;
