@@ -91,8 +91,12 @@ def trace_close(a, ref, floor_trace, tol, factor=3.0):
     bar = np.full(k, tol)
     fl = np.zeros(k)
     if floor_trace is not None:
-        fm = np.abs(np.asarray(floor_trace, dtype=np.float64)[:k] / ref[:k] - 1)
-        fl[:fm.size] = np.maximum.accumulate(fm)
+        # (a list of traces = several re-associations, e.g. 2, 3 and 4 threads: their pointwise maximum -- one
+        # realisation of the floor is itself a noisy estimate at the rounding end of a deep solve)
+        many = isinstance(floor_trace, (list, tuple)) and len(floor_trace) and np.ndim(floor_trace[0]) > 0
+        for ft in (floor_trace if many else [floor_trace]):
+            fm = np.abs(np.asarray(ft, dtype=np.float64)[:k] / ref[:k] - 1)
+            fl[:fm.size] = np.maximum(fl[:fm.size], np.maximum.accumulate(fm))
         bar = np.maximum(bar, factor * fl)
     bad = np.nonzero(e > bar)[0]
     msg = (f"max deviation {e.max():.2e} at k = {int(e.argmax())} (re-associated reference there: {fl[int(e.argmax())]:.2e}; "

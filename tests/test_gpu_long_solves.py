@@ -109,9 +109,18 @@ def test_200_iterations_recurrence_form_is_the_two_pass_form_and_the_oracle(prob
     pr, maxit = problem, 200
     kw = dict(max_iterations=maxit, kappa_fgr=1e-12, theta=1.0, trace_cap=maxit + 2)
     o = oracle.stpcg_problem(pr["op"], pr["Xb"].ravel(), pr["g"], 1e6, **kw)
-    m = oracle_omp.stpcg_problem(pr["mp"], pr["Xb"].ravel(), pr["g"], 1e6, **kw) if pr["mp"] is not None else None
+    # the floor: the same algorithm with its sums re-associated THREE ways (2, 3, 4 threads) -- at the rounding end of a
+    # solve one realisation of it moves by a factor of two from run to run (OpenMP combines the threads' partial sums in
+    # arrival order), and with it a bar of "3 x floor" (r06: the two-pass form's beta at k = 197 ... 199 of the p = 8
+    # solve, 1.1-1.2e-9, passed against one realisation and failed against the next)
+    floors = []
+    if pr["mp"] is not None:
+        for t in (2, 3, 4):
+            oracle_omp.set_threads(t)
+            floors.append(oracle_omp.stpcg_problem(pr["mp"], pr["Xb"].ravel(), pr["g"], 1e6, **kw))
+    m = floors[-1] if floors else None
     res = _device_solves(pr, maxit, monkeypatch)
-    fl_s = rel_err(m["s"], o["s"]) if m else 0.0
+    fl_s = max(rel_err(f["s"], o["s"]) for f in floors) if floors else 0.0
     red = float((o["trace"]["rv"][-1] / np.dot(pr["g"], pr["g"])) ** 0.5)
     print(f"p = {pr['p']}: oracle {o['iterations']} iterations, exit {o['exit_reason']}, residual reduction {red:.1e}; "
           f"floor of s {fl_s:.2e}")
@@ -126,7 +135,7 @@ def test_200_iterations_recurrence_form_is_the_two_pass_form_and_the_oracle(prob
         if mode == "recurrence-never-anchored":
             continue          # (measured, not held to the bars: it is what the default replaced)
         for key in ("alpha", "beta"):
-            ok, msg = trace_close(r["trace"][key], o["trace"][key], m["trace"][key] if m else None, 1e-9)
+            ok, msg = trace_close(r["trace"][key], o["trace"][key], [f["trace"][key] for f in floors] if floors else None, 1e-9)
             assert ok, f"{mode} {key}: {msg}"
         assert es <= max(1e-10, 3 * fl_s), (mode, es, fl_s)
     # the re-anchored recurrence is no further from the reference than the never-anchored one (up to rounding noise)
