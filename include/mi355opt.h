@@ -112,7 +112,7 @@ enum {
  * FORCE_LOCKSTEP, FORCE_UNIFORM_GRID, MAX_GRID, NO_DIRGRAM, DIRGRAM_DIRECT, IPC_TIMEOUT_MS, NO_FOLD, HALO_PUSH_LATE,
  * NO_PACKED, NO_WINDOW, NO_WIN_BOUNDS, NO_FAR_COMPUTED, WORDS16, NO_SPMM_STREAM, NO_SPMM_WIN, NO_UPDATE_MFMA,
  * NO_ZERO_COPY, NO_GRAM_HALF, NO_UPDATE_PAIR, SO3_NO_QUAT, SO3_NO_RQUAT, SO3_SORT_NBR, HALO_RPRIME, TWO_KERNEL_STEP, WIDE_QUAD,
- * NO_POLLED_SYNC, WARN_GENERIC, REANCHOR, NO_SPMM_SWEEP, SWEEP_ZSEGS, WIDE_WINDOW (DESIGN.md / INTEGRATION.md say what each selects).  For the boolean switches a value that
+ * NO_POLLED_SYNC, WARN_GENERIC, REANCHOR, NO_SPMM_SWEEP, SWEEP_ZSEGS, WIDE_WINDOW, EARLY_S (DESIGN.md / INTEGRATION.md say what each selects).  For the boolean switches a value that
  * is not an integer counts as 1 unless it is "no" / "false" / "off"; the integer-valued ones (MAX_GRID, IPC_TIMEOUT_MS,
  * WIDE_QUAD, WIDE_WINDOW, SO3_SORT_NBR, REANCHOR, SWEEP_ZSEGS) take integers only -- anything else is ignored with a warning and the default stays.  Any other
  * MI355OPT_* variable found in the environment (a removed or misspelt switch) gets one warning on stderr.  mi_ctx_set_option changes one on a live context (name with or without the MI355OPT_

@@ -237,6 +237,7 @@ OPT_BOOL(opt_halo_rprime, cfg.halo_rprime)
 OPT_BOOL(opt_no_gram_half, cfg.no_gram_half)
 OPT_BOOL(opt_so3_no_quat, cfg.so3_no_quat)
 OPT_BOOL(opt_so3_no_rquat, cfg.so3_no_rquat)
+OPT_BOOL(opt_early_s, cfg.early_s)
 OPT_BOOL(opt_no_update_pair, cfg.no_update_pair)
 OPT_BOOL(opt_two_kernel_step, cfg.two_kernel_step)
 OPT_BOOL(opt_warn_generic, warn_generic)
@@ -278,7 +279,7 @@ const OptionDesc kOptions[] = {
     {"WORDS16", opt_words16}, {"NO_SPMM_STREAM", opt_no_spmm_stream}, {"NO_SPMM_WIN", opt_no_spmm_win},
     {"NO_SPMM_SWEEP", opt_no_spmm_sweep}, {"SWEEP_ZSEGS", opt_sweep_zsegs, true},
     {"NO_ZERO_COPY", opt_no_zero_copy}, {"NO_POLLED_SYNC", opt_no_polled_sync}, {"WIDE_QUAD", opt_wide_quad, true}, {"WIDE_WINDOW", opt_wide_window, true},
-    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"SO3_NO_RQUAT", opt_so3_no_rquat}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
+    {"NO_UPDATE_MFMA", opt_no_update_mfma}, {"HALO_RPRIME", opt_halo_rprime}, {"NO_GRAM_HALF", opt_no_gram_half}, {"SO3_NO_QUAT", opt_so3_no_quat}, {"SO3_NO_RQUAT", opt_so3_no_rquat}, {"EARLY_S", opt_early_s}, {"NO_UPDATE_PAIR", opt_no_update_pair}, {"TWO_KERNEL_STEP", opt_two_kernel_step}, {"SO3_SORT_NBR", opt_so3_sort_nbr, true},
     {"WARN_GENERIC", opt_warn_generic}, {"REANCHOR", opt_reanchor, true},
 };
 // value of a BOOLEAN switch: an integer; anything else ("yes", "true", "on" -- and the presence-only `MI355OPT_X=` of

@@ -133,6 +133,7 @@ struct Config {
   bool halo_rprime = false;         // HALO_RPRIME: sharded STPCG exchanges the halo of r' (with the <r,v> all-reduce) and every
                                     // rank forms halo(p') = -halo(r') + beta halo(p) itself: 2 collectives per iteration
                                     // instead of 3 on the RCCL layer (`--comm rccl2`)
+  bool early_s = false;             // EARLY_S: the direction kernel of the single-context recurrence solve applies s += alpha p AHEAD of its reduction (k_cg_pupdate_early; opt-in experiment, same bits, same time)
   bool so3_no_rquat = false;        // SO3_NO_RQUAT: the SO(3)^N model assembly gathers the neighbours' rotations as 72-byte matrices
                                     // (r05 form) instead of 32-byte quaternions written by the retraction (r06; creation-time)
   bool so3_no_quat = false;         // SO3_NO_QUAT: the measurements of mi_so3n stay 3 x 3 matrices (r04 form; creation-time)

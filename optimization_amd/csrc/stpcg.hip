@@ -398,6 +398,149 @@ static_assert(kWaves + 1 >= kIpcVals, "LDS of the folded exchange");
 #undef CG_UPDATE_NAME
 #undef CG_PUPDATE_NAME
 
+// EARLY S (late r06): the direction kernel of the single-context solve without a preconditioner (v = r, plain vectors,
+// G(p) by recurrence).  alpha is the A-step's -- it is in the state this kernel STARTS from -- so s += alpha p (:374)
+// does not depend on this kernel's own reduction; only beta does.  Where a thread's whole walk is at most three
+// elements (cfg2: two grid-stride steps + the ragged one; the host checks) every operand of the kernel is requested at
+// once, behind the reduction's row loads; s is updated and stored while the other operands are still on their way;
+// what is left behind the barrier is p = -v + beta p from registers.  The read phase no longer waits for the
+// prologue and the prologue no longer idles the memory system (tools/microbench/stream_rates.hip: the bare stream of
+// this byte mix takes 15.8 us per launch, k_cg_pupdate 18.1).  Same walk, same expressions in the same translation
+// unit (same contraction), same bits as k_cg_pupdate<false, 0, NoFold>; every other form keeps that kernel.
+// MEASURED (same box, alternating, rocprofv3): 17.95 us against k_cg_pupdate's 18.10, the step 55.8 against 56.1 us -- and
+// with the reduction and its barrier compiled out altogether (timing build, wrong results) still 20.1-20.3 us by event
+// pairs against 20.0-20.1: the prologue is NOT what separates this kernel from the bare stream (EXPERIMENTS.md r06).
+// Opt-in (MI355OPT_EARLY_S=1): not the default for 0.3 us.
+template <class F>
+__device__ __forceinline__ void reduce_rows_1x512(const double *__restrict__ partials, int count, double &out, double *lds,
+                                                  F &&after_issue) {
+  // reduce_rows<1> for count <= 512: the same lane -> rows map and the same order of additions (its further eight
+  // terms per lane are zeros there)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = 0.0;
+  if (w == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = lane + 64 * j;
+      if (r < count) t[j] = partials[r];
+    }
+  }
+  after_issue();
+  if (w == 0) {
+    double v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += t[j];
+    v = wave_reduce_sum(v);
+    if (lane == 0) lds[0] = v;
+  }
+  __syncthreads();
+  out = lds[0];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cg_pupdate_early(
+    size_t n, CgConst cc, const CgState *__restrict__ st_in, CgState *__restrict__ st_out,
+    const double *__restrict__ partials_b, int nparts_b, const double *__restrict__ v, double *__restrict__ p,
+    double *__restrict__ s, HostStatus *hs, double *__restrict__ trace, size_t trace_cap, DirGramArgs dg) {
+  __shared__ double lds[kWaves + 1];
+  // (the walk of k_cg_pupdate, stpcg_kernels.inc, in 32-bit element indices: the host launches this kernel only where
+  // n / 2 <= 3 x 512 x 1024)
+  const unsigned n2 = (unsigned)(n >> 1), stride = gridDim.x * kBlock, i0 = blockIdx.x * kBlock + threadIdx.x;
+  const unsigned tail0 = (unsigned)cc.rag0, per = (unsigned)cc.rag_per;
+  const unsigned irem = (threadIdx.x < per) ? tail0 + blockIdx.x * per + threadIdx.x : n2;
+  auto next_of = [&](unsigned i_) -> unsigned {
+    const unsigned j_ = i_ + stride;
+    return j_ < tail0 ? j_ : ((i_ < tail0 && irem < n2) ? irem : n2);
+  };
+  const unsigned ifirst = i0 < tail0 ? i0 : (irem < n2 ? irem : n2);
+  unsigned Le[3];
+  {
+    unsigned L = ifirst;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Le[j] = L;
+      if (L < n2) L = next_of(L);
+    }
+  }
+  double2 pe[3], ve[3], se[3];
+  CgState cs = load_state(st_in);
+  const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+  if (cs.mode == CG_DONE) {
+    if (leader) store_state(st_out, cs);
+    return;
+  }
+  const int mode_in = cs.mode;
+  auto early_s = [&] {
+    if (mode_in != CG_RUN) return;
+    const double alpha = cs.alpha;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (Le[j] < n2) {
+        pe[j] = reinterpret_cast<double2 *>(p)[Le[j]];
+        se[j] = reinterpret_cast<double2 *>(s)[Le[j]];
+      }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (Le[j] < n2) ve[j] = reinterpret_cast<const double2 *>(v)[Le[j]];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (Le[j] < n2) {
+        double2 sv = se[j];
+        const double2 pv = pe[j];
+        sv.x = sv.x + alpha * pv.x; sv.y = sv.y + alpha * pv.y;
+        reinterpret_cast<double2 *>(s)[Le[j]] = sv;
+      }
+  };
+  double red = 0;
+  if (mode_in != CG_APPLY_SIGMA) reduce_rows_1x512(partials_b, nparts_b, red, lds, early_s);
+  step_b(cs, cc, red);
+  cs.launches = cs.launches + 1;
+  if (leader) {
+    store_state(st_out, cs);
+    if (mode_in == CG_RUN && trace && cs.k - 1 < trace_cap) {
+      const size_t k = (size_t)(cs.k - 1);
+      trace[k] = cs.alpha;
+      trace[trace_cap + k] = cs.beta;
+      trace[2 * trace_cap + k] = cs.kappa;
+      trace[3 * trace_cap + k] = cs.rv;
+    }
+    publish(hs, cs.launches, cs.mode == CG_DONE);
+    if (dg.gdir && mode_in == CG_RUN && cs.mode == CG_RUN) {  // G(p) = -G(r) + beta G(p)  (:420)
+      for (int i = 0; i < dg.ns; ++i) dg.gdir[SLOT_GDIR_P + i] = -dg.gdir[i] + cs.beta * dg.gdir[SLOT_GDIR_P + i];
+    }
+  }
+  if (mode_in == CG_KERNEL_PENDING) {
+    const double sigma = cs.sigma;
+    for (unsigned i = i0; i < n2; i += stride) {
+      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+      double2 sv = reinterpret_cast<double2 *>(s)[i];
+      sv.x += sigma * pv.x; sv.y += sigma * pv.y;
+      reinterpret_cast<double2 *>(s)[i] = sv;
+    }
+    if ((n & 1) && leader) s[n - 1] += sigma * p[n - 1];
+  } else if (mode_in == CG_RUN) {
+    const double alpha = cs.alpha, beta = cs.beta;
+    const bool dir = cs.mode == CG_RUN;
+    if (dir) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (Le[j] < n2) {
+          double2 pv = pe[j];
+          const double2 vv = ve[j];
+          pv.x = -vv.x + beta * pv.x; pv.y = -vv.y + beta * pv.y;
+          reinterpret_cast<double2 *>(p)[Le[j]] = pv;
+        }
+    }
+    if ((n & 1) && leader) {
+      s[n - 1] = s[n - 1] + alpha * p[n - 1];
+      if (dir) p[n - 1] = -v[n - 1] + beta * p[n - 1];
+    }
+  }
+}
+
+
 // ---- opt-in experiment (r05; Config::two_kernel_step) -------------------------------------------------
 // ONE kernel for the A-step and the B-step of an unpreconditioned iteration over rows of Stiefel(n,3) (v == r).  Without
 // a preconditioner <r+,r+> = <r,r> + 2 alpha <r,Hp> + alpha^2 <Hp,Hp> is known once the Hessian pass has also left
@@ -1158,7 +1301,15 @@ int mi_stpcg(mi_ctx *ctx, const mi_vec *g, mi_op *H, mi_precon *P, const mi_stpc
         if (rows && rprime) CG_CHECK(comm_rprime_exchange(ctx, dgp->halo_A, dgp->p, r->d, ctx->partials_b, 1));
         else if (rows) CG_CHECK(comm_allreduce_rows(ctx, ctx->partials_b, 1));
         KScope ks(ctx, MI_K_CG_PUPDATE);
-        LAUNCH_PUPD(k_cg_pupdate, k_cg_pupdate_s80, false);
+        // (the early-s form: single context, v = r or any plain vector, at most three elements per thread, <= 512 rows)
+        const bool early = sp == 0 && !rows && ctx->cfg.early_s && grid <= 512 && cc.rag0 <= 2ull * (size_t)grid * kBlock &&
+                           (n >> 1) < ((size_t)1 << 31);
+        if (early)
+          hipLaunchKernelGGL(k_cg_pupdate_early, dim3(grid), dim3(kBlock), 0, st, n, cc, (const CgState *)st1, st0,
+                             (const double *)ctx->partials_b, grid, (const double *)vd, p->d, s_out->d, ctx->status_dev, tr,
+                             tcap, dga);
+        else
+          LAUNCH_PUPD(k_cg_pupdate, k_cg_pupdate_s80, false);
       }
       if (rprime && (sharded || rows)) {
         const double *hr = nullptr;

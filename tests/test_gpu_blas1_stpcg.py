@@ -244,6 +244,32 @@ def test_stpcg_run_ahead_invariance(ctx):
             assert cur[0] == base[0] and cur[1] == base[1] and np.array_equal(cur[2], base[2])
 
 
+@pytest.mark.parametrize("n", [3_000_000, 2_999_999, 1_048_576 + 77, 40_000])
+def test_early_s_direction_kernel_is_the_default_one_bit_for_bit(n):
+    """MI355OPT_EARLY_S=1 (opt-in, stpcg.hip k_cg_pupdate_early): s += alpha p ahead of the direction kernel's own
+    reduction, every operand requested at once -- the same walk and expressions as k_cg_pupdate, so every bit of the step,
+    the traces, the count and the exit equal the default's; sizes: cfg2's (two grid-stride steps + the ragged one), an odd
+    length, one just past a whole step, and one small enough for a single step."""
+    from optimization_amd import capi
+    g, D, M = _diag_problem(n, seed=5, lo=1.0, hi=900.0)
+    out = []
+    for early in (0, 1):
+        c = capi.Context(0)
+        try:
+            c.set_option("EARLY_S", early)
+            G, H = c.upload(g), c.op_diag(c.upload(D))
+            c.ktime_enable("cg_pupdate", True)
+            r = c.stpcg(G, H, Delta=30.0, max_iterations=60, kappa_fgr=1e-9, theta=1.0, trace_cap=64)
+            assert c.ktime_read("cg_pupdate")[0] > 0
+            out.append((r["iterations"], r["exit_reason"], r["M_norm"], r["s"].numpy().copy(),
+                        np.array(r["trace"]["alpha"]), np.array(r["trace"]["beta"])))
+        finally:
+            c.close()
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
 def test_polled_read_back_equals_stream_synchronize():
     """r05: a scalar read-back is a one-wave kernel that stores the slots and then a sequence number into coherent pinned
     words the host polls (`stream_wait` / `read_slots_sync`, context.hip / blas1.hip: 14.4 instead of 18.8 us per dot
