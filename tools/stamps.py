@@ -27,7 +27,10 @@ capi.check(L.mi_debug_stamp_buffer(ptr))
 us1 = H.time_fused_apply(g, out, 1)   # 3 warm-up calls + 1: the last launch's stamps remain
 capi.check(L.mi_debug_stamp_buffer(None))
 st = buf.numpy().view(np.uint64).reshape(NW, NS).astype(np.int64)
-st = st[st[:, 56] > 0]  # waves that ran
+wg_of = np.arange(NW) // 4          # (4 waves per workgroup of the window kernels)
+ran = st[:, 56] > 0
+wg_of = wg_of[ran]
+st = st[ran]  # waves that ran
 t0 = st[:, 0:1]
 rel = np.where(st > 0, st - t0, -1)
 print(f"kernel {us:.2f} us/launch (stamped build)")
@@ -43,6 +46,19 @@ print("kernel entry/exit (100 MHz): launch %.2f us; first entry -> last exit %.2
       % (us, (e1.max() - e0.min()) / 100, np.median(e1 - e0) / 100, (e1 - e0).max() / 100, np.median(e0 - e0.min()) / 100,
          np.percentile(e0 - e0.min(), 90) / 100, (e0 - e0.min()).max() / 100, (e1.max() - np.median(e1)) / 100,
          np.median(e1 - eb) / 100))
+# late r06: who is late?  exit time (relative to the first entry) by XCD (workgroup % 8) and by the number of tiles a wave walked
+ntile = np.zeros(st.shape[0], dtype=int)
+for t in range(6):
+    ntile += (st[:, 2 + 8 * t] > 0).astype(int)
+ex = (e1 - e0.min()) / 100.0
+print("exit by XCD (us after the first entry): " + ", ".join("%d: median %.2f max %.2f" % (x, np.median(ex[wg_of % 8 == x]), ex[wg_of % 8 == x].max()) for x in range(8)))
+span = (e1 - e0) / 100.0
+print("wave span by XCD (us): " + ", ".join("%d: %.2f" % (x, np.median(span[wg_of % 8 == x])) for x in range(8)))
+order = np.argsort(ex)
+print("the 16 last waves: workgroups " + " ".join("%d(x%d,%.1f)" % (wg_of[i], wg_of[i] % 8, ex[i]) for i in order[-16:]))
+nwg = wg_of.max() + 1
+q = np.array([np.median(ex[(wg_of >= a) & (wg_of < a + nwg // 8)]) for a in range(0, nwg - nwg // 8 + 1, nwg // 8)])
+print("exit by eighth of the grid (launch order): " + " ".join("%.2f" % v for v in q))
 for sl in range(NS):
     v = rel[:, sl][rel[:, sl] >= 0]
     if sl == 0 or v.size == 0 or sl in (NS - 3, NS - 2, 56, 57, 58):
